@@ -1,0 +1,125 @@
+"""ctypes binding of libacgan_hip.so (include/acgan_hip.h).
+
+There is no fallback: if the HIP library has not been built (``python -c "import
+__graft_entry__ as g; g.build()"`` or ``make -C action_conditioned_gans_amd/csrc``) every
+operator raises ``RuntimeError``.  Nothing here knows about the CPU oracle.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
+
+ACG_F32, ACG_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+CONV_FWD, CONV_DGRAD, CONV_WGRAD = 0, 1, 2
+ABI_VERSION = 1
+
+LIB_NAME = 'libacgan_hip.so'
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', LIB_NAME)
+
+
+class ConvDesc(ctypes.Structure):
+    """struct acg_conv_desc."""
+    _fields_ = [(n, c_int32) for n in (
+        'batch', 'in_h', 'in_w', 'in_c', 'out_h', 'out_w', 'out_c', 'kh', 'kw',
+        'stride_h', 'stride_w', 'pad_top', 'pad_left')]
+
+    def key(self):
+        return tuple(getattr(self, n) for n, _ in self._fields_)
+
+
+_P = c_void_p
+_D = ctypes.POINTER(ConvDesc)
+_conv = [_P, _P, _P, _D, c_int32, _P, c_size_t, _P]
+_wgrad = [_P, _P, _P, c_float, _D, c_int32, _P, c_size_t, _P]
+
+# name -> (restype, argtypes); mirrors include/acgan_hip.h one to one.
+SIGNATURES = {
+    'acg_version': (c_int32, []),
+    'acg_build_info': (c_char_p, []),
+    'acg_last_error': (c_char_p, []),
+    'acg_conv_desc_init': (c_int32, [_D] + [c_int32] * 9),
+    'acg_conv2d_workspace_bytes': (c_size_t, [_D, c_int32, c_int32]),
+    'acg_conv2d_fwd': (c_int32, _conv),
+    'acg_conv2d_dgrad': (c_int32, _conv),
+    'acg_conv2d_wgrad': (c_int32, _wgrad),
+    'acg_deconv2d_fwd': (c_int32, _conv),
+    'acg_deconv2d_dgrad': (c_int32, _conv),
+    'acg_deconv2d_wgrad': (c_int32, _wgrad),
+    'acg_bn_workspace_bytes': (c_size_t, [c_int64, c_int32, c_int32]),
+    'acg_bn_act_fwd': (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_float, c_int32, c_float,
+                                 c_int32, _P, c_size_t, _P]),
+    'acg_bn_act_bwd': (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int64, c_int32, c_int32, c_int32,
+                                 c_float, c_int32, _P, c_size_t, _P]),
+    'acg_bias_workspace_bytes': (c_size_t, [c_int64, c_int32]),
+    'acg_bias_act_fwd': (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_float, c_int32, _P]),
+    'acg_bias_act_bwd': (c_int32, [_P, _P, _P, _P, c_float, c_int64, c_int32, c_int32, c_float, c_int32,
+                                   _P, c_size_t, _P]),
+    'acg_dna_fwd': (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
+    'acg_dna_bwd': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
+    'acg_concat_actions_fwd': (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
+    'acg_concat_channels_fwd': (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P]),
+    'acg_slice_channels': (c_int32, [_P, _P, c_float, c_int64, c_int32, c_int32, c_int32, c_int32, _P]),
+    'acg_add': (c_int32, [_P, _P, _P, c_int64, c_int32, _P]),
+    'acg_frame_loss_workspace_bytes': (c_size_t, [c_int64]),
+    'acg_frame_loss': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_int32,
+                                 _P, c_size_t, _P]),
+    'acg_l2norm_loss': (c_int32, [_P, _P, _P, _P, c_int64, c_float, _P]),
+    'acg_sigmoid_ce_loss': (c_int32, [_P, c_float, _P, _P, c_int64, c_float, _P]),
+    'acg_mean_loss': (c_int32, [_P, _P, _P, c_int64, c_float, _P]),
+    'acg_psnr': (c_int32, [_P, _P, _P, c_int64, c_int32, _P, c_size_t, _P]),
+    'acg_scalar_combine': (c_int32, [_P, _P, c_float, _P, c_float, _P, c_float, _P, c_float, _P]),
+    'acg_adam_step': (c_int32, [_P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float,
+                                c_int32, c_float, c_float, _P]),
+    'acg_rmsprop_step': (c_int32, [_P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int32, c_float,
+                                   c_float, _P]),
+    'acg_clip': (c_int32, [_P, c_int64, c_float, c_float, _P]),
+    'acg_step_inc': (c_int32, [_P, _P]),
+}
+
+
+class AcgError(RuntimeError):
+    pass
+
+
+class Library:
+    """A loaded C-ABI library; every int-returning entry point is checked and raises AcgError."""
+
+    def __init__(self, path):
+        self.path = path
+        self._cdll = ctypes.CDLL(path)
+        missing = [n for n in SIGNATURES if not hasattr(self._cdll, n)]
+        if missing:
+            raise AcgError('%s does not export %s' % (path, ', '.join(missing)))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self._cdll, name)
+            fn.restype, fn.argtypes = res, args
+            if res is c_int32 and name != 'acg_version':
+                fn = self._checked(name, fn)
+            setattr(self, name[4:], fn)
+        if self.version() != ABI_VERSION:
+            raise AcgError('%s: ABI version %d, expected %d' % (path, self.version(), ABI_VERSION))
+
+    def _checked(self, name, fn):
+        last_error = self._cdll.acg_last_error
+
+        def call(*a):
+            rc = fn(*a)
+            if rc != 0:
+                raise AcgError('%s failed (code %d): %s' % (name, rc, last_error().decode()))
+        call.__name__ = name
+        return call
+
+
+_LIB = None
+
+
+def get():
+    """The process-wide HIP library; raises if it was not built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                '%s not found: the HIP kernels are not built and there is no fallback path. '
+                'Run `python -c "import __graft_entry__ as g; g.build()"` first.' % LIB_PATH)
+        _LIB = Library(LIB_PATH)
+    return _LIB

@@ -1,0 +1,188 @@
+/*
+ * acgan_hip.h - C ABI of libacgan_hip.so: the MI355X (gfx950) kernels behind the
+ * conv generator / discriminator forward+backward hot path of
+ * yidingjiang/action_conditioned_GANs.
+ *
+ * The reference has no native boundary of its own: all hot-path arithmetic is TensorFlow-1.0
+ * ops invoked from Python.  Each entry point below therefore cites the
+ * reference call site(s) whose TF op it replaces (paths into /root/reference).
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes; no framework types.
+ *   - Device pointers are BORROWED from the caller (contiguous, NHWC, 16-byte aligned); the
+ *     library never allocates: scratch comes in through (workspace, workspace_bytes), sized
+ *     by the matching *_workspace_bytes() query.
+ *   - Asynchronous on `stream` (a hipStream_t passed as void*); no internal synchronisation,
+ *     safe to capture into a hipGraph.
+ *   - Return 0 (ACG_OK) on success, an ACG_ERR_* code otherwise; the message is available
+ *     from acg_last_error() (thread-local).  No global mutable state besides that.
+ *   - `dtype` selects the storage type of activations/filters (ACG_F32, ACG_BF16); per-channel
+ *     parameters, statistics, loss scalars and optimizer state are always float32.
+ */
+#ifndef ACGAN_HIP_H
+#define ACGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACG_ABI_VERSION 1
+
+typedef void* acg_stream_t; /* hipStream_t */
+
+enum { ACG_OK = 0, ACG_ERR_INVALID_ARG = 1, ACG_ERR_WORKSPACE = 2, ACG_ERR_LAUNCH = 3, ACG_ERR_UNSUPPORTED = 4 };
+enum { ACG_F32 = 0, ACG_BF16 = 1 };
+enum { ACG_ACT_NONE = 0, ACG_ACT_RELU = 1, ACG_ACT_LRELU = 2, ACG_ACT_TANH = 3 };
+enum { ACG_CONV_FWD = 0, ACG_CONV_DGRAD = 1, ACG_CONV_WGRAD = 2 };
+
+int32_t acg_version(void);          /* ACG_ABI_VERSION of the loaded library */
+const char* acg_build_info(void);   /* e.g. "hip gfx950" */
+const char* acg_last_error(void);   /* message of the calling thread's last failing call */
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution.  One descriptor serves a conv and its adjoint:
+ *   x [batch,in_h,in_w,in_c]  *  w [kh,kw,in_c,out_c] (HWIO)  ->  y [batch,out_h,out_w,out_c]
+ *   y[b,p,q,o] = sum_{i,j,c} x[b, p*stride_h - pad_top + i, q*stride_w - pad_left + j, c] * w[i,j,c,o]
+ * with zero padding; pad_top/pad_left are TF's pad_before (SAME: total//2).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct acg_conv_desc {
+  int32_t batch;
+  int32_t in_h, in_w, in_c;
+  int32_t out_h, out_w, out_c;
+  int32_t kh, kw;
+  int32_t stride_h, stride_w;
+  int32_t pad_top, pad_left;
+} acg_conv_desc;
+
+/* Fill a descriptor from slim-style arguments; same_padding != 0 -> TF 'SAME', else 'VALID'. */
+int32_t acg_conv_desc_init(acg_conv_desc* d, int32_t batch, int32_t in_h, int32_t in_w, int32_t in_c,
+                           int32_t kh, int32_t kw, int32_t out_c, int32_t stride, int32_t same_padding);
+
+size_t acg_conv2d_workspace_bytes(const acg_conv_desc* d, int32_t which /* ACG_CONV_* */, int32_t dtype);
+
+/* slim.conv2d's tf.nn.conv2d: models.py:12-15,34-37,42-51,82-88. */
+int32_t acg_conv2d_fwd(const void* x, const void* w, void* y, const acg_conv_desc* d, int32_t dtype,
+                       void* workspace, size_t workspace_bytes, acg_stream_t stream);
+/* its gradient w.r.t. x (what tf.gradients emits for train.py:100-102). */
+int32_t acg_conv2d_dgrad(const void* dy, const void* w, void* dx, const acg_conv_desc* d, int32_t dtype,
+                         void* workspace, size_t workspace_bytes, acg_stream_t stream);
+/* its gradient w.r.t. w:  dw = accumulate * dw + grad  (dw is always float32). */
+int32_t acg_conv2d_wgrad(const void* x, const void* dy, float* dw, float accumulate, const acg_conv_desc* d,
+                         int32_t dtype, void* workspace, size_t workspace_bytes, acg_stream_t stream);
+
+/* slim.conv2d_transpose's tf.nn.conv2d_transpose: models.py:17-21,39-40,53-59.
+ * The descriptor describes the ADJOINT conv: in_* is the deconv OUTPUT, out_* the deconv INPUT,
+ * and w [kh,kw,in_c,out_c] is exactly TF's deconv filter layout [kh,kw,Cout,Cin].
+ *   deconv2d_fwd   == conv2d_dgrad (x plays dy),  deconv2d_dgrad == conv2d_fwd,
+ *   deconv2d_wgrad == conv2d_wgrad with the roles of x and dy exchanged. */
+int32_t acg_deconv2d_fwd(const void* x, const void* w, void* y, const acg_conv_desc* adj, int32_t dtype,
+                         void* workspace, size_t workspace_bytes, acg_stream_t stream);
+int32_t acg_deconv2d_dgrad(const void* dy, const void* w, void* dx, const acg_conv_desc* adj, int32_t dtype,
+                           void* workspace, size_t workspace_bytes, acg_stream_t stream);
+int32_t acg_deconv2d_wgrad(const void* x, const void* dy, float* dw, float accumulate, const acg_conv_desc* adj,
+                           int32_t dtype, void* workspace, size_t workspace_bytes, acg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * slim.batch_norm (training mode, scale=False, center=True) fused with the layer activation:
+ * implicit via argscope at models.py:10-11,31-32,80-81; lrelu is ops.py:22-26.
+ * x is viewed as [rows, channels]; `groups` splits the rows into equal contiguous chunks that
+ * are normalised independently (groups=2 lets D(fake) and D(real), train.py:63-70, share one
+ * launch while keeping separate batch statistics).  save_mean/save_rstd: [groups*channels].
+ *   y = act((x - mean) * rsqrt(var + eps) + beta),  var biased.
+ * bwd:  dbeta = dbeta_accumulate * dbeta + sum(dpre),  dx through mean and variance.
+ * ---------------------------------------------------------------------------------------- */
+size_t acg_bn_workspace_bytes(int64_t rows, int32_t channels, int32_t groups);
+int32_t acg_bn_act_fwd(const void* x, const float* beta, void* y, float* save_mean, float* save_rstd,
+                       int64_t rows, int32_t channels, int32_t groups, float eps, int32_t act, float leak,
+                       int32_t dtype, void* workspace, size_t workspace_bytes, acg_stream_t stream);
+int32_t acg_bn_act_bwd(const void* x, const void* dy, const float* beta, const float* save_mean,
+                       const float* save_rstd, void* dx, float* dbeta, float dbeta_accumulate,
+                       int64_t rows, int32_t channels, int32_t groups, int32_t act, float leak,
+                       int32_t dtype, void* workspace, size_t workspace_bytes, acg_stream_t stream);
+
+/* Layers built with normalizer_fn=None: y = act(x + bias)   (models.py:20-21,44-51,54-59).
+ * bwd takes the forward OUTPUT y; dx may be NULL when act == ACG_ACT_NONE (dx == dy). */
+size_t acg_bias_workspace_bytes(int64_t rows, int32_t channels);
+int32_t acg_bias_act_fwd(const void* x, const float* bias, void* y, int64_t rows, int32_t channels,
+                         int32_t act, float leak, int32_t dtype, acg_stream_t stream);
+int32_t acg_bias_act_bwd(const void* y, const void* dy, void* dx, float* dbias, float dbias_accumulate,
+                         int64_t rows, int32_t channels, int32_t act, float leak, int32_t dtype,
+                         void* workspace, size_t workspace_bytes, acg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dynamic Neural Advection tail, models.py:60-72 (softmax + extract_image_patches + mul + sum):
+ *   out[b,y,x,c] = sum_{i,j} softmax(logits[b,y,x,:])[i*k+j] * image[b, y-p+i, x-p+j, c],
+ *   p = (k-1)/2, zero outside the image.   logits [B,H,W,k*k], image/out [B,H,W,C], C <= 4.
+ * bwd produces dlogits only (the image is a network input, train.py:53-54).
+ * ---------------------------------------------------------------------------------------- */
+int32_t acg_dna_fwd(const void* logits, const void* image, void* out, int32_t batch, int32_t h, int32_t w,
+                    int32_t c, int32_t ksize, int32_t dtype, acg_stream_t stream);
+int32_t acg_dna_bwd(const void* logits, const void* image, const void* dout, void* dlogits, int32_t batch,
+                    int32_t h, int32_t w, int32_t c, int32_t ksize, int32_t dtype, acg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Channel plumbing: tf.tile + tf.concat at train.py:48-50,64,68 and models.py:16,38,84.
+ * ---------------------------------------------------------------------------------------- */
+/* y[b,s,0:c] = x[b,s,:],  y[b,s,c:c+a] = actions[b,:]   for s in [0,hw) */
+int32_t acg_concat_actions_fwd(const void* x, const float* actions, void* y, int32_t batch, int32_t hw,
+                               int32_t c, int32_t a, int32_t dtype, acg_stream_t stream);
+/* y[r,0:ca] = a[r,:], y[r,ca:ca+cb] = b[r,:] */
+int32_t acg_concat_channels_fwd(const void* a, const void* b, void* y, int64_t rows, int32_t ca, int32_t cb,
+                                int32_t dtype, acg_stream_t stream);
+/* dst[r,:] = accumulate * dst[r,:] + src[r, c_off : c_off + c_dst] */
+int32_t acg_slice_channels(const void* src, void* dst, float accumulate, int64_t rows, int32_t c_src,
+                           int32_t c_off, int32_t c_dst, int32_t dtype, acg_stream_t stream);
+/* y = a + b (gradient fan-in where one tensor feeds two consumers, models.py:40-53) */
+int32_t acg_add(const void* a, const void* b, void* y, int64_t n, int32_t dtype, acg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Losses.  Every loss writes its scalar value(s) to a float32 device slot and, when the
+ * gradient pointer is non-NULL, d(scale * loss)/d(input) in the same pass.
+ * ---------------------------------------------------------------------------------------- */
+/* out[0] = sum|gen-gt|  (tf.norm ord=1, train.py:73);  out[1] = GDL(gen,gt) (ops.py:100-120);
+ * dgen = w_l1 * d out[0] + w_gdl * d out[1]   (tf.abs gradient: sign, 0 at 0). */
+size_t acg_frame_loss_workspace_bytes(int64_t n);
+int32_t acg_frame_loss(const void* gen, const void* gt, float* out2, void* dgen, int32_t batch, int32_t h,
+                       int32_t w, int32_t c, float w_l1, float w_gdl, int32_t dtype, void* workspace,
+                       size_t workspace_bytes, acg_stream_t stream);
+/* out[0] = ||pred-gt||_2 (tf.norm ord=2, train.py:77); dpred = scale*(pred-gt)/norm (0 if norm==0). n <= 65536 */
+int32_t acg_l2norm_loss(const float* pred, const float* gt, float* out, float* dpred, int64_t n, float scale,
+                        acg_stream_t stream);
+/* out[0] = mean(max(x,0) - x*label + log1p(exp(-|x|)))  (tf.losses.sigmoid_cross_entropy, ops.py:30-31,39-42);
+ * dlogits = scale*(sigmoid(x)-label)/n.  n <= 65536 */
+int32_t acg_sigmoid_ce_loss(const float* logits, float label, float* out, float* dlogits, int64_t n, float scale,
+                            acg_stream_t stream);
+/* out[0] = mean(x) (tf.reduce_mean, ops.py:32-33,44-45); dx = scale/n.  n <= 65536 */
+int32_t acg_mean_loss(const float* x, float* out, float* dx, int64_t n, float scale, acg_stream_t stream);
+/* out[0] = 10*log10(1/mean((a-b)^2))  (build_psnr, ops.py:19-20) */
+int32_t acg_psnr(const void* a, const void* b, float* out, int64_t n, int32_t dtype, void* workspace,
+                 size_t workspace_bytes, acg_stream_t stream);
+/* out[0] = sum_i w_i * in_i[0] over the non-NULL inputs (loss sums of train.py:73-83,85) */
+int32_t acg_scalar_combine(float* out, const float* in0, float w0, const float* in1, float w1, const float* in2,
+                           float w2, const float* in3, float w3, acg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimizers over FLAT float32 buffers (all variables of one scope are views into one buffer),
+ * TensorFlow-1.0 formulas (train.py:91-102).  grad is multiplied by grad_scale first
+ * (1/world_size after a sum all-reduce).  use_clip != 0 fuses the D weight clip of
+ * train.py:89,140-143 after the update (update -> clip order).
+ * ---------------------------------------------------------------------------------------- */
+/* tf.train.AdamOptimizer: lr_t = lr*sqrt(1-b2^t)/(1-b1^t), p -= lr_t*m/(sqrt(v)+eps); t read from *step_dev */
+int32_t acg_adam_step(float* param, const float* grad, float* m, float* v, const int32_t* step_dev, int64_t n,
+                      float lr, float beta1, float beta2, float eps, float grad_scale, int32_t use_clip,
+                      float clip_lo, float clip_hi, acg_stream_t stream);
+/* tf.train.RMSPropOptimizer (momentum 0): ms = decay*ms+(1-decay)*g*g; p -= lr*g/sqrt(ms+eps) */
+int32_t acg_rmsprop_step(float* param, const float* grad, float* ms, int64_t n, float lr, float decay, float eps,
+                         float grad_scale, int32_t use_clip, float clip_lo, float clip_hi, acg_stream_t stream);
+/* tf.clip_by_value assign (train.py:89) */
+int32_t acg_clip(float* param, int64_t n, float lo, float hi, acg_stream_t stream);
+/* *step_dev += 1 (device-resident step counter so a captured graph replays correctly) */
+int32_t acg_step_inc(int32_t* step_dev, acg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACGAN_HIP_H */

@@ -1,0 +1,389 @@
+/*
+ * acg_oracle.c - brute-force CPU restatement of the reference hot-path arithmetic, exporting the
+ * same C ABI as libacgan_hip.so (include/acgan_hip.h) on HOST pointers.
+ *
+ * TEST INFRASTRUCTURE ONLY - PARITY UNPINNED (see oracle/__init__.py): the reference's arithmetic is
+ * tensorflow==1.0.0 (requirements.txt:1), absent here; this file restates the published TF-1.0 / slim
+ * op definitions as direct index loops with double accumulation, independently
+ * of the torch composition in oracle/tf_ops.py.  The two must agree (tests/test_oracle.py).
+ * It is loaded only by tests (as the checker, and as a stand-in device library for CPU-only
+ * host-logic tests); the product never links or loads it.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/acgan_hip.h"
+
+static __thread char g_err[256];
+static int fail(int code, const char* msg) { snprintf(g_err, sizeof g_err, "%s", msg); return code; }
+#define REQUIRE_F32(dt) do { if ((dt) != ACG_F32) return fail(ACG_ERR_UNSUPPORTED, "cpu oracle: float32 only"); } while (0)
+
+int32_t acg_version(void) { return ACG_ABI_VERSION; }
+const char* acg_build_info(void) { return "cpu-oracle"; }
+const char* acg_last_error(void) { return g_err; }
+
+static double sgn(double v) { return (v > 0) - (v < 0); }
+
+/* ---- geometry: SURVEY A.1 */
+int32_t acg_conv_desc_init(acg_conv_desc* d, int32_t batch, int32_t in_h, int32_t in_w, int32_t in_c,
+                           int32_t kh, int32_t kw, int32_t out_c, int32_t stride, int32_t same) {
+  if (!d || batch <= 0 || in_h <= 0 || in_w <= 0 || in_c <= 0 || kh <= 0 || kw <= 0 || out_c <= 0 || stride <= 0)
+    return fail(ACG_ERR_INVALID_ARG, "conv_desc_init: non-positive dimension");
+  d->batch = batch; d->in_h = in_h; d->in_w = in_w; d->in_c = in_c; d->out_c = out_c;
+  d->kh = kh; d->kw = kw; d->stride_h = d->stride_w = stride;
+  if (same) {
+    d->out_h = (in_h + stride - 1) / stride; d->out_w = (in_w + stride - 1) / stride;
+    int th = (d->out_h - 1) * stride + kh - in_h; if (th < 0) th = 0;
+    int tw = (d->out_w - 1) * stride + kw - in_w; if (tw < 0) tw = 0;
+    d->pad_top = th / 2; d->pad_left = tw / 2;
+  } else {
+    if (in_h < kh || in_w < kw) return fail(ACG_ERR_INVALID_ARG, "conv_desc_init: VALID kernel larger than input");
+    d->out_h = (in_h - kh) / stride + 1; d->out_w = (in_w - kw) / stride + 1;
+    d->pad_top = d->pad_left = 0;
+  }
+  return ACG_OK;
+}
+
+size_t acg_conv2d_workspace_bytes(const acg_conv_desc* d, int32_t which, int32_t dtype) { (void)d; (void)which; (void)dtype; return 0; }
+
+#define XI(d, b, y, x, c) ((((size_t)(b) * (d)->in_h + (y)) * (d)->in_w + (x)) * (d)->in_c + (c))
+#define YI(d, b, p, q, o) ((((size_t)(b) * (d)->out_h + (p)) * (d)->out_w + (q)) * (d)->out_c + (o))
+#define WI(d, i, j, c, o) ((((size_t)(i) * (d)->kw + (j)) * (d)->in_c + (c)) * (d)->out_c + (o))
+
+/* tf.nn.conv2d (models.py:12-15,34-37,42-51,82-88); SURVEY A.1 */
+int32_t acg_conv2d_fwd(const void* xv, const void* wv, void* yv, const acg_conv_desc* d, int32_t dtype,
+                       void* ws, size_t wsb, acg_stream_t s) {
+  (void)ws; (void)wsb; (void)s; REQUIRE_F32(dtype);
+  const float* x = xv; const float* w = wv; float* y = yv;
+  for (int b = 0; b < d->batch; b++) for (int p = 0; p < d->out_h; p++) for (int q = 0; q < d->out_w; q++)
+    for (int o = 0; o < d->out_c; o++) {
+      double acc = 0;
+      for (int i = 0; i < d->kh; i++) { int yy = p * d->stride_h - d->pad_top + i; if (yy < 0 || yy >= d->in_h) continue;
+        for (int j = 0; j < d->kw; j++) { int xx = q * d->stride_w - d->pad_left + j; if (xx < 0 || xx >= d->in_w) continue;
+          for (int c = 0; c < d->in_c; c++) acc += (double)x[XI(d, b, yy, xx, c)] * w[WI(d, i, j, c, o)]; } }
+      y[YI(d, b, p, q, o)] = (float)acc;
+    }
+  return ACG_OK;
+}
+
+/* conv2d_backprop_input == tf.nn.conv2d_transpose (models.py:17-21,39-40,53-59); SURVEY A.2 (scatter form) */
+int32_t acg_conv2d_dgrad(const void* dyv, const void* wv, void* dxv, const acg_conv_desc* d, int32_t dtype,
+                         void* ws, size_t wsb, acg_stream_t s) {
+  (void)ws; (void)wsb; (void)s; REQUIRE_F32(dtype);
+  const float* dy = dyv; const float* w = wv; float* dx = dxv;
+  size_t n = (size_t)d->batch * d->in_h * d->in_w * d->in_c;
+  double* acc = calloc(n, sizeof(double));
+  if (!acc) return fail(ACG_ERR_WORKSPACE, "oracle: out of memory");
+  for (int b = 0; b < d->batch; b++) for (int p = 0; p < d->out_h; p++) for (int q = 0; q < d->out_w; q++)
+    for (int i = 0; i < d->kh; i++) { int yy = p * d->stride_h - d->pad_top + i; if (yy < 0 || yy >= d->in_h) continue;
+      for (int j = 0; j < d->kw; j++) { int xx = q * d->stride_w - d->pad_left + j; if (xx < 0 || xx >= d->in_w) continue;
+        for (int c = 0; c < d->in_c; c++) { double a = 0;
+          for (int o = 0; o < d->out_c; o++) a += (double)dy[YI(d, b, p, q, o)] * w[WI(d, i, j, c, o)];
+          acc[XI(d, b, yy, xx, c)] += a; } } }
+  for (size_t k = 0; k < n; k++) dx[k] = (float)acc[k];
+  free(acc);
+  return ACG_OK;
+}
+
+int32_t acg_conv2d_wgrad(const void* xv, const void* dyv, float* dw, float accumulate, const acg_conv_desc* d,
+                         int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
+  (void)ws; (void)wsb; (void)s; REQUIRE_F32(dtype);
+  const float* x = xv; const float* dy = dyv;
+  for (int i = 0; i < d->kh; i++) for (int j = 0; j < d->kw; j++) for (int c = 0; c < d->in_c; c++)
+    for (int o = 0; o < d->out_c; o++) {
+      double acc = 0;
+      for (int b = 0; b < d->batch; b++) for (int p = 0; p < d->out_h; p++) { int yy = p * d->stride_h - d->pad_top + i; if (yy < 0 || yy >= d->in_h) continue;
+        for (int q = 0; q < d->out_w; q++) { int xx = q * d->stride_w - d->pad_left + j; if (xx < 0 || xx >= d->in_w) continue;
+          acc += (double)x[XI(d, b, yy, xx, c)] * dy[YI(d, b, p, q, o)]; } }
+      size_t k = WI(d, i, j, c, o);
+      dw[k] = (float)((accumulate != 0.f ? (double)accumulate * dw[k] : 0.0) + acc);
+    }
+  return ACG_OK;
+}
+
+int32_t acg_deconv2d_fwd(const void* x, const void* w, void* y, const acg_conv_desc* adj, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
+  return acg_conv2d_dgrad(x, w, y, adj, dtype, ws, wsb, s); }
+int32_t acg_deconv2d_dgrad(const void* dy, const void* w, void* dx, const acg_conv_desc* adj, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
+  return acg_conv2d_fwd(dy, w, dx, adj, dtype, ws, wsb, s); }
+int32_t acg_deconv2d_wgrad(const void* x, const void* dy, float* dw, float acc, const acg_conv_desc* adj, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
+  return acg_conv2d_wgrad(dy, x, dw, acc, adj, dtype, ws, wsb, s); }
+
+/* ---- activations: value and derivative w.r.t. the pre-activation u */
+static double act_f(int act, double u, double leak) {
+  switch (act) {
+    case ACG_ACT_RELU: return u > 0 ? u : 0;
+    case ACG_ACT_LRELU: return 0.5 * (1 + leak) * u + 0.5 * (1 - leak) * fabs(u);   /* ops.py:22-26 */
+    case ACG_ACT_TANH: return tanh(u);
+    default: return u;
+  }
+}
+static double act_df(int act, double u, double leak) {
+  switch (act) {
+    case ACG_ACT_RELU: return u > 0 ? 1 : 0;
+    case ACG_ACT_LRELU: return 0.5 * (1 + leak) + 0.5 * (1 - leak) * sgn(u);
+    case ACG_ACT_TANH: { double t = tanh(u); return 1 - t * t; }
+    default: return 1;
+  }
+}
+
+/* slim.batch_norm training mode, SURVEY A.4 */
+size_t acg_bn_workspace_bytes(int64_t rows, int32_t channels, int32_t groups) { (void)rows; (void)channels; (void)groups; return 0; }
+int32_t acg_bn_act_fwd(const void* xv, const float* beta, void* yv, float* save_mean, float* save_rstd,
+                       int64_t rows, int32_t C, int32_t groups, float eps, int32_t act, float leak,
+                       int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
+  (void)ws; (void)wsb; (void)s; REQUIRE_F32(dtype);
+  if (groups <= 0 || rows % groups) return fail(ACG_ERR_INVALID_ARG, "bn: rows not divisible by groups");
+  const float* x = xv; float* y = yv; int64_t R = rows / groups;
+  for (int g = 0; g < groups; g++) for (int c = 0; c < C; c++) {
+    const float* xg = x + (size_t)g * R * C; float* yg = y + (size_t)g * R * C;
+    double m = 0, v = 0;
+    for (int64_t r = 0; r < R; r++) m += xg[r * C + c];
+    m /= (double)R;
+    for (int64_t r = 0; r < R; r++) { double t = xg[r * C + c] - m; v += t * t; }
+    v /= (double)R;
+    double rstd = 1.0 / sqrt(v + (double)eps);
+    save_mean[g * C + c] = (float)m; save_rstd[g * C + c] = (float)rstd;
+    for (int64_t r = 0; r < R; r++) yg[r * C + c] = (float)act_f(act, (xg[r * C + c] - m) * rstd + beta[c], leak);
+  }
+  return ACG_OK;
+}
+
+int32_t acg_bn_act_bwd(const void* xv, const void* dyv, const float* beta, const float* save_mean,
+                       const float* save_rstd, void* dxv, float* dbeta, float dbeta_acc,
+                       int64_t rows, int32_t C, int32_t groups, int32_t act, float leak,
+                       int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
+  (void)ws; (void)wsb; (void)s; REQUIRE_F32(dtype);
+  if (groups <= 0 || rows % groups) return fail(ACG_ERR_INVALID_ARG, "bn: rows not divisible by groups");
+  const float* x = xv; const float* dy = dyv; float* dx = dxv; int64_t R = rows / groups;
+  for (int c = 0; c < C; c++) {
+    double db_total = 0;
+    for (int g = 0; g < groups; g++) {
+      const float* xg = x + (size_t)g * R * C; const float* dyg = dy + (size_t)g * R * C; float* dxg = dx + (size_t)g * R * C;
+      double m = save_mean[g * C + c], rstd = save_rstd[g * C + c], s1 = 0, s2 = 0;
+      for (int64_t r = 0; r < R; r++) { double xh = (xg[r * C + c] - m) * rstd;
+        double dp = dyg[r * C + c] * act_df(act, xh + beta[c], leak); s1 += dp; s2 += dp * xh; }
+      db_total += s1;
+      for (int64_t r = 0; r < R; r++) { double xh = (xg[r * C + c] - m) * rstd;
+        double dp = dyg[r * C + c] * act_df(act, xh + beta[c], leak);
+        dxg[r * C + c] = (float)(rstd * (dp - s1 / (double)R - xh * s2 / (double)R)); }
+    }
+    dbeta[c] = (float)((dbeta_acc != 0.f ? (double)dbeta_acc * dbeta[c] : 0.0) + db_total);
+  }
+  return ACG_OK;
+}
+
+size_t acg_bias_workspace_bytes(int64_t rows, int32_t channels) { (void)rows; (void)channels; return 0; }
+int32_t acg_bias_act_fwd(const void* xv, const float* bias, void* yv, int64_t rows, int32_t C, int32_t act,
+                         float leak, int32_t dtype, acg_stream_t s) {
+  (void)s; REQUIRE_F32(dtype);
+  const float* x = xv; float* y = yv;
+  for (int64_t r = 0; r < rows; r++) for (int c = 0; c < C; c++)
+    y[r * C + c] = (float)act_f(act, (double)x[r * C + c] + bias[c], leak);
+  return ACG_OK;
+}
+int32_t acg_bias_act_bwd(const void* yv, const void* dyv, void* dxv, float* dbias, float dbias_acc, int64_t rows,
+                         int32_t C, int32_t act, float leak, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
+  (void)ws; (void)wsb; (void)s; REQUIRE_F32(dtype);
+  const float* y = yv; const float* dy = dyv; float* dx = dxv;
+  if (!dx && act != ACG_ACT_NONE) return fail(ACG_ERR_INVALID_ARG, "bias_act_bwd: dx NULL requires ACG_ACT_NONE");
+  for (int c = 0; c < C; c++) {
+    double sum = 0;
+    for (int64_t r = 0; r < rows; r++) {
+      double yy = y[r * C + c], d;
+      switch (act) {                                 /* derivative expressed through the OUTPUT y */
+        case ACG_ACT_RELU: d = yy > 0 ? 1 : 0; break;
+        case ACG_ACT_LRELU: d = 0.5 * (1 + leak) + 0.5 * (1 - leak) * sgn(yy); break;
+        case ACG_ACT_TANH: d = 1 - yy * yy; break;
+        default: d = 1;
+      }
+      double g = dy[r * C + c] * d; sum += g;
+      if (dx) dx[r * C + c] = (float)g;
+    }
+    dbias[c] = (float)((dbias_acc != 0.f ? (double)dbias_acc * dbias[c] : 0.0) + sum);
+  }
+  return ACG_OK;
+}
+
+/* ---- DNA tail: models.py:60-72, SURVEY A.7 */
+static int dna_check(int c, int k) { return c >= 1 && c <= 4 && k >= 1 && k <= 15; }
+int32_t acg_dna_fwd(const void* lv, const void* iv, void* ov, int32_t B, int32_t H, int32_t W, int32_t C,
+                    int32_t k, int32_t dtype, acg_stream_t s) {
+  (void)s; REQUIRE_F32(dtype);
+  if (!dna_check(C, k)) return fail(ACG_ERR_INVALID_ARG, "dna: need 1<=c<=4, 1<=ksize<=15");
+  const float* lg = lv; const float* img = iv; float* out = ov; int kk = k * k, p = (k - 1) / 2;
+  for (int b = 0; b < B; b++) for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
+    const float* l = lg + (((size_t)b * H + y) * W + x) * kk;
+    double mx = l[0], den = 0, acc[4] = {0, 0, 0, 0};
+    for (int t = 1; t < kk; t++) if (l[t] > mx) mx = l[t];
+    for (int t = 0; t < kk; t++) den += exp(l[t] - mx);
+    for (int i = 0; i < k; i++) for (int j = 0; j < k; j++) {
+      int yy = y - p + i, xx = x - p + j; if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+      double m = exp(l[i * k + j] - mx) / den;
+      for (int c = 0; c < C; c++) acc[c] += m * img[(((size_t)b * H + yy) * W + xx) * C + c];
+    }
+    for (int c = 0; c < C; c++) out[(((size_t)b * H + y) * W + x) * C + c] = (float)acc[c];
+  }
+  return ACG_OK;
+}
+int32_t acg_dna_bwd(const void* lv, const void* iv, const void* dov, void* dlv, int32_t B, int32_t H, int32_t W,
+                    int32_t C, int32_t k, int32_t dtype, acg_stream_t s) {
+  (void)s; REQUIRE_F32(dtype);
+  if (!dna_check(C, k)) return fail(ACG_ERR_INVALID_ARG, "dna: need 1<=c<=4, 1<=ksize<=15");
+  const float* lg = lv; const float* img = iv; const float* dout = dov; float* dl = dlv; int kk = k * k, p = (k - 1) / 2;
+  double m[225], g[225];
+  for (int b = 0; b < B; b++) for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
+    size_t pix = ((size_t)b * H + y) * W + x;
+    const float* l = lg + pix * kk; const float* dO = dout + pix * C;
+    double mx = l[0], den = 0, dot = 0;
+    for (int t = 1; t < kk; t++) if (l[t] > mx) mx = l[t];
+    for (int t = 0; t < kk; t++) { m[t] = exp(l[t] - mx); den += m[t]; }
+    for (int i = 0; i < k; i++) for (int j = 0; j < k; j++) {
+      int t = i * k + j, yy = y - p + i, xx = x - p + j; m[t] /= den; g[t] = 0;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+        for (int c = 0; c < C; c++) g[t] += (double)dO[c] * img[(((size_t)b * H + yy) * W + xx) * C + c];
+      dot += m[t] * g[t];
+    }
+    for (int t = 0; t < kk; t++) dl[pix * kk + t] = (float)(m[t] * (g[t] - dot));
+  }
+  return ACG_OK;
+}
+
+/* ---- channel plumbing: train.py:48-50,64,68; models.py:16,38,84 */
+int32_t acg_concat_actions_fwd(const void* xv, const float* actions, void* yv, int32_t B, int32_t hw, int32_t c,
+                               int32_t a, int32_t dtype, acg_stream_t s) {
+  (void)s; REQUIRE_F32(dtype);
+  const float* x = xv; float* y = yv;
+  for (int b = 0; b < B; b++) for (int p = 0; p < hw; p++) {
+    size_t r = (size_t)b * hw + p;
+    memcpy(y + r * (c + a), x + r * c, sizeof(float) * c);
+    memcpy(y + r * (c + a) + c, actions + (size_t)b * a, sizeof(float) * a);
+  }
+  return ACG_OK;
+}
+int32_t acg_concat_channels_fwd(const void* av, const void* bv, void* yv, int64_t rows, int32_t ca, int32_t cb,
+                                int32_t dtype, acg_stream_t s) {
+  (void)s; REQUIRE_F32(dtype);
+  const float* a = av; const float* b = bv; float* y = yv;
+  for (int64_t r = 0; r < rows; r++) { memcpy(y + r * (ca + cb), a + r * ca, sizeof(float) * ca);
+                                       memcpy(y + r * (ca + cb) + ca, b + r * cb, sizeof(float) * cb); }
+  return ACG_OK;
+}
+int32_t acg_slice_channels(const void* sv, void* dv, float acc, int64_t rows, int32_t c_src, int32_t c_off,
+                           int32_t c_dst, int32_t dtype, acg_stream_t s) {
+  (void)s; REQUIRE_F32(dtype);
+  if (c_off < 0 || c_off + c_dst > c_src) return fail(ACG_ERR_INVALID_ARG, "slice_channels: range outside source");
+  const float* src = sv; float* dst = dv;
+  for (int64_t r = 0; r < rows; r++) for (int c = 0; c < c_dst; c++)
+    dst[r * c_dst + c] = (acc != 0.f ? acc * dst[r * c_dst + c] : 0.f) + src[r * c_src + c_off + c];
+  return ACG_OK;
+}
+int32_t acg_add(const void* av, const void* bv, void* yv, int64_t n, int32_t dtype, acg_stream_t s) {
+  (void)s; REQUIRE_F32(dtype);
+  const float* a = av; const float* b = bv; float* y = yv;
+  for (int64_t i = 0; i < n; i++) y[i] = a[i] + b[i];
+  return ACG_OK;
+}
+
+/* ---- losses: SURVEY A.5 */
+size_t acg_frame_loss_workspace_bytes(int64_t n) { (void)n; return 0; }
+int32_t acg_frame_loss(const void* gv, const void* tv, float* out2, void* dgv, int32_t B, int32_t H, int32_t W,
+                       int32_t C, float w_l1, float w_gdl, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
+  (void)ws; (void)wsb; (void)s; REQUIRE_F32(dtype);
+  const float* gen = gv; const float* gt = tv; float* dgen = dgv;
+  double l1 = 0, gdl = 0;
+#define AT(t, b, y, x, c) (((y) < H && (x) < W) ? (double)(t)[((((size_t)(b)) * H + (y)) * W + (x)) * C + (c)] : 0.0)
+  for (int b = 0; b < B; b++) for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) for (int c = 0; c < C; c++) {
+    double e = AT(gen, b, y, x, c) - AT(gt, b, y, x, c);
+    l1 += fabs(e);
+    /* ops.py:100-120: dx = in[x+1]-in[x], dy = in[y]-in[y+1], zero beyond the edge */
+    double gdx = AT(gen, b, y, x + 1, c) - AT(gen, b, y, x, c), tdx = AT(gt, b, y, x + 1, c) - AT(gt, b, y, x, c);
+    double gdy = AT(gen, b, y, x, c) - AT(gen, b, y + 1, x, c), tdy = AT(gt, b, y, x, c) - AT(gt, b, y + 1, x, c);
+    gdl += fabs(fabs(tdx) - fabs(gdx)) + fabs(fabs(tdy) - fabs(gdy));
+    if (dgen) {
+      /* d/dgen[y,x]: own dx term (-), left neighbour's dx term (+), own dy term (+), upper neighbour's dy term (-) */
+      double d = -(-sgn(fabs(tdx) - fabs(gdx)) * sgn(gdx)) + (-sgn(fabs(tdy) - fabs(gdy)) * sgn(gdy));
+      if (x > 0) { double g2 = AT(gen, b, y, x, c) - AT(gen, b, y, x - 1, c), t2 = AT(gt, b, y, x, c) - AT(gt, b, y, x - 1, c);
+        d += -sgn(fabs(t2) - fabs(g2)) * sgn(g2); }
+      if (y > 0) { double g2 = AT(gen, b, y - 1, x, c) - AT(gen, b, y, x, c), t2 = AT(gt, b, y - 1, x, c) - AT(gt, b, y, x, c);
+        d -= -sgn(fabs(t2) - fabs(g2)) * sgn(g2); }
+      dgen[(((size_t)b * H + y) * W + x) * C + c] = (float)(w_l1 * sgn(e) + w_gdl * d);
+    }
+  }
+#undef AT
+  out2[0] = (float)l1; out2[1] = (float)gdl;
+  return ACG_OK;
+}
+int32_t acg_l2norm_loss(const float* p, const float* g, float* out, float* dp, int64_t n, float scale, acg_stream_t s) {
+  (void)s; double ss = 0;
+  for (int64_t i = 0; i < n; i++) { double e = (double)p[i] - g[i]; ss += e * e; }
+  double nrm = sqrt(ss); out[0] = (float)nrm;
+  if (dp) for (int64_t i = 0; i < n; i++) dp[i] = nrm > 0 ? (float)(scale * ((double)p[i] - g[i]) / nrm) : 0.f;
+  return ACG_OK;
+}
+int32_t acg_sigmoid_ce_loss(const float* x, float label, float* out, float* dx, int64_t n, float scale, acg_stream_t s) {
+  (void)s; double sum = 0;
+  for (int64_t i = 0; i < n; i++) { double v = x[i];
+    sum += (v > 0 ? v : 0) - v * label + log1p(exp(-fabs(v)));
+    if (dx) dx[i] = (float)(scale * (1.0 / (1.0 + exp(-v)) - label) / (double)n); }
+  out[0] = (float)(sum / (double)n);
+  return ACG_OK;
+}
+int32_t acg_mean_loss(const float* x, float* out, float* dx, int64_t n, float scale, acg_stream_t s) {
+  (void)s; double sum = 0;
+  for (int64_t i = 0; i < n; i++) { sum += x[i]; if (dx) dx[i] = (float)(scale / (double)n); }
+  out[0] = (float)(sum / (double)n);
+  return ACG_OK;
+}
+int32_t acg_psnr(const void* av, const void* bv, float* out, int64_t n, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
+  (void)ws; (void)wsb; (void)s; REQUIRE_F32(dtype);
+  const float* a = av; const float* b = bv; double ss = 0;
+  for (int64_t i = 0; i < n; i++) { double e = (double)a[i] - b[i]; ss += e * e; }
+  out[0] = (float)(10.0 * log(1.0 / (ss / (double)n)) / log(10.0));
+  return ACG_OK;
+}
+int32_t acg_scalar_combine(float* out, const float* i0, float w0, const float* i1, float w1, const float* i2, float w2,
+                           const float* i3, float w3, acg_stream_t s) {
+  (void)s; double v = 0;
+  if (i0) v += (double)w0 * i0[0];
+  if (i1) v += (double)w1 * i1[0];
+  if (i2) v += (double)w2 * i2[0];
+  if (i3) v += (double)w3 * i3[0];
+  out[0] = (float)v;
+  return ACG_OK;
+}
+
+/* ---- optimizers: SURVEY A.6 (TensorFlow formulas) */
+int32_t acg_adam_step(float* p, const float* g, float* m, float* v, const int32_t* step_dev, int64_t n, float lr,
+                      float b1, float b2, float eps, float gs, int32_t use_clip, float lo, float hi, acg_stream_t s) {
+  (void)s; int t = *step_dev;
+  if (t < 1) return fail(ACG_ERR_INVALID_ARG, "adam: step counter must be >= 1 (call acg_step_inc first)");
+  double lr_t = (double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t));
+  for (int64_t i = 0; i < n; i++) {
+    double gi = (double)g[i] * gs;
+    double mi = (double)b1 * m[i] + (1.0 - (double)b1) * gi;
+    double vi = (double)b2 * v[i] + (1.0 - (double)b2) * gi * gi;
+    double pi = p[i] - lr_t * mi / (sqrt(vi) + (double)eps);
+    if (use_clip) pi = pi < lo ? lo : (pi > hi ? hi : pi);
+    m[i] = (float)mi; v[i] = (float)vi; p[i] = (float)pi;
+  }
+  return ACG_OK;
+}
+int32_t acg_rmsprop_step(float* p, const float* g, float* ms, int64_t n, float lr, float decay, float eps, float gs,
+                         int32_t use_clip, float lo, float hi, acg_stream_t s) {
+  (void)s;
+  for (int64_t i = 0; i < n; i++) {
+    double gi = (double)g[i] * gs;
+    double msi = (double)decay * ms[i] + (1.0 - (double)decay) * gi * gi;
+    double pi = p[i] - (double)lr * gi / sqrt(msi + (double)eps);
+    if (use_clip) pi = pi < lo ? lo : (pi > hi ? hi : pi);
+    ms[i] = (float)msi; p[i] = (float)pi;
+  }
+  return ACG_OK;
+}
+int32_t acg_clip(float* p, int64_t n, float lo, float hi, acg_stream_t s) {
+  (void)s; for (int64_t i = 0; i < n; i++) p[i] = p[i] < lo ? lo : (p[i] > hi ? hi : p[i]);
+  return ACG_OK;
+}
+int32_t acg_step_inc(int32_t* step_dev, acg_stream_t s) { (void)s; *step_dev += 1; return ACG_OK; }

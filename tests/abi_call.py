@@ -1,0 +1,227 @@
+"""Functional helpers that call the C ABI directly on torch tensors (CPU for the C oracle,
+cuda for libacgan_hip.so).  Test-side only: allocation, descriptors and workspace handling so
+a parity test reads `y = abi.conv2d_fwd(x, w, 2, 'SAME')`."""
+import ctypes
+
+import torch
+
+from action_conditioned_gans_amd import _lib as L
+
+ACT = {None: L.ACT_NONE, 'none': L.ACT_NONE, 'relu': L.ACT_RELU, 'lrelu': L.ACT_LRELU, 'tanh': L.ACT_TANH}
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class Abi:
+    def __init__(self, lib, device):
+        self.lib, self.device = lib, torch.device(device)
+
+    # ---- plumbing
+    def stream(self):
+        if self.device.type == 'cuda':
+            return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return None
+
+    def empty(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    def ws(self, nbytes):
+        n = max(int(nbytes), 16)
+        return torch.zeros(n, dtype=torch.uint8, device=self.device), n
+
+    def desc(self, batch, h, w, c, kh, kw, cout, stride, padding):
+        d = L.ConvDesc()
+        self.lib.conv_desc_init(ctypes.byref(d), batch, h, w, c, kh, kw, cout, stride, 1 if padding == 'SAME' else 0)
+        return d
+
+    def sync(self):
+        if self.device.type == 'cuda':
+            torch.cuda.synchronize(self.device)
+
+    # ---- conv family (x NHWC, w HWIO)
+    def conv2d_fwd(self, x, w, stride, padding):
+        b, h, wd, c = x.shape
+        d = self.desc(b, h, wd, c, w.shape[0], w.shape[1], w.shape[3], stride, padding)
+        y = self.empty(b, d.out_h, d.out_w, d.out_c)
+        ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_FWD, L.ACG_F32))
+        self.lib.conv2d_fwd(_p(x), _p(w), _p(y), ctypes.byref(d), L.ACG_F32, _p(ws), n, self.stream())
+        return y
+
+    def conv2d_dgrad(self, dy, w, x_shape, stride, padding):
+        b, h, wd, c = x_shape
+        d = self.desc(b, h, wd, c, w.shape[0], w.shape[1], w.shape[3], stride, padding)
+        dx = self.empty(*x_shape)
+        ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_DGRAD, L.ACG_F32))
+        self.lib.conv2d_dgrad(_p(dy), _p(w), _p(dx), ctypes.byref(d), L.ACG_F32, _p(ws), n, self.stream())
+        return dx
+
+    def conv2d_wgrad(self, x, dy, w_shape, stride, padding, dw=None, accumulate=0.0):
+        b, h, wd, c = x.shape
+        d = self.desc(b, h, wd, c, w_shape[0], w_shape[1], w_shape[3], stride, padding)
+        if dw is None:
+            dw = self.empty(*w_shape)
+        ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_WGRAD, L.ACG_F32))
+        self.lib.conv2d_wgrad(_p(x), _p(dy), _p(dw), accumulate, ctypes.byref(d), L.ACG_F32, _p(ws), n, self.stream())
+        return dw
+
+    # ---- deconv family (x NHWC [B,IH,IW,Cin], w [kh,kw,Cout,Cin]); SAME only
+    def _adj(self, x_shape, w_shape, stride):
+        b, ih, iw, _ = x_shape
+        kh, kw, cout, cin = w_shape
+        return self.desc(b, ih * stride, iw * stride, cout, kh, kw, cin, stride, 'SAME')
+
+    def deconv2d_fwd(self, x, w, stride):
+        d = self._adj(x.shape, w.shape, stride)
+        y = self.empty(d.batch, d.in_h, d.in_w, d.in_c)
+        ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_DGRAD, L.ACG_F32))
+        self.lib.deconv2d_fwd(_p(x), _p(w), _p(y), ctypes.byref(d), L.ACG_F32, _p(ws), n, self.stream())
+        return y
+
+    def deconv2d_dgrad(self, dy, w, x_shape, stride):
+        d = self._adj(x_shape, w.shape, stride)
+        dx = self.empty(*x_shape)
+        ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_FWD, L.ACG_F32))
+        self.lib.deconv2d_dgrad(_p(dy), _p(w), _p(dx), ctypes.byref(d), L.ACG_F32, _p(ws), n, self.stream())
+        return dx
+
+    def deconv2d_wgrad(self, x, dy, w_shape, stride, dw=None, accumulate=0.0):
+        d = self._adj(x.shape, w_shape, stride)
+        if dw is None:
+            dw = self.empty(*w_shape)
+        ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_WGRAD, L.ACG_F32))
+        self.lib.deconv2d_wgrad(_p(x), _p(dy), _p(dw), accumulate, ctypes.byref(d), L.ACG_F32, _p(ws), n, self.stream())
+        return dw
+
+    # ---- bn / bias
+    def bn_act_fwd(self, x, beta, act, groups=1, eps=1e-3, leak=0.2):
+        c = x.shape[-1]
+        rows = x.numel() // c
+        y = torch.empty_like(x)
+        mean, rstd = self.empty(groups * c), self.empty(groups * c)
+        ws, n = self.ws(self.lib.bn_workspace_bytes(rows, c, groups))
+        self.lib.bn_act_fwd(_p(x), _p(beta), _p(y), _p(mean), _p(rstd), rows, c, groups, eps, ACT[act], leak,
+                            L.ACG_F32, _p(ws), n, self.stream())
+        return y, mean, rstd
+
+    def bn_act_bwd(self, x, dy, beta, mean, rstd, act, groups=1, leak=0.2, dbeta=None, accumulate=0.0):
+        c = x.shape[-1]
+        rows = x.numel() // c
+        dx = torch.empty_like(x)
+        if dbeta is None:
+            dbeta = self.empty(c)
+        ws, n = self.ws(self.lib.bn_workspace_bytes(rows, c, groups))
+        self.lib.bn_act_bwd(_p(x), _p(dy), _p(beta), _p(mean), _p(rstd), _p(dx), _p(dbeta), accumulate, rows, c,
+                            groups, ACT[act], leak, L.ACG_F32, _p(ws), n, self.stream())
+        return dx, dbeta
+
+    def bias_act_fwd(self, x, bias, act, leak=0.2):
+        c = x.shape[-1]
+        y = torch.empty_like(x)
+        self.lib.bias_act_fwd(_p(x), _p(bias), _p(y), x.numel() // c, c, ACT[act], leak, L.ACG_F32, self.stream())
+        return y
+
+    def bias_act_bwd(self, y, dy, act, leak=0.2, want_dx=True):
+        c = y.shape[-1]
+        rows = y.numel() // c
+        dx = torch.empty_like(y) if want_dx else None
+        dbias = self.empty(c)
+        ws, n = self.ws(self.lib.bias_workspace_bytes(rows, c))
+        self.lib.bias_act_bwd(_p(y), _p(dy), _p(dx), _p(dbias), 0.0, rows, c, ACT[act], leak, L.ACG_F32, _p(ws), n,
+                              self.stream())
+        return dx, dbias
+
+    # ---- dna
+    def dna_fwd(self, logits, img, k):
+        b, h, w, c = img.shape
+        out = torch.empty_like(img)
+        self.lib.dna_fwd(_p(logits), _p(img), _p(out), b, h, w, c, k, L.ACG_F32, self.stream())
+        return out
+
+    def dna_bwd(self, logits, img, dout, k):
+        b, h, w, c = img.shape
+        dl = torch.empty_like(logits)
+        self.lib.dna_bwd(_p(logits), _p(img), _p(dout), _p(dl), b, h, w, c, k, L.ACG_F32, self.stream())
+        return dl
+
+    # ---- plumbing ops
+    def concat_actions(self, x, actions):
+        b, h, w, c = x.shape
+        a = actions.shape[1]
+        y = self.empty(b, h, w, c + a)
+        self.lib.concat_actions_fwd(_p(x), _p(actions), _p(y), b, h * w, c, a, L.ACG_F32, self.stream())
+        return y
+
+    def concat_channels(self, a, b):
+        ca, cb = a.shape[-1], b.shape[-1]
+        y = self.empty(*a.shape[:-1], ca + cb)
+        self.lib.concat_channels_fwd(_p(a), _p(b), _p(y), a.numel() // ca, ca, cb, L.ACG_F32, self.stream())
+        return y
+
+    def slice_channels(self, src, off, cdst, dst=None, accumulate=0.0):
+        cs = src.shape[-1]
+        if dst is None:
+            dst = self.empty(*src.shape[:-1], cdst)
+        self.lib.slice_channels(_p(src), _p(dst), accumulate, src.numel() // cs, cs, off, cdst, L.ACG_F32, self.stream())
+        return dst
+
+    def add(self, a, b):
+        y = torch.empty_like(a)
+        self.lib.add(_p(a), _p(b), _p(y), a.numel(), L.ACG_F32, self.stream())
+        return y
+
+    # ---- losses
+    def frame_loss(self, gen, gt, w_l1, w_gdl, want_grad=True):
+        b, h, w, c = gen.shape
+        out = self.empty(2)
+        dgen = torch.empty_like(gen) if want_grad else None
+        ws, n = self.ws(self.lib.frame_loss_workspace_bytes(gen.numel()))
+        self.lib.frame_loss(_p(gen), _p(gt), _p(out), _p(dgen), b, h, w, c, w_l1, w_gdl, L.ACG_F32, _p(ws), n,
+                            self.stream())
+        return out, dgen
+
+    def l2norm_loss(self, pred, gt, scale):
+        out, d = self.empty(1), torch.empty_like(pred)
+        self.lib.l2norm_loss(_p(pred), _p(gt), _p(out), _p(d), pred.numel(), scale, self.stream())
+        return out, d
+
+    def sigmoid_ce_loss(self, logits, label, scale):
+        out, d = self.empty(1), torch.empty_like(logits)
+        self.lib.sigmoid_ce_loss(_p(logits), label, _p(out), _p(d), logits.numel(), scale, self.stream())
+        return out, d
+
+    def mean_loss(self, x, scale):
+        out, d = self.empty(1), torch.empty_like(x)
+        self.lib.mean_loss(_p(x), _p(out), _p(d), x.numel(), scale, self.stream())
+        return out, d
+
+    def psnr(self, a, b):
+        out = self.empty(1)
+        ws, n = self.ws(self.lib.frame_loss_workspace_bytes(a.numel()))
+        self.lib.psnr(_p(a), _p(b), _p(out), a.numel(), L.ACG_F32, _p(ws), n, self.stream())
+        return out
+
+    def scalar_combine(self, terms):
+        out = self.empty(1)
+        args = []
+        for i in range(4):
+            t, w = terms[i] if i < len(terms) else (None, 0.0)
+            args += [_p(t), w]
+        self.lib.scalar_combine(_p(out), *args, self.stream())
+        return out
+
+    # ---- optimizers (in place)
+    def adam_step(self, p, g, m, v, step, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, gs=1.0, clip=None):
+        self.lib.step_inc(_p(step), self.stream())
+        lo, hi = clip if clip else (0.0, 0.0)
+        self.lib.adam_step(_p(p), _p(g), _p(m), _p(v), _p(step), p.numel(), lr, b1, b2, eps, gs, 1 if clip else 0,
+                           lo, hi, self.stream())
+
+    def rmsprop_step(self, p, g, ms, lr=5e-5, decay=0.9, eps=1e-10, gs=1.0, clip=None):
+        lo, hi = clip if clip else (0.0, 0.0)
+        self.lib.rmsprop_step(_p(p), _p(g), _p(ms), p.numel(), lr, decay, eps, gs, 1 if clip else 0, lo, hi,
+                              self.stream())
+
+    def clip(self, p, lo, hi):
+        self.lib.clip(_p(p), p.numel(), lo, hi, self.stream())

@@ -1,0 +1,294 @@
+"""Per-op parity cases shared by the CPU suite (C oracle vs torch-fp64 restatement) and the
+GPU suite (libacgan_hip.so vs torch-fp64 restatement).  Every case takes an ``Abi`` (tests/abi_call.py)
+and a tolerance, builds seeded inputs, and returns nothing or raises AssertionError."""
+import numpy as np
+import torch
+
+from oracle import tf_ops as T
+
+
+def _rng(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def randn(shape, seed, scale=1.0):
+    return (torch.randn(shape, generator=_rng(seed), dtype=torch.float64) * scale).float()
+
+
+def uniform(shape, seed):
+    return (torch.rand(shape, generator=_rng(seed), dtype=torch.float64) * 2 - 1).float()
+
+
+def close(got, want, tol, what):
+    """max abs error relative to the reference tensor's scale (north_star: 1e-3 rel, fp32)."""
+    got = got.detach().double().cpu()
+    want = want.detach().double().cpu()
+    assert got.shape == want.shape, '%s: shape %s vs %s' % (what, tuple(got.shape), tuple(want.shape))
+    assert torch.isfinite(got).all(), '%s: non-finite values' % what
+    scale = max(want.abs().max().item(), 1e-30)
+    err = (got - want).abs().max().item() / scale
+    assert err <= tol, '%s: rel err %.3e > %.1e (scale %.3e)' % (what, err, tol, scale)
+    return err
+
+
+# (B, H, W, Cin, Cout, k, stride, padding)
+CONV_SHAPES = [
+    (2, 64, 64, 3, 32, 5, 2, 'SAME'),      # g/conv1 (DNA)
+    (2, 32, 32, 32, 64, 5, 2, 'SAME'),     # g/conv2
+    (2, 8, 8, 128, 256, 5, 2, 'SAME'),     # g/conv4
+    (2, 64, 64, 6, 64, 5, 2, 'SAME'),      # d/conv1
+    (2, 16, 16, 138, 128, 5, 2, 'SAME'),   # d/conv3 (128 + 10 action channels)
+    (3, 4, 4, 256, 512, 5, 2, 'SAME'),     # d/conv5, odd batch
+    (2, 2, 2, 512, 1, 2, 1, 'SAME'),       # d/conv6
+    (2, 16, 16, 128, 32, 3, 2, 'SAME'),    # g/sconv3
+    (2, 8, 8, 32, 16, 3, 2, 'SAME'),       # g/sconv4
+    (2, 4, 4, 16, 5, 4, 1, 'VALID'),       # g/sconv5
+    (1, 7, 9, 5, 7, 3, 1, 'SAME'),         # ragged: odd sizes, stride 1
+    (2, 9, 7, 4, 33, 5, 2, 'SAME'),        # ragged: odd spatial, stride 2, Cout not a tile multiple
+    (1, 5, 5, 2, 3, 5, 1, 'VALID'),        # single output pixel
+]
+CONV_SHAPES_SMALL = [CONV_SHAPES[i] for i in (0, 4, 6, 9, 10, 11, 12)]
+
+# (B, IH, IW, Cin, Cout, k, stride)   TF conv2d_transpose SAME
+DECONV_SHAPES = [
+    (2, 4, 4, 266, 128, 5, 2),     # g/tconv1 (DNA)
+    (2, 8, 8, 128, 128, 5, 2),     # g/tconv2
+    (2, 32, 32, 128, 25, 5, 2),    # g/tconv4 (DNA, k=5)
+    (2, 32, 32, 64, 3, 5, 2),      # g/tconv4 (plain)
+    (2, 4, 4, 522, 256, 5, 2),     # g/tconv1 (plain)
+    (1, 3, 5, 6, 7, 5, 2),         # ragged
+    (1, 4, 4, 8, 36, 5, 2),        # DNA k=6 logits
+    (2, 3, 3, 4, 5, 3, 1),         # stride 1
+]
+DECONV_SHAPES_SMALL = [DECONV_SHAPES[i] for i in (0, 3, 5, 7)]
+
+
+def case_conv(abi, shape, tol, seed=0):
+    b, h, w, cin, cout, k, s, pad = shape
+    x = uniform((b, h, w, cin), seed)
+    wt = randn((k, k, cin, cout), seed + 1, 0.1)
+    xd, wd = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    y_ref = T.conv2d(xd, wd, s, pad)
+    dy = randn(tuple(y_ref.shape), seed + 2)
+    dx_ref, dw_ref = torch.autograd.grad(y_ref, [xd, wd], dy.double())
+    dev = abi.device
+    xg, wg, dyg = x.to(dev), wt.to(dev), dy.to(dev)
+    tag = 'conv%s' % (shape,)
+    close(abi.conv2d_fwd(xg, wg, s, pad), y_ref, tol, tag + ' fwd')
+    close(abi.conv2d_dgrad(dyg, wg, tuple(x.shape), s, pad), dx_ref, tol, tag + ' dgrad')
+    close(abi.conv2d_wgrad(xg, dyg, tuple(wt.shape), s, pad), dw_ref, tol, tag + ' wgrad')
+    # accumulate semantics: dw = 0.5*dw0 + grad
+    dw0 = randn(tuple(wt.shape), seed + 3).to(dev)
+    got = abi.conv2d_wgrad(xg, dyg, tuple(wt.shape), s, pad, dw=dw0.clone(), accumulate=0.5)
+    close(got, 0.5 * dw0.double().cpu() + dw_ref, tol, tag + ' wgrad accumulate')
+
+
+def case_deconv(abi, shape, tol, seed=0):
+    b, ih, iw, cin, cout, k, s = shape
+    x = uniform((b, ih, iw, cin), seed)
+    wt = randn((k, k, cout, cin), seed + 1, 0.1)
+    xd, wd = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    y_ref = T.conv2d_transpose(xd, wd, s, 'SAME')
+    dy = randn(tuple(y_ref.shape), seed + 2)
+    dx_ref, dw_ref = torch.autograd.grad(y_ref, [xd, wd], dy.double())
+    dev = abi.device
+    xg, wg, dyg = x.to(dev), wt.to(dev), dy.to(dev)
+    tag = 'deconv%s' % (shape,)
+    close(abi.deconv2d_fwd(xg, wg, s), y_ref, tol, tag + ' fwd')
+    close(abi.deconv2d_dgrad(dyg, wg, tuple(x.shape), s), dx_ref, tol, tag + ' dgrad')
+    close(abi.deconv2d_wgrad(xg, dyg, tuple(wt.shape), s), dw_ref, tol, tag + ' wgrad')
+
+
+# (rows-shape, C, groups, act)
+BN_SHAPES = [
+    ((2, 32, 32), 32, 1, 'relu'), ((2, 4, 4), 256, 1, 'lrelu'), ((4, 2, 2), 1, 2, None),
+    ((2, 16, 16), 138, 1, 'lrelu'), ((6, 8, 8), 16, 2, 'relu'), ((2, 3, 5), 7, 1, 'lrelu'),
+    ((2, 64, 64), 64, 1, 'lrelu'), ((8, 1, 1), 5, 1, None),
+]
+
+
+def _bn_ref(x, beta, act, groups):
+    outs = []
+    for xg in x.chunk(groups, dim=0):
+        u = T.batch_norm_train(xg, beta)
+        outs.append({'relu': T.relu, 'lrelu': T.lrelu, None: lambda t: t}[act](u))
+    return torch.cat(outs, dim=0)
+
+
+def case_bn(abi, shape, tol, seed=0):
+    lead, c, groups, act = shape
+    x = randn(lead + (c,), seed, 1.5) + 0.7       # non-zero mean exercises the variance formula
+    beta = randn((c,), seed + 1, 0.3)
+    xd, bd = x.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y_ref = _bn_ref(xd, bd, act, groups)
+    dy = randn(tuple(y_ref.shape), seed + 2)
+    dx_ref, db_ref = torch.autograd.grad(y_ref, [xd, bd], dy.double())
+    dev = abi.device
+    xg, bg, dyg = x.to(dev), beta.to(dev), dy.to(dev)
+    tag = 'bn%s' % (shape,)
+    y, mean, rstd = abi.bn_act_fwd(xg, bg, act, groups)
+    close(y, y_ref, tol, tag + ' fwd')
+    mref = torch.stack([t.mean(dim=(0, 1, 2)) for t in x.double().chunk(groups, dim=0)]).reshape(-1)
+    close(mean, mref, tol, tag + ' mean')
+    dx, dbeta = abi.bn_act_bwd(xg, dyg, bg, mean, rstd, act, groups)
+    close(dx, dx_ref, tol * 4, tag + ' dx')
+    close(dbeta, db_ref, tol * 4, tag + ' dbeta')
+
+
+def case_bn_large_mean(abi, tol):
+    """Variance must survive a mean that dwarfs the spread (catastrophic cancellation check)."""
+    x = randn((4, 8, 8, 6), 5, 0.01) + 100.0
+    beta = torch.zeros(6)
+    y_ref = _bn_ref(x.double(), beta.double(), None, 1)
+    y, _, _ = abi.bn_act_fwd(x.to(abi.device), beta.to(abi.device), None, 1)
+    close(y, y_ref, max(tol, 2e-2), 'bn large-mean fwd')
+
+
+def case_bias(abi, tol, seed=0):
+    for lead, c, act in [((2, 64, 64), 3, 'tanh'), ((2, 64, 64), 25, None), ((2, 1, 1), 5, None),
+                         ((2, 5, 3), 7, 'relu'), ((2, 5, 3), 7, 'lrelu')]:
+        x = randn(lead + (c,), seed)
+        bias = randn((c,), seed + 1, 0.5)
+        xd, bd = x.double().requires_grad_(True), bias.double().requires_grad_(True)
+        y_ref = {'tanh': torch.tanh, 'relu': T.relu, 'lrelu': T.lrelu, None: lambda t: t}[act](xd + bd)
+        dy = randn(tuple(y_ref.shape), seed + 2)
+        dx_ref, db_ref = torch.autograd.grad(y_ref, [xd, bd], dy.double())
+        dev = abi.device
+        y = abi.bias_act_fwd(x.to(dev), bias.to(dev), act)
+        close(y, y_ref, tol, 'bias %s fwd' % act)
+        dx, db = abi.bias_act_bwd(y, dy.to(dev), act, want_dx=True)
+        close(dx, dx_ref, tol * 4, 'bias %s dx' % act)
+        close(db, db_ref, tol * 4, 'bias %s dbias' % act)
+        if act is None:
+            _, db2 = abi.bias_act_bwd(y, dy.to(dev), act, want_dx=False)
+            close(db2, db_ref, tol * 4, 'bias none dbias (dx NULL)')
+
+
+DNA_SHAPES = [(2, 64, 64, 3, 5), (1, 16, 16, 3, 6), (1, 24, 20, 3, 11), (2, 7, 5, 3, 5), (1, 3, 3, 1, 5), (1, 8, 8, 4, 3)]
+
+
+def case_dna(abi, shape, tol, seed=0):
+    b, h, w, c, k = shape
+    logits = randn((b, h, w, k * k), seed, 2.0)
+    img = uniform((b, h, w, c), seed + 1)
+    ld = logits.double().requires_grad_(True)
+    out_ref = T.dna_gather(ld, img.double(), k)
+    dout = randn(tuple(out_ref.shape), seed + 2)
+    dl_ref, = torch.autograd.grad(out_ref, [ld], dout.double())
+    dev = abi.device
+    tag = 'dna%s' % (shape,)
+    close(abi.dna_fwd(logits.to(dev), img.to(dev), k), out_ref, tol, tag + ' fwd')
+    close(abi.dna_bwd(logits.to(dev), img.to(dev), dout.to(dev), k), dl_ref, tol * 4, tag + ' bwd')
+
+
+def case_dna_extreme_logits(abi, tol):
+    """softmax must be max-subtracted: logits of +-80 overflow a naive exp in fp32."""
+    logits = randn((1, 6, 6, 25), 3, 1.0)
+    logits[0, 2, 3, 7] = 90.0
+    logits[0, 4, 1, :] = -90.0
+    img = uniform((1, 6, 6, 3), 4)
+    ref = T.dna_gather(logits.double(), img.double(), 5)
+    close(abi.dna_fwd(logits.to(abi.device), img.to(abi.device), 5), ref, tol, 'dna extreme logits')
+
+
+def case_plumbing(abi, tol):
+    dev = abi.device
+    x = randn((2, 4, 4, 256), 0)
+    a = randn((2, 10), 1)
+    ref = torch.cat([x, a.reshape(2, 1, 1, 10).expand(2, 4, 4, 10)], dim=3)
+    close(abi.concat_actions(x.to(dev), a.to(dev)), ref, 0, 'concat_actions')
+    p, q = randn((2, 8, 8, 3), 2), randn((2, 8, 8, 3), 3)
+    cat = abi.concat_channels(p.to(dev), q.to(dev))
+    close(cat, torch.cat([p, q], dim=3), 0, 'concat_channels')
+    close(abi.slice_channels(cat, 3, 3), q, 0, 'slice_channels')
+    dst = randn((2, 8, 8, 3), 4).to(dev)
+    close(abi.slice_channels(cat, 0, 3, dst=dst.clone(), accumulate=1.0), dst.cpu().double() + p.double(), 1e-6,
+          'slice_channels accumulate')
+    close(abi.add(p.to(dev), q.to(dev)), p.double() + q.double(), 1e-6, 'add')
+
+
+def case_losses(abi, tol, seed=0):
+    dev = abi.device
+    for shp in [(2, 64, 64, 3), (1, 5, 7, 3), (3, 2, 2, 1)]:
+        gen, gt = uniform(shp, seed), uniform(shp, seed + 1)
+        gd = gen.double().requires_grad_(True)
+        l1 = (gd - gt.double()).abs().sum()
+        g = T.gdl(gd, gt.double())
+        w1, w2 = 0.05 / shp[0], 1.0
+        dref, = torch.autograd.grad(w1 * l1 + w2 * g, [gd])
+        out, dgen = abi.frame_loss(gen.to(dev), gt.to(dev), w1, w2)
+        close(out, torch.stack([l1, g]).detach(), tol, 'frame_loss values %s' % (shp,))
+        # sign-type gradients are exact except where |a|-|b| ties to rounding: compare by mismatch count
+        bad = ((dgen.double().cpu() - dref).abs() > 1e-6).sum().item()
+        assert bad <= max(2, dgen.numel() // 5000), 'frame_loss grad: %d mismatching elements %s' % (bad, shp)
+        # symmetric in its arguments (reference passes them swapped, train.py:81 vs ops.py:100; defect D10)
+        out_sw, _ = abi.frame_loss(gt.to(dev), gen.to(dev), w1, w2, want_grad=False)
+        close(out_sw, out, 1e-6, 'frame_loss symmetry')
+    pred, tgt = randn((32, 5), seed + 2), randn((32, 5), seed + 3)
+    pd = pred.double().requires_grad_(True)
+    n2 = torch.sqrt(((pd - tgt.double()) ** 2).sum())
+    dref, = torch.autograd.grad(n2 / 32, [pd])
+    out, d = abi.l2norm_loss(pred.to(dev), tgt.to(dev), 1.0 / 32)
+    close(out, n2.detach().reshape(1), tol, 'l2norm value')
+    close(d, dref, tol * 4, 'l2norm grad')
+    z = torch.zeros(4, 5)
+    out, d = abi.l2norm_loss(z.to(dev), z.to(dev), 1.0)
+    assert out.item() == 0 and torch.all(d == 0), 'l2norm at zero must give zero gradient, not NaN'
+    for label in (0.0, 0.9, 1.0):
+        x = randn((32, 2, 2, 1), seed + 4, 3.0)
+        x[0, 0, 0, 0], x[1, 0, 0, 0] = 60.0, -60.0
+        xd = x.double().requires_grad_(True)
+        ce = T.sigmoid_cross_entropy(torch.full_like(xd, label), xd)
+        dref, = torch.autograd.grad(ce, [xd])
+        out, d = abi.sigmoid_ce_loss(x.to(dev), label, 1.0)
+        close(out, ce.detach().reshape(1), tol, 'sigmoid_ce value label=%g' % label)
+        close(d, dref, tol * 4, 'sigmoid_ce grad label=%g' % label)
+    x = randn((32, 2, 2, 1), seed + 5)
+    out, d = abi.mean_loss(x.to(dev), -1.0)
+    close(out, x.double().mean().reshape(1), tol, 'mean value')
+    close(d, torch.full_like(x.double(), -1.0 / x.numel()), 1e-6, 'mean grad')
+    a, b = uniform((2, 64, 64, 3), seed + 6), uniform((2, 64, 64, 3), seed + 7)
+    close(abi.psnr(a.to(dev), b.to(dev)), T.psnr(a.double(), b.double()).reshape(1), tol, 'psnr')
+    s0, s1 = torch.tensor([3.0]), torch.tensor([-2.0])
+    close(abi.scalar_combine([(s0.to(dev), 0.5), (s1.to(dev), 2.0)]), torch.tensor([-2.5]), 1e-6, 'scalar_combine')
+
+
+def case_optimizers(abi, tol, seed=0):
+    dev = abi.device
+    n = 10007
+    p0 = randn((n,), seed, 0.02)
+    grads = [randn((n,), seed + 1 + i, 0.1) for i in range(3)]
+    # Adam, TF formulas, 3 steps with and without clip + grad_scale
+    f32 = lambda v: float(np.float32(v))      # TF holds its hyper-parameters as float32 constants
+    lr, b1, b2, eps = f32(1e-3), f32(0.9), f32(0.999), f32(1e-8)
+    for clip, gs in ((None, 1.0), ((-0.01, 0.01), 0.5)):
+        p, m, v = p0.double().clone(), torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+        pg, mg, vg = p0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        step = torch.zeros(1, dtype=torch.int32, device=dev)
+        for t, g in enumerate(grads, 1):
+            gd = g.double() * gs
+            lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+            m = b1 * m + (1 - b1) * gd
+            v = b2 * v + (1 - b2) * gd * gd
+            p = p - lr_t * m / (v.sqrt() + eps)
+            if clip:
+                p = p.clamp(f32(clip[0]), f32(clip[1]))
+            abi.adam_step(pg, g.to(dev), mg, vg, step, gs=gs, clip=clip)
+        assert step.item() == 3
+        close(pg, p, tol, 'adam param clip=%s' % (clip,))
+        close(mg, m, tol, 'adam m')
+        close(vg, v, tol, 'adam v')
+    # RMSProp: ms starts at ONE
+    p, ms = p0.double().clone(), torch.ones(n, dtype=torch.float64)
+    pg, msg = p0.clone().to(dev), torch.ones(n, device=dev)
+    for g in grads:
+        gd = g.double()
+        ms = f32(0.9) * ms + (1 - f32(0.9)) * gd * gd
+        p = (p - f32(5e-5) * gd / torch.sqrt(ms + f32(1e-10))).clamp(f32(-0.01), f32(0.01))
+        abi.rmsprop_step(pg, g.to(dev), msg, clip=(-0.01, 0.01))
+    close(pg, p, tol, 'rmsprop param')
+    close(msg, ms, tol, 'rmsprop ms')
+    q = randn((n,), seed + 9, 0.05).to(dev)
+    ref = q.double().cpu().clamp(f32(-0.01), f32(0.01))
+    abi.clip(q, -0.01, 0.01)
+    close(q, ref, 1e-7, 'clip')

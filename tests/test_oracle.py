@@ -1,0 +1,52 @@
+"""CPU suite: the two independent restatements (torch-fp64 composition vs brute-force C loops)
+must agree on every op of the hot path.  This is what stands in for reference golden vectors
+(parity unpinned: the reference has none)."""
+import pytest
+
+import op_cases as C
+
+TOL = 2e-6   # the C oracle stores float32; the torch side is float64
+
+
+@pytest.mark.parametrize('shape', C.CONV_SHAPES_SMALL, ids=str)
+def test_conv(oracle_abi, shape):
+    C.case_conv(oracle_abi, shape, TOL)
+
+
+@pytest.mark.parametrize('shape', C.DECONV_SHAPES_SMALL, ids=str)
+def test_deconv(oracle_abi, shape):
+    C.case_deconv(oracle_abi, shape, TOL)
+
+
+@pytest.mark.parametrize('shape', C.BN_SHAPES, ids=str)
+def test_bn(oracle_abi, shape):
+    C.case_bn(oracle_abi, shape, TOL)
+
+
+def test_bn_large_mean(oracle_abi):
+    C.case_bn_large_mean(oracle_abi, 1e-4)
+
+
+def test_bias(oracle_abi):
+    C.case_bias(oracle_abi, TOL)
+
+
+@pytest.mark.parametrize('shape', C.DNA_SHAPES, ids=str)
+def test_dna(oracle_abi, shape):
+    C.case_dna(oracle_abi, shape, TOL)
+
+
+def test_dna_extreme(oracle_abi):
+    C.case_dna_extreme_logits(oracle_abi, TOL)
+
+
+def test_plumbing(oracle_abi):
+    C.case_plumbing(oracle_abi, TOL)
+
+
+def test_losses(oracle_abi):
+    C.case_losses(oracle_abi, TOL)
+
+
+def test_optimizers(oracle_abi):
+    C.case_optimizers(oracle_abi, TOL)

@@ -1,0 +1,81 @@
+// Shared host/device helpers for libacgan_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/acgan_hip.h"
+
+namespace acg {
+
+// Thread-local error message behind acg_last_error(); returns `code`.
+int fail(int code, const char* fmt, ...);
+// Checks the launch that was just enqueued (no synchronisation; safe under graph capture).
+int check_launch(const char* what);
+
+static inline hipStream_t to_stream(acg_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// ---- device-side reductions -----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // valid in lane 0
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Sum over a block of up to 1024 threads; result valid in thread 0.  `scratch` holds >= 16 Ts.
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* scratch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();  // scratch may still be read from a previous call
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  T r = T(0);
+  if (threadIdx.x == 0)
+    for (int i = 0; i < nw; ++i) r += scratch[i];
+  return r;
+}
+
+__device__ __forceinline__ float sgnf(float v) { return (v > 0.f) - (v < 0.f); }
+
+// Activation value / derivative w.r.t. the pre-activation u (lrelu is ops.py:22-26: f1*u + f2*|u|).
+__device__ __forceinline__ float act_apply(int act, float u, float leak) {
+  switch (act) {
+    case ACG_ACT_RELU: return u > 0.f ? u : 0.f;
+    case ACG_ACT_LRELU: return 0.5f * (1.f + leak) * u + 0.5f * (1.f - leak) * fabsf(u);
+    case ACG_ACT_TANH: return tanhf(u);
+    default: return u;
+  }
+}
+__device__ __forceinline__ float act_deriv_pre(int act, float u, float leak) {
+  switch (act) {
+    case ACG_ACT_RELU: return u > 0.f ? 1.f : 0.f;
+    case ACG_ACT_LRELU: return 0.5f * (1.f + leak) + 0.5f * (1.f - leak) * sgnf(u);
+    default: return 1.f;
+  }
+}
+// Derivative expressed through the OUTPUT y (sign(y) == sign(u) for relu/lrelu; tanh' = 1 - y^2).
+__device__ __forceinline__ float act_deriv_out(int act, float y, float leak) {
+  switch (act) {
+    case ACG_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case ACG_ACT_LRELU: return 0.5f * (1.f + leak) + 0.5f * (1.f - leak) * sgnf(y);
+    case ACG_ACT_TANH: return 1.f - y * y;
+    default: return 1.f;
+  }
+}
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace acg
+
+#define ACG_REQUIRE(cond, code, ...) \
+  do {                               \
+    if (!(cond)) return acg::fail(code, __VA_ARGS__); \
+  } while (0)
+#define ACG_REQUIRE_F32(dtype) ACG_REQUIRE((dtype) == ACG_F32, ACG_ERR_UNSUPPORTED, "%s: only ACG_F32 is implemented for this entry point", __func__)

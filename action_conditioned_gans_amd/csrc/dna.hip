@@ -1,0 +1,169 @@
+// Dynamic Neural Advection tail (models.py:60-72) as a fused softmax + LDS-windowed k x k stencil.
+//
+// The reference materialises three [B,H,W,k*k,3] tensors; here a block owns a TY x 64 pixel tile of one
+// image: the k*k logits of its pixels (one contiguous span per tile row) are streamed ONCE, coalesced,
+// into LDS ([pixel][k*k | 1] - odd pitch, so a wave's per-pixel reads hit distinct banks), the image
+// window (tile + halo, zero outside the frame = TF SAME zero padding) is staged once, and every thread
+// then runs its pixel's max / exp / weighted gather out of LDS.  Algorithmic HBM traffic:
+// (k*k + 2*C) floats per pixel forward, (2*k*k + 2*C) backward.
+// The backward pass overwrites the staged logits in place with dlogits and streams them back coalesced.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int TX = 64;
+
+template <int K, int TY, bool BWD>
+__global__ __launch_bounds__(TX* TY) void dna_kernel(const float* __restrict__ logits, const float* __restrict__ img,
+                                                     const float* __restrict__ dout, float* __restrict__ out,
+                                                     int H, int W, int C) {
+  constexpr int KK = K * K, S = KK | 1, NT = TX * TY, P = (K - 1) / 2;
+  constexpr int WW = TX + K - 1, WH = TY + K - 1;
+  __shared__ float lg[NT * S];
+  __shared__ float win[WH * WW * 4];
+
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY, b = blockIdx.z;
+  const int txv = min(TX, W - x0);
+
+  // image window (zero outside the frame)
+  for (int idx = tid; idx < WH * WW * C; idx += NT) {
+    const int c = idx % C, t = idx / C;
+    const int wx = t % WW, wy = t / WW;
+    const int y = y0 - P + wy, x = x0 - P + wx;
+    win[idx] = (y >= 0 && y < H && x >= 0 && x < W) ? img[((long long)(b * H + y) * W + x) * C + c] : 0.f;
+  }
+  // logits: TY contiguous spans of txv*KK floats
+  for (int idx = tid; idx < TY * TX * KK; idx += NT) {
+    const int ty = idx / (TX * KK), e = idx - ty * (TX * KK);
+    if (y0 + ty < H && e < txv * KK) {
+      const long long gp = (long long)(b * H + y0 + ty) * W + x0;
+      lg[(ty * TX + e / KK) * S + e % KK] = logits[gp * KK + e];
+    }
+  }
+  __syncthreads();
+
+  const int ty = tid / TX, tx = tid - ty * TX;
+  const int y = y0 + ty, x = x0 + tx;
+  const bool valid = y < H && x < W;
+  float* l = lg + tid * S;
+  const float* wbase = win + (ty * WW + tx) * C;
+
+  if (valid) {
+    float mx = l[0];
+#pragma unroll
+    for (int t = 1; t < KK; ++t) mx = fmaxf(mx, l[t]);
+    const long long pix = (long long)(b * H + y) * W + x;
+    if constexpr (!BWD) {
+      float den = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+      for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const float e = __expf(l[i * K + j] - mx);
+          const float* wp = wbase + (i * WW + j) * C;
+          den += e;
+          a0 += e * wp[0];
+          if (C > 1) a1 += e * wp[1];
+          if (C > 2) a2 += e * wp[2];
+          if (C > 3) a3 += e * wp[3];
+        }
+      const float inv = 1.f / den;
+      float* o = out + pix * C;
+      o[0] = a0 * inv;
+      if (C > 1) o[1] = a1 * inv;
+      if (C > 2) o[2] = a2 * inv;
+      if (C > 3) o[3] = a3 * inv;
+    } else {
+      const float* dO = dout + pix * C;
+      const float d0 = dO[0], d1 = C > 1 ? dO[1] : 0.f, d2 = C > 2 ? dO[2] : 0.f, d3 = C > 3 ? dO[3] : 0.f;
+      auto gfun = [&](int i, int j) {
+        const float* wp = wbase + (i * WW + j) * C;
+        float g = d0 * wp[0];
+        if (C > 1) g += d1 * wp[1];
+        if (C > 2) g += d2 * wp[2];
+        if (C > 3) g += d3 * wp[3];
+        return g;
+      };
+      float den = 0.f, dotn = 0.f;
+#pragma unroll
+      for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const float e = __expf(l[i * K + j] - mx);
+          den += e;
+          dotn += e * gfun(i, j);
+        }
+      const float inv = 1.f / den, dot = dotn * inv;
+#pragma unroll
+      for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const float mt = __expf(l[i * K + j] - mx) * inv;
+          l[i * K + j] = mt * (gfun(i, j) - dot);
+        }
+    }
+  }
+  if constexpr (BWD) {
+    __syncthreads();
+    for (int idx = tid; idx < TY * TX * KK; idx += NT) {
+      const int ty2 = idx / (TX * KK), e = idx - ty2 * (TX * KK);
+      if (y0 + ty2 < H && e < txv * KK) {
+        const long long gp = (long long)(b * H + y0 + ty2) * W + x0;
+        out[gp * KK + e] = lg[(ty2 * TX + e / KK) * S + e % KK];
+      }
+    }
+  }
+}
+
+template <int K, bool BWD>
+int launch_k(const float* logits, const float* img, const float* dout, float* out, int B, int H, int W, int C, hipStream_t st) {
+  constexpr int TY = K <= 6 ? 4 : 1;
+  const dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, B);
+  hipLaunchKernelGGL((dna_kernel<K, TY, BWD>), grid, dim3(TX * TY), 0, st, logits, img, dout, out, H, W, C);
+  return acg::check_launch(BWD ? "dna_bwd" : "dna_fwd");
+}
+
+template <bool BWD>
+int dispatch(int k, const float* logits, const float* img, const float* dout, float* out, int B, int H, int W, int C, hipStream_t st) {
+  switch (k) {
+#define ACG_DNA_CASE(KV) case KV: return launch_k<KV, BWD>(logits, img, dout, out, B, H, W, C, st);
+    ACG_DNA_CASE(1) ACG_DNA_CASE(2) ACG_DNA_CASE(3) ACG_DNA_CASE(4) ACG_DNA_CASE(5) ACG_DNA_CASE(6)
+    ACG_DNA_CASE(7) ACG_DNA_CASE(8) ACG_DNA_CASE(9) ACG_DNA_CASE(10) ACG_DNA_CASE(11)
+#undef ACG_DNA_CASE
+    default: return acg::fail(ACG_ERR_UNSUPPORTED, "dna: ksize %d outside 1..11", k);
+  }
+}
+
+int check(const char* who, int B, int H, int W, int C, int k) {
+  ACG_REQUIRE(B > 0 && H > 0 && W > 0, ACG_ERR_INVALID_ARG, "%s: non-positive size", who);
+  ACG_REQUIRE(C >= 1 && C <= 4, ACG_ERR_INVALID_ARG, "%s: channels %d outside 1..4", who, C);
+  ACG_REQUIRE(B <= 65535 && (H + 0) <= 65535 * 4, ACG_ERR_UNSUPPORTED, "%s: grid too large", who);
+  ACG_REQUIRE((long long)B * H * W * k * k < 2147483647ll, ACG_ERR_UNSUPPORTED, "%s: tensor exceeds 2^31 elements", who);
+  return ACG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t acg_dna_fwd(const void* logits, const void* image, void* out, int32_t B, int32_t H, int32_t W, int32_t C,
+                    int32_t k, int32_t dtype, acg_stream_t stream) {
+  ACG_REQUIRE_F32(dtype);
+  if (int rc = check("dna_fwd", B, H, W, C, k)) return rc;
+  ACG_REQUIRE(logits && image && out, ACG_ERR_INVALID_ARG, "dna_fwd: null pointer");
+  return dispatch<false>(k, (const float*)logits, (const float*)image, nullptr, (float*)out, B, H, W, C, acg::to_stream(stream));
+}
+
+int32_t acg_dna_bwd(const void* logits, const void* image, const void* dout, void* dlogits, int32_t B, int32_t H,
+                    int32_t W, int32_t C, int32_t k, int32_t dtype, acg_stream_t stream) {
+  ACG_REQUIRE_F32(dtype);
+  if (int rc = check("dna_bwd", B, H, W, C, k)) return rc;
+  ACG_REQUIRE(logits && image && dout && dlogits, ACG_ERR_INVALID_ARG, "dna_bwd: null pointer");
+  return dispatch<true>(k, (const float*)logits, (const float*)image, (const float*)dout, (float*)dlogits, B, H, W, C,
+                        acg::to_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,124 @@
+// Channel plumbing (tf.tile / tf.concat of train.py:48-50,64,68 and models.py:16,38,84), the gradient
+// fan-in add, and the library's error / version entry points.  All kernels are pure streaming copies:
+// one thread per output float, grid-stride, consecutive lanes on consecutive addresses.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+
+namespace acg {
+
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ACG_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return ACG_OK;
+}
+
+}  // namespace acg
+
+namespace {
+
+int grid_for(long long n) {
+  long long b = acg::ceil_div(n, 256);
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// y[r, 0:ca] = a[r, :]; y[r, ca:ca+cb] = b[r / rows_per_b, :]  (rows_per_b = 1: plain concat; = hw: tiled actions)
+__global__ __launch_bounds__(256) void concat_k(const float* __restrict__ a, const float* __restrict__ b,
+                                                float* __restrict__ y, long long rows, int ca, int cb, int rows_per_b) {
+  const int cy = ca + cb;
+  const long long n = rows * cy, stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const long long r = i / cy;
+    const int c = (int)(i - r * cy);
+    y[i] = c < ca ? a[r * ca + c] : b[(r / rows_per_b) * cb + (c - ca)];
+  }
+}
+
+__global__ __launch_bounds__(256) void slice_k(const float* __restrict__ src, float* __restrict__ dst, float acc,
+                                               long long rows, int c_src, int c_off, int c_dst) {
+  const long long n = rows * c_dst, stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const long long r = i / c_dst;
+    const int c = (int)(i - r * c_dst);
+    const float v = src[r * c_src + c_off + c];
+    dst[i] = acc != 0.f ? acc * dst[i] + v : v;
+  }
+}
+
+__global__ __launch_bounds__(256) void add_k(const float* __restrict__ a, const float* __restrict__ b,
+                                             float* __restrict__ y, long long n) {
+  const long long stride = (long long)gridDim.x * 256;
+  const long long n4 = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 ? n / 4 : 0;
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+  float4* y4 = reinterpret_cast<float4*>(y);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const float4 u = a4[i], v = b4[i];
+    y4[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+  }
+  for (long long i = n4 * 4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] = a[i] + b[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t acg_version(void) { return ACG_ABI_VERSION; }
+const char* acg_build_info(void) { return "hip gfx950 (fp32 MFMA 32x32x2)"; }
+const char* acg_last_error(void) { return acg::g_err; }
+
+int32_t acg_concat_actions_fwd(const void* x, const float* actions, void* y, int32_t B, int32_t hw, int32_t c, int32_t a,
+                               int32_t dtype, acg_stream_t stream) {
+  ACG_REQUIRE_F32(dtype);
+  ACG_REQUIRE(B > 0 && hw > 0 && c > 0 && a > 0, ACG_ERR_INVALID_ARG, "concat_actions_fwd: non-positive size");
+  ACG_REQUIRE(x && actions && y, ACG_ERR_INVALID_ARG, "concat_actions_fwd: null pointer");
+  const long long rows = (long long)B * hw;
+  hipLaunchKernelGGL(concat_k, dim3(grid_for(rows * (c + a))), dim3(256), 0, acg::to_stream(stream), (const float*)x,
+                     actions, (float*)y, rows, c, a, hw);
+  return acg::check_launch("concat_actions_fwd");
+}
+
+int32_t acg_concat_channels_fwd(const void* a, const void* b, void* y, int64_t rows, int32_t ca, int32_t cb, int32_t dtype,
+                                acg_stream_t stream) {
+  ACG_REQUIRE_F32(dtype);
+  ACG_REQUIRE(rows > 0 && ca > 0 && cb > 0, ACG_ERR_INVALID_ARG, "concat_channels_fwd: non-positive size");
+  ACG_REQUIRE(a && b && y, ACG_ERR_INVALID_ARG, "concat_channels_fwd: null pointer");
+  hipLaunchKernelGGL(concat_k, dim3(grid_for(rows * (ca + cb))), dim3(256), 0, acg::to_stream(stream), (const float*)a,
+                     (const float*)b, (float*)y, (long long)rows, ca, cb, 1);
+  return acg::check_launch("concat_channels_fwd");
+}
+
+int32_t acg_slice_channels(const void* src, void* dst, float accumulate, int64_t rows, int32_t c_src, int32_t c_off,
+                           int32_t c_dst, int32_t dtype, acg_stream_t stream) {
+  ACG_REQUIRE_F32(dtype);
+  ACG_REQUIRE(rows > 0 && c_src > 0 && c_dst > 0, ACG_ERR_INVALID_ARG, "slice_channels: non-positive size");
+  ACG_REQUIRE(c_off >= 0 && c_off + c_dst <= c_src, ACG_ERR_INVALID_ARG, "slice_channels: range outside source");
+  ACG_REQUIRE(src && dst, ACG_ERR_INVALID_ARG, "slice_channels: null pointer");
+  hipLaunchKernelGGL(slice_k, dim3(grid_for(rows * c_dst)), dim3(256), 0, acg::to_stream(stream), (const float*)src,
+                     (float*)dst, accumulate, (long long)rows, c_src, c_off, c_dst);
+  return acg::check_launch("slice_channels");
+}
+
+int32_t acg_add(const void* a, const void* b, void* y, int64_t n, int32_t dtype, acg_stream_t stream) {
+  ACG_REQUIRE_F32(dtype);
+  ACG_REQUIRE(n > 0 && a && b && y, ACG_ERR_INVALID_ARG, "add: bad argument");
+  hipLaunchKernelGGL(add_k, dim3(grid_for(n / 4 + 1)), dim3(256), 0, acg::to_stream(stream), (const float*)a,
+                     (const float*)b, (float*)y, (long long)n);
+  return acg::check_launch("add");
+}
+
+}  // extern "C"

@@ -1,0 +1,523 @@
+"""Static-graph host runtime: the reference's TF-1.0 graph/session contract, MI355X-first.
+
+The reference builds a TensorFlow graph once (Trainer.__init__, train.py:27-112) and then
+executes pruned sub-graphs with ``sess.run(fetches, feed_dict)`` (train.py:114-155).  This
+module keeps that contract and nothing more:
+
+* ``Tensor`` / ``Variable`` / ``Op`` record a static program whose every buffer is allocated
+  once (activations, gradients, workspaces) - no allocator traffic at step time;
+* ``Session.run`` prunes to the ops the fetches need (exactly TF's behaviour: the D step
+  never back-propagates into G, the G step never runs D(real), a ``test`` fetch runs G only),
+  binds each op to a C-ABI call of libacgan_hip.so, and replays the resulting launch list as
+  ONE captured HIP graph per fetch signature (segments are cut only around host-side
+  collectives);
+* all variables of a top-level scope ('g', 'd') live in ONE flat buffer and every optimizer
+  owns one flat gradient buffer with the same layout, so weight gradients are written in place
+  by the wgrad kernels, the data-parallel all-reduce works on contiguous buckets with no
+  packing copy, and a whole network is updated by one fused optimizer launch.
+
+PyTorch is used for device memory, streams, graph capture and torch.distributed only.
+"""
+import contextlib
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_ALIGN = 4  # floats: every variable starts 16-byte aligned inside its flat buffer
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class Tensor:
+    """A statically shaped float32 (or int32) value in the graph; ``buf`` is bound by the session."""
+
+    def __init__(self, graph, shape, name=None, dtype=torch.float32, op=None, init=None):
+        self.graph = graph
+        self.shape = tuple(int(s) for s in shape)
+        self.name = name
+        self.dtype = dtype
+        self.op = op                # producing Op (None: placeholder, variable, state slot)
+        self.init = init            # constant fill value for state slots (optimizer slots, counters)
+        self.view_of = None         # (base Tensor, element offset): a window into a flat buffer
+        self.alias_of = None        # same storage as another tensor, different shape (reshape)
+        self.buf = None
+        self.id = graph._next_id()
+
+    @property
+    def numel(self):
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+    def view(self, offset, shape, name=None):
+        t = Tensor(self.graph, shape, name=name, dtype=self.dtype)
+        t.view_of = (self, int(offset))
+        return t
+
+    def reshape(self, shape, name=None):
+        t = Tensor(self.graph, shape, name=name, dtype=self.dtype, op=self.op)
+        assert t.numel == self.numel, 'reshape changes element count'
+        t.alias_of = self
+        return t
+
+    def root(self):
+        t = self
+        while t.alias_of is not None or t.view_of is not None:
+            t = t.alias_of if t.alias_of is not None else t.view_of[0]
+        return t
+
+    def __repr__(self):
+        return 'Tensor(%s, %s)' % (self.name, self.shape)
+
+
+class Placeholder(Tensor):
+    pass
+
+
+class Variable(Tensor):
+    """A trainable parameter; ``value`` holds the host initial value until the initializer runs."""
+
+    def __init__(self, graph, name, value, trainable=True):
+        super().__init__(graph, value.shape, name=name)
+        self.value = value.detach().to(torch.float32).contiguous()
+        self.trainable = trainable
+        self.scope = name.split('/')[0]
+
+
+class Op:
+    """One node of the static program.  ``bind(rt)`` returns ``fn(stream_ptr)`` that enqueues it."""
+    host = False        # True: cannot be captured into a HIP graph (collectives)
+    run_last = False    # True: ordered after everything else in a program (weight clip, defect D6)
+
+    def __init__(self, graph, name, inputs, outputs, control_inputs=()):
+        self.graph, self.name = graph, name
+        self.inputs, self.outputs = list(inputs), list(outputs)
+        self.control_inputs = list(control_inputs)
+        self.index = float(graph._next_id())
+        for o in self.outputs:
+            if o.op is None:
+                o.op = self
+        graph.ops.append(self)
+
+    def bind(self, rt):
+        raise NotImplementedError
+
+    def grad(self, gouts, needs, ctx):
+        raise NotImplementedError('%s has no gradient' % type(self).__name__)
+
+    def __repr__(self):
+        return '%s(%s)' % (type(self).__name__, self.name)
+
+
+class Graph:
+    def __init__(self):
+        self.ops = []
+        self.variables = {}          # name -> Variable, creation order
+        self.state = []              # state slots with constant init (optimizer slots, counters)
+        self._id = 0
+        self._layouts = {}           # top-level scope -> (offsets dict, total numel, flat Tensor)
+        self.collections = {}
+
+    def _next_id(self):
+        self._id += 1
+        return self._id
+
+    # ---- variables ------------------------------------------------------------------------
+    def get_variable(self, name, shape, initializer, reuse):
+        """tf.get_variable under variable_scope(reuse=...): create, or fetch when reuse is set."""
+        if name in self.variables:
+            if not reuse:
+                raise ValueError('Variable %s already exists, disallowed. Did you mean to set reuse=True?' % name)
+            v = self.variables[name]
+            if v.shape != tuple(shape):
+                raise ValueError('Trying to share variable %s, but specified shape %s and found shape %s'
+                                 % (name, tuple(shape), v.shape))
+            return v
+        if reuse:
+            raise ValueError('Variable %s does not exist, or was not created with get_variable()' % name)
+        scope = name.split('/')[0]
+        if scope in self._layouts:
+            raise ValueError('scope %r is frozen (an optimizer or the initializer already laid it out)' % scope)
+        v = Variable(self, name, initializer(tuple(shape)))
+        self.variables[name] = v
+        return v
+
+    def trainable_variables(self, scope=None):
+        """tf.get_collection(TRAINABLE_VARIABLES, scope) (train.py:87-88): prefix match on the name."""
+        return [v for n, v in self.variables.items()
+                if v.trainable and (scope is None or n == scope or n.startswith(scope.rstrip('/') + '/'))]
+
+    def layout(self, scope):
+        """Freeze a top-level scope into one flat buffer; returns (offsets, total, flat Tensor)."""
+        if scope not in self._layouts:
+            offs, total = {}, 0
+            for n, v in self.variables.items():
+                if v.scope == scope:
+                    offs[n] = total
+                    total += -(-v.numel // _ALIGN) * _ALIGN
+            if total == 0:
+                raise ValueError('no variables in scope %r' % scope)
+            flat = Tensor(self, (total,), name=scope + '/flat_params')
+            for n, off in offs.items():
+                self.variables[n].view_of = (flat, off)
+            self._layouts[scope] = (offs, total, flat)
+        return self._layouts[scope]
+
+    def new_state(self, shape, init, name, dtype=torch.float32):
+        t = Tensor(self, shape, name=name, dtype=dtype, init=init)
+        self.state.append(t)
+        return t
+
+
+_default = [Graph()]
+
+
+def get_default_graph():
+    return _default[-1]
+
+
+def reset_default_graph():
+    _default[-1] = Graph()
+    return _default[-1]
+
+
+def placeholder(shape, name=None, dtype=torch.float32):
+    return Placeholder(get_default_graph(), shape, name=name, dtype=dtype)
+
+
+class InitOp(Op):
+    """tf.global_variables_initializer(): lays variables out flat and fills variables + slots."""
+
+    def __init__(self, graph):
+        super().__init__(graph, 'init', [], [])
+
+
+def global_variables_initializer():
+    return InitOp(get_default_graph())
+
+
+# ---- gradient construction -------------------------------------------------------------------
+class GradContext:
+    """Hands each wgrad-type op its window of the optimizer's flat gradient buffer."""
+
+    def __init__(self, graph, var_list, flat_grad, offsets):
+        self.graph = graph
+        self.flat_grad = flat_grad
+        self.offsets = offsets
+        self.var_set = {v.name for v in var_list}
+        self.writers = {}            # var name -> list of ops that wrote its gradient
+
+    def wants(self, var):
+        return var.name in self.var_set
+
+    def slot(self, var):
+        """-> (gradient window Tensor, accumulate flag: 0.0 first write, 1.0 afterwards)."""
+        first = var.name not in self.writers
+        self.writers.setdefault(var.name, [])
+        return self.flat_grad.view(self.offsets[var.name], var.shape, name='grad/' + var.name), (0.0 if first else 1.0)
+
+    def wrote(self, var, op):
+        self.writers[var.name].append(op)
+
+
+def build_gradients(graph, seeds, var_list, flat_grad, offsets, add_op):
+    """Reverse walk over the recorded ops (what tf.gradients does for train.py:100-102).
+
+    seeds: list of (Tensor, gradient Tensor).  Only paths that reach ``var_list`` are built, so
+    e.g. the D step gets no dgrad through G and none for d/conv1.  Returns the GradContext.
+    """
+    var_names = {v.name for v in var_list}
+    last = max(o.index for o in graph.ops)
+    reach = set()                                  # tensor ids that depend on a variable in var_list
+    fwd_ops = [o for o in graph.ops if o.index <= last]
+    for op in fwd_ops:
+        if any((isinstance(i, Variable) and i.name in var_names) or i.root().id in reach for i in op.inputs):
+            for o in op.outputs:
+                reach.add(o.root().id)
+    pending = {}
+    for t, g in seeds:
+        r = t.root().id
+        pending[r] = g if r not in pending else add_op(pending[r], g)
+    ctx = GradContext(graph, var_list, flat_grad, offsets)
+    for op in reversed(fwd_ops):
+        gouts = [pending.get(o.root().id) for o in op.outputs]
+        if all(g is None for g in gouts):
+            continue
+        needs = [(isinstance(i, Variable) and i.name in var_names) or (not isinstance(i, Variable) and i.root().id in reach)
+                 for i in op.inputs]
+        if not any(needs):
+            continue
+        gins = op.grad(gouts, needs, ctx)
+        for i, g in zip(op.inputs, gins):
+            if g is None or isinstance(i, Variable):
+                continue
+            r = i.root().id
+            pending[r] = g if r not in pending else add_op(pending[r], g)
+    return ctx
+
+
+# ---- session ----------------------------------------------------------------------------------------
+class _Program:
+    def __init__(self, segments, fetch_tensors, feeds):
+        self.segments = segments     # list of ('dev', [fn...]) / ('host', fn)
+        self.fetch_tensors = fetch_tensors
+        self.feeds = feeds
+        self.graphs = None           # captured HIP graphs, one per 'dev' segment
+        self.runs = 0
+
+
+class Runtime:
+    """What an Op needs to bind itself: the kernel library, the device, buffers, process group."""
+
+    def __init__(self, lib, device, world_size=1, rank=0, process_group=None):
+        self.lib, self.device = lib, torch.device(device)
+        self.world_size, self.rank, self.process_group = world_size, rank, process_group
+        self.is_cuda = self.device.type == 'cuda'
+        self.comm_stream = torch.cuda.Stream(self.device) if self.is_cuda else None
+        self._scratch = {}
+
+    def workspace(self, nbytes):
+        """A private zero-initialised scratch buffer (never shared: ops may overlap across streams)."""
+        n = max(int(nbytes), 16)
+        return torch.zeros(n, dtype=torch.uint8, device=self.device), n
+
+    def stream_ptr(self):
+        if self.is_cuda:
+            return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return None
+
+
+class Session:
+    """``tf.Session`` stand-in bound to one GPU (one process per GPU)."""
+
+    def __init__(self, device='cuda:0', graph=None, use_hip_graphs=True, lib=None,
+                 world_size=1, rank=0, process_group=None):
+        self.graph = graph or get_default_graph()
+        dev = torch.device(device)
+        if lib is None:
+            lib = _lib.get()      # raises when libacgan_hip.so is not built: there is no fallback
+            if dev.type != 'cuda':
+                raise RuntimeError('the HIP library runs on a GPU device, got %s' % dev)
+            if not torch.cuda.is_available():
+                raise RuntimeError('no GPU visible: the HIP path cannot run and there is no CPU fallback')
+        self.rt = Runtime(lib, dev, world_size, rank, process_group)
+        if dev.type == 'cuda':
+            torch.cuda.set_device(dev)
+        self.use_hip_graphs = use_hip_graphs and dev.type == 'cuda'
+        self._programs = {}
+        self._initialized = False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    # ---- buffers
+    def _materialize(self, t):
+        if t.buf is not None:
+            return t.buf
+        if t.alias_of is not None:
+            t.buf = self._materialize(t.alias_of).view(t.shape)
+        elif t.view_of is not None:
+            base, off = t.view_of
+            t.buf = self._materialize(base)[off:off + t.numel].view(t.shape)
+        else:
+            if t.init is not None:
+                t.buf = torch.full(t.shape, t.init, dtype=t.dtype, device=self.rt.device)
+            else:
+                t.buf = torch.zeros(t.shape, dtype=t.dtype, device=self.rt.device)
+        return t.buf
+
+    def _initialize(self):
+        g = self.graph
+        for scope in sorted({v.scope for v in g.variables.values()}):
+            g.layout(scope)
+        for v in g.variables.values():
+            v.buf = None
+            self._materialize(v).copy_(v.value)
+        for s in g.state:
+            buf = self._materialize(s)
+            buf.fill_(s.init)
+        self._initialized = True
+
+    # ---- variable access (checkpoint / parity tests)
+    def get_value(self, var):
+        return self._materialize(var).detach().cpu().clone()
+
+    def set_value(self, var, value):
+        self._materialize(var).copy_(torch.as_tensor(np.asarray(value) if not torch.is_tensor(value) else value)
+                                     .to(torch.float32).reshape(var.shape))
+
+    # ---- compile
+    @staticmethod
+    def _flatten(fetches):
+        out = []
+
+        def rec(f):
+            if isinstance(f, (list, tuple)):
+                for x in f:
+                    rec(x)
+            else:
+                out.append(f)
+        rec(fetches)
+        return out
+
+    def _compile(self, flat_fetches, feeds):
+        g = self.graph
+        needed, stack = {}, []
+        for f in flat_fetches:
+            if isinstance(f, Op):
+                stack.append(f)
+            elif isinstance(f, Tensor) or hasattr(f, 'tensor'):
+                t = f if isinstance(f, Tensor) else f.tensor()
+                if t.op is not None:
+                    stack.append(t.op)
+            else:
+                raise TypeError('Fetch argument %r has invalid type %s' % (f, type(f)))
+        while stack:
+            op = stack.pop()
+            if id(op) in needed:
+                continue
+            needed[id(op)] = op
+            for t in op.inputs:
+                if t.op is not None and id(t.op) not in needed:
+                    stack.append(t.op)
+            stack.extend(c for c in op.control_inputs if id(c) not in needed)
+        ops = sorted(needed.values(), key=lambda o: (o.run_last, o.index))
+        if any(isinstance(o, InitOp) for o in ops):
+            return None
+        if not self._initialized:
+            raise RuntimeError('Attempting to use uninitialized variables: run global_variables_initializer() first')
+        ops = self._fold_clips(ops)
+        for op in ops:
+            for t in op.inputs + op.outputs:
+                self._materialize(t)
+        segments, cur = [], []
+        for op in ops:
+            fn = op.bind(self.rt)
+            if fn is None:
+                continue
+            if op.host:
+                if cur:
+                    segments.append(('dev', cur))
+                    cur = []
+                segments.append(('host', fn))
+            else:
+                cur.append(fn)
+        if cur:
+            segments.append(('dev', cur))
+        fetch_tensors = []
+        for f in flat_fetches:
+            if isinstance(f, Op):
+                fetch_tensors.append(None)
+            else:
+                t = f.tensor() if hasattr(f, 'tensor') else f
+                self._materialize(t)
+                fetch_tensors.append(t)
+        for ph in feeds:
+            self._materialize(ph)
+        return _Program(segments, fetch_tensors, list(feeds))
+
+    @staticmethod
+    def _fold_clips(ops):
+        """Weight clips fetched together with an optimizer step over the same flat buffer are fused
+        into that step's kernel (update -> clip; the reference leaves the order undefined, D6)."""
+        clips = [o for o in ops if getattr(o, 'is_clip', False)]
+        steps = [o for o in ops if getattr(o, 'is_optimizer_step', False)]
+        for st in steps:
+            st.program_clip = None
+        if not clips or not steps:
+            return ops
+        for st in steps:
+            mine = [c for c in clips if c.var.scope == st.scope]
+            names = {c.var.name for c in mine}
+            bounds = {(c.lo, c.hi) for c in mine}
+            if mine and names == set(st.var_names) and len(bounds) == 1:
+                st.program_clip = next(iter(bounds))
+                ops = [o for o in ops if o not in mine]
+        return ops
+
+    # ---- run
+    def run(self, fetches, feed_dict=None, device_fetch=False):
+        feed_dict = feed_dict or {}
+        single = not isinstance(fetches, (list, tuple))
+        flat = self._flatten(fetches)
+        if any(isinstance(f, InitOp) for f in flat):
+            self._initialize()
+            return None if single else [None] * len(flat)
+        key = (tuple(id(f) for f in flat), tuple(id(k) for k in feed_dict))
+        prog = self._programs.get(key)
+        if prog is None:
+            prog = self._compile(flat, list(feed_dict.keys()))
+            self._programs[key] = prog
+        for ph, val in feed_dict.items():
+            src = val if torch.is_tensor(val) else torch.from_numpy(np.ascontiguousarray(val))
+            if tuple(src.shape) != ph.shape:
+                raise ValueError('Cannot feed value of shape %s for %r' % (tuple(src.shape), ph))
+            ph.buf.copy_(src.to(ph.dtype), non_blocking=True)
+        self._execute(prog)
+        results = []
+        for t in prog.fetch_tensors:
+            if t is None:
+                results.append(None)
+            elif device_fetch:
+                results.append(t.buf)
+            else:
+                results.append(t.buf.detach().cpu().numpy().copy())
+        if single:
+            return results[0]
+        return self._unflatten(fetches, iter(results))
+
+    def _unflatten(self, fetches, it):
+        if isinstance(fetches, (list, tuple)):
+            return [self._unflatten(f, it) for f in fetches]
+        return next(it)
+
+    def _execute(self, prog):
+        rt = self.rt
+        prog.runs += 1
+        if not self.use_hip_graphs or prog.runs == 1:
+            # eager launch list (first run of a program is always eager: it also warms every kernel)
+            for kind, seg in prog.segments:
+                if kind == 'host':
+                    seg()
+                else:
+                    sp = rt.stream_ptr()
+                    for fn in seg:
+                        fn(sp)
+            return
+        if prog.graphs is None:
+            prog.graphs = []
+            torch.cuda.synchronize(rt.device)
+            for kind, seg in prog.segments:
+                if kind == 'host':
+                    prog.graphs.append(None)
+                    continue
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    sp = rt.stream_ptr()       # the capture stream
+                    for fn in seg:
+                        fn(sp)
+                prog.graphs.append(gr)
+        for (kind, seg), gr in zip(prog.segments, prog.graphs):
+            if kind == 'host':
+                seg()
+            else:
+                gr.replay()
+
+
+@contextlib.contextmanager
+def default_graph(graph=None):
+    g = graph or Graph()
+    _default.append(g)
+    try:
+        yield g
+    finally:
+        _default.pop()

@@ -1,0 +1,78 @@
+"""GPU parity: every C-ABI entry point of libacgan_hip.so against the torch-fp64 restatement
+(oracle/tf_ops.py) on seeded inputs, through the C ABI (tests/abi_call.py).
+Tolerance: north_star asks 1e-3 rel in fp32; the per-op bars here are tighter."""
+import pytest
+
+import op_cases as C
+
+pytestmark = pytest.mark.gpu
+
+TOL_CONV = 1e-4    # fp32 MFMA fma-chains over K <= 13050 products
+TOL = 2e-5
+
+
+@pytest.mark.parametrize('shape', C.CONV_SHAPES, ids=str)
+def test_conv(hip_abi, shape):
+    C.case_conv(hip_abi, shape, TOL_CONV)
+
+
+@pytest.mark.parametrize('shape', C.DECONV_SHAPES, ids=str)
+def test_deconv(hip_abi, shape):
+    C.case_deconv(hip_abi, shape, TOL_CONV)
+
+
+@pytest.mark.parametrize('shape', [(32, 16, 16, 128, 128, 5, 2, 'SAME'), (32, 4, 4, 256, 512, 5, 2, 'SAME'),
+                                   (16, 32, 32, 64, 128, 5, 2, 'SAME')], ids=str)
+def test_conv_batch32(hip_abi, shape):
+    """BASELINE config-2 batch: exercises the 128x128 tile and split-K paths."""
+    C.case_conv(hip_abi, shape, TOL_CONV)
+
+
+@pytest.mark.parametrize('shape', [(32, 16, 16, 128, 128, 5, 2), (8, 32, 32, 128, 25, 5, 2)], ids=str)
+def test_deconv_batch32(hip_abi, shape):
+    C.case_deconv(hip_abi, shape, TOL_CONV)
+
+
+@pytest.mark.parametrize('shape', C.BN_SHAPES + [((32, 32, 32), 128, 1, 'relu'), ((64, 4, 4), 512, 2, 'lrelu')], ids=str)
+def test_bn(hip_abi, shape):
+    C.case_bn(hip_abi, shape, TOL)
+
+
+def test_bn_large_mean(hip_abi):
+    C.case_bn_large_mean(hip_abi, 2e-2)
+
+
+def test_bias(hip_abi):
+    C.case_bias(hip_abi, TOL)
+
+
+@pytest.mark.parametrize('shape', C.DNA_SHAPES + [(32, 64, 64, 3, 5), (2, 128, 128, 3, 11)], ids=str)
+def test_dna(hip_abi, shape):
+    C.case_dna(hip_abi, shape, TOL)
+
+
+def test_dna_extreme(hip_abi):
+    C.case_dna_extreme_logits(hip_abi, TOL)
+
+
+def test_plumbing(hip_abi):
+    C.case_plumbing(hip_abi, TOL)
+
+
+def test_losses(hip_abi):
+    C.case_losses(hip_abi, TOL)
+
+
+def test_optimizers(hip_abi):
+    C.case_optimizers(hip_abi, TOL)
+
+
+def test_error_reporting(hip_abi):
+    """Bad arguments come back as a non-zero code + message, never a launch."""
+    import torch
+    from action_conditioned_gans_amd._lib import AcgError
+    x = torch.zeros(2, 4, 4, 3, device='cuda')
+    with pytest.raises(AcgError):
+        hip_abi.dna_fwd(torch.zeros(2, 4, 4, 144, device='cuda'), x, 12)        # ksize > 11
+    with pytest.raises(AcgError):
+        hip_abi.bn_act_fwd(torch.zeros(3, 4, 4, 8, device='cuda'), torch.zeros(8, device='cuda'), 'relu', groups=5)

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void bias_act_fwd_k(const float* __restrict__ 
   for (int ch = 0; ch < m.nchunk; ++ch) {
     const int c = ch * m.Cb + m.cl;
     if (c >= C) continue;
-    const float bt = bias[c];
+    const float bt = bias ? bias[c] : 0.f;
     for (long long r = (long long)blockIdx.x * m.RPP + m.rsub; r < R; r += (long long)gridDim.x * m.RPP)
       y[r * C + c] = acg::act_apply(act, x[r * C + c] + bt, leak);
   }
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_partial(const float* __restr
       }
     }
     reduce_rsub(m, s1, s2, sh);
-    if (m.active && m.rsub == 0 && c < C) part[(long long)b * C + c] = s1;
+    if (part && m.active && m.rsub == 0 && c < C) part[(long long)b * C + c] = s1;
   }
 }
 
@@ -303,7 +303,7 @@ int32_t acg_bias_act_fwd(const void* x, const float* bias, void* y, int64_t rows
                          int32_t dtype, acg_stream_t stream) {
   ACG_REQUIRE_F32(dtype);
   ACG_REQUIRE(rows > 0 && C > 0, ACG_ERR_INVALID_ARG, "bias_act_fwd: non-positive size");
-  ACG_REQUIRE(x && bias && y, ACG_ERR_INVALID_ARG, "bias_act_fwd: null pointer");
+  ACG_REQUIRE(x && y, ACG_ERR_INVALID_ARG, "bias_act_fwd: null pointer");
   ACG_REQUIRE(act >= ACG_ACT_NONE && act <= ACG_ACT_TANH, ACG_ERR_INVALID_ARG, "bias_act_fwd: activation %d", act);
   hipLaunchKernelGGL(bias_act_fwd_k, dim3(apply_blocks(rows, C)), dim3(256), 0, acg::to_stream(stream), (const float*)x,
                      bias, (float*)y, (long long)rows, C, act, leak);
@@ -314,15 +314,16 @@ int32_t acg_bias_act_bwd(const void* y, const void* dy, void* dx, float* dbias, 
                          int32_t act, float leak, int32_t dtype, void* ws, size_t wsb, acg_stream_t stream) {
   ACG_REQUIRE_F32(dtype);
   ACG_REQUIRE(rows > 0 && C > 0, ACG_ERR_INVALID_ARG, "bias_act_bwd: non-positive size");
-  ACG_REQUIRE(y && dy && dbias, ACG_ERR_INVALID_ARG, "bias_act_bwd: null pointer");
+  ACG_REQUIRE(y && dy && (dbias || dx), ACG_ERR_INVALID_ARG, "bias_act_bwd: null pointer");
   ACG_REQUIRE(act >= ACG_ACT_NONE && act <= ACG_ACT_TANH, ACG_ERR_INVALID_ARG, "bias_act_bwd: activation %d", act);
   ACG_REQUIRE(dx || act == ACG_ACT_NONE, ACG_ERR_INVALID_ARG, "bias_act_bwd: dx NULL requires ACG_ACT_NONE");
-  ACG_REQUIRE(ws && wsb >= acg_bias_workspace_bytes(rows, C), ACG_ERR_WORKSPACE, "bias_act_bwd: workspace too small");
+  ACG_REQUIRE(!dbias || (ws && wsb >= acg_bias_workspace_bytes(rows, C)), ACG_ERR_WORKSPACE, "bias_act_bwd: workspace too small");
   const int nblk = partial_blocks(rows, C);
   hipStream_t st = acg::to_stream(stream);
   hipLaunchKernelGGL(bias_act_bwd_partial, dim3(nblk), dim3(256), 0, st, (const float*)y, (const float*)dy, (float*)dx,
-                     (float*)ws, (long long)rows, C, nblk, act, leak);
+                     dbias ? (float*)ws : (float*)nullptr, (long long)rows, C, nblk, act, leak);
   if (int rc = acg::check_launch("bias_act_bwd_partial")) return rc;
+  if (!dbias) return ACG_OK;
   hipLaunchKernelGGL(colsum_finalize, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)ws, dbias, dbias_acc, C, nblk);
   return acg::check_launch("colsum_finalize");
 }

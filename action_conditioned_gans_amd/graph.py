@@ -226,11 +226,12 @@ class GradContext:
         self.writers[var.name].append(op)
 
 
-def build_gradients(graph, seeds, var_list, flat_grad, offsets, add_op):
+def build_gradients(graph, heads, var_list, flat_grad, offsets, add_op):
     """Reverse walk over the recorded ops (what tf.gradients does for train.py:100-102).
 
-    seeds: list of (Tensor, gradient Tensor).  Only paths that reach ``var_list`` are built, so
-    e.g. the D step gets no dgrad through G and none for d/conv1.  Returns the GradContext.
+    heads: {loss-head Op: {output index: weight}}; each head emits its own seed gradient(s).
+    Only paths that reach ``var_list`` are built, so e.g. the D step gets no dgrad through G and
+    none for d/conv1.  Returns the GradContext.
     """
     var_names = {v.name for v in var_list}
     last = max(o.index for o in graph.ops)
@@ -241,9 +242,13 @@ def build_gradients(graph, seeds, var_list, flat_grad, offsets, add_op):
             for o in op.outputs:
                 reach.add(o.root().id)
     pending = {}
-    for t, g in seeds:
-        r = t.root().id
-        pending[r] = g if r not in pending else add_op(pending[r], g)
+    for head, weights in heads.items():
+        needs = [(not isinstance(i, Variable)) and i.root().id in reach for i in head.inputs]
+        if not any(needs):
+            continue
+        for t, g in head.seed(weights, needs):
+            r = t.root().id
+            pending[r] = g if r not in pending else add_op(pending[r], g)
     ctx = GradContext(graph, var_list, flat_grad, offsets)
     for op in reversed(fwd_ops):
         gouts = [pending.get(o.root().id) for o in op.outputs]

@@ -1,0 +1,778 @@
+"""Operator surface of the hot path: conv2d / deconv2d / batch_norm / lrelu / dna_gather + losses.
+
+Mirrors what the reference's ``ops.py`` and its ``slim.*`` call sites offer (ops.py:19-50,100-120;
+models.py:10-21,31-72,80-88), with the same keyword arguments and ``ValueError`` behaviour, but every
+function records graph ops (graph.py) that bind to hand-written HIP kernels through the C ABI
+(include/acgan_hip.h).  The slim layer contract is kept: ``conv -> (normalizer | +bias) ->
+activation``, xavier-uniform weights, zero biases/beta, ``reuse`` sharing by variable name.
+Layer-level fusion happens here: BatchNorm + activation is one op, bias + activation is one op.
+"""
+import contextlib
+import ctypes
+import functools
+import math
+
+import torch
+
+from . import _lib
+from . import graph as G
+from ._lib import ACG_F32, CONV_DGRAD, CONV_FWD, CONV_WGRAD, ConvDesc
+
+DNA_KERN_SIZE = 5          # ops.py:12
+_ACT_CODE = {None: _lib.ACT_NONE, 'relu': _lib.ACT_RELU, 'lrelu': _lib.ACT_LRELU, 'tanh': _lib.ACT_TANH}
+_p = G._ptr
+
+
+# ================================================================================================
+# scopes (tf.variable_scope / slim.arg_scope)
+# ================================================================================================
+_scope_stack = []     # [(name, reuse)]
+_arg_stack = []       # [{func: kwargs}]
+_seed = [0]
+_rng = [None]
+
+
+def set_random_seed(seed):
+    _seed[0] = int(seed)
+    _rng[0] = None
+
+
+def _generator():
+    if _rng[0] is None:
+        _rng[0] = torch.Generator().manual_seed(_seed[0])
+    return _rng[0]
+
+
+@contextlib.contextmanager
+def variable_scope(name, reuse=None):
+    _scope_stack.append((name, reuse))
+    try:
+        yield
+    finally:
+        _scope_stack.pop()
+
+
+def _scope_name(leaf=None):
+    parts = [n for n, _ in _scope_stack if n]
+    if leaf:
+        parts.append(leaf)
+    return '/'.join(parts)
+
+
+def _scope_reuse():
+    for _, r in reversed(_scope_stack):
+        if r is not None:
+            return bool(r)
+    return False
+
+
+@contextlib.contextmanager
+def arg_scope(funcs, **kwargs):
+    """slim.arg_scope: default keyword arguments for the listed layer functions."""
+    for f in funcs:
+        if not getattr(f, '_acg_arg_scoped', False):
+            raise ValueError('%s is not decorated with @add_arg_scope' % getattr(f, '__name__', f))
+    _arg_stack.append({getattr(f, '_acg_key'): dict(kwargs) for f in funcs})
+    try:
+        yield
+    finally:
+        _arg_stack.pop()
+
+
+def add_arg_scope(fn):
+    key = fn.__name__
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        merged = {}
+        for frame in _arg_stack:
+            merged.update(frame.get(key, {}))
+        merged.update(kwargs)
+        return fn(*args, **merged)
+    wrapper._acg_arg_scoped = True
+    wrapper._acg_key = key
+    return wrapper
+
+
+def xavier_initializer():
+    """slim.xavier_initializer(uniform=True): U(-l, l), l = sqrt(6/(fan_in+fan_out)), fans = kh*kw*shape[-2|-1]."""
+    def init(shape):
+        rf = 1
+        for s in shape[:-2]:
+            rf *= s
+        limit = math.sqrt(6.0 / (rf * shape[-2] + rf * shape[-1]))
+        return ((torch.rand(shape, generator=_generator(), dtype=torch.float64) * 2 - 1) * limit).float()
+    return init
+
+
+def zeros_initializer():
+    return lambda shape: torch.zeros(shape, dtype=torch.float32)
+
+
+# ================================================================================================
+# graph ops
+# ================================================================================================
+def _new(shape, name):
+    return G.Tensor(G.get_default_graph(), shape, name=name)
+
+
+def _check_nhwc(x, what):
+    if not isinstance(x, G.Tensor) or len(x.shape) != 4:
+        raise ValueError('%s expects a rank-4 NHWC tensor, got %r' % (what, x))
+
+
+def _desc(lib_free_args):
+    """Build an acg_conv_desc in Python (same arithmetic as acg_conv_desc_init)."""
+    batch, h, w, c, kh, kw, cout, stride, padding = lib_free_args
+    d = ConvDesc()
+    d.batch, d.in_h, d.in_w, d.in_c, d.out_c, d.kh, d.kw = batch, h, w, c, cout, kh, kw
+    d.stride_h = d.stride_w = stride
+    if padding == 'SAME':
+        d.out_h, d.out_w = -(-h // stride), -(-w // stride)
+        d.pad_top = max((d.out_h - 1) * stride + kh - h, 0) // 2
+        d.pad_left = max((d.out_w - 1) * stride + kw - w, 0) // 2
+    elif padding == 'VALID':
+        if h < kh or w < kw:
+            raise ValueError('VALID convolution: kernel %dx%d larger than input %dx%d' % (kh, kw, h, w))
+        d.out_h, d.out_w = (h - kh) // stride + 1, (w - kw) // stride + 1
+        d.pad_top = d.pad_left = 0
+    else:
+        raise ValueError('unexpected padding argument')
+    return d
+
+
+class _ConvBase(G.Op):
+    """Shared binder: one C-ABI call with (a, b, out, desc, dtype, workspace, n, stream)."""
+    which = CONV_FWD
+
+    def _bind(self, rt, entry, a, b, out, accumulate=None):
+        lib, d = rt.lib, self.desc
+        ws, n = rt.workspace(lib.conv2d_workspace_bytes(ctypes.byref(d), self.which, ACG_F32))
+        self._keep = (ws, d)
+        fn = getattr(lib, entry)
+        pa, pb, po, dref, pws = _p(a.buf), _p(b.buf), _p(out.buf), ctypes.byref(d), _p(ws)
+        if accumulate is None:
+            return lambda s: fn(pa, pb, po, dref, ACG_F32, pws, n, s)
+        return lambda s: fn(pa, pb, po, accumulate, dref, ACG_F32, pws, n, s)
+
+
+class Conv2dOp(_ConvBase):
+    """y = conv(x, w) (transposed=False) or TF conv2d_transpose(x, w) (transposed=True; desc is the adjoint conv)."""
+
+    def __init__(self, x, w, desc, transposed, name):
+        g = G.get_default_graph()
+        self.desc, self.transposed = desc, transposed
+        self.which = CONV_DGRAD if transposed else CONV_FWD
+        shape = (desc.batch, desc.in_h, desc.in_w, desc.in_c) if transposed else (desc.batch, desc.out_h, desc.out_w, desc.out_c)
+        super().__init__(g, name, [x, w], [_new(shape, name + ':0')])
+
+    def bind(self, rt):
+        x, w = self.inputs
+        return self._bind(rt, 'deconv2d_fwd' if self.transposed else 'conv2d_fwd', x, w, self.outputs[0])
+
+    def grad(self, gouts, needs, ctx):
+        x, w = self.inputs
+        dy = gouts[0]
+        dx = None
+        if needs[0]:
+            dx = ConvDgradOp(dy, w, x.shape, self.desc, self.transposed, self.name + '/dgrad').outputs[0]
+        if needs[1] and ctx.wants(w):
+            dst, acc = ctx.slot(w)
+            ctx.wrote(w, ConvWgradOp(x, dy, dst, acc, self.desc, self.transposed, self.name + '/wgrad'))
+        return [dx, None]
+
+
+class ConvDgradOp(_ConvBase):
+    def __init__(self, dy, w, x_shape, desc, transposed, name):
+        self.desc, self.transposed = desc, transposed
+        self.which = CONV_FWD if transposed else CONV_DGRAD
+        super().__init__(G.get_default_graph(), name, [dy, w], [_new(x_shape, name + ':0')])
+
+    def bind(self, rt):
+        dy, w = self.inputs
+        return self._bind(rt, 'deconv2d_dgrad' if self.transposed else 'conv2d_dgrad', dy, w, self.outputs[0])
+
+
+class ConvWgradOp(_ConvBase):
+    which = CONV_WGRAD
+
+    def __init__(self, x, dy, dst, accumulate, desc, transposed, name):
+        self.desc, self.transposed, self.accumulate = desc, transposed, float(accumulate)
+        super().__init__(G.get_default_graph(), name, [x, dy], [dst])
+
+    def bind(self, rt):
+        x, dy = self.inputs
+        return self._bind(rt, 'deconv2d_wgrad' if self.transposed else 'conv2d_wgrad', x, dy, self.outputs[0],
+                          accumulate=self.accumulate)
+
+
+class BnActOp(G.Op):
+    """slim.batch_norm (batch statistics, beta only) fused with the layer activation."""
+
+    def __init__(self, x, beta, act, leak, eps, groups, name):
+        g = G.get_default_graph()
+        c = x.shape[-1]
+        self.act, self.leak, self.eps, self.groups = act, float(leak), float(eps), int(groups)
+        self.rows, self.c = x.numel // c, c
+        if self.rows % self.groups:
+            raise ValueError('batch_norm: %d rows not divisible by %d groups' % (self.rows, self.groups))
+        self.mean, self.rstd = _new((groups * c,), name + '/mean'), _new((groups * c,), name + '/rstd')
+        super().__init__(g, name, [x, beta], [_new(x.shape, name + ':0'), self.mean, self.rstd])
+
+    def bind(self, rt):
+        lib = rt.lib
+        ws, n = rt.workspace(lib.bn_workspace_bytes(self.rows, self.c, self.groups))
+        self._keep = ws
+        x, beta = self.inputs
+        y, mean, rstd = self.outputs
+        args = (_p(x.buf), _p(beta.buf), _p(y.buf), _p(mean.buf), _p(rstd.buf), self.rows, self.c, self.groups, self.eps,
+                _ACT_CODE[self.act], self.leak, ACG_F32, _p(ws), n)
+        fn = lib.bn_act_fwd
+        return lambda s: fn(*args, s)
+
+    def grad(self, gouts, needs, ctx):
+        x, beta = self.inputs
+        dst, acc = ctx.slot(beta) if (needs[1] and ctx.wants(beta)) else (None, 0.0)
+        op = BnActBwdOp(self, gouts[0], dst, acc, self.name + '/bwd')
+        if dst is not None:
+            ctx.wrote(beta, op)
+        return [op.outputs[0] if needs[0] else None, None]
+
+
+class BnActBwdOp(G.Op):
+    def __init__(self, fwd, dy, dbeta_dst, accumulate, name):
+        g = G.get_default_graph()
+        self.fwd, self.accumulate = fwd, float(accumulate)
+        x, beta = fwd.inputs
+        if dbeta_dst is None:                      # beta frozen in this pass: private scratch slot
+            dbeta_dst = _new((fwd.c,), name + '/dbeta_scratch')
+        super().__init__(g, name, [x, dy, beta, fwd.mean, fwd.rstd], [_new(x.shape, name + ':0'), dbeta_dst])
+
+    def bind(self, rt):
+        lib, f = rt.lib, self.fwd
+        ws, n = rt.workspace(lib.bn_workspace_bytes(f.rows, f.c, f.groups))
+        self._keep = ws
+        x, dy, beta, mean, rstd = self.inputs
+        dx, dbeta = self.outputs
+        args = (_p(x.buf), _p(dy.buf), _p(beta.buf), _p(mean.buf), _p(rstd.buf), _p(dx.buf), _p(dbeta.buf), self.accumulate,
+                f.rows, f.c, f.groups, _ACT_CODE[f.act], f.leak, ACG_F32, _p(ws), n)
+        fn = lib.bn_act_bwd
+        return lambda s: fn(*args, s)
+
+
+class BiasActOp(G.Op):
+    """y = act(x + bias); bias None gives the bare activation."""
+
+    def __init__(self, x, bias, act, leak, name):
+        g = G.get_default_graph()
+        self.act, self.leak = act, float(leak)
+        self.c = x.shape[-1]
+        self.rows = x.numel // self.c
+        super().__init__(g, name, [x] + ([bias] if bias is not None else []), [_new(x.shape, name + ':0')])
+        self.has_bias = bias is not None
+
+    def bind(self, rt):
+        x = self.inputs[0]
+        pb = _p(self.inputs[1].buf) if self.has_bias else None
+        args = (_p(x.buf), pb, _p(self.outputs[0].buf), self.rows, self.c, _ACT_CODE[self.act], self.leak, ACG_F32)
+        fn = rt.lib.bias_act_fwd
+        return lambda s: fn(*args, s)
+
+    def grad(self, gouts, needs, ctx):
+        dy = gouts[0]
+        dst, acc = (None, 0.0)
+        if self.has_bias and needs[1] and ctx.wants(self.inputs[1]):
+            dst, acc = ctx.slot(self.inputs[1])
+        want_dx = needs[0]
+        if dst is None and self.act is None:
+            return [dy if want_dx else None] + ([None] if self.has_bias else [])
+        op = BiasActBwdOp(self, dy, dst, acc, want_dx, self.name + '/bwd')
+        if dst is not None:
+            ctx.wrote(self.inputs[1], op)
+        dx = (dy if self.act is None else op.dx) if want_dx else None
+        return [dx] + ([None] if self.has_bias else [])
+
+
+class BiasActBwdOp(G.Op):
+    def __init__(self, fwd, dy, dbias_dst, accumulate, want_dx, name):
+        g = G.get_default_graph()
+        self.fwd, self.accumulate = fwd, float(accumulate)
+        self.dx = _new(dy.shape, name + ':0') if (want_dx and fwd.act is not None) else None
+        self.dbias = dbias_dst
+        outs = [t for t in (self.dx, self.dbias) if t is not None]
+        super().__init__(g, name, [fwd.outputs[0], dy], outs)
+
+    def bind(self, rt):
+        lib, f = rt.lib, self.fwd
+        ws, n = rt.workspace(lib.bias_workspace_bytes(f.rows, f.c))
+        self._keep = ws
+        y, dy = self.inputs
+        args = (_p(y.buf), _p(dy.buf), _p(self.dx.buf) if self.dx is not None else None,
+                _p(self.dbias.buf) if self.dbias is not None else None, self.accumulate, f.rows, f.c,
+                _ACT_CODE[f.act], f.leak, ACG_F32, _p(ws), n)
+        fn = lib.bias_act_bwd
+        return lambda s: fn(*args, s)
+
+
+class DnaOp(G.Op):
+    def __init__(self, logits, image, ksize, name):
+        self.ksize = int(ksize)
+        super().__init__(G.get_default_graph(), name, [logits, image], [_new(image.shape, name + ':0')])
+
+    def bind(self, rt):
+        lg, img = self.inputs
+        b, h, w, c = img.shape
+        args = (_p(lg.buf), _p(img.buf), _p(self.outputs[0].buf), b, h, w, c, self.ksize, ACG_F32)
+        fn = rt.lib.dna_fwd
+        return lambda s: fn(*args, s)
+
+    def grad(self, gouts, needs, ctx):
+        if needs[1]:
+            raise NotImplementedError('dna_gather: gradient w.r.t. the image is not part of the hot path '
+                                      '(the image is a network input, train.py:53-54)')
+        return [DnaBwdOp(self, gouts[0], self.name + '/bwd').outputs[0] if needs[0] else None, None]
+
+
+class DnaBwdOp(G.Op):
+    def __init__(self, fwd, dout, name):
+        self.fwd = fwd
+        lg, img = fwd.inputs
+        super().__init__(G.get_default_graph(), name, [lg, img, dout], [_new(lg.shape, name + ':0')])
+
+    def bind(self, rt):
+        lg, img, dout = self.inputs
+        b, h, w, c = img.shape
+        args = (_p(lg.buf), _p(img.buf), _p(dout.buf), _p(self.outputs[0].buf), b, h, w, c, self.fwd.ksize, ACG_F32)
+        fn = rt.lib.dna_bwd
+        return lambda s: fn(*args, s)
+
+
+class ConcatActionsOp(G.Op):
+    """tf.tile([B,1,1,A] -> [B,h,w,A]) + tf.concat(axis=3) in one pass (train.py:48-50; models.py:16,38,84)."""
+
+    def __init__(self, x, actions, name):
+        b, h, w, c = x.shape
+        if len(actions.shape) != 2 or actions.shape[0] != b:
+            raise ValueError('concat_actions: actions must be [batch, A], got %s' % (actions.shape,))
+        super().__init__(G.get_default_graph(), name, [x, actions], [_new((b, h, w, c + actions.shape[1]), name + ':0')])
+
+    def bind(self, rt):
+        x, a = self.inputs
+        b, h, w, c = x.shape
+        args = (_p(x.buf), _p(a.buf), _p(self.outputs[0].buf), b, h * w, c, a.shape[1], ACG_F32)
+        fn = rt.lib.concat_actions_fwd
+        return lambda s: fn(*args, s)
+
+    def grad(self, gouts, needs, ctx):
+        if needs[1]:
+            raise NotImplementedError('concat_actions: actions are inputs, no gradient path')
+        x = self.inputs[0]
+        return [SliceOp(gouts[0], 0, x.shape[-1], x.shape, self.name + '/bwd').outputs[0] if needs[0] else None, None]
+
+
+class ConcatChannelsOp(G.Op):
+    def __init__(self, a, b, name):
+        if a.shape[:-1] != b.shape[:-1]:
+            raise ValueError('concat: leading dimensions differ: %s vs %s' % (a.shape, b.shape))
+        super().__init__(G.get_default_graph(), name, [a, b], [_new(a.shape[:-1] + (a.shape[-1] + b.shape[-1],), name + ':0')])
+
+    def bind(self, rt):
+        a, b = self.inputs
+        args = (_p(a.buf), _p(b.buf), _p(self.outputs[0].buf), a.numel // a.shape[-1], a.shape[-1], b.shape[-1], ACG_F32)
+        fn = rt.lib.concat_channels_fwd
+        return lambda s: fn(*args, s)
+
+    def grad(self, gouts, needs, ctx):
+        a, b = self.inputs
+        ga = SliceOp(gouts[0], 0, a.shape[-1], a.shape, self.name + '/bwd_a').outputs[0] if needs[0] else None
+        gb = SliceOp(gouts[0], a.shape[-1], b.shape[-1], b.shape, self.name + '/bwd_b').outputs[0] if needs[1] else None
+        return [ga, gb]
+
+
+class SliceOp(G.Op):
+    def __init__(self, src, c_off, c_dst, out_shape, name):
+        self.c_off, self.c_dst = int(c_off), int(c_dst)
+        super().__init__(G.get_default_graph(), name, [src], [_new(out_shape, name + ':0')])
+
+    def bind(self, rt):
+        src = self.inputs[0]
+        cs = src.shape[-1]
+        args = (_p(src.buf), _p(self.outputs[0].buf), 0.0, src.numel // cs, cs, self.c_off, self.c_dst, ACG_F32)
+        fn = rt.lib.slice_channels
+        return lambda s: fn(*args, s)
+
+
+class AddOp(G.Op):
+    def __init__(self, a, b, name='grad_add'):
+        if a.numel != b.numel:
+            raise ValueError('add: %s vs %s' % (a.shape, b.shape))
+        super().__init__(G.get_default_graph(), name, [a, b], [_new(a.shape, name + ':0')])
+
+    def bind(self, rt):
+        a, b = self.inputs
+        args = (_p(a.buf), _p(b.buf), _p(self.outputs[0].buf), a.numel, ACG_F32)
+        fn = rt.lib.add
+        return lambda s: fn(*args, s)
+
+
+def _add(a, b):
+    return AddOp(a, b).outputs[0]
+
+
+# ================================================================================================
+# public layer functions
+# ================================================================================================
+def relu(x, name='relu'):
+    return BiasActOp(x, None, 'relu', 0.0, _scope_name(name)).outputs[0]
+
+
+def lrelu(x, leak=0.2, name='lrelu'):
+    """ops.py:22-26:  0.5(1+leak) x + 0.5(1-leak) |x|."""
+    return BiasActOp(x, None, 'lrelu', leak, _scope_name(name)).outputs[0]
+
+
+def tanh(x, name='tanh'):
+    return BiasActOp(x, None, 'tanh', 0.0, _scope_name(name)).outputs[0]
+
+
+relu._acg_act = ('relu', 0.0)
+lrelu._acg_act = ('lrelu', 0.2)
+tanh._acg_act = ('tanh', 0.0)
+
+
+def _act_of(fn):
+    """Map an activation_fn argument onto a fusable (kind, leak) or None if it is an arbitrary callable."""
+    if fn is None:
+        return (None, 0.0)
+    if isinstance(fn, functools.partial) and getattr(fn.func, '_acg_act', None) and not fn.args:
+        kind, leak = fn.func._acg_act
+        return (kind, fn.keywords.get('leak', leak))
+    return getattr(fn, '_acg_act', None)
+
+
+@add_arg_scope
+def batch_norm(inputs, decay=0.999, center=True, scale=False, epsilon=0.001, activation_fn=None, is_training=True,
+               reuse=None, scope=None, groups=1):
+    """slim.batch_norm as the reference uses it: batch moments over (B,H,W), beta only.
+
+    ``groups`` > 1 normalises equal contiguous chunks of the batch independently (several logical
+    batches sharing one launch).  The moving averages of slim exist only as never-updated, never-read
+    variables in the reference (UPDATE_OPS is never run), so they are not materialised.
+    """
+    if scale or not center:
+        raise ValueError('batch_norm: only center=True, scale=False (the reference configuration) is implemented')
+    if not is_training:
+        raise ValueError('batch_norm: the reference never leaves training mode (moving averages are never updated)')
+    act = _act_of(activation_fn)
+    c = inputs.shape[-1]
+    with variable_scope(scope or 'BatchNorm', reuse=reuse):
+        beta = G.get_default_graph().get_variable(_scope_name('beta'), (c,), zeros_initializer(), _scope_reuse())
+        name = _scope_name()
+    fused = act if act is not None else (None, 0.0)
+    out = BnActOp(inputs, beta, fused[0], fused[1], epsilon, groups, name).outputs[0]
+    return out if act is not None else activation_fn(out)
+
+
+def _layer(inputs, num_outputs, kernel_size, stride, padding, activation_fn, normalizer_fn, normalizer_params,
+           weights_initializer, biases_initializer, reuse, scope, transposed, default_scope):
+    _check_nhwc(inputs, default_scope)
+    kh, kw = (kernel_size, kernel_size) if isinstance(kernel_size, int) else tuple(kernel_size)
+    b, h, w, cin = inputs.shape
+    g = G.get_default_graph()
+    with variable_scope(scope or default_scope, reuse=reuse):
+        share = _scope_reuse()
+        winit = weights_initializer or xavier_initializer()
+        if transposed:
+            if padding != 'SAME':
+                raise ValueError('conv2d_transpose: only SAME padding is implemented (the reference uses no other)')
+            wshape = (kh, kw, num_outputs, cin)
+            desc = _desc((b, h * stride, w * stride, num_outputs, kh, kw, cin, stride, 'SAME'))
+        else:
+            wshape = (kh, kw, cin, num_outputs)
+            desc = _desc((b, h, w, cin, kh, kw, num_outputs, stride, padding))
+        weights = g.get_variable(_scope_name('weights'), wshape, winit, share)
+        name = _scope_name()
+        out = Conv2dOp(inputs, weights, desc, transposed, name + ('/conv2d_transpose' if transposed else '/conv2d')).outputs[0]
+        act = _act_of(activation_fn)
+        if normalizer_fn is not None:
+            params = dict(normalizer_params or {})
+            if getattr(normalizer_fn, '_acg_key', None) == 'batch_norm' and act is not None:
+                out = normalizer_fn(out, activation_fn=activation_fn, **params)      # fused BN + activation
+                return out
+            out = normalizer_fn(out, **params)
+        else:
+            bias = g.get_variable(_scope_name('biases'), (num_outputs,), biases_initializer or zeros_initializer(), share)
+            if act is not None:
+                return BiasActOp(out, bias, act[0], act[1], name + '/bias_act').outputs[0]
+            out = BiasActOp(out, bias, None, 0.0, name + '/bias').outputs[0]
+        if activation_fn is not None:
+            out = BiasActOp(out, None, act[0], act[1], name + '/act').outputs[0] if act is not None else activation_fn(out)
+        return out
+
+
+@add_arg_scope
+def conv2d(inputs, num_outputs, kernel_size, stride=1, padding='SAME', activation_fn=relu, normalizer_fn=None,
+           normalizer_params=None, weights_initializer=None, biases_initializer=None, reuse=None, scope=None):
+    """slim.conv2d (models.py:12-15,34-37,42-51,82-88): NHWC, HWIO weights, TF SAME/VALID geometry."""
+    return _layer(inputs, num_outputs, kernel_size, stride, padding, activation_fn, normalizer_fn, normalizer_params,
+                  weights_initializer, biases_initializer, reuse, scope, False, 'Conv')
+
+
+@add_arg_scope
+def deconv2d(inputs, num_outputs, kernel_size, stride=1, padding='SAME', activation_fn=relu, normalizer_fn=None,
+             normalizer_params=None, weights_initializer=None, biases_initializer=None, reuse=None, scope=None):
+    """slim.conv2d_transpose (models.py:17-21,39-40,53-59): weights [kh,kw,Cout,Cin], output = input*stride."""
+    return _layer(inputs, num_outputs, kernel_size, stride, padding, activation_fn, normalizer_fn, normalizer_params,
+                  weights_initializer, biases_initializer, reuse, scope, True, 'Conv2d_transpose')
+
+
+conv2d_transpose = deconv2d
+
+
+def dna_gather(logits, image, ksize=DNA_KERN_SIZE, name='dna'):
+    """models.py:60-72 in one op: softmax over the k*k logits, then the per-pixel k x k gather of ``image``."""
+    _check_nhwc(logits, 'dna_gather')
+    _check_nhwc(image, 'dna_gather')
+    if logits.shape[:3] != image.shape[:3] or logits.shape[3] != ksize * ksize:
+        raise ValueError('dna_gather: logits %s do not match image %s with ksize %d' % (logits.shape, image.shape, ksize))
+    if not 1 <= ksize <= 11:
+        raise ValueError('dna_gather: ksize outside 1..11')
+    if not 1 <= image.shape[3] <= 4:
+        raise ValueError('dna_gather: image channels outside 1..4')
+    return DnaOp(logits, image, ksize, _scope_name(name)).outputs[0]
+
+
+def concat_actions(x, actions, name='concat_actions'):
+    """x [B,h,w,C] ++ actions [B,A] broadcast over (h,w): the tile+concat of train.py:48-50 / models.py:16,38,84."""
+    _check_nhwc(x, 'concat_actions')
+    return ConcatActionsOp(x, actions, _scope_name(name)).outputs[0]
+
+
+def concat(values, axis=3, name='concat'):
+    """tf.concat on the channel axis (train.py:64,68)."""
+    if axis not in (3, -1) or len(values) != 2:
+        raise ValueError('concat: only two tensors on the channel axis are supported')
+    return ConcatChannelsOp(values[0], values[1], _scope_name(name)).outputs[0]
+
+
+def squeeze(x, name=None):
+    """tf.squeeze (models.py:74): drop size-1 dimensions (a storage alias, no kernel)."""
+    return x.reshape(tuple(s for s in x.shape if s != 1) or (1,), name=name)
+
+
+# ================================================================================================
+# losses (ops.py:19-50,100-120; train.py:72-85)
+# ================================================================================================
+class Scalar:
+    """A loss value: a fixed linear combination of loss-head outputs, kept symbolic so that
+    ``minimize`` can seed every head's fused value+gradient kernel with the right weight."""
+
+    def __init__(self, terms):
+        self.terms = list(terms)        # [(head Op, output index, weight)]
+        self._tensor = None
+
+    def __add__(self, other):
+        if isinstance(other, (int, float)) and other == 0:
+            return self
+        return Scalar(self.terms + other.terms)
+
+    __radd__ = __add__
+
+    def __mul__(self, k):
+        return Scalar([(h, i, w * float(k)) for h, i, w in self.terms])
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, k):
+        return self * (1.0 / float(k))
+
+    def __neg__(self):
+        return self * -1.0
+
+    def tensor(self):
+        if self._tensor is None:
+            if len(self.terms) > 4:
+                raise ValueError('a loss may combine at most 4 heads')
+            self._tensor = CombineOp(self.terms).outputs[0]
+        return self._tensor
+
+
+class CombineOp(G.Op):
+    def __init__(self, terms):
+        self.terms = terms
+        ins = [h.outputs[i] for h, i, _ in terms]
+        super().__init__(G.get_default_graph(), 'loss_value', ins, [_new((1,), 'loss_value:0')])
+
+    def bind(self, rt):
+        args = [_p(self.outputs[0].buf)]
+        for k in range(4):
+            if k < len(self.terms):
+                args += [_p(self.inputs[k].buf), float(self.terms[k][2])]
+            else:
+                args += [None, 0.0]
+        fn = rt.lib.scalar_combine
+        return lambda s: fn(*args, s)
+
+
+class LossHead(G.Op):
+    """A loss head: outputs scalar values; ``seed(weights)`` emits the op writing d(sum w_i out_i)/d input."""
+
+    def seed(self, weights, needs):
+        raise NotImplementedError
+
+
+class FrameLossOp(LossHead):
+    """out0 = sum|gen-gt| (tf.norm ord=1, train.py:73), out1 = GDL (ops.py:100-120)."""
+
+    def __init__(self, gen, gt, grad_weights=None, name='frame_loss'):
+        if gen.shape != gt.shape:
+            raise ValueError('frame loss: shapes differ %s vs %s' % (gen.shape, gt.shape))
+        g = G.get_default_graph()
+        self.grad_weights = grad_weights
+        vals = _new((2,), name + '/values')
+        outs = [vals.view(0, (1,), name + '/l1'), vals.view(1, (1,), name + '/gdl')]
+        self.vals = vals
+        self.dgen = _new(gen.shape, name + '/dgen') if grad_weights else None
+        super().__init__(g, name, [gen, gt], outs + ([self.dgen] if self.dgen is not None else []))
+
+    def bind(self, rt):
+        gen, gt = self.inputs
+        b, h, w, c = gen.shape
+        ws, n = rt.workspace(rt.lib.frame_loss_workspace_bytes(gen.numel))
+        self._keep = ws
+        w1, w2 = self.grad_weights or (0.0, 0.0)
+        args = (_p(gen.buf), _p(gt.buf), _p(self.outputs[0].buf), _p(self.dgen.buf) if self.dgen is not None else None,
+                b, h, w, c, float(w1), float(w2), ACG_F32, _p(ws), n)
+        fn = rt.lib.frame_loss
+        return lambda s: fn(*args, s)
+
+    def seed(self, weights, needs):
+        a, b = self.inputs
+        if needs[0] and needs[1]:
+            raise NotImplementedError('frame loss: gradient w.r.t. both arguments')
+        if needs[1]:                       # both terms are symmetric: differentiate w.r.t. the other argument
+            a, b = b, a
+        op = FrameLossOp(a, b, (weights.get(0, 0.0), weights.get(1, 0.0)), self.name + '/grad')
+        return [(a, op.dgen)]
+
+
+class SmallLossOp(LossHead):
+    """One-block heads: 'l2norm' (train.py:77), 'sigmoid_ce' (ops.py:30-31,39-42), 'mean' (ops.py:32-33,44-45)."""
+
+    def __init__(self, kind, x, other=None, label=0.0, grad_scale=None, name=None):
+        g = G.get_default_graph()
+        self.kind, self.label, self.grad_scale = kind, float(label), grad_scale
+        if x.numel > 65536:
+            raise ValueError('%s loss: more than 65536 elements' % kind)
+        name = name or kind
+        self.dx = _new(x.shape, name + '/dx') if grad_scale is not None else None
+        ins = [x] + ([other] if other is not None else [])
+        super().__init__(g, name, ins, [_new((1,), name + ':0')] + ([self.dx] if self.dx is not None else []))
+
+    def bind(self, rt):
+        x = self.inputs[0]
+        out, dx = _p(self.outputs[0].buf), (_p(self.dx.buf) if self.dx is not None else None)
+        sc = float(self.grad_scale or 0.0)
+        if self.kind == 'l2norm':
+            args, fn = (_p(x.buf), _p(self.inputs[1].buf), out, dx, x.numel, sc), rt.lib.l2norm_loss
+        elif self.kind == 'sigmoid_ce':
+            args, fn = (_p(x.buf), self.label, out, dx, x.numel, sc), rt.lib.sigmoid_ce_loss
+        else:
+            args, fn = (_p(x.buf), out, dx, x.numel, sc), rt.lib.mean_loss
+        return lambda s: fn(*args, s)
+
+    def seed(self, weights, needs):
+        a = self.inputs[0]
+        b = self.inputs[1] if len(self.inputs) > 1 else None
+        sign = 1.0
+        if b is not None and needs[1]:
+            if needs[0]:
+                raise NotImplementedError('l2norm: gradient w.r.t. both arguments')
+            a, b = b, a                    # ||a-b|| is symmetric
+        op = SmallLossOp(self.kind, a, b, self.label, sign * weights.get(0, 0.0), self.name + '/grad')
+        return [(a, op.dx)]
+
+
+class PsnrOp(LossHead):
+    def __init__(self, true, pred, name='psnr'):
+        super().__init__(G.get_default_graph(), name, [true, pred], [_new((1,), name + ':0')])
+
+    def bind(self, rt):
+        a, b = self.inputs
+        ws, n = rt.workspace(rt.lib.frame_loss_workspace_bytes(a.numel))
+        self._keep = ws
+        args = (_p(a.buf), _p(b.buf), _p(self.outputs[0].buf), a.numel, ACG_F32, _p(ws), n)
+        fn = rt.lib.psnr
+        return lambda s: fn(*args, s)
+
+    def seed(self, weights, needs):
+        raise NotImplementedError('psnr is a metric (ops.py:19-20), not a training loss')
+
+
+def build_psnr(true, pred):
+    """ops.py:19-20."""
+    return Scalar([(PsnrOp(true, pred), 0, 1.0)])
+
+
+def sigmoid_cross_entropy(label, logits, name='sigmoid_ce'):
+    """tf.losses.sigmoid_cross_entropy against a constant label, mean over all elements."""
+    return Scalar([(SmallLossOp('sigmoid_ce', logits, label=label, name=name), 0, 1.0)])
+
+
+def reduce_mean(x, name='mean'):
+    return Scalar([(SmallLossOp('mean', x, name=name), 0, 1.0)])
+
+
+def build_g_adv_loss(d_out_gen, arg_loss):
+    """ops.py:28-35."""
+    if arg_loss == 'bce':
+        return sigmoid_cross_entropy(1.0, d_out_gen, 'g_adv_bce')
+    elif arg_loss == 'wass':
+        return reduce_mean(d_out_gen, 'g_adv_wass')
+    else:
+        raise ValueError('unexpected loss argument')
+
+
+def build_d_loss(d_out_direct, d_out_gen, arg_loss, summaries=None):
+    """ops.py:37-50 (one-sided label smoothing 0.9).  ``summaries`` receives the two named parts."""
+    if arg_loss == 'bce':
+        d_direct_loss = sigmoid_cross_entropy(0.9, d_out_direct, 'd_direct_bce')
+        d_gen_loss = sigmoid_cross_entropy(0.0, d_out_gen, 'd_gen_bce')
+    elif arg_loss == 'wass':
+        d_direct_loss = reduce_mean(d_out_direct, 'd_direct_wass')
+        d_gen_loss = -reduce_mean(d_out_gen, 'd_gen_wass')
+    else:
+        raise ValueError('unexpected loss argument')
+    if summaries is not None:
+        summaries['discriminator_direct_loss'] = d_direct_loss
+        summaries['discriminator_gen_loss'] = d_gen_loss
+    return d_direct_loss + d_gen_loss
+
+
+def frame_losses(g_out, next_frames):
+    """-> (sum|g_out-next_frames|, GDL) from one fused kernel (train.py:73; ops.py:100-120, alpha=1)."""
+    cache = G.get_default_graph().collections.setdefault('frame_loss_heads', {})
+    key = frozenset((g_out.root().id, next_frames.root().id))
+    head = cache.get(key)
+    if head is None:
+        head = cache[key] = FrameLossOp(g_out, next_frames)
+    return Scalar([(head, 0, 1.0)]), Scalar([(head, 1, 1.0)])
+
+
+def build_gdl(g_out, next_frames, alpha=1):
+    """ops.py:100-120 (the loss is symmetric in its arguments; the reference passes them swapped, D10)."""
+    if alpha != 1:
+        raise ValueError('build_gdl: only alpha=1 (the reference value) is implemented')
+    return frame_losses(g_out, next_frames)[1]
+
+
+def l1_norm(a, b):
+    """tf.norm(a-b, ord=1, axis=None) (train.py:73)."""
+    return frame_losses(a, b)[0]
+
+
+def l2_norm(a, b, name='l2norm'):
+    """tf.norm(a-b, ord=2, axis=None) (train.py:77)."""
+    if a.numel != b.numel:
+        raise ValueError('l2_norm: %s vs %s' % (a.shape, b.shape))
+    return Scalar([(SmallLossOp('l2norm', a, other=b, name=name), 0, 1.0)])

@@ -1,0 +1,228 @@
+"""Optimizers, the discriminator weight clip and the data-parallel gradient all-reduce.
+
+``AdamOptimizer(lr, name).minimize(loss, var_list)`` / ``RMSPropOptimizer`` keep the reference's call
+shape (train.py:91-102) and TensorFlow-1.0's update formulas.  ``minimize``:
+
+1. lays the scope's variables out in one flat parameter buffer and allocates one flat gradient buffer
+   with the same layout (graph.py), so wgrad kernels write gradients in place;
+2. builds the backward ops (graph.build_gradients) - only along paths that reach ``var_list``;
+3. with world_size > 1, cuts the flat gradient buffer into contiguous buckets in backward-completion
+   order and inserts one RCCL all-reduce per bucket right after the op that completes it, issued on a
+   side HIP stream so it overlaps the rest of backward; the optimizer step waits on all of them;
+4. appends ONE fused update launch over the flat buffers (+ the weight clip when it is fetched with it).
+"""
+import torch
+import torch.distributed as dist
+
+from . import graph as G
+from . import ops as O
+
+_p = G._ptr
+
+
+def _f32(v):
+    """TF-1.0 holds optimizer hyper-parameters as float32 constants."""
+    import numpy as np
+    return float(np.float32(v))
+
+
+class DataParallel:
+    """Per-graph data-parallel configuration (one process per GPU; RCCL via torch.distributed)."""
+
+    def __init__(self, world_size=1, n_buckets=3):
+        self.world_size, self.n_buckets = int(world_size), int(n_buckets)
+
+
+def set_data_parallel(world_size, n_buckets=3, graph=None):
+    (graph or G.get_default_graph()).collections['data_parallel'] = DataParallel(world_size, n_buckets)
+
+
+def _dp(graph):
+    return graph.collections.get('data_parallel') or DataParallel(1)
+
+
+class AllReduceOp(G.Op):
+    """Sum-all-reduce of one contiguous gradient bucket on the communication stream."""
+    host = True
+
+    def __init__(self, flat_grad, start, end, after, name):
+        super().__init__(flat_grad.graph, name, [], [], control_inputs=after)
+        self.flat_grad, self.start, self.end = flat_grad, start, end
+        self.index = max(o.index for o in after) + 0.5     # right behind the op that completes the bucket
+        self.work = None
+
+    def bind(self, rt):
+        view = self.flat_grad.buf[self.start:self.end]
+        op = self
+
+        def launch():
+            if rt.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(rt.device))
+                rt.comm_stream.wait_event(ev)
+                with torch.cuda.stream(rt.comm_stream):
+                    op.work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=rt.process_group, async_op=True)
+            else:
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=rt.process_group)
+        return launch
+
+
+class AllReduceWaitOp(G.Op):
+    """Makes the compute stream wait for every outstanding bucket (no host synchronisation)."""
+    host = True
+
+    def __init__(self, graph, reduces, name):
+        super().__init__(graph, name, [], [], control_inputs=reduces)
+        self.reduces = reduces
+
+    def bind(self, rt):
+        reduces = self.reduces
+
+        def wait():
+            for r in reduces:
+                if r.work is not None:
+                    r.work.wait()
+                    r.work = None
+        return wait
+
+
+class StepOp(G.Op):
+    """One fused optimizer launch over the flat buffers of a scope."""
+    is_optimizer_step = True
+
+    def __init__(self, opt, scope, var_names, flat_param, flat_grad, slots, deps, grad_scale):
+        super().__init__(flat_param.graph, opt.name + '/update', [flat_param, flat_grad] + slots, [], control_inputs=deps)
+        self.opt, self.scope, self.var_names, self.grad_scale = opt, scope, list(var_names), grad_scale
+        self.program_clip = None
+
+    def bind(self, rt):
+        return self.opt._bind_step(rt, self, self.program_clip)
+
+
+class ClipOp(G.Op):
+    """p.assign(tf.clip_by_value(p, lo, hi)) (train.py:89).  Ordered after the update of the same
+    program (defect D6), and folded into the optimizer kernel when it covers the optimizer's scope."""
+    is_clip = True
+    run_last = True
+
+    def __init__(self, var, lo, hi):
+        super().__init__(var.graph, 'clip/' + var.name, [var], [])
+        self.var, self.lo, self.hi = var, _f32(lo), _f32(hi)
+
+    def bind(self, rt):
+        args = (_p(self.var.buf), self.var.numel, self.lo, self.hi)
+        fn = rt.lib.clip
+        return lambda s: fn(*args, s)
+
+
+def clip_by_value_assign(var, lo, hi):
+    return ClipOp(var, lo, hi)
+
+
+class Optimizer:
+    def __init__(self, learning_rate, name):
+        self.lr, self.name = _f32(learning_rate), name
+
+    def _make_slots(self, graph, total):
+        raise NotImplementedError
+
+    def _bind_step(self, rt, step_op, clip):
+        raise NotImplementedError
+
+    def minimize(self, loss, var_list=None):
+        if not isinstance(loss, O.Scalar):
+            raise TypeError('minimize expects a loss built from this package\'s loss functions')
+        g = G.get_default_graph()
+        if var_list is None:
+            var_list = g.trainable_variables()
+        if not var_list:
+            raise ValueError('No variables to optimize.')
+        scopes = {v.scope for v in var_list}
+        if len(scopes) != 1:
+            raise ValueError('minimize: var_list must come from one top-level scope, got %s' % sorted(scopes))
+        scope = scopes.pop()
+        offsets, total, flat_param = g.layout(scope)
+        flat_grad = g.new_state((total,), 0.0, self.name + '/flat_grad')
+        heads = {}
+        for head, idx, w in loss.terms:
+            heads.setdefault(head, {})
+            heads[head][idx] = heads[head].get(idx, 0.0) + w
+        ctx = G.build_gradients(g, heads, var_list, flat_grad, offsets, O._add)
+        missing = [v.name for v in var_list if v.name not in ctx.writers]
+        if len(missing) == len(var_list):
+            raise ValueError('No gradients provided for any variable: %s' % missing)
+        writers = [op for ops_ in ctx.writers.values() for op in ops_]
+        deps = list(writers)
+        dp = _dp(g)
+        if dp.world_size > 1:
+            reduces = self._insert_allreduce(g, dp, var_list, ctx, flat_grad, offsets, total)
+            deps.append(AllReduceWaitOp(g, reduces, self.name + '/allreduce_wait'))
+        slots = self._make_slots(g, total)
+        return StepOp(self, scope, [v.name for v in var_list], flat_param, flat_grad, slots, deps, 1.0 / dp.world_size)
+
+    def _insert_allreduce(self, g, dp, var_list, ctx, flat_grad, offsets, total):
+        # Buckets are contiguous windows of the flat gradient buffer, cut from the END of the layout
+        # (the last-created layers finish their wgrad first), each reduced as soon as its last writer ran.
+        order = sorted(var_list, key=lambda v: offsets[v.name])
+        target = max(total // max(dp.n_buckets, 1), 1)
+        buckets, hi, acc = [], total, 0
+        for v in reversed(order):
+            acc = hi - offsets[v.name]
+            if acc >= target:
+                buckets.append((offsets[v.name], hi))
+                hi, acc = offsets[v.name], 0
+        if hi > 0:
+            buckets.append((0, hi))
+        reduces = []
+        for k, (lo, hi_) in enumerate(buckets):
+            after = [op for v in order if lo <= offsets[v.name] < hi_ for op in ctx.writers.get(v.name, [])]
+            if not after:
+                continue
+            reduces.append(AllReduceOp(flat_grad, lo, hi_, after, '%s/allreduce_%d' % (self.name, k)))
+        return reduces
+
+
+class AdamOptimizer(Optimizer):
+    """tf.train.AdamOptimizer: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps)."""
+
+    def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8, name='Adam'):
+        super().__init__(learning_rate, name)
+        self.b1, self.b2, self.eps = _f32(beta1), _f32(beta2), _f32(epsilon)
+
+    def _make_slots(self, graph, total):
+        return [graph.new_state((total,), 0.0, self.name + '/m'), graph.new_state((total,), 0.0, self.name + '/v'),
+                graph.new_state((1,), 0, self.name + '/step', dtype=torch.int32)]
+
+    def _bind_step(self, rt, op, clip):
+        p, g, m, v, step = op.inputs
+        lo, hi = clip if clip else (0.0, 0.0)
+        inc, adam = rt.lib.step_inc, rt.lib.adam_step
+        ps = _p(step.buf)
+        args = (_p(p.buf), _p(g.buf), _p(m.buf), _p(v.buf), ps, p.numel, self.lr, self.b1, self.b2, self.eps,
+                op.grad_scale, 1 if clip else 0, lo, hi)
+
+        def launch(s):
+            inc(ps, s)
+            adam(*args, s)
+        return launch
+
+
+class RMSPropOptimizer(Optimizer):
+    """tf.train.RMSPropOptimizer (momentum 0): ms starts at ONE; p -= lr*g/sqrt(ms+eps)."""
+
+    def __init__(self, learning_rate, decay=0.9, momentum=0.0, epsilon=1e-10, name='RMSProp'):
+        super().__init__(learning_rate, name)
+        if momentum != 0.0:
+            raise ValueError('RMSPropOptimizer: momentum is not used by the reference and is not implemented')
+        self.decay, self.eps = _f32(decay), _f32(epsilon)
+
+    def _make_slots(self, graph, total):
+        return [graph.new_state((total,), 1.0, self.name + '/ms')]
+
+    def _bind_step(self, rt, op, clip):
+        p, g, ms = op.inputs
+        lo, hi = clip if clip else (0.0, 0.0)
+        args = (_p(p.buf), _p(g.buf), _p(ms.buf), p.numel, self.lr, self.decay, self.eps, op.grad_scale,
+                1 if clip else 0, lo, hi)
+        fn = rt.lib.rmsprop_step
+        return lambda s: fn(*args, s)

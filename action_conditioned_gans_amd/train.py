@@ -1,0 +1,261 @@
+"""Adversarial training step and loop with the reference's Trainer / CLI surface (train.py:27-333).
+
+``Trainer(sess, arg_adv, arg_loss, arg_opt, arg_transform)`` builds the static graph once -
+placeholders, G, D(fake), D(real), losses, three optimizers, the D weight clip - and its step methods
+are single ``sess.run`` calls exactly as in the reference; the session prunes each fetch to what it
+needs and replays it as one HIP graph (graph.py).  Hyper-parameters the reference hard-codes as module
+constants (train.py:16-25) are constructor arguments here so that the BASELINE configurations (batch
+2/32/128/256, 128x128, ksize 11, n_critic) are expressible.
+
+Reference defects resolved here: D1 `==`; D3 D actions tiled to H/4; D4 state head
+optional in ``test``; D6 update -> clip; D7 eval uses its own states; D8 boolean flags accept
+``--adv`` and ``--adv True|False``; D9 ksize is a parameter (default 5).
+"""
+import argparse
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import graph as G
+from . import models as M
+from . import ops as O
+from . import optim
+from .util import build_all_mask
+
+ADAM_LR = 1e-3          # train.py:20
+RMSPROP_LR = 5e-5       # train.py:93
+L2_WEIGHT = 0.05        # train.py:22
+CLIP_VALUE = 0.01       # train.py:89
+PRETRAIN_ITER = 20      # train.py:24
+TRAIN_ITER = 60000      # train.py:25
+ACTION_DIM, STATE_DIM = 10, 5
+
+
+class Trainer:
+    def __init__(self, sess, arg_adv, arg_loss, arg_opt, arg_transform, batch_size=64, img_size=64, ksize=5,
+                 seed=0):
+        self.sess = sess
+        self.batch_size, self.img_size, self.ksize = batch_size, img_size, ksize
+        self.arg_adv, self.arg_loss, self.arg_opt, self.arg_transform = arg_adv, arg_loss, arg_opt, arg_transform
+        if arg_loss not in ('bce', 'wass'):
+            raise ValueError('unexpected loss argument')
+        B, S = batch_size, img_size
+        O.set_random_seed(seed)
+
+        self.img_ph = G.placeholder((B, S, S, 3), name='current_frame')
+        self.next_frame_ph = G.placeholder((B, S, S, 3), name='next_frame')
+        self.action_ph = G.placeholder((B, ACTION_DIM), name='action')
+        self.next_state = G.placeholder((B, STATE_DIM), name='next_state')
+
+        # generator (train.py:52-61); the action tile + concat is fused inside the model builders
+        if arg_transform:
+            self.g_out, self.g_state_out = M.build_generator_transform(self.img_ph, self.action_ph, batch_size=B,
+                                                                       ksize=ksize)
+        else:
+            self.g_out, self.g_state_out = M.build_generator(self.img_ph, self.action_ph), None
+        self.g_next_frame = self.g_out
+
+        # discriminator on (x_t, fake) then (x_t, real), sharing variables (train.py:63-70)
+        self.d_out_gen = M.build_discriminator(O.concat([self.img_ph, self.g_next_frame], axis=3, name='d_in_gen'),
+                                               self.action_ph, reuse=False)
+        self.d_out_real = M.build_discriminator(O.concat([self.img_ph, self.next_frame_ph], axis=3, name='d_in_real'),
+                                                self.action_ph, reuse=True)
+
+        # losses (train.py:72-85)
+        self.g_psnr = O.build_psnr(self.next_frame_ph, self.g_next_frame)
+        l1, gdl = O.frame_losses(self.g_out, self.next_frame_ph)
+        g_l2_loss = l1 / B
+        if arg_transform:
+            g_l2_loss = g_l2_loss * L2_WEIGHT + O.l2_norm(self.g_state_out, self.next_state, name='g_state_loss') / B
+        self.g_l2_loss = g_l2_loss
+        self.summaries = {}
+        if arg_adv:
+            self.g_adv_loss = O.build_g_adv_loss(self.d_out_gen, arg_loss)
+            self.g_loss = g_l2_loss + self.g_adv_loss + gdl
+            self.summaries['g_adv_loss'] = self.g_adv_loss
+        else:
+            self.g_loss = g_l2_loss
+        self.d_loss = O.build_d_loss(self.d_out_real, self.d_out_gen, arg_loss, summaries=self.summaries)
+
+        graph = G.get_default_graph()
+        self.g_vars = graph.trainable_variables('g')
+        self.d_vars = graph.trainable_variables('d')
+        self.clip_d = [optim.clip_by_value_assign(p, -CLIP_VALUE, CLIP_VALUE) for p in self.d_vars]
+
+        if arg_opt == 'rmsprop':
+            make = lambda name: optim.RMSPropOptimizer(RMSPROP_LR, name=name)
+        elif arg_opt == 'adam':
+            make = lambda name: optim.AdamOptimizer(ADAM_LR, name=name)
+        else:
+            raise ValueError('unexpected opt argument')
+        self.g_opt_op = make('g_opt').minimize(self.g_loss, var_list=self.g_vars)
+        self.g_pretrain_opt_op = make('g_pretrain_opt').minimize(g_l2_loss, var_list=self.g_vars)
+        self.d_opt_op = make('d_opt').minimize(self.d_loss, var_list=self.d_vars)
+
+        # the seven tf.summary scalars of ops.py:48-49 / train.py:104-111, names kept
+        self.summaries.update({'discriminator_loss': self.d_loss, 'g_loss': self.g_loss, 'g_l2_loss': g_l2_loss,
+                               'g_psnr': self.g_psnr})
+        self._summary_names = sorted(self.summaries)
+        self.merged_summaries = [self.summaries[k] for k in self._summary_names]
+        self._zero_state = np.zeros((B, STATE_DIM), np.float32)
+
+    # ---- steps: one sess.run each (train.py:114-155)
+    def _feed(self, input_images, next_frame, actions, state=None):
+        return {self.img_ph: input_images, self.next_frame_ph: next_frame, self.action_ph: actions,
+                self.next_state: self._zero_state if state is None else state}
+
+    def pretrain_g(self, input_images, next_frame, actions, state):
+        _, g_res = self.sess.run([self.g_pretrain_opt_op, self.g_loss], self._feed(input_images, next_frame, actions, state))
+        return float(g_res[0])
+
+    def train_g(self, input_images, next_frame, actions, state, device_fetch=False):
+        _, gen_next_frames = self.sess.run([self.g_opt_op, self.g_next_frame],
+                                           self._feed(input_images, next_frame, actions, state), device_fetch=device_fetch)
+        return gen_next_frames
+
+    def train_d(self, input_images, next_frame, actions, summarize=False):
+        fd = self._feed(input_images, next_frame, actions)
+        if summarize:
+            _, summ, _ = self.sess.run([self.d_opt_op, self.merged_summaries, self.clip_d], fd)
+            return self._named(summ)
+        self.sess.run([self.d_opt_op, self.clip_d], fd)
+        return None
+
+    def test(self, input_images, next_frame, actions):
+        tensors = [self.g_next_frame] + ([self.g_state_out] if self.g_state_out is not None else []) + [self.merged_summaries]
+        res = self.sess.run(tensors, self._feed(input_images, next_frame, actions))
+        gen_next_frames, summ = res[0], res[-1]
+        gen_next_state = res[1] if self.g_state_out is not None else None      # defect D4
+        return gen_next_frames, gen_next_state, self._named(summ)
+
+    def test_sequence(self, input_images, test_next_frame, test_actions, steps=None):
+        """Recursive rollout (train.py:157-176): feed each prediction (and predicted state) back in."""
+        steps = steps if steps is not None else test_next_frame.shape[1] - 1
+        predicted, summ0 = [], None
+        current_frame = input_images[:, 0]
+        current_state = test_actions[:, 0, 5:]
+        for j in range(steps):
+            acs = np.concatenate((test_actions[:, j, :5], current_state), axis=1).astype(np.float32)
+            out, st, summ = self.test(current_frame, test_next_frame[:, j + 1], acs)
+            summ0 = summ0 or summ
+            predicted.append(out)
+            current_frame = out
+            current_state = st if st is not None else test_actions[:, j + 1, 5:]
+        return np.transpose(np.array(predicted), (1, 0, 2, 3, 4)), summ0
+
+    def _named(self, values):
+        return {k: float(np.asarray(v).reshape(-1)[0]) for k, v in zip(self._summary_names, values)}
+
+
+# ---- synthetic push-style data (rng(7), frames U(-1,1), action||state N(0,1)) ----------
+class SyntheticPush:
+    def __init__(self, batch_size, seq_len=8, img_size=64, seed=7, rank=0):
+        self.rng = np.random.default_rng(seed + 1000 * rank)
+        self.shape = (batch_size, seq_len, img_size, img_size, 3)
+        self.batch_size, self.seq_len = batch_size, seq_len
+
+    def get_batch(self):
+        """-> (frames, frames, action||state [B,T,10], state [B,T,5]) like ops.get_batch (ops.py:15-17)."""
+        img = self.rng.uniform(-1.0, 1.0, self.shape).astype(np.float32)
+        acts = self.rng.standard_normal((self.batch_size, self.seq_len, ACTION_DIM)).astype(np.float32)
+        return img, img, acts, acts[:, :, 5:].copy()
+
+
+def select_pairs(rng_randint, boolean_mask, batch_size):
+    """(t, t+1) selection of train.py:231-232,249-250,258-259."""
+    start_mask = boolean_mask[rng_randint(0, len(boolean_mask), size=batch_size)]
+    return start_mask, np.roll(start_mask, 1, axis=1)
+
+
+def _log_jsonl(path, record):
+    with open(path, 'a') as f:
+        f.write(json.dumps(record) + '\n')
+
+
+def train(input_path, output_path, test_output_path, log_dir, model_dir, arg_adv, arg_loss, arg_opt, arg_transform,
+          batch_size=64, img_size=64, seq_len=8, ksize=5, train_iter=TRAIN_ITER, pretrain_iter=PRETRAIN_ITER,
+          n_critic=None, device='cuda:0', world_size=1, rank=0, process_group=None, log_every=100, quiet=False):
+    """Training loop of train.py:179-309 on synthetic sequences (the TFRecord pipeline is out of scope)."""
+    if input_path not in (None, '', 'synthetic'):
+        raise ValueError('only synthetic input is supported (input_path="synthetic"); the push-dataset TFRecord '
+                         'pipeline of ops.py:122-223 is outside the hot path')
+    np.random.seed(7)                                           # train.py:14
+    data = SyntheticPush(batch_size, seq_len, img_size, rank=rank)
+    boolean_mask = build_all_mask(seq_len)
+    G.reset_default_graph()
+    optim.set_data_parallel(world_size)
+    with G.Session(device=device, world_size=world_size, rank=rank, process_group=process_group) as sess:
+        trainer = Trainer(sess, arg_adv, arg_loss, arg_opt, arg_transform, batch_size, img_size, ksize)
+        sess.run(G.global_variables_initializer())
+        D_per_G = n_critic if n_critic else (5 if arg_loss == 'wass' else 1)      # train.py:217-220
+        log_file = os.path.join(log_dir, 'train.jsonl') if log_dir else None
+        t0 = time.time()
+        for i in range(train_iter):
+            if i < pretrain_iter:
+                inp, nxt, acts, states = data.get_batch()
+                sm, em = select_pairs(np.random.randint, boolean_mask, batch_size)
+                loss = trainer.pretrain_g(inp[sm], nxt[em], acts[sm], states[em])
+                if not quiet:
+                    print('pre-train iter: ' + str(i))
+                continue
+            summ = None
+            for j in range(D_per_G):
+                inp, nxt, acts, states = data.get_batch()
+                sm, em = select_pairs(np.random.randint, boolean_mask, batch_size)
+                summ = trainer.train_d(inp[sm], nxt[em], acts[sm], summarize=(i % log_every == 0) and (j == D_per_G - 1))
+            sm, em = select_pairs(np.random.randint, boolean_mask, batch_size)
+            trainer.train_g(inp[sm], nxt[em], acts[sm], states[em])
+            if i % log_every == 0 and rank == 0:
+                if not quiet:
+                    print('Iteration {:d}'.format(i))
+                if log_file and summ:
+                    _log_jsonl(log_file, dict(summ, iteration=i, wall_s=time.time() - t0))
+        return trainer
+
+
+def _flag(v):
+    if isinstance(v, bool):
+        return v
+    if v.lower() in ('true', '1', 'yes'):
+        return True
+    if v.lower() in ('false', '0', 'no'):
+        return False
+    raise argparse.ArgumentTypeError('boolean expected')
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(description='action-conditioned video-prediction GAN on MI355X')
+    parser.add_argument('input_path', type=str)
+    parser.add_argument('output_path', type=str)
+    parser.add_argument('--adv', nargs='?', const=True, default=False, type=_flag)
+    parser.add_argument('--loss', type=str, default='bce')
+    parser.add_argument('--opt', type=str, default='adam')
+    parser.add_argument('--dna', nargs='?', const=True, default=False, type=_flag)
+    parser.add_argument('--batch_size', type=int, default=64)
+    parser.add_argument('--img_size', type=int, default=64)
+    parser.add_argument('--seq_len', type=int, default=8)
+    parser.add_argument('--ksize', type=int, default=5)
+    parser.add_argument('--n_critic', type=int, default=None)
+    parser.add_argument('--train_iter', type=int, default=TRAIN_ITER)
+    parser.add_argument('--pretrain_iter', type=int, default=PRETRAIN_ITER)
+    args = parser.parse_args(argv)
+    model_dir = os.path.join(args.output_path, 'models')
+    log_dir = os.path.join(args.output_path, 'logs')
+    os.makedirs(args.output_path)
+    os.makedirs(model_dir)
+    os.makedirs(log_dir)
+    world_size, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world_size > 1:
+        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    train(args.input_path, os.path.join(args.output_path, 'train_output'), os.path.join(args.output_path, 'test_output'),
+          log_dir, model_dir, args.adv, args.loss, args.opt, args.dna, batch_size=args.batch_size, img_size=args.img_size,
+          seq_len=args.seq_len, ksize=args.ksize, train_iter=args.train_iter, pretrain_iter=args.pretrain_iter,
+          n_critic=args.n_critic, device='cuda:%d' % local_rank, world_size=world_size, rank=rank)
+
+
+if __name__ == '__main__':
+    main()

@@ -104,7 +104,8 @@ int32_t acg_bn_act_bwd(const void* x, const void* dy, const float* beta, const f
                        int32_t dtype, void* workspace, size_t workspace_bytes, acg_stream_t stream);
 
 /* Layers built with normalizer_fn=None: y = act(x + bias)   (models.py:20-21,44-51,54-59).
- * bwd takes the forward OUTPUT y; dx may be NULL when act == ACG_ACT_NONE (dx == dy). */
+ * bwd takes the forward OUTPUT y; dx may be NULL when act == ACG_ACT_NONE (dx == dy).
+ * bias == NULL (fwd) / dbias == NULL (bwd) give the plain activation (ops.py:22-26 lrelu called on its own). */
 size_t acg_bias_workspace_bytes(int64_t rows, int32_t channels);
 int32_t acg_bias_act_fwd(const void* x, const float* bias, void* y, int64_t rows, int32_t channels,
                          int32_t act, float leak, int32_t dtype, acg_stream_t stream);

@@ -180,7 +180,7 @@ int32_t acg_bias_act_fwd(const void* xv, const float* bias, void* yv, int64_t ro
   (void)s; REQUIRE_F32(dtype);
   const float* x = xv; float* y = yv;
   for (int64_t r = 0; r < rows; r++) for (int c = 0; c < C; c++)
-    y[r * C + c] = (float)act_f(act, (double)x[r * C + c] + bias[c], leak);
+    y[r * C + c] = (float)act_f(act, (double)x[r * C + c] + (bias ? bias[c] : 0.f), leak);
   return ACG_OK;
 }
 int32_t acg_bias_act_bwd(const void* yv, const void* dyv, void* dxv, float* dbias, float dbias_acc, int64_t rows,
@@ -201,7 +201,7 @@ int32_t acg_bias_act_bwd(const void* yv, const void* dyv, void* dxv, float* dbia
       double g = dy[r * C + c] * d; sum += g;
       if (dx) dx[r * C + c] = (float)g;
     }
-    dbias[c] = (float)((dbias_acc != 0.f ? (double)dbias_acc * dbias[c] : 0.0) + sum);
+    if (dbias) dbias[c] = (float)((dbias_acc != 0.f ? (double)dbias_acc * dbias[c] : 0.0) + sum);
   }
   return ACG_OK;
 }

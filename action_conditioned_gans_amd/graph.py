@@ -415,7 +415,7 @@ class Session:
                     cur = []
                 segments.append(('host', fn))
             else:
-                cur.append(fn)
+                cur.append((op, fn))
         if cur:
             segments.append(('dev', cur))
         fetch_tensors = []
@@ -480,6 +480,42 @@ class Session:
             return results[0]
         return self._unflatten(fetches, iter(results))
 
+    def profile_ops(self, fetches, feed_dict=None, repeats=3):
+        """Instrumented eager pass of a fetch: every device op is bracketed by events recorded on the
+        launch stream.  Returns [(op, mean milliseconds)] in program order.  Executes the program
+        ``repeats`` times for real (optimizer steps included)."""
+        if not self.rt.is_cuda:
+            raise RuntimeError('profile_ops needs a GPU session')
+        flat = self._flatten(fetches)
+        key = (tuple(id(f) for f in flat), tuple(id(k) for k in (feed_dict or {})))
+        if key not in self._programs:
+            self.run(fetches, feed_dict)
+        prog = self._programs[key]
+        for ph, val in (feed_dict or {}).items():
+            ph.buf.copy_(val if torch.is_tensor(val) else torch.from_numpy(np.ascontiguousarray(val)), non_blocking=True)
+        stream = torch.cuda.current_stream(self.rt.device)
+        records = []
+        for _ in range(repeats):
+            for kind, seg in prog.segments:
+                if kind == 'host':
+                    seg()
+                    continue
+                sp = self.rt.stream_ptr()
+                for op, fn in seg:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    fn(sp)
+                    e1.record(stream)
+                    records.append((op, e0, e1))
+        torch.cuda.synchronize(self.rt.device)
+        totals, order = {}, []
+        for op, e0, e1 in records:
+            if id(op) not in totals:
+                totals[id(op)] = [op, 0.0]
+                order.append(id(op))
+            totals[id(op)][1] += e0.elapsed_time(e1)
+        return [(totals[i][0], totals[i][1] / repeats) for i in order]
+
     def _unflatten(self, fetches, it):
         if isinstance(fetches, (list, tuple)):
             return [self._unflatten(f, it) for f in fetches]
@@ -495,7 +531,7 @@ class Session:
                     seg()
                 else:
                     sp = rt.stream_ptr()
-                    for fn in seg:
+                    for _, fn in seg:
                         fn(sp)
             return
         if prog.graphs is None:
@@ -508,7 +544,7 @@ class Session:
                 gr = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gr):
                     sp = rt.stream_ptr()       # the capture stream
-                    for fn in seg:
+                    for _, fn in seg:
                         fn(sp)
                 prog.graphs.append(gr)
         for (kind, seg), gr in zip(prog.segments, prog.graphs):

@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""Headline benchmark: GAN train steps/sec (G+D) on synthetic 64x64x3 T=8 push-style sequences.
+
+One step = n_critic discriminator steps + 1 generator step exactly as train.py:241-263 sequences them
+(n_critic = 1 for bce, 5 for wass), at BASELINE config 2 per GPU: batch 32, --adv --loss bce --dna (k=5),
+Adam, fp32.  N > 1 (launched by torch.distributed.run, one rank per GPU) is weak scaling: every rank
+runs the same per-GPU batch and gradients are all-reduced over RCCL; `value` counts the batch-32 steps
+completed by ALL ranks per second.  Inputs are resident in HBM before the timed region.
+
+Besides the contract line it reports
+  roofline      conv_mfma_f32 launches (every conv/deconv fwd, dgrad, wgrad of the step): algorithmic
+                FLOPs (2*B*OH*OW*KH*KW*Cin*Cout per contraction) / their event-timed
+                duration, against the fp32 matrix-core peak (157.3 TFLOP/s);
+  roofline_dna  the DNA stencil forward: algorithmic bytes (k*k+6)*4 per pixel / event-timed duration,
+                against 8 TB/s;
+  cpu_baseline  the CPU restatement of the reference step (oracle/, torch-CPU fp32; TF-1.0 itself cannot
+                run here) on this host's cores, on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md chip table
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='per-GPU batch')
+    ap.add_argument('--img', type=int, default=64)
+    ap.add_argument('--seq_len', type=int, default=8)
+    ap.add_argument('--ksize', type=int, default=5)
+    ap.add_argument('--loss', default='bce')
+    ap.add_argument('--opt', default='adam')
+    ap.add_argument('--plain', action='store_true', help='plain generator instead of DNA')
+    ap.add_argument('--no-adv', action='store_true')
+    ap.add_argument('--no-graphs', action='store_true', help='eager launches instead of HIP-graph replay')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--profile-repeats', type=int, default=3)
+    ap.add_argument('--cpu-steps', type=int, default=20)
+    return ap.parse_args()
+
+
+def conv_flops(op):
+    d = op.desc
+    return 2.0 * d.batch * d.out_h * d.out_w * d.kh * d.kw * d.in_c * d.out_c
+
+
+def cpu_baseline(args, n_critic):
+    """The CPU restatement of the reference step on this host (the checker, timed - never shipped)."""
+    from oracle import models as OM
+    from oracle.trainer import OracleTrainer
+    B, S = args.batch, args.img
+    cores = torch.get_num_threads()
+    params = OM.init_params(not args.plain, batch=2, img=S, ksize=args.ksize, seed=0, dtype=torch.float32)
+    tr = OracleTrainer(params, not args.no_adv, args.loss, args.opt, not args.plain, args.ksize)
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(B, S, S, 3, generator=g) * 2 - 1
+    y = torch.rand(B, S, S, 3, generator=g) * 2 - 1
+    a = torch.randn(B, 10, generator=g)
+    s = torch.randn(B, 5, generator=g)
+
+    def step():
+        for _ in range(n_critic):
+            tr.train_d(x, y, a)
+        tr.train_g(x, y, a, s)
+    step()
+    t0 = time.time()
+    n = 0
+    while n < args.cpu_steps and (n == 0 or time.time() - t0 < 30.0):
+        step()
+        n += 1
+    dt = time.time() - t0
+    return {'value': n / dt, 'unit': 'steps/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d (D+G) steps at the same shapes (batch %d), torch-CPU fp32 restatement of the TF-1.0 step, '
+                      '%d threads' % (n, B, cores)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('--gpus %d needs torch.distributed.run with --nproc-per-node %d' % (args.gpus, args.gpus))
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=device)
+
+    from action_conditioned_gans_amd import graph as G, ops as O, optim, train as T
+
+    B, S, dna, adv = args.batch, args.img, not args.plain, not args.no_adv
+    n_critic = 5 if args.loss == 'wass' else 1
+    G.reset_default_graph()
+    optim.set_data_parallel(world)
+    sess = G.Session(device=device, use_hip_graphs=not args.no_graphs, world_size=world, rank=rank, process_group=pg)
+    tr = T.Trainer(sess, adv, args.loss, args.opt, dna, batch_size=B, img_size=S, ksize=args.ksize, seed=0)
+    sess.run(G.global_variables_initializer())
+
+    # synthetic push-style sequences, resident in HBM; (t, t+1) pairs selected as train.py:231-237 does
+    rng = np.random.default_rng(7 + 1000 * rank)
+    np.random.seed(7 + rank)
+    mask = T.build_all_mask(args.seq_len)
+    pool = []
+    for _ in range(4):
+        img = rng.uniform(-1, 1, (B, args.seq_len, S, S, 3)).astype(np.float32)
+        acts = rng.standard_normal((B, args.seq_len, 10)).astype(np.float32)
+        sm, em = T.select_pairs(np.random.randint, mask, B)
+        pool.append(tuple(torch.from_numpy(t).to(device) for t in (img[sm], img[em], acts[sm], acts[:, :, 5:][em])))
+    torch.cuda.synchronize()
+
+    def step(i):
+        for j in range(n_critic):
+            x, y, a, s = pool[(i * n_critic + j) % len(pool)]
+            tr.train_d(x, y, a)
+        x, y, a, s = pool[i % len(pool)]
+        return tr.train_g(x, y, a, s, device_fetch=True)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(3):            # run 1 eager, run 2 captures the HIP graphs, run 3 replays
+        step(i)
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        frames = step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(frames).all(), 'generated frames are not finite'
+
+    # ---- per-kernel event timing (instrumented eager pass, after the timed region) --------------
+    roof, roof_dna, kernel_ms = None, None, {}
+    if rank == 0:
+        x, y, a, s = pool[0]
+        zero_state = torch.zeros(B, 5, device=device)
+        recs = []
+        recs += sess.profile_ops([tr.d_opt_op, tr.clip_d], tr._feed(x, y, a, zero_state), repeats=args.profile_repeats) * n_critic
+        recs += sess.profile_ops([tr.g_opt_op, tr.g_next_frame], tr._feed(x, y, a, s), repeats=args.profile_repeats)
+        conv_ms = conv_fl = 0.0
+        n_conv = 0
+        dna_ms = dna_bytes = 0.0
+        for op, ms in recs:
+            kind = type(op).__name__
+            kernel_ms[kind] = kernel_ms.get(kind, 0.0) + ms
+            if isinstance(op, O._ConvBase):
+                conv_ms += ms
+                conv_fl += conv_flops(op)
+                n_conv += 1
+            elif kind == 'DnaOp':
+                b, h, w, c = op.inputs[1].shape
+                dna_ms += ms
+                dna_bytes += b * h * w * (op.ksize * op.ksize + 2 * c) * 4.0
+        if conv_ms > 0:
+            ach = conv_fl / (conv_ms * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                    'kernel': 'conv_mfma_f32<*> (+splitk_reduce): %d conv/deconv fwd+dgrad+wgrad launches per step' % n_conv,
+                    'algorithmic_gflop_per_step': round(conv_fl / 1e9, 2), 'ms_per_step_in_kernel': round(conv_ms, 4),
+                    'avg_launch_us': round(conv_ms * 1e3 / max(n_conv, 1), 2)}
+        if dna_ms > 0:
+            gbs = dna_bytes / (dna_ms * 1e-3) / 1e9
+            roof_dna = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                        'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': None, 'kernel': 'dna_kernel<K,TY,fwd>',
+                        'algorithmic_mb_per_step': round(dna_bytes / 1e6, 2), 'ms_per_step_in_kernel': round(dna_ms, 4)}
+
+    if rank != 0:
+        return
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, n_critic)
+    line = {
+        'metric': 'GAN train steps/sec (G+D) on 64x64x3xT=8 push seq', 'value': round(world * args.steps / elapsed, 3),
+        'unit': 'steps/s (batch-%d G+D steps, all ranks)' % B, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'BASELINE config 2 per GPU: batch=%d %dx%dx3 T=%d %s--loss %s %s(k=%d) --opt %s fp32'
+                               % (B, S, S, args.seq_len, '--adv ' if adv else '', args.loss, '--dna ' if dna else 'plain-G ',
+                                  args.ksize, args.opt),
+                   'global_batch': B * world, 'n_critic': n_critic, 'parallelism': 'dp%d' % world,
+                   'hip_graphs': not args.no_graphs, 'sequences_per_s': round(world * B * args.steps / elapsed, 1)},
+        'roofline': roof, 'roofline_dna': roof_dna, 'cpu_baseline': cpu,
+        'op_ms_per_step': {k: round(v, 4) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])},
+    }
+    print(json.dumps(line))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,65 @@
+"""GPU parity of the whole training step (host runtime over libacgan_hip.so) against the fp64-oracle
+golden vectors, plus HIP-graph replay equivalence.  Tolerance: 1e-3 rel (north_star) on frames and
+losses; gradients are compared per variable by L2 norm at 10x that."""
+import numpy as np
+import pytest
+import torch
+
+import train_cases as TC
+
+from action_conditioned_gans_amd import graph as G
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_session(**kw):
+    return G.Session(device='cuda:0', **kw)
+
+
+@pytest.mark.parametrize('name', sorted(TC.MG.CASES))
+def test_trainer_matches_golden(name):
+    TC.case_golden(gpu_session, name, 1e-3)
+
+
+@pytest.mark.parametrize('name', ['c2_dna_bce_adam', 'c4_dna_wass_rmsprop'])
+def test_hip_graph_replay_equals_eager(name):
+    """Run 1 is eager, run 2 captures, run 3+ replays: the weights must match an all-eager session bit for bit."""
+    x, y, a, s = TC.MG.inputs(2)
+    finals = []
+    for use_graphs in (False, True):
+        sess, tr = TC.build_trainer(gpu_session, name, use_hip_graphs=use_graphs)
+        for _ in range(4):
+            tr.train_d(x, y, a)
+            frames = tr.train_g(x, y, a, s)
+        torch.cuda.synchronize()
+        finals.append(({n: sess.get_value(v) for n, v in G.get_default_graph().variables.items()}, frames))
+        if use_graphs:
+            assert all(p.graphs is not None for p in sess._programs.values() if p.runs >= 2)
+    (pe, fe), (pg, fg) = finals
+    for n in pe:
+        assert torch.equal(pe[n], pg[n]), n
+    assert np.array_equal(fe, fg)
+
+
+def test_batch32_step_is_finite_and_learns():
+    """BASELINE config 2 shapes (B=32, DNA k=5, bce, Adam): a few steps run, stay finite, and the pretrain
+    loss goes down on a fixed batch."""
+    from action_conditioned_gans_amd import optim, train as T
+    G.reset_default_graph()
+    optim.set_data_parallel(1)
+    sess = gpu_session()
+    tr = T.Trainer(sess, True, 'bce', 'adam', True, batch_size=32, img_size=64, ksize=5)
+    sess.run(G.global_variables_initializer())
+    rng = np.random.default_rng(7)
+    x = rng.uniform(-1, 1, (32, 64, 64, 3)).astype(np.float32)
+    y = np.roll(x, 1, axis=2)
+    a = rng.standard_normal((32, 10)).astype(np.float32)
+    s = rng.standard_normal((32, 5)).astype(np.float32)
+    losses = [tr.pretrain_g(x, y, a, s) for _ in range(8)]
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses
+    for _ in range(3):
+        summ = tr.train_d(x, y, a, summarize=True)
+        frames = tr.train_g(x, y, a, s)
+    assert all(np.isfinite(v) for v in summ.values()), summ
+    assert np.isfinite(frames).all()

@@ -1,0 +1,116 @@
+"""Trainer-level parity cases shared by the CPU suite (host runtime over the C-oracle stand-in library)
+and the GPU suite (host runtime over libacgan_hip.so).  Targets: tests/golden/*.npz (fp64 oracle)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+
+import make_golden as MG                                     # noqa: E402
+from oracle import models as OM                              # noqa: E402
+
+from action_conditioned_gans_amd import graph as G           # noqa: E402
+from action_conditioned_gans_amd import optim                # noqa: E402
+from action_conditioned_gans_amd import train as T           # noqa: E402
+
+
+def golden(name):
+    return dict(np.load(os.path.join(HERE, 'golden', name + '.npz')))
+
+
+def rel(got, want):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+
+
+def build_trainer(make_session, name, world_size=1, **sess_kw):
+    adv, loss, opt, dna, batch, ksize = MG.CASES[name]
+    G.reset_default_graph()
+    optim.set_data_parallel(world_size)
+    sess = make_session(**sess_kw)
+    tr = T.Trainer(sess, adv, loss, opt, dna, batch_size=batch, img_size=64, ksize=ksize)
+    sess.run(G.global_variables_initializer())
+    params = OM.init_params(dna, batch=batch, ksize=ksize, seed=MG.PARAM_SEED, dtype=torch.float32)
+    g = G.get_default_graph()
+    assert set(params) == set(g.variables), sorted(set(params) ^ set(g.variables))
+    for n, v in g.variables.items():
+        assert tuple(params[n].shape) == v.shape, (n, tuple(params[n].shape), v.shape)
+        sess.set_value(v, params[n])
+    return sess, tr
+
+
+def flat_grad_norms(sess, step_op):
+    """Per-variable L2 norms of an optimizer's flat gradient buffer."""
+    g = G.get_default_graph()
+    offs, _, _ = g.layout(step_op.scope)
+    flat = step_op.inputs[1].buf.detach().double().cpu()
+    return {n: float(flat[o:o + g.variables[n].numel].norm()) for n, o in offs.items()}
+
+
+def check_norms(got, gold, prefix, tol, what):
+    ref = {k[len(prefix):]: float(v) for k, v in gold.items() if k.startswith(prefix)}
+    assert ref, 'no golden entries for ' + prefix
+    scale = max(max(ref.values()), 0.1)
+    for n, want in ref.items():
+        if want < 1e-7 * scale:            # analytically (near-)zero gradient (e.g. the wass D step): bound it instead
+            assert got[n] <= 1e-4 * scale, '%s %s: %g should be ~0' % (what, n, got[n])
+        else:
+            assert abs(got[n] - want) <= tol * want + 1e-6 * scale, '%s %s: %g vs %g' % (what, n, got[n], want)
+
+
+def case_golden(make_session, name, tol):
+    """frames / losses / gradients / (RMSProp) updated weights against the golden vectors."""
+    adv, loss, opt, dna, batch, ksize = MG.CASES[name]
+    gold = golden(name)
+    x, y, a, s = MG.inputs(batch)
+    sess, tr = build_trainer(make_session, name)
+    frame, state, summ = tr.test(x, y, a)
+    assert rel(frame, gold['frame']) <= tol, 'frame rel err %g' % rel(frame, gold['frame'])
+    if dna:
+        assert rel(state, gold['state']) <= tol, 'state rel err %g' % rel(state, gold['state'])
+    assert abs(summ['g_psnr'] - gold['psnr']) <= tol * abs(gold['psnr']) + 1e-4
+    # D step
+    dsumm = tr.train_d(x, y, a, summarize=True)
+    dscale = max(abs(gold['d_direct_loss']), abs(gold['d_gen_loss']), 1.0)   # logits are O(1); wass sums cancel to ~0
+    assert abs(dsumm['discriminator_loss'] - gold['d_loss']) <= tol * dscale
+    assert abs(dsumm['discriminator_direct_loss'] - gold['d_direct_loss']) <= tol * dscale
+    assert abs(dsumm['discriminator_gen_loss'] - gold['d_gen_loss']) <= tol * dscale
+    check_norms(flat_grad_norms(sess, tr.d_opt_op), gold, 'dgrad_norm/', 10 * tol, 'D grad')
+    # G step (values are those of the forward pass inside the step, i.e. before the update)
+    fetch = [tr.g_opt_op, tr.g_loss, tr.g_l2_loss] + ([tr.g_adv_loss] if adv else [])
+    res = sess.run(fetch, tr._feed(x, y, a, s))
+    assert abs(res[1][0] - gold['g_loss']) <= tol * abs(gold['g_loss'])
+    assert abs(res[2][0] - gold['g_l2_loss']) <= tol * abs(gold['g_l2_loss'])
+    if adv:
+        assert abs(res[3][0] - gold['g_adv_loss']) <= tol * max(abs(gold['g_adv_loss']), 1e-2)
+    check_norms(flat_grad_norms(sess, tr.g_opt_op), gold, 'ggrad_norm/', 10 * tol, 'G grad')
+    if opt == 'rmsprop':
+        g = G.get_default_graph()
+        got = {n: float(sess.get_value(v).double().norm()) for n, v in g.variables.items()}
+        check_norms(got, gold, 'param_norm/', tol, 'param after 1D+1G')
+    return sess, tr
+
+
+def program_op_names(sess, fetches, feeds):
+    """Names of the ops a fetch compiles to (after pruning), without running it."""
+    flat = sess._flatten(fetches)
+    g = sess.graph
+    needed, stack = {}, []
+    for f in flat:
+        if isinstance(f, G.Op):
+            stack.append(f)
+        else:
+            t = f if isinstance(f, G.Tensor) else f.tensor()
+            if t.op is not None:
+                stack.append(t.op)
+    while stack:
+        op = stack.pop()
+        if id(op) in needed:
+            continue
+        needed[id(op)] = op
+        stack.extend(t.op for t in op.inputs if t.op is not None)
+        stack.extend(op.control_inputs)
+    return sorted((o.index, type(o).__name__, o.name) for o in needed.values())

@@ -39,6 +39,7 @@ SIGNATURES = {
     'acg_last_error': (c_char_p, []),
     'acg_conv_desc_init': (c_int32, [_D] + [c_int32] * 9),
     'acg_conv2d_workspace_bytes': (c_size_t, [_D, c_int32, c_int32]),
+    'acg_debug_conv_plan': (c_int32, [c_int32, c_int32]),
     'acg_conv2d_fwd': (c_int32, _conv),
     'acg_conv2d_dgrad': (c_int32, _conv),
     'acg_conv2d_wgrad': (c_int32, _wgrad),

@@ -2,17 +2,17 @@
 //
 // HBM-bound; every pass walks memory in address order: a 256-thread block is laid out as
 // (256 / Cb) rows x Cb channels (Cb = min(C, 256)), so consecutive lanes touch consecutive floats and
-// a wave never needs a per-element modulo.  Per-channel statistics: pass 1 leaves per-block partial
-// sums (shifted by the group's first row, so E[x^2]-E[x]^2 cannot cancel catastrophically) in the
-// workspace; pass 2 re-derives mean / rstd from the partials in fp64 inside every block (a few KB from
-// L2) and applies normalise + activation - two launches, no atomics, deterministic.
+// a wave never needs a per-element modulo; lanes move float4 when C % 4 == 0.  Per-channel statistics:
+// pass 1 leaves per-block partial sums (shifted by the group's first row, so E[x^2]-E[x]^2 cannot
+// cancel catastrophically) in the workspace; a one-wave-per-channel finalize combines them in fp64;
+// pass 2 applies normalise + activation.  Three launches, no atomics, deterministic.
 #include <hip/hip_runtime.h>
 
 #include "common.h"
 
 namespace {
 
-constexpr int kMaxPartialBlocks = 128;
+constexpr int kMaxPartialBlocks = 512;
 constexpr int kMaxC = 1024;
 
 struct ColMap {
@@ -43,136 +43,227 @@ __device__ __forceinline__ void reduce_rsub(const ColMap& m, float& a, float& b,
   }
 }
 
+// ---- vectorised [rows, C] walking ----------------------------------------------------------------------
+// V = 4 floats per lane when C % 4 == 0 (every BatchNorm'd layer of the models except d/conv6), else 1.
+template <int V>
+struct VMap {
+  int Cv, Cb, RPP, cl, rsub, nchunk;
+  bool active;
+};
+template <int V>
+__device__ __forceinline__ VMap<V> vmap(int C) {
+  VMap<V> m;
+  m.Cv = C / V;
+  m.Cb = m.Cv < 256 ? m.Cv : 256;
+  m.RPP = 256 / m.Cb;
+  m.cl = threadIdx.x % m.Cb;
+  m.rsub = threadIdx.x / m.Cb;
+  m.active = m.rsub < m.RPP;
+  m.nchunk = (m.Cv + m.Cb - 1) / m.Cb;
+  return m;
+}
+template <int V>
+__device__ __forceinline__ void ldv(const float* p, float (&v)[V]) {
+  if constexpr (V == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+  else v[0] = *p;
+}
+template <int V>
+__device__ __forceinline__ void stv(float* p, const float (&v)[V]) {
+  if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  else *p = v[0];
+}
+
+// Reduce 2*V per-thread values over the rsub dimension through LDS (sh: 2*V*256 floats); valid where rsub == 0.
+template <int V>
+__device__ __forceinline__ void reduce_rsub_v(const VMap<V>& m, float (&a)[V], float (&b)[V], float* sh) {
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < V; ++j) { sh[j * 256 + threadIdx.x] = a[j]; sh[(V + j) * 256 + threadIdx.x] = b[j]; }
+  __syncthreads();
+  if (m.active && m.rsub == 0) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float sa = 0.f, sb = 0.f;
+      for (int r = 0; r < m.RPP; ++r) { sa += sh[j * 256 + r * m.Cb + m.cl]; sb += sh[(V + j) * 256 + r * m.Cb + m.cl]; }
+      a[j] = sa; b[j] = sb;
+    }
+  }
+}
+
+// partial layout: part[((g * nblk + b) * 2 + which) * C + c]
 // ---- BN forward ---------------------------------------------------------------------------------------
+template <int V>
 __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ x, float* __restrict__ part,
                                                         long long R, int C, int nblk) {
-  __shared__ float sh[512];
-  const ColMap m = col_map(C);
+  __shared__ float sh[2 * V * 256];
+  const VMap<V> m = vmap<V>(C);
   const int g = blockIdx.y, b = blockIdx.x;
   const float* xg = x + (long long)g * R * C;
   const long long rpb = (R + nblk - 1) / nblk;
   const long long r0 = (long long)b * rpb, r1 = min(R, r0 + rpb);
   for (int ch = 0; ch < m.nchunk; ++ch) {
-    const int c = ch * m.Cb + m.cl;
-    float s1 = 0.f, s2 = 0.f;
-    if (m.active && c < C) {
-      const float pivot = xg[c];
+    const int cv = ch * m.Cb + m.cl, c = cv * V;
+    float s1[V], s2[V], pv[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { s1[j] = 0.f; s2[j] = 0.f; pv[j] = 0.f; }
+    if (m.active && cv < m.Cv) {
+      ldv<V>(xg + c, pv);   // shift by the group's first row: E[d^2]-E[d]^2 cannot cancel catastrophically
+#pragma unroll 4
       for (long long r = r0 + m.rsub; r < r1; r += m.RPP) {
-        const float d = xg[r * C + c] - pivot;
-        s1 += d; s2 += d * d;
+        float v[V];
+        ldv<V>(xg + r * C + c, v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) { const float d = v[j] - pv[j]; s1[j] += d; s2[j] += d * d; }
       }
     }
-    reduce_rsub(m, s1, s2, sh);
-    if (m.active && m.rsub == 0 && c < C) {
-      float* o = part + (((long long)g * nblk + b) * C + c) * 2;
-      o[0] = s1; o[1] = s2;
+    reduce_rsub_v<V>(m, s1, s2, sh);
+    if (m.active && m.rsub == 0 && cv < m.Cv) {
+      float* o = part + ((long long)g * nblk + b) * 2 * C + c;
+      stv<V>(o, s1);
+      stv<V>(o + C, s2);
     }
   }
 }
 
+// one wave per (group, channel): mean / rstd from the partials, fp64 combine
+__global__ __launch_bounds__(256) void bn_finalize_fwd(const float* __restrict__ x, const float* __restrict__ part,
+                                                       float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                       long long R, int C, int nblk, float eps) {
+  const int g = blockIdx.y, c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = lane; b < nblk; b += 64) {
+    const float* o = part + ((long long)g * nblk + b) * 2 * C + c;
+    s1 += o[0]; s2 += o[C];
+  }
+  s1 = acg::wave_sum(s1); s2 = acg::wave_sum(s2);
+  if (lane == 0) {
+    const double inv = 1.0 / (double)R, dm = s1 * inv;
+    double var = s2 * inv - dm * dm;
+    var = var > 0.0 ? var : 0.0;
+    save_mean[g * C + c] = (float)((double)x[(long long)g * R * C + c] + dm);
+    save_rstd[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+template <int V>
 __global__ __launch_bounds__(256) void bn_apply_fwd(const float* __restrict__ x, const float* __restrict__ beta,
-                                                    const float* __restrict__ part, float* __restrict__ y,
-                                                    float* __restrict__ save_mean, float* __restrict__ save_rstd,
-                                                    long long R, int C, int nblk, float eps, int act, float leak) {
-  __shared__ float smean[kMaxC], srstd[kMaxC];
+                                                    const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
+                                                    float* __restrict__ y, long long R, int C, int act, float leak) {
+  const VMap<V> m = vmap<V>(C);
+  if (!m.active) return;
   const int g = blockIdx.y;
   const float* xg = x + (long long)g * R * C;
   float* yg = y + (long long)g * R * C;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-      const float* o = part + (((long long)g * nblk + b) * C + c) * 2;
-      s1 += o[0]; s2 += o[1];
-    }
-    const double inv = 1.0 / (double)R;
-    const double dm = s1 * inv;
-    double var = s2 * inv - dm * dm;
-    var = var > 0.0 ? var : 0.0;
-    const float mean = (float)((double)xg[c] + dm);
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    smean[c] = mean; srstd[c] = rstd;
-    if (blockIdx.x == 0) { save_mean[g * C + c] = mean; save_rstd[g * C + c] = rstd; }
-  }
-  __syncthreads();
-  const ColMap m = col_map(C);
-  if (!m.active) return;
   for (int ch = 0; ch < m.nchunk; ++ch) {
-    const int c = ch * m.Cb + m.cl;
-    if (c >= C) continue;
-    const float mean = smean[c], rstd = srstd[c], bt = beta[c];
-    for (long long r = (long long)blockIdx.x * m.RPP + m.rsub; r < R; r += (long long)gridDim.x * m.RPP)
-      yg[r * C + c] = acg::act_apply(act, (xg[r * C + c] - mean) * rstd + bt, leak);
+    const int cv = ch * m.Cb + m.cl, c = cv * V;
+    if (cv >= m.Cv) continue;
+    float mean[V], rstd[V], bt[V];
+    ldv<V>(save_mean + g * C + c, mean); ldv<V>(save_rstd + g * C + c, rstd); ldv<V>(beta + c, bt);
+#pragma unroll 4
+    for (long long r = (long long)blockIdx.x * m.RPP + m.rsub; r < R; r += (long long)gridDim.x * m.RPP) {
+      float v[V];
+      ldv<V>(xg + r * C + c, v);
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[j] = acg::act_apply(act, (v[j] - mean[j]) * rstd[j] + bt[j], leak);
+      stv<V>(yg + r * C + c, v);
+    }
   }
 }
 
 // ---- BN backward ----------------------------------------------------------------------------------------
+template <int V>
 __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ x, const float* __restrict__ dy,
                                                       const float* __restrict__ beta, const float* __restrict__ save_mean,
                                                       const float* __restrict__ save_rstd, float* __restrict__ part,
                                                       long long R, int C, int nblk, int act, float leak) {
-  __shared__ float sh[512];
-  const ColMap m = col_map(C);
+  __shared__ float sh[2 * V * 256];
+  const VMap<V> m = vmap<V>(C);
   const int g = blockIdx.y, b = blockIdx.x;
   const float* xg = x + (long long)g * R * C;
   const float* dyg = dy + (long long)g * R * C;
   const long long rpb = (R + nblk - 1) / nblk;
   const long long r0 = (long long)b * rpb, r1 = min(R, r0 + rpb);
   for (int ch = 0; ch < m.nchunk; ++ch) {
-    const int c = ch * m.Cb + m.cl;
-    float s1 = 0.f, s2 = 0.f;
-    if (m.active && c < C) {
-      const float mean = save_mean[g * C + c], rstd = save_rstd[g * C + c], bt = beta[c];
+    const int cv = ch * m.Cb + m.cl, c = cv * V;
+    float s1[V], s2[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    if (m.active && cv < m.Cv) {
+      float mean[V], rstd[V], bt[V];
+      ldv<V>(save_mean + g * C + c, mean); ldv<V>(save_rstd + g * C + c, rstd); ldv<V>(beta + c, bt);
+#pragma unroll 4
       for (long long r = r0 + m.rsub; r < r1; r += m.RPP) {
-        const float xh = (xg[r * C + c] - mean) * rstd;
-        const float dp = dyg[r * C + c] * acg::act_deriv_pre(act, xh + bt, leak);
-        s1 += dp; s2 += dp * xh;
+        float xv[V], dv[V];
+        ldv<V>(xg + r * C + c, xv); ldv<V>(dyg + r * C + c, dv);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const float xh = (xv[j] - mean[j]) * rstd[j];
+          const float dp = dv[j] * acg::act_deriv_pre(act, xh + bt[j], leak);
+          s1[j] += dp; s2[j] += dp * xh;
+        }
       }
     }
-    reduce_rsub(m, s1, s2, sh);
-    if (m.active && m.rsub == 0 && c < C) {
-      float* o = part + (((long long)g * nblk + b) * C + c) * 2;
-      o[0] = s1; o[1] = s2;
+    reduce_rsub_v<V>(m, s1, s2, sh);
+    if (m.active && m.rsub == 0 && cv < m.Cv) {
+      float* o = part + ((long long)g * nblk + b) * 2 * C + c;
+      stv<V>(o, s1);
+      stv<V>(o + C, s2);
     }
   }
 }
 
+// one wave per channel: per-group means m1 = s1/R, m2 = s2/R into msum[(g*2+which)*C + c]; dbeta over all groups
+__global__ __launch_bounds__(256) void bn_finalize_bwd(const float* __restrict__ part, float* __restrict__ msum,
+                                                       float* __restrict__ dbeta, float dbeta_acc, long long R, int C,
+                                                       int groups, int nblk) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  double total = 0.0;
+  for (int g = 0; g < groups; ++g) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = lane; b < nblk; b += 64) {
+      const float* o = part + ((long long)g * nblk + b) * 2 * C + c;
+      s1 += o[0]; s2 += o[C];
+    }
+    s1 = acg::wave_sum(s1); s2 = acg::wave_sum(s2);
+    if (lane == 0) {
+      msum[(g * 2 + 0) * C + c] = (float)(s1 / (double)R);
+      msum[(g * 2 + 1) * C + c] = (float)(s2 / (double)R);
+      total += s1;
+    }
+  }
+  if (lane == 0) dbeta[c] = (dbeta_acc != 0.f ? dbeta_acc * dbeta[c] : 0.f) + (float)total;
+}
+
+template <int V>
 __global__ __launch_bounds__(256) void bn_apply_bwd(const float* __restrict__ x, const float* __restrict__ dy,
                                                     const float* __restrict__ beta, const float* __restrict__ save_mean,
-                                                    const float* __restrict__ save_rstd, const float* __restrict__ part,
-                                                    float* __restrict__ dx, float* __restrict__ dbeta, float dbeta_acc,
-                                                    long long R, int C, int groups, int nblk, int act, float leak) {
-  __shared__ float sm1[kMaxC], sm2[kMaxC];  // s1/R, s2/R of this block's group
-  const int g = blockIdx.y;
-  const bool writer = blockIdx.x == 0 && g == 0;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    double total = 0.0;
-    for (int gg = 0; gg < groups; ++gg) {
-      if (gg != g && !writer) continue;
-      double s1 = 0.0, s2 = 0.0;
-      for (int b = 0; b < nblk; ++b) {
-        const float* o = part + (((long long)gg * nblk + b) * C + c) * 2;
-        s1 += o[0]; s2 += o[1];
-      }
-      total += s1;
-      if (gg == g) { sm1[c] = (float)(s1 / (double)R); sm2[c] = (float)(s2 / (double)R); }
-    }
-    if (writer) dbeta[c] = (dbeta_acc != 0.f ? dbeta_acc * dbeta[c] : 0.f) + (float)total;
-  }
-  __syncthreads();
-  const ColMap m = col_map(C);
+                                                    const float* __restrict__ save_rstd, const float* __restrict__ msum,
+                                                    float* __restrict__ dx, long long R, int C, int act, float leak) {
+  const VMap<V> m = vmap<V>(C);
   if (!m.active) return;
+  const int g = blockIdx.y;
   const float* xg = x + (long long)g * R * C;
   const float* dyg = dy + (long long)g * R * C;
   float* dxg = dx + (long long)g * R * C;
   for (int ch = 0; ch < m.nchunk; ++ch) {
-    const int c = ch * m.Cb + m.cl;
-    if (c >= C) continue;
-    const float mean = save_mean[g * C + c], rstd = save_rstd[g * C + c], bt = beta[c];
-    const float m1 = sm1[c], m2 = sm2[c];
+    const int cv = ch * m.Cb + m.cl, c = cv * V;
+    if (cv >= m.Cv) continue;
+    float mean[V], rstd[V], bt[V], m1[V], m2[V];
+    ldv<V>(save_mean + g * C + c, mean); ldv<V>(save_rstd + g * C + c, rstd); ldv<V>(beta + c, bt);
+    ldv<V>(msum + (g * 2 + 0) * C + c, m1); ldv<V>(msum + (g * 2 + 1) * C + c, m2);
+#pragma unroll 4
     for (long long r = (long long)blockIdx.x * m.RPP + m.rsub; r < R; r += (long long)gridDim.x * m.RPP) {
-      const float xh = (xg[r * C + c] - mean) * rstd;
-      const float dp = dyg[r * C + c] * acg::act_deriv_pre(act, xh + bt, leak);
-      dxg[r * C + c] = rstd * (dp - m1 - xh * m2);
+      float xv[V], dv[V];
+      ldv<V>(xg + r * C + c, xv); ldv<V>(dyg + r * C + c, dv);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float xh = (xv[j] - mean[j]) * rstd[j];
+        const float dp = dv[j] * acg::act_deriv_pre(act, xh + bt[j], leak);
+        dv[j] = rstd[j] * (dp - m1[j] - xh * m2[j]);
+      }
+      stv<V>(dxg + r * C + c, dv);
     }
   }
 }
@@ -228,7 +319,7 @@ int partial_blocks(long long R, int C) {
   const int Cb = C < 256 ? C : 256, RPP = 256 / Cb;
   long long n = R / ((long long)RPP * 8);
   if (n < 1) n = 1;
-  if (n > kMaxPartialBlocks) n = kMaxPartialBlocks;
+  if (n > 128) n = 128;
   return (int)n;
 }
 int apply_blocks(long long R, int C) {
@@ -236,6 +327,21 @@ int apply_blocks(long long R, int C) {
   long long n = acg::ceil_div(R, (long long)RPP * 4);
   if (n < 1) n = 1;
   if (n > 1024) n = 1024;
+  return (int)n;
+}
+// vectorised variants: columns are C/V wide
+int vpartial_blocks(long long R, int C, int V) {
+  const int Cv = C / V, Cb = Cv < 256 ? Cv : 256, RPP = 256 / Cb;
+  long long n = acg::ceil_div(R, (long long)RPP * 16);
+  if (n < 1) n = 1;
+  if (n > kMaxPartialBlocks) n = kMaxPartialBlocks;
+  return (int)n;
+}
+int vapply_blocks(long long R, int C, int V) {
+  const int Cv = C / V, Cb = Cv < 256 ? Cv : 256, RPP = 256 / Cb;
+  long long n = acg::ceil_div(R, (long long)RPP * 4);
+  if (n < 1) n = 1;
+  if (n > 2048) n = 2048;
   return (int)n;
 }
 
@@ -247,6 +353,10 @@ int check_bn(const char* who, long long rows, int C, int groups) {
   return ACG_OK;
 }
 
+bool vec4_ok(int C, const void* a, const void* b, const void* c) {
+  return C % 4 == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -254,7 +364,7 @@ extern "C" {
 size_t acg_bn_workspace_bytes(int64_t rows, int32_t channels, int32_t groups) {
   (void)rows;
   if (channels <= 0 || groups <= 0) return 0;
-  return (size_t)groups * kMaxPartialBlocks * (size_t)channels * 2 * sizeof(float);
+  return (size_t)groups * ((size_t)kMaxPartialBlocks * 2 + 2) * (size_t)channels * sizeof(float);
 }
 
 int32_t acg_bn_act_fwd(const void* x, const float* beta, void* y, float* save_mean, float* save_rstd, int64_t rows,
@@ -266,12 +376,21 @@ int32_t acg_bn_act_fwd(const void* x, const float* beta, void* y, float* save_me
   ACG_REQUIRE(act == ACG_ACT_NONE || act == ACG_ACT_RELU || act == ACG_ACT_LRELU, ACG_ERR_UNSUPPORTED, "bn_act_fwd: activation %d", act);
   ACG_REQUIRE(ws && wsb >= acg_bn_workspace_bytes(rows, C, groups), ACG_ERR_WORKSPACE, "bn_act_fwd: workspace too small");
   const long long R = rows / groups;
-  const int nblk = partial_blocks(R, C);
   hipStream_t st = acg::to_stream(stream);
-  hipLaunchKernelGGL(bn_stats_partial, dim3(nblk, groups), dim3(256), 0, st, (const float*)x, (float*)ws, R, C, nblk);
+  const float* xf = (const float*)x;
+  float* part = (float*)ws;
+  const bool v4 = vec4_ok(C, x, y, beta) && vec4_ok(C, save_mean, save_rstd, ws);
+  const int V = v4 ? 4 : 1;
+  const int nblk = vpartial_blocks(R, C, V);
+  if (v4) hipLaunchKernelGGL(bn_stats_partial<4>, dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk);
+  else hipLaunchKernelGGL(bn_stats_partial<1>, dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk);
   if (int rc = acg::check_launch("bn_stats_partial")) return rc;
-  hipLaunchKernelGGL(bn_apply_fwd, dim3(apply_blocks(R, C), groups), dim3(256), 0, st, (const float*)x, beta,
-                     (const float*)ws, (float*)y, save_mean, save_rstd, R, C, nblk, eps, act, leak);
+  hipLaunchKernelGGL(bn_finalize_fwd, dim3((C + 3) / 4, groups), dim3(256), 0, st, xf, (const float*)part, save_mean, save_rstd,
+                     R, C, nblk, eps);
+  if (int rc = acg::check_launch("bn_finalize_fwd")) return rc;
+  const dim3 ag(vapply_blocks(R, C, V), groups);
+  if (v4) hipLaunchKernelGGL(bn_apply_fwd<4>, ag, dim3(256), 0, st, xf, beta, (const float*)save_mean, (const float*)save_rstd, (float*)y, R, C, act, leak);
+  else hipLaunchKernelGGL(bn_apply_fwd<1>, ag, dim3(256), 0, st, xf, beta, (const float*)save_mean, (const float*)save_rstd, (float*)y, R, C, act, leak);
   return acg::check_launch("bn_apply_fwd");
 }
 
@@ -284,13 +403,22 @@ int32_t acg_bn_act_bwd(const void* x, const void* dy, const float* beta, const f
   ACG_REQUIRE(act == ACG_ACT_NONE || act == ACG_ACT_RELU || act == ACG_ACT_LRELU, ACG_ERR_UNSUPPORTED, "bn_act_bwd: activation %d", act);
   ACG_REQUIRE(ws && wsb >= acg_bn_workspace_bytes(rows, C, groups), ACG_ERR_WORKSPACE, "bn_act_bwd: workspace too small");
   const long long R = rows / groups;
-  const int nblk = partial_blocks(R, C);
   hipStream_t st = acg::to_stream(stream);
-  hipLaunchKernelGGL(bn_bwd_partial, dim3(nblk, groups), dim3(256), 0, st, (const float*)x, (const float*)dy, beta,
-                     save_mean, save_rstd, (float*)ws, R, C, nblk, act, leak);
+  const float* xf = (const float*)x;
+  const float* dyf = (const float*)dy;
+  float* part = (float*)ws;
+  float* msum = part + (size_t)groups * kMaxPartialBlocks * 2 * C;
+  const bool v4 = vec4_ok(C, x, dy, dx) && vec4_ok(C, save_mean, save_rstd, ws) && vec4_ok(C, beta, msum, ws);
+  const int V = v4 ? 4 : 1;
+  const int nblk = vpartial_blocks(R, C, V);
+  if (v4) hipLaunchKernelGGL(bn_bwd_partial<4>, dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak);
+  else hipLaunchKernelGGL(bn_bwd_partial<1>, dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak);
   if (int rc = acg::check_launch("bn_bwd_partial")) return rc;
-  hipLaunchKernelGGL(bn_apply_bwd, dim3(apply_blocks(R, C), groups), dim3(256), 0, st, (const float*)x, (const float*)dy,
-                     beta, save_mean, save_rstd, (const float*)ws, (float*)dx, dbeta, dbeta_acc, R, C, groups, nblk, act, leak);
+  hipLaunchKernelGGL(bn_finalize_bwd, dim3((C + 3) / 4), dim3(256), 0, st, (const float*)part, msum, dbeta, dbeta_acc, R, C, groups, nblk);
+  if (int rc = acg::check_launch("bn_finalize_bwd")) return rc;
+  const dim3 ag(vapply_blocks(R, C, V), groups);
+  if (v4) hipLaunchKernelGGL(bn_apply_bwd<4>, ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)msum, (float*)dx, R, C, act, leak);
+  else hipLaunchKernelGGL(bn_apply_bwd<1>, ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)msum, (float*)dx, R, C, act, leak);
   return acg::check_launch("bn_apply_bwd");
 }
 

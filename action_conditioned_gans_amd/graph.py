@@ -56,9 +56,16 @@ class Tensor:
         return n
 
     def view(self, offset, shape, name=None):
-        t = Tensor(self.graph, shape, name=name, dtype=self.dtype)
+        t = Tensor(self.graph, shape, name=name, dtype=self.dtype, op=self.op)
         t.view_of = (self, int(offset))
         return t
+
+    def akey(self):
+        """Identity for differentiation: reshapes share their source's gradient, windows do not."""
+        t = self
+        while t.alias_of is not None:
+            t = t.alias_of
+        return t.id
 
     def reshape(self, shape, name=None):
         t = Tensor(self.graph, shape, name=name, dtype=self.dtype, op=self.op)
@@ -238,23 +245,23 @@ def build_gradients(graph, heads, var_list, flat_grad, offsets, add_op):
     reach = set()                                  # tensor ids that depend on a variable in var_list
     fwd_ops = [o for o in graph.ops if o.index <= last]
     for op in fwd_ops:
-        if any((isinstance(i, Variable) and i.name in var_names) or i.root().id in reach for i in op.inputs):
+        if any((isinstance(i, Variable) and i.name in var_names) or i.akey() in reach for i in op.inputs):
             for o in op.outputs:
-                reach.add(o.root().id)
+                reach.add(o.akey())
     pending = {}
     for head, weights in heads.items():
-        needs = [(not isinstance(i, Variable)) and i.root().id in reach for i in head.inputs]
+        needs = [(not isinstance(i, Variable)) and i.akey() in reach for i in head.inputs]
         if not any(needs):
             continue
         for t, g in head.seed(weights, needs):
-            r = t.root().id
+            r = t.akey()
             pending[r] = g if r not in pending else add_op(pending[r], g)
     ctx = GradContext(graph, var_list, flat_grad, offsets)
     for op in reversed(fwd_ops):
-        gouts = [pending.get(o.root().id) for o in op.outputs]
+        gouts = [pending.get(o.akey()) for o in op.outputs]
         if all(g is None for g in gouts):
             continue
-        needs = [(isinstance(i, Variable) and i.name in var_names) or (not isinstance(i, Variable) and i.root().id in reach)
+        needs = [(isinstance(i, Variable) and i.name in var_names) or (not isinstance(i, Variable) and i.akey() in reach)
                  for i in op.inputs]
         if not any(needs):
             continue
@@ -262,7 +269,7 @@ def build_gradients(graph, heads, var_list, flat_grad, offsets, add_op):
         for i, g in zip(op.inputs, gins):
             if g is None or isinstance(i, Variable):
                 continue
-            r = i.root().id
+            r = i.akey()
             pending[r] = g if r not in pending else add_op(pending[r], g)
     return ctx
 
@@ -332,7 +339,7 @@ class Session:
             t.buf = self._materialize(t.alias_of).view(t.shape)
         elif t.view_of is not None:
             base, off = t.view_of
-            t.buf = self._materialize(base)[off:off + t.numel].view(t.shape)
+            t.buf = self._materialize(base).view(-1)[off:off + t.numel].view(t.shape)
         else:
             if t.init is not None:
                 t.buf = torch.full(t.shape, t.init, dtype=t.dtype, device=self.rt.device)

@@ -371,10 +371,13 @@ class ConcatActionsOp(G.Op):
 
 
 class ConcatChannelsOp(G.Op):
-    def __init__(self, a, b, name):
+    def __init__(self, a, b, name, out=None):
         if a.shape[:-1] != b.shape[:-1]:
             raise ValueError('concat: leading dimensions differ: %s vs %s' % (a.shape, b.shape))
-        super().__init__(G.get_default_graph(), name, [a, b], [_new(a.shape[:-1] + (a.shape[-1] + b.shape[-1],), name + ':0')])
+        shape = a.shape[:-1] + (a.shape[-1] + b.shape[-1],)
+        if out is not None and out.shape != shape:
+            raise ValueError('concat: out has shape %s, expected %s' % (out.shape, shape))
+        super().__init__(G.get_default_graph(), name, [a, b], [out if out is not None else _new(shape, name + ':0')])
 
     def bind(self, rt):
         a, b = self.inputs
@@ -387,6 +390,42 @@ class ConcatChannelsOp(G.Op):
         ga = SliceOp(gouts[0], 0, a.shape[-1], a.shape, self.name + '/bwd_a').outputs[0] if needs[0] else None
         gb = SliceOp(gouts[0], a.shape[-1], b.shape[-1], b.shape, self.name + '/bwd_b').outputs[0] if needs[1] else None
         return [ga, gb]
+
+
+class JoinOp(G.Op):
+    """Batch-axis join with no copy: the parts are windows of ``whole`` that their producers write in place."""
+
+    def __init__(self, parts, whole, name):
+        super().__init__(G.get_default_graph(), name, list(parts), [whole])
+
+    def bind(self, rt):
+        return None
+
+    def grad(self, gouts, needs, ctx):
+        off, out = 0, []
+        for part, need in zip(self.inputs, needs):
+            out.append(gouts[0].view(off, part.shape) if need else None)
+            off += part.numel
+        return out
+
+
+def batch_join(producers, part_shape, name='batch_join'):
+    """Join equally shaped tensors along the batch axis without a copy.
+
+    ``producers`` are callables ``f(out)`` that build the op writing one part into the window ``out``.
+    Returns ``(whole, parts)``."""
+    n = len(producers)
+    whole = _new((part_shape[0] * n,) + tuple(part_shape[1:]), name + ':0')
+    numel = 1
+    for d in part_shape:
+        numel *= d
+    parts = []
+    for k, f in enumerate(producers):
+        win = whole.view(k * numel, part_shape, name='%s/part%d' % (name, k))
+        f(win)
+        parts.append(win)
+    JoinOp(parts, whole, name)
+    return whole, parts
 
 
 class SliceOp(G.Op):
@@ -548,11 +587,19 @@ def concat_actions(x, actions, name='concat_actions'):
     return ConcatActionsOp(x, actions, _scope_name(name)).outputs[0]
 
 
-def concat(values, axis=3, name='concat'):
-    """tf.concat on the channel axis (train.py:64,68)."""
+def concat(values, axis=3, name='concat', out=None):
+    """tf.concat on the channel axis (train.py:64,68); ``out`` lets the result land in a window of a larger tensor."""
     if axis not in (3, -1) or len(values) != 2:
         raise ValueError('concat: only two tensors on the channel axis are supported')
-    return ConcatChannelsOp(values[0], values[1], _scope_name(name)).outputs[0]
+    return ConcatChannelsOp(values[0], values[1], _scope_name(name), out=out).outputs[0]
+
+
+def repeat_batch(x, times, name='repeat_batch'):
+    """tf.tile along the batch axis for small side inputs (the action vector shared by several sub-batches)."""
+    if times != 2:
+        raise ValueError('repeat_batch: only times=2 is implemented')
+    flat = x.reshape((1, x.numel))
+    return ConcatChannelsOp(flat, flat, _scope_name(name)).outputs[0].reshape((x.shape[0] * 2,) + x.shape[1:])
 
 
 def squeeze(x, name=None):
@@ -693,6 +740,43 @@ class SmallLossOp(LossHead):
         return [(a, op.dx)]
 
 
+class PairedLossOp(LossHead):
+    """Two 'sigmoid_ce' / 'mean' heads over the two halves of one batched tensor (D(fake) | D(real) run as one
+    launch sequence with per-half BatchNorm statistics): out0 is the loss of the first half, out1 of the second."""
+
+    def __init__(self, kind, x, labels=(0.0, 0.0), grad_scales=None, name=None):
+        g = G.get_default_graph()
+        if x.numel % 2 or x.numel // 2 > 65536:
+            raise ValueError('%s loss: halves must be equal and at most 65536 elements' % kind)
+        self.kind, self.labels, self.grad_scales = kind, tuple(float(v) for v in labels), grad_scales
+        name = name or ('paired_' + kind)
+        vals = _new((2,), name + '/values')
+        self.dx = _new(x.shape, name + '/dx') if grad_scales is not None else None
+        outs = [vals.view(0, (1,), name + '/first'), vals.view(1, (1,), name + '/second')]
+        super().__init__(g, name, [x], outs + ([self.dx] if self.dx is not None else []))
+
+    def bind(self, rt):
+        x = self.inputs[0]
+        half = x.numel // 2
+        fn = rt.lib.sigmoid_ce_loss if self.kind == 'sigmoid_ce' else rt.lib.mean_loss
+        calls = []
+        for k in range(2):
+            px = ctypes.c_void_p(x.buf.data_ptr() + 4 * half * k)
+            po = ctypes.c_void_p(self.outputs[0].buf.data_ptr() + 4 * k)
+            pd = ctypes.c_void_p(self.dx.buf.data_ptr() + 4 * half * k) if self.dx is not None else None
+            sc = float(self.grad_scales[k]) if self.grad_scales is not None else 0.0
+            calls.append((px, self.labels[k], po, pd, half, sc) if self.kind == 'sigmoid_ce' else (px, po, pd, half, sc))
+
+        def launch(s):
+            fn(*calls[0], s)
+            fn(*calls[1], s)
+        return launch
+
+    def seed(self, weights, needs):
+        op = PairedLossOp(self.kind, self.inputs[0], self.labels, (weights.get(0, 0.0), weights.get(1, 0.0)), self.name + '/grad')
+        return [(self.inputs[0], op.dx)]
+
+
 class PsnrOp(LossHead):
     def __init__(self, true, pred, name='psnr'):
         super().__init__(G.get_default_graph(), name, [true, pred], [_new((1,), name + ':0')])
@@ -741,6 +825,23 @@ def build_d_loss(d_out_direct, d_out_gen, arg_loss, summaries=None):
     elif arg_loss == 'wass':
         d_direct_loss = reduce_mean(d_out_direct, 'd_direct_wass')
         d_gen_loss = -reduce_mean(d_out_gen, 'd_gen_wass')
+    else:
+        raise ValueError('unexpected loss argument')
+    if summaries is not None:
+        summaries['discriminator_direct_loss'] = d_direct_loss
+        summaries['discriminator_gen_loss'] = d_gen_loss
+    return d_direct_loss + d_gen_loss
+
+
+def build_d_loss_batched(d_out_both, arg_loss, summaries=None):
+    """ops.py:37-50 for a discriminator run ONCE on [fake ; real] stacked along the batch (BatchNorm per half):
+    the first half of ``d_out_both`` is D(fake) = d_out_gen, the second D(real) = d_out_direct."""
+    if arg_loss == 'bce':
+        head = PairedLossOp('sigmoid_ce', d_out_both, labels=(0.0, 0.9), name='d_bce')
+        d_gen_loss, d_direct_loss = Scalar([(head, 0, 1.0)]), Scalar([(head, 1, 1.0)])
+    elif arg_loss == 'wass':
+        head = PairedLossOp('mean', d_out_both, name='d_wass')
+        d_gen_loss, d_direct_loss = Scalar([(head, 0, -1.0)]), Scalar([(head, 1, 1.0)])
     else:
         raise ValueError('unexpected loss argument')
     if summaries is not None:

@@ -36,7 +36,7 @@ ACTION_DIM, STATE_DIM = 10, 5
 
 class Trainer:
     def __init__(self, sess, arg_adv, arg_loss, arg_opt, arg_transform, batch_size=64, img_size=64, ksize=5,
-                 seed=0):
+                 seed=0, batched_d=True):
         self.sess = sess
         self.batch_size, self.img_size, self.ksize = batch_size, img_size, ksize
         self.arg_adv, self.arg_loss, self.arg_opt, self.arg_transform = arg_adv, arg_loss, arg_opt, arg_transform
@@ -58,11 +58,26 @@ class Trainer:
             self.g_out, self.g_state_out = M.build_generator(self.img_ph, self.action_ph), None
         self.g_next_frame = self.g_out
 
-        # discriminator on (x_t, fake) then (x_t, real), sharing variables (train.py:63-70)
-        self.d_out_gen = M.build_discriminator(O.concat([self.img_ph, self.g_next_frame], axis=3, name='d_in_gen'),
-                                               self.action_ph, reuse=False)
-        self.d_out_real = M.build_discriminator(O.concat([self.img_ph, self.next_frame_ph], axis=3, name='d_in_real'),
-                                                self.action_ph, reuse=True)
+        # discriminator on (x_t, fake) then (x_t, real), sharing variables (train.py:63-70).
+        # batched_d: the D step runs D ONCE on [fake ; real] stacked along the batch, BatchNorm statistics kept
+        # per half (groups=2) - arithmetically the two reference calls, at twice the GEMM height and half the
+        # launches.  The G step still uses the batch-B D(fake) graph (D(real) is pruned there anyway).
+        if batched_d:
+            d_in_both, (d_in_gen, d_in_real) = O.batch_join(
+                [lambda out: O.concat([self.img_ph, self.g_next_frame], axis=3, name='d_in_gen', out=out),
+                 lambda out: O.concat([self.img_ph, self.next_frame_ph], axis=3, name='d_in_real', out=out)],
+                (B, S, S, 6), name='d_in_both')
+        else:
+            d_in_gen = O.concat([self.img_ph, self.g_next_frame], axis=3, name='d_in_gen')
+            d_in_real = O.concat([self.img_ph, self.next_frame_ph], axis=3, name='d_in_real')
+        self.d_out_gen = M.build_discriminator(d_in_gen, self.action_ph, reuse=False)
+        if batched_d:
+            with O.arg_scope([O.batch_norm], groups=2):
+                self.d_out_both = M.build_discriminator(d_in_both, O.repeat_batch(self.action_ph, 2), reuse=True)
+            self.d_out_real = self.d_out_both.view(self.d_out_gen.numel, self.d_out_gen.shape, name='d_out_real')
+        else:
+            self.d_out_both = None
+            self.d_out_real = M.build_discriminator(d_in_real, self.action_ph, reuse=True)
 
         # losses (train.py:72-85)
         self.g_psnr = O.build_psnr(self.next_frame_ph, self.g_next_frame)
@@ -78,7 +93,10 @@ class Trainer:
             self.summaries['g_adv_loss'] = self.g_adv_loss
         else:
             self.g_loss = g_l2_loss
-        self.d_loss = O.build_d_loss(self.d_out_real, self.d_out_gen, arg_loss, summaries=self.summaries)
+        if batched_d:
+            self.d_loss = O.build_d_loss_batched(self.d_out_both, arg_loss, summaries=self.summaries)
+        else:
+            self.d_loss = O.build_d_loss(self.d_out_real, self.d_out_gen, arg_loss, summaries=self.summaries)
 
         graph = G.get_default_graph()
         self.g_vars = graph.trainable_variables('g')

@@ -63,6 +63,11 @@ int32_t acg_conv_desc_init(acg_conv_desc* d, int32_t batch, int32_t in_h, int32_
 
 size_t acg_conv2d_workspace_bytes(const acg_conv_desc* d, int32_t which /* ACG_CONV_* */, int32_t dtype);
 
+/* Tuning hook (process-wide, not for production use): force the tile configuration (0: 128x128, 1: 128x64,
+ * 2: 128x32, 3: 64x64) and/or the split-K factor chosen by the planner; -1 restores the heuristic.
+ * Affects acg_conv2d_workspace_bytes too, so query the workspace after setting it. */
+int32_t acg_debug_conv_plan(int32_t cfg, int32_t splits);
+
 /* slim.conv2d's tf.nn.conv2d: models.py:12-15,34-37,42-51,82-88. */
 int32_t acg_conv2d_fwd(const void* x, const void* w, void* y, const acg_conv_desc* d, int32_t dtype,
                        void* workspace, size_t workspace_bytes, acg_stream_t stream);

@@ -47,6 +47,7 @@ int32_t acg_conv_desc_init(acg_conv_desc* d, int32_t batch, int32_t in_h, int32_
 }
 
 size_t acg_conv2d_workspace_bytes(const acg_conv_desc* d, int32_t which, int32_t dtype) { (void)d; (void)which; (void)dtype; return 0; }
+int32_t acg_debug_conv_plan(int32_t cfg, int32_t splits) { (void)cfg; (void)splits; return ACG_OK; }
 
 #define XI(d, b, y, x, c) ((((size_t)(b) * (d)->in_h + (y)) * (d)->in_w + (x)) * (d)->in_c + (c))
 #define YI(d, b, p, q, o) ((((size_t)(b) * (d)->out_h + (p)) * (d)->out_w + (q)) * (d)->out_c + (o))

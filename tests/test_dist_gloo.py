@@ -1,0 +1,99 @@
+"""Data-parallel path on CPU: world_size 2 over gloo, kernels from the C-oracle stand-in library.
+
+Checks the construction the multi-GPU bench relies on (one process per GPU, bucketed all-reduce of the
+flat gradient buffer placed behind the wgrads that complete each bucket, 1/world_size folded into the
+fused optimizer step): after one D step the reduced buffer equals the SUM of the two ranks'
+independent gradients, the weights equal a hand-computed RMSProp+clip update with the MEAN gradient,
+and both ranks hold identical weights after a further G step."""
+import os
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CASE = 'dna_k6_bce_rmsprop'
+
+
+def _inputs(rank):
+    rng = np.random.default_rng(100 + rank)
+    return (rng.uniform(-1, 1, (2, 64, 64, 3)).astype(np.float32), rng.uniform(-1, 1, (2, 64, 64, 3)).astype(np.float32),
+            rng.standard_normal((2, 10)).astype(np.float32), rng.standard_normal((2, 5)).astype(np.float32))
+
+
+def _flat(t):
+    return t.buf.detach().clone().cpu().numpy()
+
+
+def _worker(rank, world, port, outdir):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(2)
+    import train_cases as TC
+    from oracle import cbind
+    from action_conditioned_gans_amd import graph as G
+    if world > 1:
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    sess, tr = TC.build_trainer(lambda **kw: G.Session(device='cpu', lib=cbind.load(), world_size=world, rank=rank, **kw),
+                                CASE, world_size=world)
+    x, y, a, s = _inputs(rank)
+    out = {'d_param0': _flat(tr.d_opt_op.inputs[0])}
+    tr.train_d(x, y, a)
+    out['d_grad'] = _flat(tr.d_opt_op.inputs[1])
+    out['d_param1'] = _flat(tr.d_opt_op.inputs[0])
+    tr.train_g(x, y, a, s)
+    out['g_grad'] = _flat(tr.g_opt_op.inputs[1])
+    out['g_param1'] = _flat(tr.g_opt_op.inputs[0])
+    if world > 1:
+        kinds = [type(o).__name__ for o in G.get_default_graph().ops]
+        out['n_allreduce'] = np.array(kinds.count('AllReduceOp'))
+        segs = [k for k, _ in sess._programs[next(iter(sess._programs))].segments]
+        out['n_host_segments'] = np.array(segs.count('host'))
+    np.savez(os.path.join(outdir, 'w%d_r%d.npz' % (world, rank)), **out)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_allreduce_matches_mean_gradient_update():
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        for r in (0, 1):                      # independent single-process references on each shard
+            mp.spawn(_single, args=(r, d), nprocs=1, join=True)
+        dp = [dict(np.load(os.path.join(d, 'w2_r%d.npz' % r))) for r in (0, 1)]
+        ref = [dict(np.load(os.path.join(d, 'w1_r%d.npz' % r))) for r in (0, 1)]
+    # the reduced buffer holds the SUM of per-rank gradients, identical on both ranks
+    want_sum = ref[0]['d_grad'].astype(np.float64) + ref[1]['d_grad']
+    scale = np.abs(want_sum).max()
+    for r in (0, 1):
+        assert np.abs(dp[r]['d_grad'] - want_sum).max() <= 1e-6 * scale
+    assert np.array_equal(dp[0]['d_grad'], dp[1]['d_grad'])
+    # RMSProp (ms starts at 1) + clip with the MEAN gradient (TF formulas)
+    f32 = lambda v: float(np.float32(v))
+    g = want_sum * 0.5
+    ms = f32(0.9) * 1.0 + (1 - f32(0.9)) * g * g
+    want_p = np.clip(dp[0]['d_param0'].astype(np.float64) - f32(5e-5) * g / np.sqrt(ms + f32(1e-10)), f32(-0.01), f32(0.01))
+    for r in (0, 1):
+        assert np.abs(dp[r]['d_param1'] - want_p).max() <= 2e-7
+    # replicas stay bit-identical through the following G step
+    assert np.array_equal(dp[0]['g_param1'], dp[1]['g_param1'])
+    assert np.array_equal(dp[0]['g_grad'], dp[1]['g_grad'])
+    assert int(dp[0]['n_allreduce']) >= 4 and int(dp[0]['n_host_segments']) >= 2    # bucketed, several per optimizer
+
+
+def _single(_, rank, outdir):
+    _worker(rank, 1, 0, outdir)

@@ -45,12 +45,37 @@ def test_fetch_pruning_matches_tf_semantics():
     d_ops = names([tr.d_opt_op, tr.clip_d])
     assert not any(n.startswith('g/') and ('/dgrad' in n or '/wgrad' in n or '/bwd' in n) for n in d_ops)  # no backprop into G
     assert 'd/conv1/conv2d/dgrad' not in d_ops                                       # images need no gradient
-    assert sum(n.endswith('/wgrad') and n.startswith('d/conv2/') for n in d_ops) == 2  # D(fake) and D(real) both feed dW
+    # batched D step: D runs once on [fake ; real] (BatchNorm per half), so each D variable has ONE wgrad
+    assert sum(n.endswith('/wgrad') and n.startswith('d/conv2/') for n in d_ops) == 1
+    assert tr.d_out_both.shape == (4, 2, 2, 1)
     g_kinds, g_ops = kinds([tr.g_opt_op, tr.g_next_frame]), names([tr.g_opt_op, tr.g_next_frame])
     assert not any(n.startswith('d/') and n.endswith('/wgrad') for n in g_ops)        # D weights are frozen in the G step
     assert 'd/conv1/conv2d/dgrad' in g_ops                                            # gradient flows through D into G
     assert sum(n == 'd/conv1/conv2d' for n in g_ops) == 1                             # D(real) is pruned
     assert 'StepOp' in g_kinds
+
+
+def test_unbatched_d_step_matches_golden_and_accumulates_two_wgrads():
+    """The reference's literal structure (two D calls sharing variables): second wgrad accumulates in place."""
+    import make_golden as MG
+    adv, loss, opt, dna, batch, ksize = MG.CASES['c2_dna_bce_adam']
+    gold = TC.golden('c2_dna_bce_adam')
+    from action_conditioned_gans_amd import train as T
+    G.reset_default_graph()
+    optim.set_data_parallel(1)
+    sess = cpu_session()
+    tr = T.Trainer(sess, adv, loss, opt, dna, batch_size=batch, ksize=ksize, batched_d=False)
+    sess.run(G.global_variables_initializer())
+    from oracle import models as OM
+    params = OM.init_params(dna, batch=batch, ksize=ksize, seed=MG.PARAM_SEED, dtype=torch.float32)
+    for n, v in G.get_default_graph().variables.items():
+        sess.set_value(v, params[n])
+    x, y, a, s = MG.inputs(batch)
+    d_ops = [n for _, _, n in TC.program_op_names(sess, [tr.d_opt_op, tr.clip_d], tr._feed(x, y, a))]
+    assert sum(n.endswith('/wgrad') and n.startswith('d/conv2/') for n in d_ops) == 2
+    summ = tr.train_d(x, y, a, summarize=True)
+    assert abs(summ['discriminator_loss'] - gold['d_loss']) <= 1e-5
+    TC.check_norms(TC.flat_grad_norms(sess, tr.d_opt_op), gold, 'dgrad_norm/', 1e-4, 'D grad (unbatched)')
 
 
 def test_clip_is_fused_after_the_update():

@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+"""Sweep tile configuration x split-K for every distinct conv contraction of a Trainer graph on the GPU.
+
+Uses the acg_debug_conv_plan tuning hook.  Output: one line per (layer, kind, cfg, splits) with the mean
+launch time and the achieved algorithmic TFLOP/s, plus the planner's current choice.  Evidence for the
+planner heuristic in csrc/conv_f32.hip (see profiles/).
+  python tools/tune_conv.py [--batch 32] [--plain] > gpurun_out/tune_conv.txt
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from action_conditioned_gans_amd import _lib, graph as G, ops as O, optim, train as T   # noqa: E402
+
+CFG = {0: '128x128', 1: '128x64', 2: '128x32', 3: '64x64'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--plain', action='store_true')
+    ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--splits', default='1,2,3,4,6,8,12,16,32')
+    args = ap.parse_args()
+    lib = _lib.get()
+    dev = torch.device('cuda:0')
+    G.reset_default_graph()
+    optim.set_data_parallel(1)
+    sess = G.Session(device=dev)
+    T.Trainer(sess, True, 'bce', 'adam', not args.plain, batch_size=args.batch)
+    seen = {}
+    for op in G.get_default_graph().ops:
+        if isinstance(op, O._ConvBase):
+            kind = type(op).__name__ + ('T' if op.transposed else '')
+            key = (op.which, op.desc.key(), isinstance(op, O.ConvWgradOp))
+            seen.setdefault(key, (op, kind, []))[2].append(op.name)
+    splits_list = [int(s) for s in args.splits.split(',')]
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    print('# batch %d; columns: name kind which M-ish desc | cfg splits us TFLOP/s' % args.batch)
+    for (which, dkey, is_w), (op, kind, names) in seen.items():
+        d = op.desc
+        flops = 2.0 * d.batch * d.out_h * d.out_w * d.kh * d.kw * d.in_c * d.out_c
+        nx = d.batch * d.in_h * d.in_w * d.in_c
+        ny = d.batch * d.out_h * d.out_w * d.out_c
+        nw = d.kh * d.kw * d.in_c * d.out_c
+        x = torch.randn(nx, device=dev)
+        y = torch.randn(ny, device=dev)
+        w = torch.randn(nw, device=dev)
+        if which == _lib.CONV_FWD:
+            a, b, out, fn = x, w, y, lib.conv2d_fwd
+        elif which == _lib.CONV_DGRAD:
+            a, b, out, fn = y, w, x, lib.conv2d_dgrad
+        else:
+            a, b, out, fn = x, y, w, lib.conv2d_wgrad
+        results = []
+        for cfg in (-1, 0, 1, 2, 3):
+            for sp in ([-1] if cfg == -1 else splits_list):
+                lib.debug_conv_plan(cfg, sp)
+                nbytes = lib.conv2d_workspace_bytes(ctypes.byref(d), which, 0)
+                if nbytes > (2 << 30):
+                    continue
+                ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+                pa, pb, po, pw = (ctypes.c_void_p(t.data_ptr()) for t in (a, b, out, ws))
+
+                def call():
+                    if which == _lib.CONV_WGRAD:
+                        fn(pa, pb, po, 0.0, ctypes.byref(d), 0, pw, nbytes, stream)
+                    else:
+                        fn(pa, pb, po, ctypes.byref(d), 0, pw, nbytes, stream)
+                for _ in range(3):
+                    call()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.reps):
+                    call()
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / args.reps
+                results.append((us, cfg, sp))
+        lib.debug_conv_plan(-1, -1)
+        auto = [r for r in results if r[1] == -1][0]
+        best = min(results)
+        print('%-28s %-14s x%d  flops %.2fG  auto %.1fus (%.1f TF)  best %s s=%d %.1fus (%.1f TF)' % (
+            names[0], kind, len(names), flops / 1e9, auto[0], flops / auto[0] / 1e6, CFG.get(best[1], 'auto'), best[2], best[0],
+            flops / best[0] / 1e6))
+        for us, cfg, sp in sorted(results)[:6]:
+            print('      %-8s s=%-3d %8.1f us  %6.1f TF' % (CFG.get(cfg, 'auto'), sp, us, flops / us / 1e6))
+        sys.stdout.flush()
+
+
+if __name__ == '__main__':
+    main()

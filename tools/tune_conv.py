@@ -27,13 +27,16 @@ def main():
     ap.add_argument('--plain', action='store_true')
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--splits', default='1,2,3,4,6,8,12,16,32')
+    ap.add_argument('--only', default='', help='substring filter on the op name (e.g. d/conv2/conv2d/wgrad)')
+    ap.add_argument('--cfgs', default='-1,0,1,2,3', help='tile configurations to try (-1 = planner)')
+    ap.add_argument('--unbatched-d', action='store_true')
     args = ap.parse_args()
     lib = _lib.get()
     dev = torch.device('cuda:0')
     G.reset_default_graph()
     optim.set_data_parallel(1)
     sess = G.Session(device=dev)
-    T.Trainer(sess, True, 'bce', 'adam', not args.plain, batch_size=args.batch)
+    T.Trainer(sess, True, 'bce', 'adam', not args.plain, batch_size=args.batch, batched_d=not args.unbatched_d)
     seen = {}
     for op in G.get_default_graph().ops:
         if isinstance(op, O._ConvBase):
@@ -43,7 +46,10 @@ def main():
     splits_list = [int(s) for s in args.splits.split(',')]
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     print('# batch %d; columns: name kind which M-ish desc | cfg splits us TFLOP/s' % args.batch)
+    cfgs = [int(c) for c in args.cfgs.split(',')]
     for (which, dkey, is_w), (op, kind, names) in seen.items():
+        if args.only and not any(n == args.only for n in names):
+            continue
         d = op.desc
         flops = 2.0 * d.batch * d.out_h * d.out_w * d.kh * d.kw * d.in_c * d.out_c
         nx = d.batch * d.in_h * d.in_w * d.in_c
@@ -59,7 +65,7 @@ def main():
         else:
             a, b, out, fn = x, y, w, lib.conv2d_wgrad
         results = []
-        for cfg in (-1, 0, 1, 2, 3):
+        for cfg in cfgs:
             for sp in ([-1] if cfg == -1 else splits_list):
                 lib.debug_conv_plan(cfg, sp)
                 nbytes = lib.conv2d_workspace_bytes(ctypes.byref(d), which, 0)
@@ -84,7 +90,7 @@ def main():
                 us = e0.elapsed_time(e1) * 1e3 / args.reps
                 results.append((us, cfg, sp))
         lib.debug_conv_plan(-1, -1)
-        auto = [r for r in results if r[1] == -1][0]
+        auto = ([r for r in results if r[1] == -1] or [min(results)])[0]
         best = min(results)
         print('%-28s %-14s x%d  flops %.2fG  auto %.1fus (%.1f TF)  best %s s=%d %.1fus (%.1f TF)' % (
             names[0], kind, len(names), flops / 1e9, auto[0], flops / auto[0] / 1e6, CFG.get(best[1], 'auto'), best[2], best[0],

@@ -4,9 +4,13 @@
 // (256 / Cb) rows x Cb channels (Cb = min(C, 256)), so consecutive lanes touch consecutive floats and
 // a wave never needs a per-element modulo; lanes move float4 when C % 4 == 0.  Per-channel statistics:
 // pass 1 leaves per-block partial sums (shifted by the group's first row, so E[x^2]-E[x]^2 cannot
-// cancel catastrophically) in the workspace; a one-wave-per-channel finalize combines them in fp64;
-// pass 2 applies normalise + activation.  Three launches, no atomics, deterministic.
+// cancel catastrophically) in the workspace; pass 2 is tiled rows x 32 channels, re-derives the statistics
+// of its own channels from the partials (fp64 combine) and applies normalise + activation.  Two launches per
+// direction (a trivial launch costs ~4.7 us on this part - more than the few redundant L2 reads), no atomics,
+// deterministic.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 
 #include "common.h"
 
@@ -125,49 +129,77 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
   }
 }
 
-// one wave per (group, channel): mean / rstd from the partials, fp64 combine
-__global__ __launch_bounds__(256) void bn_finalize_fwd(const float* __restrict__ x, const float* __restrict__ part,
-                                                       float* __restrict__ save_mean, float* __restrict__ save_rstd,
-                                                       long long R, int C, int nblk, float eps) {
-  const int g = blockIdx.y, c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = lane; b < nblk; b += 64) {
-    const float* o = part + ((long long)g * nblk + b) * 2 * C + c;
-    s1 += o[0]; s2 += o[C];
+// Tile mapping of the apply kernels: 256 threads = 8 channel lanes (V floats each) x 32 row lanes; a block owns
+// the 8*V channels [blockIdx.y*8V, ...) of group blockIdx.z and walks row chunks.  Each block first re-derives
+// the statistics of ITS channels from the per-block partials (nblk * 8V * 2 floats, L2-resident: a few loads per
+// thread), so no separate finalize launch exists - a launch costs more than this prologue (profiles/r1).
+template <int V>
+__device__ __forceinline__ void sum_partials(const float* __restrict__ part, int g, int nblk, int C, int c, bool cvalid,
+                                             int rl, float (&s1)[V], float (&s2)[V], float* sh /* 2*V*32 floats */) {
+#pragma unroll
+  for (int j = 0; j < V; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  if (cvalid) {
+    for (int b = rl; b < nblk; b += 32) {
+      const float* o = part + ((long long)g * nblk + b) * 2 * C + c;
+      float a[V], q[V];
+      ldv<V>(o, a); ldv<V>(o + C, q);
+#pragma unroll
+      for (int j = 0; j < V; ++j) { s1[j] += a[j]; s2[j] += q[j]; }
+    }
   }
-  s1 = acg::wave_sum(s1); s2 = acg::wave_sum(s2);
-  if (lane == 0) {
-    const double inv = 1.0 / (double)R, dm = s1 * inv;
-    double var = s2 * inv - dm * dm;
-    var = var > 0.0 ? var : 0.0;
-    save_mean[g * C + c] = (float)((double)x[(long long)g * R * C + c] + dm);
-    save_rstd[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+  // lanes of one channel lane are 8 apart: fold the 8 row lanes of the wave, then the 4 waves through LDS
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) { s1[j] += __shfl_xor(s1[j], off, 64); s2[j] += __shfl_xor(s2[j], off, 64); }
+  }
+  const int cq = threadIdx.x & 7, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) < 8) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) { sh[(wave * 8 + cq) * 2 * V + j] = s1[j]; sh[(wave * 8 + cq) * 2 * V + V + j] = s2[j]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    s1[j] = sh[(0 * 8 + cq) * 2 * V + j] + sh[(1 * 8 + cq) * 2 * V + j] + sh[(2 * 8 + cq) * 2 * V + j] + sh[(3 * 8 + cq) * 2 * V + j];
+    s2[j] = sh[(0 * 8 + cq) * 2 * V + V + j] + sh[(1 * 8 + cq) * 2 * V + V + j] + sh[(2 * 8 + cq) * 2 * V + V + j] + sh[(3 * 8 + cq) * 2 * V + V + j];
   }
 }
 
 template <int V>
 __global__ __launch_bounds__(256) void bn_apply_fwd(const float* __restrict__ x, const float* __restrict__ beta,
-                                                    const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
-                                                    float* __restrict__ y, long long R, int C, int act, float leak) {
-  const VMap<V> m = vmap<V>(C);
-  if (!m.active) return;
-  const int g = blockIdx.y;
+                                                    const float* __restrict__ part, float* __restrict__ y,
+                                                    float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                    long long R, int C, int nblk, float eps, int act, float leak) {
+  __shared__ float sh[4 * 8 * 2 * V];
+  const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3, g = blockIdx.z;
+  const int c = (blockIdx.y * 8 + cq) * V;
+  const bool cvalid = c < C;
+  float s1[V], s2[V];
+  sum_partials<V>(part, g, nblk, C, c, cvalid, rl, s1, s2, sh);
+  if (!cvalid) return;
   const float* xg = x + (long long)g * R * C;
   float* yg = y + (long long)g * R * C;
-  for (int ch = 0; ch < m.nchunk; ++ch) {
-    const int cv = ch * m.Cb + m.cl, c = cv * V;
-    if (cv >= m.Cv) continue;
-    float mean[V], rstd[V], bt[V];
-    ldv<V>(save_mean + g * C + c, mean); ldv<V>(save_rstd + g * C + c, rstd); ldv<V>(beta + c, bt);
-#pragma unroll 4
-    for (long long r = (long long)blockIdx.x * m.RPP + m.rsub; r < R; r += (long long)gridDim.x * m.RPP) {
-      float v[V];
-      ldv<V>(xg + r * C + c, v);
+  float pv[V], mean[V], rstd[V], bt[V];
+  ldv<V>(xg + c, pv);
+  ldv<V>(beta + c, bt);
 #pragma unroll
-      for (int j = 0; j < V; ++j) v[j] = acg::act_apply(act, (v[j] - mean[j]) * rstd[j] + bt[j], leak);
-      stv<V>(yg + r * C + c, v);
-    }
+  for (int j = 0; j < V; ++j) {
+    const double inv = 1.0 / (double)R, dm = (double)s1[j] * inv;
+    double var = (double)s2[j] * inv - dm * dm;
+    var = var > 0.0 ? var : 0.0;
+    mean[j] = (float)((double)pv[j] + dm);
+    rstd[j] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  if (blockIdx.x == 0 && rl == 0) { stv<V>(save_mean + g * C + c, mean); stv<V>(save_rstd + g * C + c, rstd); }
+#pragma unroll 4
+  for (long long r = (long long)blockIdx.x * 32 + rl; r < R; r += (long long)gridDim.x * 32) {
+    float v[V];
+    ldv<V>(xg + r * C + c, v);
+#pragma unroll
+    for (int j = 0; j < V; ++j) v[j] = acg::act_apply(act, (v[j] - mean[j]) * rstd[j] + bt[j], leak);
+    stv<V>(yg + r * C + c, v);
   }
 }
 
@@ -213,58 +245,64 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
   }
 }
 
-// one wave per channel: per-group means m1 = s1/R, m2 = s2/R into msum[(g*2+which)*C + c]; dbeta over all groups
-__global__ __launch_bounds__(256) void bn_finalize_bwd(const float* __restrict__ part, float* __restrict__ msum,
-                                                       float* __restrict__ dbeta, float dbeta_acc, long long R, int C,
-                                                       int groups, int nblk) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (c >= C) return;
-  double total = 0.0;
-  for (int g = 0; g < groups; ++g) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = lane; b < nblk; b += 64) {
-      const float* o = part + ((long long)g * nblk + b) * 2 * C + c;
-      s1 += o[0]; s2 += o[C];
-    }
-    s1 = acg::wave_sum(s1); s2 = acg::wave_sum(s2);
-    if (lane == 0) {
-      msum[(g * 2 + 0) * C + c] = (float)(s1 / (double)R);
-      msum[(g * 2 + 1) * C + c] = (float)(s2 / (double)R);
-      total += s1;
-    }
-  }
-  if (lane == 0) dbeta[c] = (dbeta_acc != 0.f ? dbeta_acc * dbeta[c] : 0.f) + (float)total;
-}
-
 template <int V>
 __global__ __launch_bounds__(256) void bn_apply_bwd(const float* __restrict__ x, const float* __restrict__ dy,
                                                     const float* __restrict__ beta, const float* __restrict__ save_mean,
-                                                    const float* __restrict__ save_rstd, const float* __restrict__ msum,
-                                                    float* __restrict__ dx, long long R, int C, int act, float leak) {
-  const VMap<V> m = vmap<V>(C);
-  if (!m.active) return;
-  const int g = blockIdx.y;
+                                                    const float* __restrict__ save_rstd, const float* __restrict__ part,
+                                                    float* __restrict__ dx, float* __restrict__ dbeta, float dbeta_acc,
+                                                    long long R, int C, int groups, int nblk, int act, float leak) {
+  __shared__ float sh[4 * 8 * 2 * V];
+  const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3, g = blockIdx.z;
+  const int c = (blockIdx.y * 8 + cq) * V;
+  const bool cvalid = c < C;
+  float s1[V], s2[V];
+  if (blockIdx.x == 0 && g == 0) {   // this block also owns dbeta of its channels: sum over every group
+    float tot[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) tot[j] = 0.f;
+    float k1[V], k2[V];
+    for (int gg = groups - 1; gg >= 0; --gg) {   // ends on group 0 = this block's own statistics
+      sum_partials<V>(part, gg, nblk, C, c, cvalid, rl, k1, k2, sh);
+#pragma unroll
+      for (int j = 0; j < V; ++j) tot[j] += k1[j];
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) { s1[j] = k1[j]; s2[j] = k2[j]; }
+    if (cvalid && rl == 0) {
+      float d[V];
+      if (dbeta_acc != 0.f) {
+        ldv<V>(dbeta + c, d);
+#pragma unroll
+        for (int j = 0; j < V; ++j) d[j] = dbeta_acc * d[j] + tot[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) d[j] = tot[j];
+      }
+      stv<V>(dbeta + c, d);
+    }
+  } else {
+    sum_partials<V>(part, g, nblk, C, c, cvalid, rl, s1, s2, sh);
+  }
+  if (!cvalid) return;
   const float* xg = x + (long long)g * R * C;
   const float* dyg = dy + (long long)g * R * C;
   float* dxg = dx + (long long)g * R * C;
-  for (int ch = 0; ch < m.nchunk; ++ch) {
-    const int cv = ch * m.Cb + m.cl, c = cv * V;
-    if (cv >= m.Cv) continue;
-    float mean[V], rstd[V], bt[V], m1[V], m2[V];
-    ldv<V>(save_mean + g * C + c, mean); ldv<V>(save_rstd + g * C + c, rstd); ldv<V>(beta + c, bt);
-    ldv<V>(msum + (g * 2 + 0) * C + c, m1); ldv<V>(msum + (g * 2 + 1) * C + c, m2);
-#pragma unroll 4
-    for (long long r = (long long)blockIdx.x * m.RPP + m.rsub; r < R; r += (long long)gridDim.x * m.RPP) {
-      float xv[V], dv[V];
-      ldv<V>(xg + r * C + c, xv); ldv<V>(dyg + r * C + c, dv);
+  float mean[V], rstd[V], bt[V], m1[V], m2[V];
+  ldv<V>(save_mean + g * C + c, mean); ldv<V>(save_rstd + g * C + c, rstd); ldv<V>(beta + c, bt);
+  const float invR = 1.f / (float)R;
 #pragma unroll
-      for (int j = 0; j < V; ++j) {
-        const float xh = (xv[j] - mean[j]) * rstd[j];
-        const float dp = dv[j] * acg::act_deriv_pre(act, xh + bt[j], leak);
-        dv[j] = rstd[j] * (dp - m1[j] - xh * m2[j]);
-      }
-      stv<V>(dxg + r * C + c, dv);
+  for (int j = 0; j < V; ++j) { m1[j] = s1[j] * invR; m2[j] = s2[j] * invR; }
+#pragma unroll 4
+  for (long long r = (long long)blockIdx.x * 32 + rl; r < R; r += (long long)gridDim.x * 32) {
+    float xv[V], dv[V];
+    ldv<V>(xg + r * C + c, xv); ldv<V>(dyg + r * C + c, dv);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float xh = (xv[j] - mean[j]) * rstd[j];
+      const float dp = dv[j] * acg::act_deriv_pre(act, xh + bt[j], leak);
+      dv[j] = rstd[j] * (dp - m1[j] - xh * m2[j]);
     }
+    stv<V>(dxg + r * C + c, dv);
   }
 }
 
@@ -345,6 +383,16 @@ int vapply_blocks(long long R, int C, int V) {
   return (int)n;
 }
 
+// row-chunk count of the tiled apply kernels: ~4 passes of 32 rows per block, total blocks capped
+int tile_row_blocks(long long R, int C, int V) {
+  const long long cchunks = (C + 8 * V - 1) / (8 * V);
+  long long n = acg::ceil_div(R, 32 * 4);
+  const long long cap = std::max<long long>(1, 4096 / cchunks);
+  if (n > cap) n = cap;
+  if (n < 1) n = 1;
+  return (int)n;
+}
+
 int check_bn(const char* who, long long rows, int C, int groups) {
   ACG_REQUIRE(rows > 0 && C > 0 && groups > 0, ACG_ERR_INVALID_ARG, "%s: non-positive size", who);
   ACG_REQUIRE(rows % groups == 0, ACG_ERR_INVALID_ARG, "%s: rows (%lld) not divisible by groups (%d)", who, rows, groups);
@@ -385,12 +433,9 @@ int32_t acg_bn_act_fwd(const void* x, const float* beta, void* y, float* save_me
   if (v4) hipLaunchKernelGGL(bn_stats_partial<4>, dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk);
   else hipLaunchKernelGGL(bn_stats_partial<1>, dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk);
   if (int rc = acg::check_launch("bn_stats_partial")) return rc;
-  hipLaunchKernelGGL(bn_finalize_fwd, dim3((C + 3) / 4, groups), dim3(256), 0, st, xf, (const float*)part, save_mean, save_rstd,
-                     R, C, nblk, eps);
-  if (int rc = acg::check_launch("bn_finalize_fwd")) return rc;
-  const dim3 ag(vapply_blocks(R, C, V), groups);
-  if (v4) hipLaunchKernelGGL(bn_apply_fwd<4>, ag, dim3(256), 0, st, xf, beta, (const float*)save_mean, (const float*)save_rstd, (float*)y, R, C, act, leak);
-  else hipLaunchKernelGGL(bn_apply_fwd<1>, ag, dim3(256), 0, st, xf, beta, (const float*)save_mean, (const float*)save_rstd, (float*)y, R, C, act, leak);
+  const dim3 ag(tile_row_blocks(R, C, V), (C + 8 * V - 1) / (8 * V), groups);
+  if (v4) hipLaunchKernelGGL(bn_apply_fwd<4>, ag, dim3(256), 0, st, xf, beta, (const float*)part, (float*)y, save_mean, save_rstd, R, C, nblk, eps, act, leak);
+  else hipLaunchKernelGGL(bn_apply_fwd<1>, ag, dim3(256), 0, st, xf, beta, (const float*)part, (float*)y, save_mean, save_rstd, R, C, nblk, eps, act, leak);
   return acg::check_launch("bn_apply_fwd");
 }
 
@@ -407,18 +452,15 @@ int32_t acg_bn_act_bwd(const void* x, const void* dy, const float* beta, const f
   const float* xf = (const float*)x;
   const float* dyf = (const float*)dy;
   float* part = (float*)ws;
-  float* msum = part + (size_t)groups * kMaxPartialBlocks * 2 * C;
-  const bool v4 = vec4_ok(C, x, dy, dx) && vec4_ok(C, save_mean, save_rstd, ws) && vec4_ok(C, beta, msum, ws);
+  const bool v4 = vec4_ok(C, x, dy, dx) && vec4_ok(C, save_mean, save_rstd, ws) && vec4_ok(C, beta, dbeta, ws);
   const int V = v4 ? 4 : 1;
   const int nblk = vpartial_blocks(R, C, V);
   if (v4) hipLaunchKernelGGL(bn_bwd_partial<4>, dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak);
   else hipLaunchKernelGGL(bn_bwd_partial<1>, dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak);
   if (int rc = acg::check_launch("bn_bwd_partial")) return rc;
-  hipLaunchKernelGGL(bn_finalize_bwd, dim3((C + 3) / 4), dim3(256), 0, st, (const float*)part, msum, dbeta, dbeta_acc, R, C, groups, nblk);
-  if (int rc = acg::check_launch("bn_finalize_bwd")) return rc;
-  const dim3 ag(vapply_blocks(R, C, V), groups);
-  if (v4) hipLaunchKernelGGL(bn_apply_bwd<4>, ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)msum, (float*)dx, R, C, act, leak);
-  else hipLaunchKernelGGL(bn_apply_bwd<1>, ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)msum, (float*)dx, R, C, act, leak);
+  const dim3 ag(tile_row_blocks(R, C, V), (C + 8 * V - 1) / (8 * V), groups);
+  if (v4) hipLaunchKernelGGL(bn_apply_bwd<4>, ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)part, (float*)dx, dbeta, dbeta_acc, R, C, groups, nblk, act, leak);
+  else hipLaunchKernelGGL(bn_apply_bwd<1>, ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)part, (float*)dx, dbeta, dbeta_acc, R, C, groups, nblk, act, leak);
   return acg::check_launch("bn_apply_bwd");
 }
 

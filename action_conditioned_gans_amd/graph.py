@@ -100,6 +100,7 @@ class Variable(Tensor):
 class Op:
     """One node of the static program.  ``bind(rt)`` returns ``fn(stream_ptr)`` that enqueues it."""
     host = False        # True: cannot be captured into a HIP graph (collectives)
+    side_stream = False  # True: may run on the session's second stream, overlapping the main chain
     run_last = False    # True: ordered after everything else in a program (weight clip, defect D6)
 
     def __init__(self, graph, name, inputs, outputs, control_inputs=()):
@@ -292,6 +293,7 @@ class Runtime:
         self.world_size, self.rank, self.process_group = world_size, rank, process_group
         self.is_cuda = self.device.type == 'cuda'
         self.comm_stream = torch.cuda.Stream(self.device) if self.is_cuda else None
+        self.side_stream = torch.cuda.Stream(self.device) if self.is_cuda else None
         self._scratch = {}
 
     def workspace(self, nbytes):
@@ -309,7 +311,7 @@ class Session:
     """``tf.Session`` stand-in bound to one GPU (one process per GPU)."""
 
     def __init__(self, device='cuda:0', graph=None, use_hip_graphs=True, lib=None,
-                 world_size=1, rank=0, process_group=None):
+                 world_size=1, rank=0, process_group=None, overlap_wgrad=False):
         self.graph = graph or get_default_graph()
         dev = torch.device(device)
         if lib is None:
@@ -322,6 +324,7 @@ class Session:
         if dev.type == 'cuda':
             torch.cuda.set_device(dev)
         self.use_hip_graphs = use_hip_graphs and dev.type == 'cuda'
+        self.overlap_wgrad = overlap_wgrad and dev.type == 'cuda'
         self._programs = {}
         self._initialized = False
 
@@ -528,6 +531,44 @@ class Session:
             return [self._unflatten(f, it) for f in fetches]
         return next(it)
 
+    def _launch_segment(self, seg):
+        """Enqueue one device segment.  With ``overlap_wgrad`` (off by default) ops flagged ``side_stream``
+        (weight gradients: nothing on the dgrad chain consumes them) go to a second HIP stream, ordered behind
+        their producers by an event and joined before the first op that depends on them - a fork/join in the
+        captured graph.  Measured on MI355X at config 2 it LOSES (254 vs 274 steps/s: every conv launch already
+        fills the chip, so the fork only adds event nodes and contention), hence the default."""
+        rt = self.rt
+        if not (rt.is_cuda and self.overlap_wgrad):
+            sp = rt.stream_ptr()
+            for _, fn in seg:
+                fn(sp)
+            return
+        main = torch.cuda.current_stream(rt.device)
+        side = rt.side_stream
+        sp_main = ctypes.c_void_p(main.cuda_stream)
+        sp_side = ctypes.c_void_p(side.cuda_stream)
+        pending = set()                 # ids of side-stream ops not yet joined into the main stream
+
+        def join():
+            ev = torch.cuda.Event()
+            ev.record(side)
+            main.wait_event(ev)
+            pending.clear()
+        for op, fn in seg:
+            if op.side_stream:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                fn(sp_side)
+                pending.add(id(op))
+            else:
+                if pending and (any(id(c) in pending for c in op.control_inputs) or
+                                any(t.op is not None and id(t.op) in pending for t in op.inputs)):
+                    join()
+                fn(sp_main)
+        if pending:
+            join()
+
     def _execute(self, prog):
         rt = self.rt
         prog.runs += 1
@@ -537,9 +578,7 @@ class Session:
                 if kind == 'host':
                     seg()
                 else:
-                    sp = rt.stream_ptr()
-                    for _, fn in seg:
-                        fn(sp)
+                    self._launch_segment(seg)
             return
         if prog.graphs is None:
             prog.graphs = []
@@ -550,9 +589,7 @@ class Session:
                     continue
                 gr = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gr):
-                    sp = rt.stream_ptr()       # the capture stream
-                    for _, fn in seg:
-                        fn(sp)
+                    self._launch_segment(seg)     # current stream = the capture stream
                 prog.graphs.append(gr)
         for (kind, seg), gr in zip(prog.segments, prog.graphs):
             if kind == 'host':

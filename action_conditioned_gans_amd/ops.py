@@ -195,6 +195,7 @@ class ConvDgradOp(_ConvBase):
 
 class ConvWgradOp(_ConvBase):
     which = CONV_WGRAD
+    side_stream = True      # only the optimizer step consumes it: overlaps the dgrad chain (graph.py)
 
     def __init__(self, x, dy, dst, accumulate, desc, transposed, name):
         self.desc, self.transposed, self.accumulate = desc, transposed, float(accumulate)

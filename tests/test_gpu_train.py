@@ -23,11 +23,12 @@ def test_trainer_matches_golden(name):
 
 @pytest.mark.parametrize('name', ['c2_dna_bce_adam', 'c4_dna_wass_rmsprop'])
 def test_hip_graph_replay_equals_eager(name):
-    """Run 1 is eager, run 2 captures, run 3+ replays: the weights must match an all-eager session bit for bit."""
+    """Run 1 is eager, run 2 captures, run 3+ replays (with the weight-gradient kernels forked onto a second
+    stream): the weights must match an all-eager, single-stream session bit for bit."""
     x, y, a, s = TC.MG.inputs(2)
     finals = []
     for use_graphs in (False, True):
-        sess, tr = TC.build_trainer(gpu_session, name, use_hip_graphs=use_graphs)
+        sess, tr = TC.build_trainer(gpu_session, name, use_hip_graphs=use_graphs, overlap_wgrad=False)
         for _ in range(4):
             tr.train_d(x, y, a)
             frames = tr.train_g(x, y, a, s)

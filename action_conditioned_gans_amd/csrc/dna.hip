@@ -15,32 +15,47 @@ namespace {
 
 constexpr int TX = 64;
 
-template <int K, int TY, bool BWD>
+// CC: compile-time channel count (3 = RGB fast path) or 0 = runtime C.
+template <int K, int TY, bool BWD, int CC>
 __global__ __launch_bounds__(TX* TY) void dna_kernel(const float* __restrict__ logits, const float* __restrict__ img,
                                                      const float* __restrict__ dout, float* __restrict__ out,
-                                                     int H, int W, int C) {
+                                                     int H, int W, int Crt) {
   constexpr int KK = K * K, S = KK | 1, NT = TX * TY, P = (K - 1) / 2;
   constexpr int WW = TX + K - 1, WH = TY + K - 1;
-  __shared__ float lg[NT * S];
+  __shared__ __attribute__((aligned(16))) float lg[NT * S];
   __shared__ float win[WH * WW * 4];
+  const int C = CC ? CC : Crt;
 
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY, b = blockIdx.z;
   const int txv = min(TX, W - x0);
 
-  // image window (zero outside the frame)
-  for (int idx = tid; idx < WH * WW * C; idx += NT) {
-    const int c = idx % C, t = idx / C;
-    const int wx = t % WW, wy = t / WW;
-    const int y = y0 - P + wy, x = x0 - P + wx;
-    win[idx] = (y >= 0 && y < H && x >= 0 && x < W) ? img[((long long)(b * H + y) * W + x) * C + c] : 0.f;
+  // image window (zero outside the frame): each window row is one contiguous span of the image row
+  for (int wy = tid / 64; wy < WH; wy += NT / 64) {
+    const int y = y0 - P + wy;
+    const bool yok = y >= 0 && y < H;
+    const long long rowbase = (long long)(b * H + (yok ? y : 0)) * W * C;
+    for (int f = tid % 64; f < WW * C; f += 64) {
+      const int gx = (x0 - P) * C + f;          // element index inside the image row
+      win[wy * WW * C + f] = (yok && gx >= 0 && gx < W * C) ? img[rowbase + gx] : 0.f;
+    }
   }
-  // logits: TY contiguous spans of txv*KK floats
-  for (int idx = tid; idx < TY * TX * KK; idx += NT) {
-    const int ty = idx / (TX * KK), e = idx - ty * (TX * KK);
-    if (y0 + ty < H && e < txv * KK) {
-      const long long gp = (long long)(b * H + y0 + ty) * W + x0;
-      lg[(ty * TX + e / KK) * S + e % KK] = logits[gp * KK + e];
+  // logits: TY contiguous spans of txv*KK floats; float4 when the span is 16-byte aligned and LDS is linear
+  const long long pix0 = (long long)(b * H + y0) * W + x0;
+  const bool vec = (S == KK) && ((pix0 * KK) % 4 == 0) && (((long long)W * KK) % 4 == 0) && ((txv * KK) % 4 == 0) &&
+                   ((reinterpret_cast<uintptr_t>(logits) & 15) == 0);
+  if (vec) {
+    const int span4 = txv * KK / 4;
+    for (int ty = 0; ty < TY; ++ty) {
+      if (y0 + ty >= H) break;
+      const float4* src = reinterpret_cast<const float4*>(logits + (pix0 + (long long)ty * W) * KK);
+      float4* dst = reinterpret_cast<float4*>(lg + ty * TX * S);
+      for (int i = tid; i < span4; i += NT) dst[i] = src[i];
+    }
+  } else {
+    for (int idx = tid; idx < TY * TX * KK; idx += NT) {
+      const int ty = idx / (TX * KK), e = idx - ty * (TX * KK);
+      if (y0 + ty < H && e < txv * KK) lg[(ty * TX + e / KK) * S + e % KK] = logits[(pix0 + (long long)ty * W) * KK + e];
     }
   }
   __syncthreads();
@@ -108,11 +123,18 @@ __global__ __launch_bounds__(TX* TY) void dna_kernel(const float* __restrict__ l
   }
   if constexpr (BWD) {
     __syncthreads();
-    for (int idx = tid; idx < TY * TX * KK; idx += NT) {
-      const int ty2 = idx / (TX * KK), e = idx - ty2 * (TX * KK);
-      if (y0 + ty2 < H && e < txv * KK) {
-        const long long gp = (long long)(b * H + y0 + ty2) * W + x0;
-        out[gp * KK + e] = lg[(ty2 * TX + e / KK) * S + e % KK];
+    if (vec) {
+      const int span4 = txv * KK / 4;
+      for (int ty2 = 0; ty2 < TY; ++ty2) {
+        if (y0 + ty2 >= H) break;
+        float4* dstg = reinterpret_cast<float4*>(out + (pix0 + (long long)ty2 * W) * KK);
+        const float4* srcl = reinterpret_cast<const float4*>(lg + ty2 * TX * S);
+        for (int i = tid; i < span4; i += NT) dstg[i] = srcl[i];
+      }
+    } else {
+      for (int idx = tid; idx < TY * TX * KK; idx += NT) {
+        const int ty2 = idx / (TX * KK), e = idx - ty2 * (TX * KK);
+        if (y0 + ty2 < H && e < txv * KK) out[(pix0 + (long long)ty2 * W) * KK + e] = lg[(ty2 * TX + e / KK) * S + e % KK];
       }
     }
   }
@@ -122,7 +144,8 @@ template <int K, bool BWD>
 int launch_k(const float* logits, const float* img, const float* dout, float* out, int B, int H, int W, int C, hipStream_t st) {
   constexpr int TY = K <= 6 ? 4 : 1;
   const dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, B);
-  hipLaunchKernelGGL((dna_kernel<K, TY, BWD>), grid, dim3(TX * TY), 0, st, logits, img, dout, out, H, W, C);
+  if (C == 3) hipLaunchKernelGGL((dna_kernel<K, TY, BWD, 3>), grid, dim3(TX * TY), 0, st, logits, img, dout, out, H, W, C);
+  else hipLaunchKernelGGL((dna_kernel<K, TY, BWD, 0>), grid, dim3(TX * TY), 0, st, logits, img, dout, out, H, W, C);
   return acg::check_launch(BWD ? "dna_bwd" : "dna_fwd");
 }
 

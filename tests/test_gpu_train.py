@@ -64,3 +64,57 @@ def test_batch32_step_is_finite_and_learns():
         frames = tr.train_g(x, y, a, s)
     assert all(np.isfinite(v) for v in summ.values()), summ
     assert np.isfinite(frames).all()
+
+
+def test_config5_shapes_128x128_k11_match_oracle():
+    """BASELINE config 5 geometry (128x128, 11x11 DNA kernel; fp32 here): action tile H/16 = 8, D logits 4x4,
+    state head 8x8 VALID (64 taps).  Checked live against the fp64 oracle at batch 2."""
+    import torch
+    from oracle import models as OM
+    from oracle.trainer import OracleTrainer
+    from action_conditioned_gans_amd import optim, train as T
+    B, S, K = 2, 128, 11
+    params = OM.init_params(True, batch=B, img=S, ksize=K, seed=5, dtype=torch.float32)
+    G.reset_default_graph()
+    optim.set_data_parallel(1)
+    sess = gpu_session()
+    tr = T.Trainer(sess, True, 'bce', 'rmsprop', True, batch_size=B, img_size=S, ksize=K)
+    sess.run(G.global_variables_initializer())
+    g = G.get_default_graph()
+    assert set(params) == set(g.variables)
+    for n, v in g.variables.items():
+        assert tuple(params[n].shape) == v.shape, n
+        sess.set_value(v, params[n])
+    assert tr.d_out_gen.shape == (B, 4, 4, 1) and g.variables['g/sconv5/weights'].shape == (8, 8, 16, 5)
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, (B, S, S, 3)).astype(np.float32)
+    y = rng.uniform(-1, 1, (B, S, S, 3)).astype(np.float32)
+    a = rng.standard_normal((B, 10)).astype(np.float32)
+    s = rng.standard_normal((B, 5)).astype(np.float32)
+    td = lambda t: torch.from_numpy(t).double()
+    ot = OracleTrainer({k: v.double() for k, v in params.items()}, True, 'bce', 'rmsprop', True, K)
+    frame, state, summ = tr.test(x, y, a)
+    oframe, ostate, opsnr = ot.test(td(x), td(y), td(a))
+    assert TC.rel(frame, oframe.numpy()) <= 1e-3 and TC.rel(state, ostate.numpy()) <= 1e-3
+    dsumm = tr.train_d(x, y, a, summarize=True)
+    od = ot.train_d(td(x), td(y), td(a), return_all=True)
+    assert abs(dsumm['discriminator_loss'] - float(od['d_loss'])) <= 1e-3
+    res = sess.run([tr.g_opt_op, tr.g_loss], tr._feed(x, y, a, s))
+    og = ot.train_g(td(x), td(y), td(a), td(s), return_all=True)
+    assert abs(res[1][0] - float(og['g_loss'])) <= 1e-3 * abs(float(og['g_loss']))
+    for n, v in g.variables.items():                       # RMSProp: weights after 1 D + 1 G step
+        got, want = sess.get_value(v).double(), ot.p[n]
+        assert (got - want).abs().max().item() <= 1e-3 * max(want.abs().max().item(), 1e-3) + 2e-6, n
+
+
+def test_training_loop_runs_wass_rmsprop_n_critic():
+    """train() end to end on synthetic sequences: pretrain iterations, then n_critic=5 D steps per G step
+    (train.py:217-263) with weight clip; weights stay finite and inside the clip range."""
+    from action_conditioned_gans_amd import train as T
+    tr = T.train('synthetic', None, None, None, None, True, 'wass', 'rmsprop', True, batch_size=4, seq_len=8,
+                 train_iter=6, pretrain_iter=2, device='cuda:0', quiet=True)
+    for v in tr.d_vars:
+        val = tr.sess.get_value(v)
+        assert torch.isfinite(val).all() and val.abs().max().item() <= 0.01 + 1e-7, v.name
+    for v in tr.g_vars:
+        assert torch.isfinite(tr.sess.get_value(v)).all(), v.name

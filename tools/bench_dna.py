@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""DNA stencil micro-benchmark: back-to-back launches of acg_dna_fwd / acg_dna_bwd through the C ABI,
+timed with events on the launch stream; reports algorithmic GB/s ((k*k+2C)*4 B/pixel
+forward, (2*k*k+2C)*4 backward) against the 8 TB/s HBM peak.  The batch sweep separates the launch floor
+(config-2 size is 16 MB per launch) from the streaming rate."""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from action_conditioned_gans_amd import _lib   # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batches', default='32,128,512,2048')
+    ap.add_argument('--img', type=int, default=64)
+    ap.add_argument('--ksize', type=int, default=5)
+    ap.add_argument('--reps', type=int, default=50)
+    args = ap.parse_args()
+    lib, dev = _lib.get(), torch.device('cuda:0')
+    k, S, C = args.ksize, args.img, 3
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    for B in [int(b) for b in args.batches.split(',')]:
+        logits = torch.randn(B, S, S, k * k, device=dev)
+        img = torch.rand(B, S, S, C, device=dev) * 2 - 1
+        out = torch.empty_like(img)
+        dout = torch.randn_like(img)
+        dl = torch.empty_like(logits)
+        for name, fn, nbytes in (
+                ('fwd', lambda: lib.dna_fwd(p(logits), p(img), p(out), B, S, S, C, k, 0, stream), B * S * S * (k * k + 2 * C) * 4),
+                ('bwd', lambda: lib.dna_bwd(p(logits), p(img), p(dout), p(dl), B, S, S, C, k, 0, stream), B * S * S * (2 * k * k + 2 * C) * 4)):
+            for _ in range(5):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / args.reps
+            print('dna_%s k=%d B=%-5d %7.2f MB  %8.2f us  %7.1f GB/s  (%.1f%% of 8 TB/s)' % (
+                name, k, B, nbytes / 1e6, us, nbytes / us / 1e3, 100 * nbytes / us / 1e3 / 8000))
+        del logits, dl
+
+
+if __name__ == '__main__':
+    main()

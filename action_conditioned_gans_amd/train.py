@@ -23,6 +23,7 @@ from . import graph as G
 from . import models as M
 from . import ops as O
 from . import optim
+from .saver import Saver
 from .util import build_all_mask
 
 ADAM_LR = 1e-3          # train.py:20
@@ -195,7 +196,8 @@ def _log_jsonl(path, record):
 
 def train(input_path, output_path, test_output_path, log_dir, model_dir, arg_adv, arg_loss, arg_opt, arg_transform,
           batch_size=64, img_size=64, seq_len=8, ksize=5, train_iter=TRAIN_ITER, pretrain_iter=PRETRAIN_ITER,
-          n_critic=None, device='cuda:0', world_size=1, rank=0, process_group=None, log_every=100, quiet=False):
+          n_critic=None, device='cuda:0', world_size=1, rank=0, process_group=None, log_every=100, quiet=False,
+          eval_every=500, resume=None):
     """Training loop of train.py:179-309 on synthetic sequences (the TFRecord pipeline is out of scope)."""
     if input_path not in (None, '', 'synthetic'):
         raise ValueError('only synthetic input is supported (input_path="synthetic"); the push-dataset TFRecord '
@@ -208,6 +210,10 @@ def train(input_path, output_path, test_output_path, log_dir, model_dir, arg_adv
     with G.Session(device=device, world_size=world_size, rank=rank, process_group=process_group) as sess:
         trainer = Trainer(sess, arg_adv, arg_loss, arg_opt, arg_transform, batch_size, img_size, ksize)
         sess.run(G.global_variables_initializer())
+        saver = Saver()                                                           # train.py:215
+        if resume:
+            saver.restore(sess, resume)
+        eval_data = SyntheticPush(batch_size, seq_len, img_size, seed=1007, rank=rank)
         D_per_G = n_critic if n_critic else (5 if arg_loss == 'wass' else 1)      # train.py:217-220
         log_file = os.path.join(log_dir, 'train.jsonl') if log_dir else None
         t0 = time.time()
@@ -231,6 +237,16 @@ def train(input_path, output_path, test_output_path, log_dir, model_dir, arg_adv
                     print('Iteration {:d}'.format(i))
                 if log_file and summ:
                     _log_jsonl(log_file, dict(summ, iteration=i, wall_s=time.time() - t0))
+                if model_dir:
+                    saver.save(sess, os.path.join(model_dir, 'model{:d}'.format(i)))         # train.py:274
+            if eval_every and i % eval_every == 0 and rank == 0:
+                # recursive rollout over T-1 steps on held-out sequences (train.py:278-309; defect D7: own states)
+                t_img, _, t_acts, _ = eval_data.get_batch()
+                predicted, e_summ = trainer.test_sequence(t_img, t_img, t_acts)
+                psnr = [float(10.0 * np.log10(1.0 / max(np.mean((predicted[:, j] - t_img[:, j + 1]) ** 2), 1e-30)))
+                        for j in range(predicted.shape[1])]
+                if log_file:
+                    _log_jsonl(os.path.join(log_dir, 'test.jsonl'), dict(e_summ or {}, iteration=i, rollout_psnr=psnr))
         return trainer
 
 

@@ -151,6 +151,33 @@ def test_uninitialized_and_missing_library():
         G.Session(device='cpu')                                               # product path: no CPU fallback
 
 
+def test_checkpoint_roundtrip_and_rollout(tmp_path):
+    """Saver (train.py:215,274; test.py:29-30): weights AND optimizer slots survive a save/restore, so a resumed
+    run continues bit-identically; test_sequence is the recursive rollout of train.py:157-176."""
+    from action_conditioned_gans_amd.saver import Saver, latest_checkpoint
+    x, y, a, s = TC.MG.inputs(2)
+    sess, tr = TC.build_trainer(cpu_session, 'c4_dna_wass_rmsprop')
+    tr.train_d(x, y, a)
+    tr.train_g(x, y, a, s)
+    path = Saver().save(sess, str(tmp_path / 'model100'))
+    Saver().save(sess, str(tmp_path / 'model20'))
+    assert latest_checkpoint(str(tmp_path)) == str(tmp_path / 'model100') and path.endswith('model100.npz')
+    tr.train_d(x, y, a)
+    tr.train_g(x, y, a, s)
+    want = {n: sess.get_value(v) for n, v in G.get_default_graph().variables.items()}
+    sess2, tr2 = TC.build_trainer(cpu_session, 'c4_dna_wass_rmsprop')
+    Saver().restore(sess2, str(tmp_path / 'model100'))
+    tr2.train_d(x, y, a)
+    tr2.train_g(x, y, a, s)
+    for n, v in G.get_default_graph().variables.items():
+        assert torch.equal(sess2.get_value(v), want[n]), n
+    rng = np.random.default_rng(3)
+    frames = rng.uniform(-1, 1, (2, 4, 64, 64, 3)).astype(np.float32)
+    acts = rng.standard_normal((2, 4, 10)).astype(np.float32)
+    pred, summ = tr2.test_sequence(frames, frames, acts)
+    assert pred.shape == (2, 3, 64, 64, 3) and np.isfinite(pred).all() and 'g_psnr' in summ
+
+
 def test_c_abi_exports_every_declared_symbol():
     """include/acgan_hip.h <-> both libraries: every declared entry point is exported (no compute here)."""
     import re, os, ctypes

@@ -62,11 +62,11 @@ int validate(const acg_conv_desc* d, const char* who) {
   ACG_REQUIRE(d->pad_top < d->kh && d->pad_left < d->kw, ACG_ERR_INVALID_ARG, "%s: padding not smaller than the filter", who);
   ACG_REQUIRE((d->out_h - 1) * d->stride_h - d->pad_top < d->in_h && (d->out_w - 1) * d->stride_w - d->pad_left < d->in_w,
               ACG_ERR_INVALID_ARG, "%s: output extent reads entirely outside the input", who);
-  const long long lim = 2147483647ll;
+  const long long lim = 1ll << 30;   // 32-bit byte offsets in the buffer descriptors
   const long long nx = (long long)d->batch * d->in_h * d->in_w * d->in_c;
   const long long ny = (long long)d->batch * d->out_h * d->out_w * d->out_c;
   const long long nw = (long long)d->kh * d->kw * ((d->in_c + 3) & ~3) * d->out_c;
-  ACG_REQUIRE(nx < lim && ny < lim && nw < lim, ACG_ERR_UNSUPPORTED, "%s: tensor exceeds 2^31 elements", who);
+  ACG_REQUIRE(nx < lim && ny < lim && nw < lim, ACG_ERR_UNSUPPORTED, "%s: tensor exceeds 2^30 elements", who);
   return ACG_OK;
 }
 
@@ -125,6 +125,13 @@ int run(int which, const float* gsrc, const float* dense, float* out, float accu
   ConvArgs a{};
   a.gsrc = gsrc; a.dense = dense; a.out = pl.splits > 1 ? (float*)ws : out; a.out_numel = pl.out_numel;
   a.accumulate = accumulate;
+  {
+    const long long nx = (long long)d->batch * d->in_h * d->in_w * d->in_c, ny = (long long)d->batch * d->out_h * d->out_w * d->out_c;
+    const long long nw = (long long)d->kh * d->kw * d->in_c * d->out_c;
+    const long long ng = which == ACG_CONV_DGRAD ? ny : nx;                       // gathered tensor
+    const long long nd = which == ACG_CONV_WGRAD ? ny : nw;                       // dense operand
+    a.g_bytes = (unsigned)(ng * 4); a.d_bytes = (unsigned)(nd * 4);
+  }
   a.batch = d->batch; a.H = d->in_h; a.W = d->in_w; a.C = d->in_c; a.OH = d->out_h; a.OW = d->out_w; a.K = d->out_c;
   a.KH = d->kh; a.KW = d->kw; a.sh = d->stride_h; a.sw = d->stride_w; a.pt = d->pad_top; a.pl = d->pad_left;
   a.splits = pl.splits;

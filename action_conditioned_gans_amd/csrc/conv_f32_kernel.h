@@ -24,6 +24,7 @@ struct ConvArgs {
   const float* dense;  // w (FWD, DGRAD) or dy (WGRAD)
   float* out;          // final tensor (splits == 1) or `splits` slabs of out_numel floats
   long long out_numel;
+  unsigned g_bytes, d_bytes;   // sizes of gsrc / dense for the buffer descriptors (hardware range check)
   float accumulate;    // WGRAD with splits == 1: out = accumulate * out + value
   int batch, H, W, C, OH, OW, K, KH, KW, sh, sw, pt, pl;
   int splits;
@@ -49,27 +50,32 @@ __device__ __forceinline__ bool tap_ok(const RowInfo& ri, int t) {
   return (mk >> t) & 1ull;
 }
 
-// Branch-free guarded loads.  A divergent `if (ok) load` makes hipcc wait for every load inside its
-// branch (vmcnt(0) per load: the loads of a K-step serialise), and zeroing the loaded VALUE with a select
-// drags the wait up to the load as well.  Instead the POINTER is selected: a masked lane reads 16 bytes
-// of zeros that live in the code object (always valid, always cached), so every load of a stage issues
-// back to back and is first waited for two K-steps later, when the stage is stored to LDS.
-__device__ __attribute__((aligned(16))) float g_zero_quad[4];  // zero-initialised, never written (non-const keeps it in the global address space: no flat loads)
+// Branch-free guarded loads through buffer descriptors.  A divergent `if (ok) load` makes hipcc wait for every
+// load inside its branch (vmcnt(0) per load: the loads of a K-step serialise), and selecting the loaded VALUE
+// drags the wait up to the load as well.  Instead each operand tensor is addressed through a raw buffer
+// resource (base + 32-bit byte offset, hardware range check): a masked lane gets an offset beyond the buffer
+// and the load returns zeros without touching memory.  One v_cndmask on a 32-bit offset per load, no 64-bit
+// pointer arithmetic, and every load of a stage issues back to back; the first wait is two K-steps later.
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOob = 0xFFFFFF00u;   // >= any num_records (tensors are < 2^30 elements)
 
-__device__ __forceinline__ f4 guarded_quad(const float* base, long long off, bool ok) {
-  const float* q = ok ? base + off : g_zero_quad;
-  const f4u v = *reinterpret_cast<const f4u*>(q);
-  return f4{v.x, v.y, v.z, v.w};
+__device__ __forceinline__ f4 guarded_quad(__amdgpu_buffer_rsrc_t rs, int elem_off, bool ok) {
+  const unsigned off = ok ? (unsigned)elem_off * 4u : kOob;
+  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
 }
 // Ragged quad (channel count not a multiple of 4): only the first nvalid (1..3) elements exist.
-__device__ __forceinline__ f4 guarded_ragged(const float* base, long long off, bool ok, int nvalid) {
+__device__ __forceinline__ f4 guarded_ragged(__amdgpu_buffer_rsrc_t rs, int elem_off, bool ok, int nvalid) {
   f4 r;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) r[e] = *((ok && e < nvalid) ? base + off + e : g_zero_quad);
+  for (int e = 0; e < 4; ++e) {
+    const unsigned off = (ok && e < nvalid) ? (unsigned)(elem_off + e) * 4u : kOob;
+    r[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+  }
   return r;
 }
-__device__ __forceinline__ float guarded_scalar(const float* base, long long off, bool ok) {
-  return *(ok ? base + off : g_zero_quad);
+__device__ __forceinline__ float guarded_scalar(__amdgpu_buffer_rsrc_t rs, int elem_off, bool ok) {
+  const unsigned off = ok ? (unsigned)elem_off * 4u : kOob;
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
 }
 
 // RAGGED: gathered channel count not a multiple of 4; NVEC: dense operand rows are float4-loadable (N % 4 == 0).
@@ -88,6 +94,8 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
   __shared__ int tapB[kMaxTaps];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gsrc), 0, p.g_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dense), 0, p.d_bytes, 0x00020000);
 
   // ---- problem geometry (wave-uniform) -------------------------------------------------------
   // Cs: channels of the gathered tensor; Cp: Cs padded to a multiple of 4 (quad granularity per tap).
@@ -219,13 +227,13 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const RowInfo ri = rows[4 * kqa + e];
-            ra[ST][e] = guarded_quad(p.gsrc, (long long)ri.base + wg_off, wg_nvalid > 0 && tap_ok(ri, wg_t));
+            ra[ST][e] = guarded_quad(rs_g, ri.base + wg_off, wg_nvalid > 0 && tap_ok(ri, wg_t));
           }
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const RowInfo ri = rows[4 * kqa + e];
-            ra[ST][e] = guarded_ragged(p.gsrc, (long long)ri.base + wg_off, wg_nvalid > 0 && tap_ok(ri, wg_t), wg_nvalid);
+            ra[ST][e] = guarded_ragged(rs_g, ri.base + wg_off, wg_nvalid > 0 && tap_ok(ri, wg_t), wg_nvalid);
           }
         }
       }
@@ -240,28 +248,28 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
 #pragma unroll
         for (int u = 0; u < QA; ++u) {
           const RowInfo ri = rows[rg + 32 * u];
-          ra[ST][u] = guarded_quad(p.gsrc, (long long)ri.base + aoff, kv && tap_ok(ri, t));
+          ra[ST][u] = guarded_quad(rs_g, ri.base + aoff, kv && tap_ok(ri, t));
         }
       } else {
 #pragma unroll
         for (int u = 0; u < QA; ++u) {
           const RowInfo ri = rows[rg + 32 * u];
-          ra[ST][u] = guarded_ragged(p.gsrc, (long long)ri.base + aoff, kv && tap_ok(ri, t), nvalid);
+          ra[ST][u] = guarded_ragged(rs_g, ri.base + aoff, kv && tap_ok(ri, t), nvalid);
         }
       }
       if constexpr (MODE == MODE_DGRAD) {  // B[k=(tap,o)][n=c] = W[tap][c][o], contiguous along o
-        const long long boff = (long long)tapB[t] + kc;
+        const int boff = tapB[t] + kc;
         if constexpr (!ragged) {
 #pragma unroll
           for (int u = 0; u < QB; ++u) {
             const int n = n0 + rg + 32 * u;
-            rb[ST][u] = guarded_quad(p.dense, boff + (long long)n * p.K, kv && n < N);
+            rb[ST][u] = guarded_quad(rs_d, boff + n * p.K, kv && n < N);
           }
         } else {
 #pragma unroll
           for (int u = 0; u < QB; ++u) {
             const int n = n0 + rg + 32 * u;
-            rb[ST][u] = guarded_ragged(p.dense, boff + (long long)n * p.K, kv && n < N, nvalid);
+            rb[ST][u] = guarded_ragged(rs_d, boff + n * p.K, kv && n < N, nvalid);
           }
         }
       }
@@ -275,11 +283,11 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
           const int n = n0 + 4 * jb;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            long long row;
+            int row;
             bool ok;
-            if constexpr (MODE == MODE_FWD) { row = (long long)bt * Cs + bc + e; ok = bt < ntaps && bc + e < Cs; }
-            else { row = (long long)ks * BK + 4 * kqb + e; ok = row < Kdim; }
-            rb[ST][e] = guarded_quad(p.dense, row * N + n, ok && n < N);   // raw row; transposed at store time
+            if constexpr (MODE == MODE_FWD) { row = bt * Cs + bc + e; ok = bt < ntaps && bc + e < Cs; }
+            else { row = ks * BK + 4 * kqb + e; ok = row < Kdim; }
+            rb[ST][e] = guarded_quad(rs_d, row * N + n, ok && n < N);   // raw row; transposed at store time
           }
         }
       } else {  // ragged N (25, 5, 3, 1 ...): 4 k-rows of one column per quad, lanes along n
@@ -294,11 +302,11 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
             while (c2 >= Cp) { c2 -= Cp; ++t2; }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              v[e] = guarded_scalar(p.dense, ((long long)t2 * Cs + c2 + e) * N + n, t2 < ntaps && c2 + e < Cs && n < N);
+              v[e] = guarded_scalar(rs_d, (t2 * Cs + c2 + e) * N + n, t2 < ntaps && c2 + e < Cs && n < N);
           } else {
-            const long long r = (long long)ks * BK + 4 * kq;
+            const int r = ks * BK + 4 * kq;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = guarded_scalar(p.dense, (r + e) * N + n, r + e < Kdim && n < N);
+            for (int e = 0; e < 4; ++e) v[e] = guarded_scalar(rs_d, (r + e) * N + n, r + e < Kdim && n < N);
           }
           rb[ST][u] = v;
         }

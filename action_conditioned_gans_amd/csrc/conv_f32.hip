@@ -58,12 +58,13 @@ int validate(const acg_conv_desc* d, const char* who) {
   ACG_REQUIRE(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->in_c > 0 && d->out_h > 0 && d->out_w > 0 && d->out_c > 0 &&
                   d->kh > 0 && d->kw > 0 && d->stride_h > 0 && d->stride_w > 0 && d->pad_top >= 0 && d->pad_left >= 0,
               ACG_ERR_INVALID_ARG, "%s: non-positive dimension in descriptor", who);
+  ACG_REQUIRE(d->in_pitch == 0 || d->in_pitch >= d->in_c, ACG_ERR_INVALID_ARG, "%s: in_pitch %d smaller than in_c %d", who, d->in_pitch, d->in_c);
   ACG_REQUIRE(d->kh * d->kw <= kMaxTaps, ACG_ERR_UNSUPPORTED, "%s: %dx%d filter exceeds %d taps", who, d->kh, d->kw, kMaxTaps);
   ACG_REQUIRE(d->pad_top < d->kh && d->pad_left < d->kw, ACG_ERR_INVALID_ARG, "%s: padding not smaller than the filter", who);
   ACG_REQUIRE((d->out_h - 1) * d->stride_h - d->pad_top < d->in_h && (d->out_w - 1) * d->stride_w - d->pad_left < d->in_w,
               ACG_ERR_INVALID_ARG, "%s: output extent reads entirely outside the input", who);
   const long long lim = 1ll << 30;   // 32-bit byte offsets in the buffer descriptors
-  const long long nx = (long long)d->batch * d->in_h * d->in_w * d->in_c;
+  const long long nx = (long long)d->batch * d->in_h * d->in_w * (d->in_pitch > 0 ? d->in_pitch : d->in_c);
   const long long ny = (long long)d->batch * d->out_h * d->out_w * d->out_c;
   const long long nw = (long long)d->kh * d->kw * ((d->in_c + 3) & ~3) * d->out_c;
   ACG_REQUIRE(nx < lim && ny < lim && nw < lim, ACG_ERR_UNSUPPORTED, "%s: tensor exceeds 2^30 elements", who);
@@ -85,12 +86,13 @@ Plan make_plan(const acg_conv_desc& d, int which) {
     pl.M = (long long)d.batch * hc * wc; pl.N = d.in_c;
     K = (long long)((d.kh + d.stride_h - 1) / d.stride_h) * ((d.kw + d.stride_w - 1) / d.stride_w) * cout_p;
     pl.classes = d.stride_h * d.stride_w;
-    pl.out_numel = (long long)d.batch * d.in_h * d.in_w * d.in_c;
+    pl.out_numel = (long long)d.batch * d.in_h * d.in_w * (d.in_pitch > 0 ? d.in_pitch : d.in_c);
   } else {
     pl.M = (long long)d.kh * d.kw * cin_p; pl.N = d.out_c; K = (long long)d.batch * d.out_h * d.out_w; pl.classes = 1;
     pl.out_numel = (long long)d.kh * d.kw * d.in_c * d.out_c;
   }
-  const int cs = which == ACG_CONV_DGRAD ? d.out_c : d.in_c;       // channels of the gathered tensor
+  // channel pitch of the gathered tensor decides whether its quads are 16-byte loads
+  const int cs = which == ACG_CONV_DGRAD ? d.out_c : (d.in_pitch > 0 ? d.in_pitch : d.in_c);
   pl.ragged = (cs & 3) != 0;
   pl.nvec = (pl.N & 3) == 0;
   pl.nk = (int)((K + BK - 1) / BK);
@@ -101,14 +103,15 @@ Plan make_plan(const acg_conv_desc& d, int which) {
   // buys little, while small tiles keep >= 3 blocks per CU resident and even out the DGRAD parity classes;
   // only weight gradients with a large [taps*Cin, Cout] face prefer the 128x128 tile + heavy split-K.
   if (pl.N <= 32) pl.cfg = 2;
+  else if (which == ACG_CONV_WGRAD && tiles_for(128, 128) >= 128) pl.cfg = 1;
   else if (which == ACG_CONV_WGRAD && tiles_for(128, 128) >= 16) pl.cfg = 0;
   else pl.cfg = 3;
   if (g_force_cfg >= 0 && g_force_cfg < 4) pl.cfg = g_force_cfg;
   pl.bm = kBM[pl.cfg]; pl.bn = kBN[pl.cfg];
   pl.tiles = tiles_for(pl.bm, pl.bn);
-  const long long target = pl.cfg == 0 ? 448 : 1024;
+  const long long target = 448;   // ~2 resident blocks per CU; more splits only grow the slab reduction
   long long s = (target + pl.tiles / 2) / pl.tiles;
-  s = std::min<long long>(s, std::max(1, pl.nk / 4));
+  s = std::min<long long>(s, std::max(1, pl.nk / 6));
   s = std::min<long long>(s, 64);
   if (g_force_splits >= 1) s = std::min<long long>(g_force_splits, pl.nk);
   pl.splits = (int)std::max<long long>(s, 1);
@@ -126,12 +129,13 @@ int run(int which, const float* gsrc, const float* dense, float* out, float accu
   a.gsrc = gsrc; a.dense = dense; a.out = pl.splits > 1 ? (float*)ws : out; a.out_numel = pl.out_numel;
   a.accumulate = accumulate;
   {
-    const long long nx = (long long)d->batch * d->in_h * d->in_w * d->in_c, ny = (long long)d->batch * d->out_h * d->out_w * d->out_c;
+    const long long nx = (long long)d->batch * d->in_h * d->in_w * (d->in_pitch > 0 ? d->in_pitch : d->in_c), ny = (long long)d->batch * d->out_h * d->out_w * d->out_c;
     const long long nw = (long long)d->kh * d->kw * d->in_c * d->out_c;
     const long long ng = which == ACG_CONV_DGRAD ? ny : nx;                       // gathered tensor
     const long long nd = which == ACG_CONV_WGRAD ? ny : nw;                       // dense operand
     a.g_bytes = (unsigned)(ng * 4); a.d_bytes = (unsigned)(nd * 4);
   }
+  a.Cx = d->in_pitch > 0 ? d->in_pitch : d->in_c;
   a.batch = d->batch; a.H = d->in_h; a.W = d->in_w; a.C = d->in_c; a.OH = d->out_h; a.OW = d->out_w; a.K = d->out_c;
   a.KH = d->kh; a.KW = d->kw; a.sh = d->stride_h; a.sw = d->stride_w; a.pt = d->pad_top; a.pl = d->pad_left;
   a.splits = pl.splits;
@@ -159,7 +163,7 @@ int32_t acg_conv_desc_init(acg_conv_desc* d, int32_t batch, int32_t in_h, int32_
   ACG_REQUIRE(d && batch > 0 && in_h > 0 && in_w > 0 && in_c > 0 && kh > 0 && kw > 0 && out_c > 0 && stride > 0,
               ACG_ERR_INVALID_ARG, "conv_desc_init: non-positive dimension");
   d->batch = batch; d->in_h = in_h; d->in_w = in_w; d->in_c = in_c; d->out_c = out_c;
-  d->kh = kh; d->kw = kw; d->stride_h = d->stride_w = stride;
+  d->kh = kh; d->kw = kw; d->stride_h = d->stride_w = stride; d->in_pitch = 0;
   if (same) {  // TF 'SAME' (SURVEY A.1): out = ceil(in/s), pad_before = total // 2
     d->out_h = (in_h + stride - 1) / stride; d->out_w = (in_w + stride - 1) / stride;
     const int th = std::max((d->out_h - 1) * stride + kh - in_h, 0), tw = std::max((d->out_w - 1) * stride + kw - in_w, 0);

@@ -27,6 +27,7 @@ struct ConvArgs {
   unsigned g_bytes, d_bytes;   // sizes of gsrc / dense for the buffer descriptors (hardware range check)
   float accumulate;    // WGRAD with splits == 1: out = accumulate * out + value
   int batch, H, W, C, OH, OW, K, KH, KW, sh, sw, pt, pl;
+  int Cx;              // channel pitch of x / dx in memory (>= C)
   int splits;
 };
 
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
       tapB[t] = ((i0 + p.sh * ti) * p.KW + (j0 + p.sw * tj)) * p.C * p.K;
     } else {
       const int i = t / p.KW, j = t - i * p.KW;
-      tapA[t] = (i * p.W + j) * p.C;
+      tapA[t] = (i * p.W + j) * p.Cx;
       tapB[t] = 0;
     }
   }
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
     if (r < limit) {
       const int q = r % p.OW; const int t2 = r / p.OW; const int pp = t2 % p.OH; const int b = t2 / p.OH;
       const int y0 = pp * p.sh - p.pt, x0 = q * p.sw - p.pl;
-      ri.base = ((b * p.H + y0) * p.W + x0) * p.C;
+      ri.base = ((b * p.H + y0) * p.W + x0) * p.Cx;
       const unsigned long long m = tap_mask(max(0, -y0), min(p.KH, p.H - y0), max(0, -x0), min(p.KW, p.W - x0), p.KW);
       ri.mask_lo = (unsigned)m; ri.mask_hi = (unsigned)(m >> 32);
     }
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
         const int w2 = m % Wc; const int t2 = m / Wc; const int h2 = t2 % Hc; const int b = t2 / Hc;
         const int y0 = h2 + dp0, x0 = w2 + dq0;  // dY coordinates of tap (0,0)
         ri.base = ((b * p.OH + y0) * p.OW + x0) * p.K;
-        ri.out_off = ((b * p.H + h2 * p.sh + ph) * p.W + (w2 * p.sw + pw)) * p.C;
+        ri.out_off = ((b * p.H + h2 * p.sh + ph) * p.W + (w2 * p.sw + pw)) * p.Cx;
         // tap (ti,tj) reads dY[y0 - ti][x0 - tj]
         const unsigned long long mk = tap_mask(max(0, y0 - p.OH + 1), min(nti, y0 + 1), max(0, x0 - p.OW + 1), min(ntj, x0 + 1), ntj);
         ri.mask_lo = (unsigned)mk; ri.mask_hi = (unsigned)(mk >> 32);

@@ -36,15 +36,17 @@ int grid_for(long long n) {
   return (int)b;
 }
 
-// y[r, 0:ca] = a[r, :]; y[r, ca:ca+cb] = b[r / rows_per_b, :]  (rows_per_b = 1: plain concat; = hw: tiled actions)
+// y[r, 0:ca] = a[r, :]; y[r, ca:ca+cb] = b[r / rows_per_b, :]  (rows_per_b = 1: plain concat; = hw: tiled actions);
+// y rows are `pitch` floats apart, pad channels are not written
 __global__ __launch_bounds__(256) void concat_k(const float* __restrict__ a, const float* __restrict__ b,
-                                                float* __restrict__ y, long long rows, int ca, int cb, int rows_per_b) {
+                                                float* __restrict__ y, long long rows, int ca, int cb, int rows_per_b,
+                                                int pitch) {
   const int cy = ca + cb;
   const long long n = rows * cy, stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     const long long r = i / cy;
     const int c = (int)(i - r * cy);
-    y[i] = c < ca ? a[r * ca + c] : b[(r / rows_per_b) * cb + (c - ca)];
+    y[r * pitch + c] = c < ca ? a[r * ca + c] : b[(r / rows_per_b) * cb + (c - ca)];
   }
 }
 
@@ -88,17 +90,19 @@ int32_t acg_concat_actions_fwd(const void* x, const float* actions, void* y, int
   ACG_REQUIRE(x && actions && y, ACG_ERR_INVALID_ARG, "concat_actions_fwd: null pointer");
   const long long rows = (long long)B * hw;
   hipLaunchKernelGGL(concat_k, dim3(grid_for(rows * (c + a))), dim3(256), 0, acg::to_stream(stream), (const float*)x,
-                     actions, (float*)y, rows, c, a, hw);
+                     actions, (float*)y, rows, c, a, hw, c + a);
   return acg::check_launch("concat_actions_fwd");
 }
 
-int32_t acg_concat_channels_fwd(const void* a, const void* b, void* y, int64_t rows, int32_t ca, int32_t cb, int32_t dtype,
-                                acg_stream_t stream) {
+int32_t acg_concat_channels_fwd(const void* a, const void* b, void* y, int64_t rows, int32_t ca, int32_t cb, int32_t y_pitch,
+                                int32_t dtype, acg_stream_t stream) {
   ACG_REQUIRE_F32(dtype);
-  ACG_REQUIRE(rows > 0 && ca > 0 && cb > 0, ACG_ERR_INVALID_ARG, "concat_channels_fwd: non-positive size");
-  ACG_REQUIRE(a && b && y, ACG_ERR_INVALID_ARG, "concat_channels_fwd: null pointer");
+  ACG_REQUIRE(rows > 0 && ca > 0 && cb >= 0, ACG_ERR_INVALID_ARG, "concat_channels_fwd: non-positive size");
+  ACG_REQUIRE(a && (b || cb == 0) && y, ACG_ERR_INVALID_ARG, "concat_channels_fwd: null pointer");
+  const int pitch = y_pitch > 0 ? y_pitch : ca + cb;
+  ACG_REQUIRE(pitch >= ca + cb, ACG_ERR_INVALID_ARG, "concat_channels_fwd: pitch smaller than the row");
   hipLaunchKernelGGL(concat_k, dim3(grid_for(rows * (ca + cb))), dim3(256), 0, acg::to_stream(stream), (const float*)a,
-                     (const float*)b, (float*)y, (long long)rows, ca, cb, 1);
+                     (const float*)b, (float*)y, (long long)rows, ca, cb, 1, pitch);
   return acg::check_launch("concat_channels_fwd");
 }
 

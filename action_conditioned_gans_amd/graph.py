@@ -46,6 +46,7 @@ class Tensor:
         self.view_of = None         # (base Tensor, element offset): a window into a flat buffer
         self.alias_of = None        # same storage as another tensor, different shape (reshape)
         self.buf = None
+        self.valid_c = None         # logical channel count when the last dimension is a padded channel pitch
         self.id = graph._next_id()
 
     @property
@@ -195,7 +196,13 @@ def reset_default_graph():
     return _default[-1]
 
 
-def placeholder(shape, name=None, dtype=torch.float32):
+def placeholder(shape, name=None, dtype=torch.float32, channel_pitch=None):
+    """tf.placeholder.  ``channel_pitch`` stores the last dimension with that pitch (zero pad channels) so that 3-
+    or 6-channel images can be gathered with 16-byte loads by the first conv layer."""
+    if channel_pitch and channel_pitch != shape[-1]:
+        ph = Placeholder(get_default_graph(), tuple(shape[:-1]) + (channel_pitch,), name=name, dtype=dtype)
+        ph.valid_c = shape[-1]
+        return ph
     return Placeholder(get_default_graph(), shape, name=name, dtype=dtype)
 
 
@@ -474,9 +481,10 @@ class Session:
             self._programs[key] = prog
         for ph, val in feed_dict.items():
             src = val if torch.is_tensor(val) else torch.from_numpy(np.ascontiguousarray(val))
-            if tuple(src.shape) != ph.shape:
+            dst = ph.buf if ph.valid_c is None else ph.buf[..., :ph.valid_c]     # pad channels stay zero
+            if tuple(src.shape) != tuple(dst.shape):
                 raise ValueError('Cannot feed value of shape %s for %r' % (tuple(src.shape), ph))
-            ph.buf.copy_(src.to(ph.dtype), non_blocking=True)
+            dst.copy_(src.to(ph.dtype), non_blocking=True)
         self._execute(prog)
         results = []
         for t in prog.fetch_tensors:
@@ -502,7 +510,8 @@ class Session:
             self.run(fetches, feed_dict)
         prog = self._programs[key]
         for ph, val in (feed_dict or {}).items():
-            ph.buf.copy_(val if torch.is_tensor(val) else torch.from_numpy(np.ascontiguousarray(val)), non_blocking=True)
+            dst = ph.buf if ph.valid_c is None else ph.buf[..., :ph.valid_c]
+            dst.copy_(val if torch.is_tensor(val) else torch.from_numpy(np.ascontiguousarray(val)), non_blocking=True)
         stream = torch.cuda.current_stream(self.rt.device)
         records = []
         for _ in range(repeats):

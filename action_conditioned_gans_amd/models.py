@@ -10,7 +10,8 @@ Deviations from the reference text, which does not run as committed (SURVEY sect
   D2  ``slim.argscope`` is read as ``slim.arg_scope``.
   D3  the discriminator tiles its actions to its own conv2 output size, not to 4x4.
   D9  ``ksize`` is honoured (default 5) and H, W come from the tensor instead of a literal 64.
-Actions may be given as ``[B, A]`` (tiled and concatenated in one fused op) or already tiled
+``images.padded`` (optional attribute): the same frames stored with a channel pitch of 4; g/conv1 then gathers
+with 16-byte loads.  Actions may be given as ``[B, A]`` (tiled and concatenated in one fused op) or already tiled
 ``[B, h, w, A]`` as the reference Trainer passes them (train.py:48-50).
 """
 from . import graph as G
@@ -45,7 +46,7 @@ def build_generator(images, actions, reuse=False):
     with O.variable_scope('g', reuse=reuse), \
             O.arg_scope([O.conv2d, O.deconv2d], activation_fn=O.relu, stride=2, padding='SAME',
                         normalizer_fn=O.batch_norm, reuse=reuse):
-        net = _stack(images, G_PLAIN['encoder'], O.conv2d)
+        net = _stack(getattr(images, 'padded', images), G_PLAIN['encoder'], O.conv2d)
         net = _with_actions(net, actions, 'actions')
         net = _stack(net, G_PLAIN['decoder'], O.deconv2d)
         return O.deconv2d(net, images.shape[3], [5, 5], activation_fn=O.tanh, normalizer_fn=None, scope='tconv4')
@@ -64,7 +65,7 @@ def build_generator_transform(images, actions, batch_size=None, reuse=False, col
     with O.variable_scope('g', reuse=reuse), \
             O.arg_scope([O.conv2d, O.deconv2d], activation_fn=O.relu, stride=2, padding='SAME',
                         normalizer_fn=O.batch_norm, reuse=reuse):
-        net = _stack(images, G_DNA['encoder'], O.conv2d)
+        net = _stack(getattr(images, 'padded', images), G_DNA['encoder'], O.conv2d)
         net = _with_actions(net, actions, 'actions')
         net = _stack(net, G_DNA['decoder_a'], O.deconv2d)
 

@@ -123,8 +123,9 @@ def _check_nhwc(x, what):
 
 def _desc(lib_free_args):
     """Build an acg_conv_desc in Python (same arithmetic as acg_conv_desc_init)."""
-    batch, h, w, c, kh, kw, cout, stride, padding = lib_free_args
+    batch, h, w, c, kh, kw, cout, stride, padding = lib_free_args[:9]
     d = ConvDesc()
+    d.in_pitch = lib_free_args[9] if len(lib_free_args) > 9 else 0
     d.batch, d.in_h, d.in_w, d.in_c, d.out_c, d.kh, d.kw = batch, h, w, c, cout, kh, kw
     d.stride_h = d.stride_w = stride
     if padding == 'SAME':
@@ -176,6 +177,7 @@ class Conv2dOp(_ConvBase):
         dx = None
         if needs[0]:
             dx = ConvDgradOp(dy, w, x.shape, self.desc, self.transposed, self.name + '/dgrad').outputs[0]
+            dx.valid_c = x.valid_c
         if needs[1] and ctx.wants(w):
             dst, acc = ctx.slot(w)
             ctx.wrote(w, ConvWgradOp(x, dy, dst, acc, self.desc, self.transposed, self.name + '/wgrad'))
@@ -372,17 +374,29 @@ class ConcatActionsOp(G.Op):
 
 
 class ConcatChannelsOp(G.Op):
-    def __init__(self, a, b, name, out=None):
+    """a ++ b on the channel axis; ``pitch`` > ca+cb stores the result with zero pad channels (``valid_c`` set)."""
+
+    def __init__(self, a, b, name, out=None, pitch=0):
         if a.shape[:-1] != b.shape[:-1]:
             raise ValueError('concat: leading dimensions differ: %s vs %s' % (a.shape, b.shape))
-        shape = a.shape[:-1] + (a.shape[-1] + b.shape[-1],)
+        if a.valid_c or b.valid_c:
+            raise ValueError('concat: channel-padded inputs are not supported')
+        csum = a.shape[-1] + b.shape[-1]
+        shape = a.shape[:-1] + (pitch or csum,)
+        if pitch and pitch < csum:
+            raise ValueError('concat: pitch %d smaller than %d channels' % (pitch, csum))
         if out is not None and out.shape != shape:
             raise ValueError('concat: out has shape %s, expected %s' % (out.shape, shape))
-        super().__init__(G.get_default_graph(), name, [a, b], [out if out is not None else _new(shape, name + ':0')])
+        self.pitch = pitch if pitch and pitch != csum else 0
+        y = out if out is not None else _new(shape, name + ':0')
+        if self.pitch:
+            y.valid_c = csum
+        super().__init__(G.get_default_graph(), name, [a, b], [y])
 
     def bind(self, rt):
         a, b = self.inputs
-        args = (_p(a.buf), _p(b.buf), _p(self.outputs[0].buf), a.numel // a.shape[-1], a.shape[-1], b.shape[-1], ACG_F32)
+        args = (_p(a.buf), _p(b.buf), _p(self.outputs[0].buf), a.numel // a.shape[-1], a.shape[-1], b.shape[-1], self.pitch,
+                ACG_F32)
         fn = rt.lib.concat_channels_fwd
         return lambda s: fn(*args, s)
 
@@ -426,6 +440,7 @@ def batch_join(producers, part_shape, name='batch_join'):
         f(win)
         parts.append(win)
     JoinOp(parts, whole, name)
+    whole.valid_c = parts[0].valid_c
     return whole, parts
 
 
@@ -517,7 +532,9 @@ def _layer(inputs, num_outputs, kernel_size, stride, padding, activation_fn, nor
            weights_initializer, biases_initializer, reuse, scope, transposed, default_scope):
     _check_nhwc(inputs, default_scope)
     kh, kw = (kernel_size, kernel_size) if isinstance(kernel_size, int) else tuple(kernel_size)
-    b, h, w, cin = inputs.shape
+    b, h, w, cphys = inputs.shape
+    cin = inputs.valid_c or cphys              # padded channel pitch: the filter sees the logical channels only
+    pitch = cphys if cin != cphys else 0
     g = G.get_default_graph()
     with variable_scope(scope or default_scope, reuse=reuse):
         share = _scope_reuse()
@@ -525,11 +542,13 @@ def _layer(inputs, num_outputs, kernel_size, stride, padding, activation_fn, nor
         if transposed:
             if padding != 'SAME':
                 raise ValueError('conv2d_transpose: only SAME padding is implemented (the reference uses no other)')
+            if pitch:
+                raise ValueError('conv2d_transpose: channel-padded inputs are not supported')
             wshape = (kh, kw, num_outputs, cin)
             desc = _desc((b, h * stride, w * stride, num_outputs, kh, kw, cin, stride, 'SAME'))
         else:
             wshape = (kh, kw, cin, num_outputs)
-            desc = _desc((b, h, w, cin, kh, kw, num_outputs, stride, padding))
+            desc = _desc((b, h, w, cin, kh, kw, num_outputs, stride, padding, pitch))
         weights = g.get_variable(_scope_name('weights'), wshape, winit, share)
         name = _scope_name()
         out = Conv2dOp(inputs, weights, desc, transposed, name + ('/conv2d_transpose' if transposed else '/conv2d')).outputs[0]
@@ -588,11 +607,12 @@ def concat_actions(x, actions, name='concat_actions'):
     return ConcatActionsOp(x, actions, _scope_name(name)).outputs[0]
 
 
-def concat(values, axis=3, name='concat', out=None):
-    """tf.concat on the channel axis (train.py:64,68); ``out`` lets the result land in a window of a larger tensor."""
+def concat(values, axis=3, name='concat', out=None, pitch=0):
+    """tf.concat on the channel axis (train.py:64,68); ``out`` lets the result land in a window of a larger tensor,
+    ``pitch`` stores it with zero pad channels up to that channel pitch."""
     if axis not in (3, -1) or len(values) != 2:
         raise ValueError('concat: only two tensors on the channel axis are supported')
-    return ConcatChannelsOp(values[0], values[1], _scope_name(name), out=out).outputs[0]
+    return ConcatChannelsOp(values[0], values[1], _scope_name(name), out=out, pitch=pitch).outputs[0]
 
 
 def repeat_batch(x, times, name='repeat_batch'):

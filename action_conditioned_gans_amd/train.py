@@ -47,6 +47,8 @@ class Trainer:
         O.set_random_seed(seed)
 
         self.img_ph = G.placeholder((B, S, S, 3), name='current_frame')
+        # the same frames with a channel pitch of 4 (zero pad channel): lets g/conv1 gather with 16-byte loads
+        self.img_ph.padded = self._img_pad = G.placeholder((B, S, S, 3), name='current_frame_pitch4', channel_pitch=4)
         self.next_frame_ph = G.placeholder((B, S, S, 3), name='next_frame')
         self.action_ph = G.placeholder((B, ACTION_DIM), name='action')
         self.next_state = G.placeholder((B, STATE_DIM), name='next_state')
@@ -65,12 +67,12 @@ class Trainer:
         # launches.  The G step still uses the batch-B D(fake) graph (D(real) is pruned there anyway).
         if batched_d:
             d_in_both, (d_in_gen, d_in_real) = O.batch_join(
-                [lambda out: O.concat([self.img_ph, self.g_next_frame], axis=3, name='d_in_gen', out=out),
-                 lambda out: O.concat([self.img_ph, self.next_frame_ph], axis=3, name='d_in_real', out=out)],
-                (B, S, S, 6), name='d_in_both')
+                [lambda out: O.concat([self.img_ph, self.g_next_frame], axis=3, name='d_in_gen', out=out, pitch=8),
+                 lambda out: O.concat([self.img_ph, self.next_frame_ph], axis=3, name='d_in_real', out=out, pitch=8)],
+                (B, S, S, 8), name='d_in_both')          # 6 channels at a pitch of 8: 16-byte gathers in d/conv1
         else:
-            d_in_gen = O.concat([self.img_ph, self.g_next_frame], axis=3, name='d_in_gen')
-            d_in_real = O.concat([self.img_ph, self.next_frame_ph], axis=3, name='d_in_real')
+            d_in_gen = O.concat([self.img_ph, self.g_next_frame], axis=3, name='d_in_gen', pitch=8)
+            d_in_real = O.concat([self.img_ph, self.next_frame_ph], axis=3, name='d_in_real', pitch=8)
         self.d_out_gen = M.build_discriminator(d_in_gen, self.action_ph, reuse=False)
         if batched_d:
             with O.arg_scope([O.batch_norm], groups=2):
@@ -123,8 +125,8 @@ class Trainer:
 
     # ---- steps: one sess.run each (train.py:114-155)
     def _feed(self, input_images, next_frame, actions, state=None):
-        return {self.img_ph: input_images, self.next_frame_ph: next_frame, self.action_ph: actions,
-                self.next_state: self._zero_state if state is None else state}
+        return {self.img_ph: input_images, self._img_pad: input_images, self.next_frame_ph: next_frame,
+                self.action_ph: actions, self.next_state: self._zero_state if state is None else state}
 
     def pretrain_g(self, input_images, next_frame, actions, state):
         _, g_res = self.sess.run([self.g_pretrain_opt_op, self.g_loss], self._feed(input_images, next_frame, actions, state))

@@ -55,6 +55,9 @@ typedef struct acg_conv_desc {
   int32_t kh, kw;
   int32_t stride_h, stride_w;
   int32_t pad_top, pad_left;
+  int32_t in_pitch; /* channel pitch (floats) of x / dx in memory; 0 = dense (= in_c).  A pitch that is a
+                       multiple of 4 lets 3- or 6-channel inputs (g/conv1, d/conv1) take the 16-byte gather path;
+                       the pad channels of x must hold finite values (zeros), those of dx are left untouched. */
 } acg_conv_desc;
 
 /* Fill a descriptor from slim-style arguments; same_padding != 0 -> TF 'SAME', else 'VALID'. */
@@ -135,9 +138,10 @@ int32_t acg_dna_bwd(const void* logits, const void* image, const void* dout, voi
 /* y[b,s,0:c] = x[b,s,:],  y[b,s,c:c+a] = actions[b,:]   for s in [0,hw) */
 int32_t acg_concat_actions_fwd(const void* x, const float* actions, void* y, int32_t batch, int32_t hw,
                                int32_t c, int32_t a, int32_t dtype, acg_stream_t stream);
-/* y[r,0:ca] = a[r,:], y[r,ca:ca+cb] = b[r,:] */
+/* y[r,0:ca] = a[r,:], y[r,ca:ca+cb] = b[r,:]; y rows are y_pitch floats apart (0 = dense = ca+cb); pad channels
+ * are not written.  cb may be 0 (b ignored): a plain re-pitching copy. */
 int32_t acg_concat_channels_fwd(const void* a, const void* b, void* y, int64_t rows, int32_t ca, int32_t cb,
-                                int32_t dtype, acg_stream_t stream);
+                                int32_t y_pitch, int32_t dtype, acg_stream_t stream);
 /* dst[r,:] = accumulate * dst[r,:] + src[r, c_off : c_off + c_dst] */
 int32_t acg_slice_channels(const void* src, void* dst, float accumulate, int64_t rows, int32_t c_src,
                            int32_t c_off, int32_t c_dst, int32_t dtype, acg_stream_t stream);

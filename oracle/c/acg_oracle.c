@@ -32,7 +32,7 @@ int32_t acg_conv_desc_init(acg_conv_desc* d, int32_t batch, int32_t in_h, int32_
   if (!d || batch <= 0 || in_h <= 0 || in_w <= 0 || in_c <= 0 || kh <= 0 || kw <= 0 || out_c <= 0 || stride <= 0)
     return fail(ACG_ERR_INVALID_ARG, "conv_desc_init: non-positive dimension");
   d->batch = batch; d->in_h = in_h; d->in_w = in_w; d->in_c = in_c; d->out_c = out_c;
-  d->kh = kh; d->kw = kw; d->stride_h = d->stride_w = stride;
+  d->kh = kh; d->kw = kw; d->stride_h = d->stride_w = stride; d->in_pitch = 0;
   if (same) {
     d->out_h = (in_h + stride - 1) / stride; d->out_w = (in_w + stride - 1) / stride;
     int th = (d->out_h - 1) * stride + kh - in_h; if (th < 0) th = 0;
@@ -49,7 +49,8 @@ int32_t acg_conv_desc_init(acg_conv_desc* d, int32_t batch, int32_t in_h, int32_
 size_t acg_conv2d_workspace_bytes(const acg_conv_desc* d, int32_t which, int32_t dtype) { (void)d; (void)which; (void)dtype; return 0; }
 int32_t acg_debug_conv_plan(int32_t cfg, int32_t splits) { (void)cfg; (void)splits; return ACG_OK; }
 
-#define XI(d, b, y, x, c) ((((size_t)(b) * (d)->in_h + (y)) * (d)->in_w + (x)) * (d)->in_c + (c))
+#define XPITCH(d) ((d)->in_pitch > 0 ? (d)->in_pitch : (d)->in_c)
+#define XI(d, b, y, x, c) ((((size_t)(b) * (d)->in_h + (y)) * (d)->in_w + (x)) * XPITCH(d) + (c))
 #define YI(d, b, p, q, o) ((((size_t)(b) * (d)->out_h + (p)) * (d)->out_w + (q)) * (d)->out_c + (o))
 #define WI(d, i, j, c, o) ((((size_t)(i) * (d)->kw + (j)) * (d)->in_c + (c)) * (d)->out_c + (o))
 
@@ -74,7 +75,7 @@ int32_t acg_conv2d_dgrad(const void* dyv, const void* wv, void* dxv, const acg_c
                          void* ws, size_t wsb, acg_stream_t s) {
   (void)ws; (void)wsb; (void)s; REQUIRE_F32(dtype);
   const float* dy = dyv; const float* w = wv; float* dx = dxv;
-  size_t n = (size_t)d->batch * d->in_h * d->in_w * d->in_c;
+  size_t n = (size_t)d->batch * d->in_h * d->in_w * XPITCH(d);
   double* acc = calloc(n, sizeof(double));
   if (!acc) return fail(ACG_ERR_WORKSPACE, "oracle: out of memory");
   for (int b = 0; b < d->batch; b++) for (int p = 0; p < d->out_h; p++) for (int q = 0; q < d->out_w; q++)
@@ -83,7 +84,7 @@ int32_t acg_conv2d_dgrad(const void* dyv, const void* wv, void* dxv, const acg_c
         for (int c = 0; c < d->in_c; c++) { double a = 0;
           for (int o = 0; o < d->out_c; o++) a += (double)dy[YI(d, b, p, q, o)] * w[WI(d, i, j, c, o)];
           acc[XI(d, b, yy, xx, c)] += a; } } }
-  for (size_t k = 0; k < n; k++) dx[k] = (float)acc[k];
+  for (size_t k = 0; k < n; k++) if ((int)(k % XPITCH(d)) < d->in_c) dx[k] = (float)acc[k];   /* pad channels untouched */
   free(acc);
   return ACG_OK;
 }
@@ -264,11 +265,13 @@ int32_t acg_concat_actions_fwd(const void* xv, const float* actions, void* yv, i
   return ACG_OK;
 }
 int32_t acg_concat_channels_fwd(const void* av, const void* bv, void* yv, int64_t rows, int32_t ca, int32_t cb,
-                                int32_t dtype, acg_stream_t s) {
+                                int32_t y_pitch, int32_t dtype, acg_stream_t s) {
   (void)s; REQUIRE_F32(dtype);
   const float* a = av; const float* b = bv; float* y = yv;
-  for (int64_t r = 0; r < rows; r++) { memcpy(y + r * (ca + cb), a + r * ca, sizeof(float) * ca);
-                                       memcpy(y + r * (ca + cb) + ca, b + r * cb, sizeof(float) * cb); }
+  const int64_t py = y_pitch > 0 ? y_pitch : ca + cb;
+  if (py < ca + cb) return fail(ACG_ERR_INVALID_ARG, "concat_channels: pitch smaller than the row");
+  for (int64_t r = 0; r < rows; r++) { memcpy(y + r * py, a + r * ca, sizeof(float) * ca);
+                                       if (cb > 0) memcpy(y + r * py + ca, b + r * cb, sizeof(float) * cb); }
   return ACG_OK;
 }
 int32_t acg_slice_channels(const void* sv, void* dv, float acc, int64_t rows, int32_t c_src, int32_t c_off,

@@ -31,9 +31,10 @@ class Abi:
         n = max(int(nbytes), 16)
         return torch.zeros(n, dtype=torch.uint8, device=self.device), n
 
-    def desc(self, batch, h, w, c, kh, kw, cout, stride, padding):
+    def desc(self, batch, h, w, c, kh, kw, cout, stride, padding, pitch=0):
         d = L.ConvDesc()
         self.lib.conv_desc_init(ctypes.byref(d), batch, h, w, c, kh, kw, cout, stride, 1 if padding == 'SAME' else 0)
+        d.in_pitch = pitch
         return d
 
     def sync(self):
@@ -43,7 +44,8 @@ class Abi:
     # ---- conv family (x NHWC, w HWIO)
     def conv2d_fwd(self, x, w, stride, padding):
         b, h, wd, c = x.shape
-        d = self.desc(b, h, wd, c, w.shape[0], w.shape[1], w.shape[3], stride, padding)
+        pitch = c if c != w.shape[2] else 0            # x carries pad channels beyond the filter's Cin
+        d = self.desc(b, h, wd, w.shape[2], w.shape[0], w.shape[1], w.shape[3], stride, padding, pitch)
         y = self.empty(b, d.out_h, d.out_w, d.out_c)
         ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_FWD, L.ACG_F32))
         self.lib.conv2d_fwd(_p(x), _p(w), _p(y), ctypes.byref(d), L.ACG_F32, _p(ws), n, self.stream())
@@ -51,15 +53,17 @@ class Abi:
 
     def conv2d_dgrad(self, dy, w, x_shape, stride, padding):
         b, h, wd, c = x_shape
-        d = self.desc(b, h, wd, c, w.shape[0], w.shape[1], w.shape[3], stride, padding)
-        dx = self.empty(*x_shape)
+        pitch = c if c != w.shape[2] else 0
+        d = self.desc(b, h, wd, w.shape[2], w.shape[0], w.shape[1], w.shape[3], stride, padding, pitch)
+        dx = torch.zeros(*x_shape, device=self.device)
         ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_DGRAD, L.ACG_F32))
         self.lib.conv2d_dgrad(_p(dy), _p(w), _p(dx), ctypes.byref(d), L.ACG_F32, _p(ws), n, self.stream())
         return dx
 
     def conv2d_wgrad(self, x, dy, w_shape, stride, padding, dw=None, accumulate=0.0):
         b, h, wd, c = x.shape
-        d = self.desc(b, h, wd, c, w_shape[0], w_shape[1], w_shape[3], stride, padding)
+        pitch = c if c != w_shape[2] else 0
+        d = self.desc(b, h, wd, w_shape[2], w_shape[0], w_shape[1], w_shape[3], stride, padding, pitch)
         if dw is None:
             dw = self.empty(*w_shape)
         ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_WGRAD, L.ACG_F32))
@@ -153,10 +157,10 @@ class Abi:
         self.lib.concat_actions_fwd(_p(x), _p(actions), _p(y), b, h * w, c, a, L.ACG_F32, self.stream())
         return y
 
-    def concat_channels(self, a, b):
-        ca, cb = a.shape[-1], b.shape[-1]
-        y = self.empty(*a.shape[:-1], ca + cb)
-        self.lib.concat_channels_fwd(_p(a), _p(b), _p(y), a.numel() // ca, ca, cb, L.ACG_F32, self.stream())
+    def concat_channels(self, a, b, pitch=0):
+        ca, cb = a.shape[-1], (b.shape[-1] if b is not None else 0)
+        y = torch.zeros(*a.shape[:-1], pitch or (ca + cb), device=self.device)
+        self.lib.concat_channels_fwd(_p(a), _p(b), _p(y), a.numel() // ca, ca, cb, pitch, L.ACG_F32, self.stream())
         return y
 
     def slice_channels(self, src, off, cdst, dst=None, accumulate=0.0):

@@ -83,6 +83,27 @@ def case_conv(abi, shape, tol, seed=0):
     close(got, 0.5 * dw0.double().cpu() + dw_ref, tol, tag + ' wgrad accumulate')
 
 
+def case_conv_pitched(abi, tol, seed=0):
+    """3- and 6-channel inputs stored with a channel pitch of 4 / 8 (in_pitch): same results as the dense tensor,
+    pad channels of dx untouched."""
+    for (b, h, w, cin, cout, pitch) in [(2, 16, 16, 3, 32, 4), (2, 12, 10, 6, 64, 8), (1, 9, 7, 5, 7, 8)]:
+        x = uniform((b, h, w, cin), seed)
+        wt = randn((5, 5, cin, cout), seed + 1, 0.1)
+        xd, wd = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+        y_ref = T.conv2d(xd, wd, 2, 'SAME')
+        dy = randn(tuple(y_ref.shape), seed + 2)
+        dx_ref, dw_ref = torch.autograd.grad(y_ref, [xd, wd], dy.double())
+        dev = abi.device
+        xp = abi.concat_channels(x.to(dev), None, pitch=pitch)
+        assert xp.shape[-1] == pitch and torch.equal(xp[..., :cin].cpu(), x) and torch.all(xp[..., cin:] == 0)
+        tag = 'conv pitched %s' % ((b, h, w, cin, cout, pitch),)
+        close(abi.conv2d_fwd(xp, wt.to(dev), 2, 'SAME'), y_ref, tol, tag + ' fwd')
+        dxp = abi.conv2d_dgrad(dy.to(dev), wt.to(dev), tuple(xp.shape), 2, 'SAME')
+        close(dxp[..., :cin], dx_ref, tol, tag + ' dgrad')
+        assert torch.all(dxp[..., cin:] == 0), tag + ': pad channels of dx were written'
+        close(abi.conv2d_wgrad(xp, dy.to(dev), tuple(wt.shape), 2, 'SAME'), dw_ref, tol, tag + ' wgrad')
+
+
 def case_deconv(abi, shape, tol, seed=0):
     b, ih, iw, cin, cout, k, s = shape
     x = uniform((b, ih, iw, cin), seed)

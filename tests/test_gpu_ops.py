@@ -16,6 +16,10 @@ def test_conv(hip_abi, shape):
     C.case_conv(hip_abi, shape, TOL_CONV)
 
 
+def test_conv_pitched(hip_abi):
+    C.case_conv_pitched(hip_abi, TOL_CONV)
+
+
 @pytest.mark.parametrize('shape', C.DECONV_SHAPES, ids=str)
 def test_deconv(hip_abi, shape):
     C.case_deconv(hip_abi, shape, TOL_CONV)

@@ -13,6 +13,10 @@ def test_conv(oracle_abi, shape):
     C.case_conv(oracle_abi, shape, TOL)
 
 
+def test_conv_pitched(oracle_abi):
+    C.case_conv_pitched(oracle_abi, TOL)
+
+
 @pytest.mark.parametrize('shape', C.DECONV_SHAPES_SMALL, ids=str)
 def test_deconv(oracle_abi, shape):
     C.case_deconv(oracle_abi, shape, TOL)

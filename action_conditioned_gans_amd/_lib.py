@@ -21,7 +21,7 @@ class ConvDesc(ctypes.Structure):
     """struct acg_conv_desc."""
     _fields_ = [(n, c_int32) for n in (
         'batch', 'in_h', 'in_w', 'in_c', 'out_h', 'out_w', 'out_c', 'kh', 'kw',
-        'stride_h', 'stride_w', 'pad_top', 'pad_left', 'in_pitch')]
+        'stride_h', 'stride_w', 'pad_top', 'pad_left', 'in_pitch', 'out_pitch')]
 
     def key(self):
         return tuple(getattr(self, n) for n, _ in self._fields_)
@@ -57,7 +57,7 @@ SIGNATURES = {
                                    _P, c_size_t, _P]),
     'acg_dna_fwd': (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     'acg_dna_bwd': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
-    'acg_concat_actions_fwd': (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
+    'acg_concat_actions_fwd': (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     'acg_concat_channels_fwd': (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P]),
     'acg_slice_channels': (c_int32, [_P, _P, c_float, c_int64, c_int32, c_int32, c_int32, c_int32, _P]),
     'acg_add': (c_int32, [_P, _P, _P, c_int64, c_int32, _P]),

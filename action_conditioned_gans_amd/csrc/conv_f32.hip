@@ -59,13 +59,14 @@ int validate(const acg_conv_desc* d, const char* who) {
                   d->kh > 0 && d->kw > 0 && d->stride_h > 0 && d->stride_w > 0 && d->pad_top >= 0 && d->pad_left >= 0,
               ACG_ERR_INVALID_ARG, "%s: non-positive dimension in descriptor", who);
   ACG_REQUIRE(d->in_pitch == 0 || d->in_pitch >= d->in_c, ACG_ERR_INVALID_ARG, "%s: in_pitch %d smaller than in_c %d", who, d->in_pitch, d->in_c);
+  ACG_REQUIRE(d->out_pitch == 0 || d->out_pitch >= d->out_c, ACG_ERR_INVALID_ARG, "%s: out_pitch %d smaller than out_c %d", who, d->out_pitch, d->out_c);
   ACG_REQUIRE(d->kh * d->kw <= kMaxTaps, ACG_ERR_UNSUPPORTED, "%s: %dx%d filter exceeds %d taps", who, d->kh, d->kw, kMaxTaps);
   ACG_REQUIRE(d->pad_top < d->kh && d->pad_left < d->kw, ACG_ERR_INVALID_ARG, "%s: padding not smaller than the filter", who);
   ACG_REQUIRE((d->out_h - 1) * d->stride_h - d->pad_top < d->in_h && (d->out_w - 1) * d->stride_w - d->pad_left < d->in_w,
               ACG_ERR_INVALID_ARG, "%s: output extent reads entirely outside the input", who);
   const long long lim = 1ll << 30;   // 32-bit byte offsets in the buffer descriptors
   const long long nx = (long long)d->batch * d->in_h * d->in_w * (d->in_pitch > 0 ? d->in_pitch : d->in_c);
-  const long long ny = (long long)d->batch * d->out_h * d->out_w * d->out_c;
+  const long long ny = (long long)d->batch * d->out_h * d->out_w * (d->out_pitch > 0 ? d->out_pitch : d->out_c);
   const long long nw = (long long)d->kh * d->kw * ((d->in_c + 3) & ~3) * d->out_c;
   ACG_REQUIRE(nx < lim && ny < lim && nw < lim, ACG_ERR_UNSUPPORTED, "%s: tensor exceeds 2^30 elements", who);
   return ACG_OK;
@@ -80,7 +81,7 @@ Plan make_plan(const acg_conv_desc& d, int which) {
   const long long cin_p = (d.in_c + 3) & ~3, cout_p = (d.out_c + 3) & ~3;
   if (which == ACG_CONV_FWD) {
     pl.M = (long long)d.batch * d.out_h * d.out_w; pl.N = d.out_c; K = (long long)d.kh * d.kw * cin_p; pl.classes = 1;
-    pl.out_numel = pl.M * pl.N;
+    pl.out_numel = pl.M * (d.out_pitch > 0 ? d.out_pitch : d.out_c);
   } else if (which == ACG_CONV_DGRAD) {
     const int hc = (d.in_h + d.stride_h - 1) / d.stride_h, wc = (d.in_w + d.stride_w - 1) / d.stride_w;
     pl.M = (long long)d.batch * hc * wc; pl.N = d.in_c;
@@ -92,9 +93,11 @@ Plan make_plan(const acg_conv_desc& d, int which) {
     pl.out_numel = (long long)d.kh * d.kw * d.in_c * d.out_c;
   }
   // channel pitch of the gathered tensor decides whether its quads are 16-byte loads
-  const int cs = which == ACG_CONV_DGRAD ? d.out_c : (d.in_pitch > 0 ? d.in_pitch : d.in_c);
+  const int ky = d.out_pitch > 0 ? d.out_pitch : d.out_c;
+  const int cs = which == ACG_CONV_DGRAD ? ky : (d.in_pitch > 0 ? d.in_pitch : d.in_c);
   pl.ragged = (cs & 3) != 0;
-  pl.nvec = (pl.N & 3) == 0;
+  // dense operand rows: the filter [.., N] (FWD) or dY at its channel pitch (WGRAD)
+  pl.nvec = ((which == ACG_CONV_WGRAD ? ky : (int)pl.N) & 3) == 0;
   pl.nk = (int)((K + BK - 1) / BK);
   if (pl.nk < 1) pl.nk = 1;
   auto tiles_for = [&](int bm, int bn) { return acg::ceil_div(pl.M, bm) * acg::ceil_div(pl.N, bn) * pl.classes; };
@@ -129,13 +132,14 @@ int run(int which, const float* gsrc, const float* dense, float* out, float accu
   a.gsrc = gsrc; a.dense = dense; a.out = pl.splits > 1 ? (float*)ws : out; a.out_numel = pl.out_numel;
   a.accumulate = accumulate;
   {
-    const long long nx = (long long)d->batch * d->in_h * d->in_w * (d->in_pitch > 0 ? d->in_pitch : d->in_c), ny = (long long)d->batch * d->out_h * d->out_w * d->out_c;
+    const long long nx = (long long)d->batch * d->in_h * d->in_w * (d->in_pitch > 0 ? d->in_pitch : d->in_c), ny = (long long)d->batch * d->out_h * d->out_w * (d->out_pitch > 0 ? d->out_pitch : d->out_c);
     const long long nw = (long long)d->kh * d->kw * d->in_c * d->out_c;
     const long long ng = which == ACG_CONV_DGRAD ? ny : nx;                       // gathered tensor
     const long long nd = which == ACG_CONV_WGRAD ? ny : nw;                       // dense operand
     a.g_bytes = (unsigned)(ng * 4); a.d_bytes = (unsigned)(nd * 4);
   }
   a.Cx = d->in_pitch > 0 ? d->in_pitch : d->in_c;
+  a.Ky = d->out_pitch > 0 ? d->out_pitch : d->out_c;
   a.batch = d->batch; a.H = d->in_h; a.W = d->in_w; a.C = d->in_c; a.OH = d->out_h; a.OW = d->out_w; a.K = d->out_c;
   a.KH = d->kh; a.KW = d->kw; a.sh = d->stride_h; a.sw = d->stride_w; a.pt = d->pad_top; a.pl = d->pad_left;
   a.splits = pl.splits;
@@ -163,7 +167,7 @@ int32_t acg_conv_desc_init(acg_conv_desc* d, int32_t batch, int32_t in_h, int32_
   ACG_REQUIRE(d && batch > 0 && in_h > 0 && in_w > 0 && in_c > 0 && kh > 0 && kw > 0 && out_c > 0 && stride > 0,
               ACG_ERR_INVALID_ARG, "conv_desc_init: non-positive dimension");
   d->batch = batch; d->in_h = in_h; d->in_w = in_w; d->in_c = in_c; d->out_c = out_c;
-  d->kh = kh; d->kw = kw; d->stride_h = d->stride_w = stride; d->in_pitch = 0;
+  d->kh = kh; d->kw = kw; d->stride_h = d->stride_w = stride; d->in_pitch = 0; d->out_pitch = 0;
   if (same) {  // TF 'SAME' (SURVEY A.1): out = ceil(in/s), pad_before = total // 2
     d->out_h = (in_h + stride - 1) / stride; d->out_w = (in_w + stride - 1) / stride;
     const int th = std::max((d->out_h - 1) * stride + kh - in_h, 0), tw = std::max((d->out_w - 1) * stride + kw - in_w, 0);

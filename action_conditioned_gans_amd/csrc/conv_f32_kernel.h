@@ -28,6 +28,7 @@ struct ConvArgs {
   float accumulate;    // WGRAD with splits == 1: out = accumulate * out + value
   int batch, H, W, C, OH, OW, K, KH, KW, sh, sw, pt, pl;
   int Cx;              // channel pitch of x / dx in memory (>= C)
+  int Ky;              // channel pitch of y / dy in memory (>= K)
   int splits;
 };
 
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
     const int t = tid;
     if constexpr (MODE == MODE_DGRAD) {
       const int ti = t / ntj, tj = t - ti * ntj;
-      tapA[t] = -(ti * p.OW + tj) * p.K;
+      tapA[t] = -(ti * p.OW + tj) * p.Ky;
       tapB[t] = ((i0 + p.sh * ti) * p.KW + (j0 + p.sw * tj)) * p.C * p.K;
     } else {
       const int i = t / p.KW, j = t - i * p.KW;
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
       if (m < M) {
         const int w2 = m % Wc; const int t2 = m / Wc; const int h2 = t2 % Hc; const int b = t2 / Hc;
         const int y0 = h2 + dp0, x0 = w2 + dq0;  // dY coordinates of tap (0,0)
-        ri.base = ((b * p.OH + y0) * p.OW + x0) * p.K;
+        ri.base = ((b * p.OH + y0) * p.OW + x0) * p.Ky;
         ri.out_off = ((b * p.H + h2 * p.sh + ph) * p.W + (w2 * p.sw + pw)) * p.Cx;
         // tap (ti,tj) reads dY[y0 - ti][x0 - tj]
         const unsigned long long mk = tap_mask(max(0, y0 - p.OH + 1), min(nti, y0 + 1), max(0, x0 - p.OW + 1), min(ntj, x0 + 1), ntj);
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
             bool ok;
             if constexpr (MODE == MODE_FWD) { row = bt * Cs + bc + e; ok = bt < ntaps && bc + e < Cs; }
             else { row = ks * BK + 4 * kqb + e; ok = row < Kdim; }
-            rb[ST][e] = guarded_quad(rs_d, row * N + n, ok && n < N);   // raw row; transposed at store time
+            rb[ST][e] = guarded_quad(rs_d, row * (MODE == MODE_WGRAD ? p.Ky : N) + n, ok && n < N);   // raw row; transposed at store time
           }
         }
       } else {  // ragged N (25, 5, 3, 1 ...): 4 k-rows of one column per quad, lanes along n
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
           } else {
             const int r = ks * BK + 4 * kq;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = guarded_scalar(rs_d, (r + e) * N + n, r + e < Kdim && n < N);
+            for (int e = 0; e < 4; ++e) v[e] = guarded_scalar(rs_d, (r + e) * p.Ky + n, r + e < Kdim && n < N);
           }
           rb[ST][u] = v;
         }
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
               idx = ((long long)t * Cs + c) * N + n;
             }
           } else {
-            idx = (long long)m * N + n;
+            idx = (long long)m * p.Ky + n;
           }
           if (ok) {
             float v = acc[a][b][r];

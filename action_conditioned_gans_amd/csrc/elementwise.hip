@@ -84,13 +84,15 @@ const char* acg_build_info(void) { return "hip gfx950 (fp32 MFMA 32x32x2)"; }
 const char* acg_last_error(void) { return acg::g_err; }
 
 int32_t acg_concat_actions_fwd(const void* x, const float* actions, void* y, int32_t B, int32_t hw, int32_t c, int32_t a,
-                               int32_t dtype, acg_stream_t stream) {
+                               int32_t y_pitch, int32_t dtype, acg_stream_t stream) {
   ACG_REQUIRE_F32(dtype);
   ACG_REQUIRE(B > 0 && hw > 0 && c > 0 && a > 0, ACG_ERR_INVALID_ARG, "concat_actions_fwd: non-positive size");
   ACG_REQUIRE(x && actions && y, ACG_ERR_INVALID_ARG, "concat_actions_fwd: null pointer");
+  const int pitch = y_pitch > 0 ? y_pitch : c + a;
+  ACG_REQUIRE(pitch >= c + a, ACG_ERR_INVALID_ARG, "concat_actions_fwd: pitch smaller than the row");
   const long long rows = (long long)B * hw;
   hipLaunchKernelGGL(concat_k, dim3(grid_for(rows * (c + a))), dim3(256), 0, acg::to_stream(stream), (const float*)x,
-                     actions, (float*)y, rows, c, a, hw, c + a);
+                     actions, (float*)y, rows, c, a, hw, pitch);
   return acg::check_launch("concat_actions_fwd");
 }
 

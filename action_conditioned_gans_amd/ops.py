@@ -126,6 +126,7 @@ def _desc(lib_free_args):
     batch, h, w, c, kh, kw, cout, stride, padding = lib_free_args[:9]
     d = ConvDesc()
     d.in_pitch = lib_free_args[9] if len(lib_free_args) > 9 else 0
+    d.out_pitch = lib_free_args[10] if len(lib_free_args) > 10 else 0
     d.batch, d.in_h, d.in_w, d.in_c, d.out_c, d.kh, d.kw = batch, h, w, c, cout, kh, kw
     d.stride_h = d.stride_w = stride
     if padding == 'SAME':
@@ -351,18 +352,25 @@ class DnaBwdOp(G.Op):
 
 
 class ConcatActionsOp(G.Op):
-    """tf.tile([B,1,1,A] -> [B,h,w,A]) + tf.concat(axis=3) in one pass (train.py:48-50; models.py:16,38,84)."""
+    """tf.tile([B,1,1,A] -> [B,h,w,A]) + tf.concat(axis=3) in one pass (train.py:48-50; models.py:16,38,84).
+    The result is stored at a channel pitch rounded up to 4 (138 -> 140, 266 -> 268; zero pad channels) so that
+    the consuming conv / deconv gathers it with 16-byte loads."""
 
     def __init__(self, x, actions, name):
         b, h, w, c = x.shape
         if len(actions.shape) != 2 or actions.shape[0] != b:
             raise ValueError('concat_actions: actions must be [batch, A], got %s' % (actions.shape,))
-        super().__init__(G.get_default_graph(), name, [x, actions], [_new((b, h, w, c + actions.shape[1]), name + ':0')])
+        csum = c + actions.shape[1]
+        self.pitch = -(-csum // 4) * 4
+        y = _new((b, h, w, self.pitch), name + ':0')
+        if self.pitch != csum:
+            y.valid_c = csum
+        super().__init__(G.get_default_graph(), name, [x, actions], [y])
 
     def bind(self, rt):
         x, a = self.inputs
         b, h, w, c = x.shape
-        args = (_p(x.buf), _p(a.buf), _p(self.outputs[0].buf), b, h * w, c, a.shape[1], ACG_F32)
+        args = (_p(x.buf), _p(a.buf), _p(self.outputs[0].buf), b, h * w, c, a.shape[1], self.pitch, ACG_F32)
         fn = rt.lib.concat_actions_fwd
         return lambda s: fn(*args, s)
 
@@ -542,10 +550,8 @@ def _layer(inputs, num_outputs, kernel_size, stride, padding, activation_fn, nor
         if transposed:
             if padding != 'SAME':
                 raise ValueError('conv2d_transpose: only SAME padding is implemented (the reference uses no other)')
-            if pitch:
-                raise ValueError('conv2d_transpose: channel-padded inputs are not supported')
-            wshape = (kh, kw, num_outputs, cin)
-            desc = _desc((b, h * stride, w * stride, num_outputs, kh, kw, cin, stride, 'SAME'))
+            wshape = (kh, kw, num_outputs, cin)      # the deconv input is the adjoint conv's y: its pitch is out_pitch
+            desc = _desc((b, h * stride, w * stride, num_outputs, kh, kw, cin, stride, 'SAME', 0, pitch))
         else:
             wshape = (kh, kw, cin, num_outputs)
             desc = _desc((b, h, w, cin, kh, kw, num_outputs, stride, padding, pitch))

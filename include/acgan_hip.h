@@ -58,6 +58,8 @@ typedef struct acg_conv_desc {
   int32_t in_pitch; /* channel pitch (floats) of x / dx in memory; 0 = dense (= in_c).  A pitch that is a
                        multiple of 4 lets 3- or 6-channel inputs (g/conv1, d/conv1) take the 16-byte gather path;
                        the pad channels of x must hold finite values (zeros), those of dx are left untouched. */
+  int32_t out_pitch; /* same for y / dy (0 = dense = out_c): the 138- and 266-channel action-concatenated maps feeding
+                        d/conv3 and g/tconv1 are stored at a pitch of 140 / 268.  Pad channels of dy must be zero. */
 } acg_conv_desc;
 
 /* Fill a descriptor from slim-style arguments; same_padding != 0 -> TF 'SAME', else 'VALID'. */
@@ -135,9 +137,10 @@ int32_t acg_dna_bwd(const void* logits, const void* image, const void* dout, voi
 /* ------------------------------------------------------------------------------------------
  * Channel plumbing: tf.tile + tf.concat at train.py:48-50,64,68 and models.py:16,38,84.
  * ---------------------------------------------------------------------------------------- */
-/* y[b,s,0:c] = x[b,s,:],  y[b,s,c:c+a] = actions[b,:]   for s in [0,hw) */
+/* y[b,s,0:c] = x[b,s,:],  y[b,s,c:c+a] = actions[b,:]   for s in [0,hw); y rows are y_pitch floats apart
+ * (0 = dense = c+a), pad channels are not written */
 int32_t acg_concat_actions_fwd(const void* x, const float* actions, void* y, int32_t batch, int32_t hw,
-                               int32_t c, int32_t a, int32_t dtype, acg_stream_t stream);
+                               int32_t c, int32_t a, int32_t y_pitch, int32_t dtype, acg_stream_t stream);
 /* y[r,0:ca] = a[r,:], y[r,ca:ca+cb] = b[r,:]; y rows are y_pitch floats apart (0 = dense = ca+cb); pad channels
  * are not written.  cb may be 0 (b ignored): a plain re-pitching copy. */
 int32_t acg_concat_channels_fwd(const void* a, const void* b, void* y, int64_t rows, int32_t ca, int32_t cb,

@@ -32,7 +32,7 @@ int32_t acg_conv_desc_init(acg_conv_desc* d, int32_t batch, int32_t in_h, int32_
   if (!d || batch <= 0 || in_h <= 0 || in_w <= 0 || in_c <= 0 || kh <= 0 || kw <= 0 || out_c <= 0 || stride <= 0)
     return fail(ACG_ERR_INVALID_ARG, "conv_desc_init: non-positive dimension");
   d->batch = batch; d->in_h = in_h; d->in_w = in_w; d->in_c = in_c; d->out_c = out_c;
-  d->kh = kh; d->kw = kw; d->stride_h = d->stride_w = stride; d->in_pitch = 0;
+  d->kh = kh; d->kw = kw; d->stride_h = d->stride_w = stride; d->in_pitch = 0; d->out_pitch = 0;
   if (same) {
     d->out_h = (in_h + stride - 1) / stride; d->out_w = (in_w + stride - 1) / stride;
     int th = (d->out_h - 1) * stride + kh - in_h; if (th < 0) th = 0;
@@ -51,7 +51,8 @@ int32_t acg_debug_conv_plan(int32_t cfg, int32_t splits) { (void)cfg; (void)spli
 
 #define XPITCH(d) ((d)->in_pitch > 0 ? (d)->in_pitch : (d)->in_c)
 #define XI(d, b, y, x, c) ((((size_t)(b) * (d)->in_h + (y)) * (d)->in_w + (x)) * XPITCH(d) + (c))
-#define YI(d, b, p, q, o) ((((size_t)(b) * (d)->out_h + (p)) * (d)->out_w + (q)) * (d)->out_c + (o))
+#define YPITCH(d) ((d)->out_pitch > 0 ? (d)->out_pitch : (d)->out_c)
+#define YI(d, b, p, q, o) ((((size_t)(b) * (d)->out_h + (p)) * (d)->out_w + (q)) * YPITCH(d) + (o))
 #define WI(d, i, j, c, o) ((((size_t)(i) * (d)->kw + (j)) * (d)->in_c + (c)) * (d)->out_c + (o))
 
 /* tf.nn.conv2d (models.py:12-15,34-37,42-51,82-88); SURVEY A.1 */
@@ -254,13 +255,15 @@ int32_t acg_dna_bwd(const void* lv, const void* iv, const void* dov, void* dlv, 
 
 /* ---- channel plumbing: train.py:48-50,64,68; models.py:16,38,84 */
 int32_t acg_concat_actions_fwd(const void* xv, const float* actions, void* yv, int32_t B, int32_t hw, int32_t c,
-                               int32_t a, int32_t dtype, acg_stream_t s) {
+                               int32_t a, int32_t y_pitch, int32_t dtype, acg_stream_t s) {
   (void)s; REQUIRE_F32(dtype);
   const float* x = xv; float* y = yv;
+  const size_t py = y_pitch > 0 ? (size_t)y_pitch : (size_t)(c + a);
+  if (py < (size_t)(c + a)) return fail(ACG_ERR_INVALID_ARG, "concat_actions: pitch smaller than the row");
   for (int b = 0; b < B; b++) for (int p = 0; p < hw; p++) {
     size_t r = (size_t)b * hw + p;
-    memcpy(y + r * (c + a), x + r * c, sizeof(float) * c);
-    memcpy(y + r * (c + a) + c, actions + (size_t)b * a, sizeof(float) * a);
+    memcpy(y + r * py, x + r * c, sizeof(float) * c);
+    memcpy(y + r * py + c, actions + (size_t)b * a, sizeof(float) * a);
   }
   return ACG_OK;
 }

@@ -72,9 +72,11 @@ class Abi:
 
     # ---- deconv family (x NHWC [B,IH,IW,Cin], w [kh,kw,Cout,Cin]); SAME only
     def _adj(self, x_shape, w_shape, stride):
-        b, ih, iw, _ = x_shape
+        b, ih, iw, cphys = x_shape
         kh, kw, cout, cin = w_shape
-        return self.desc(b, ih * stride, iw * stride, cout, kh, kw, cin, stride, 'SAME')
+        d = self.desc(b, ih * stride, iw * stride, cout, kh, kw, cin, stride, 'SAME')
+        d.out_pitch = cphys if cphys != cin else 0     # deconv input stored with pad channels
+        return d
 
     def deconv2d_fwd(self, x, w, stride):
         d = self._adj(x.shape, w.shape, stride)
@@ -85,7 +87,7 @@ class Abi:
 
     def deconv2d_dgrad(self, dy, w, x_shape, stride):
         d = self._adj(x_shape, w.shape, stride)
-        dx = self.empty(*x_shape)
+        dx = torch.zeros(*x_shape, device=self.device)
         ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_FWD, L.ACG_F32))
         self.lib.deconv2d_dgrad(_p(dy), _p(w), _p(dx), ctypes.byref(d), L.ACG_F32, _p(ws), n, self.stream())
         return dx
@@ -154,7 +156,7 @@ class Abi:
         b, h, w, c = x.shape
         a = actions.shape[1]
         y = self.empty(b, h, w, c + a)
-        self.lib.concat_actions_fwd(_p(x), _p(actions), _p(y), b, h * w, c, a, L.ACG_F32, self.stream())
+        self.lib.concat_actions_fwd(_p(x), _p(actions), _p(y), b, h * w, c, a, 0, L.ACG_F32, self.stream())
         return y
 
     def concat_channels(self, a, b, pitch=0):

@@ -104,6 +104,25 @@ def case_conv_pitched(abi, tol, seed=0):
         close(abi.conv2d_wgrad(xp, dy.to(dev), tuple(wt.shape), 2, 'SAME'), dw_ref, tol, tag + ' wgrad')
 
 
+def case_deconv_pitched(abi, tol, seed=0):
+    """conv2d_transpose whose 266- / 10-channel input is stored at a pitch of 268 / 12 (out_pitch of the adjoint)."""
+    for (b, ih, iw, cin, cout, pitch) in [(2, 4, 4, 266, 128, 268), (1, 3, 5, 10, 7, 12)]:
+        x = uniform((b, ih, iw, cin), seed)
+        wt = randn((5, 5, cout, cin), seed + 1, 0.1)
+        xd, wd = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+        y_ref = T.conv2d_transpose(xd, wd, 2, 'SAME')
+        dy = randn(tuple(y_ref.shape), seed + 2)
+        dx_ref, dw_ref = torch.autograd.grad(y_ref, [xd, wd], dy.double())
+        dev = abi.device
+        xp = abi.concat_channels(x.to(dev), None, pitch=pitch)
+        tag = 'deconv pitched %s' % ((b, ih, iw, cin, cout, pitch),)
+        close(abi.deconv2d_fwd(xp, wt.to(dev), 2), y_ref, tol, tag + ' fwd')
+        dxp = abi.deconv2d_dgrad(dy.to(dev), wt.to(dev), tuple(xp.shape), 2)
+        close(dxp[..., :cin], dx_ref, tol, tag + ' dgrad')
+        assert torch.all(dxp[..., cin:] == 0), tag + ': pad channels of dx were written'
+        close(abi.deconv2d_wgrad(xp, dy.to(dev), tuple(wt.shape), 2), dw_ref, tol, tag + ' wgrad')
+
+
 def case_deconv(abi, shape, tol, seed=0):
     b, ih, iw, cin, cout, k, s = shape
     x = uniform((b, ih, iw, cin), seed)

@@ -16,6 +16,10 @@ def test_conv(hip_abi, shape):
     C.case_conv(hip_abi, shape, TOL_CONV)
 
 
+def test_deconv_pitched(hip_abi):
+    C.case_deconv_pitched(hip_abi, TOL_CONV)
+
+
 def test_conv_pitched(hip_abi):
     C.case_conv_pitched(hip_abi, TOL_CONV)
 

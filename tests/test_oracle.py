@@ -13,6 +13,10 @@ def test_conv(oracle_abi, shape):
     C.case_conv(oracle_abi, shape, TOL)
 
 
+def test_deconv_pitched(oracle_abi):
+    C.case_deconv_pitched(oracle_abi, TOL)
+
+
 def test_conv_pitched(oracle_abi):
     C.case_conv_pitched(oracle_abi, TOL)
 

@@ -123,7 +123,15 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
     M = ntaps * Cp; N = p.K; Kdim = p.batch * p.OH * p.OW;
   }
   const int tiles_n = (N + BN - 1) / BN;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  // XCD-aware order: consecutive workgroup ids are dealt round-robin over the 8 XCDs (each with its own L2), so
+  // give every XCD a CONTIGUOUS run of tiles - neighbours in the run share A rows / filter columns in that L2.
+  // Bijective for any grid size; placement affects speed only.
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   if (m0 >= M) return;  // block-uniform: DGRAD classes smaller than class 0
 

@@ -121,11 +121,13 @@ Plan make_plan(const acg_conv_desc& d, int which) {
   return pl;
 }
 
-int run(int which, const float* gsrc, const float* dense, float* out, float accumulate, const acg_conv_desc* d,
+int run(int which, const float* gsrc, const float* dense, float* out, float accumulate, const acg_conv_desc* d, int dtype,
         void* ws, size_t ws_bytes, acg_stream_t stream, const char* who) {
+  ACG_REQUIRE(dtype == ACG_F32 || dtype == ACG_BF16, ACG_ERR_UNSUPPORTED, "%s: dtype %d", who, dtype);
   if (int rc = validate(d, who)) return rc;
   ACG_REQUIRE(gsrc && dense && out, ACG_ERR_INVALID_ARG, "%s: null tensor pointer", who);
-  const Plan pl = make_plan(*d, which);
+  Plan pl = make_plan(*d, which);
+  pl.bf16 = dtype == ACG_BF16;
   const size_t need = pl.splits > 1 ? (size_t)pl.splits * (size_t)pl.out_numel * sizeof(float) : 0;
   ACG_REQUIRE(ws_bytes >= need && (need == 0 || ws != nullptr), ACG_ERR_WORKSPACE, "%s: workspace %zu bytes < required %zu", who, ws_bytes, need);
   ConvArgs a{};
@@ -194,34 +196,28 @@ size_t acg_conv2d_workspace_bytes(const acg_conv_desc* d, int32_t which, int32_t
 
 int32_t acg_conv2d_fwd(const void* x, const void* w, void* y, const acg_conv_desc* d, int32_t dtype, void* ws,
                        size_t wsb, acg_stream_t s) {
-  ACG_REQUIRE_F32(dtype);
-  return run(ACG_CONV_FWD, (const float*)x, (const float*)w, (float*)y, 0.f, d, ws, wsb, s, "conv2d_fwd");
+  return run(ACG_CONV_FWD, (const float*)x, (const float*)w, (float*)y, 0.f, d, dtype, ws, wsb, s, "conv2d_fwd");
 }
 int32_t acg_conv2d_dgrad(const void* dy, const void* w, void* dx, const acg_conv_desc* d, int32_t dtype, void* ws,
                          size_t wsb, acg_stream_t s) {
-  ACG_REQUIRE_F32(dtype);
-  return run(ACG_CONV_DGRAD, (const float*)dy, (const float*)w, (float*)dx, 0.f, d, ws, wsb, s, "conv2d_dgrad");
+  return run(ACG_CONV_DGRAD, (const float*)dy, (const float*)w, (float*)dx, 0.f, d, dtype, ws, wsb, s, "conv2d_dgrad");
 }
 int32_t acg_conv2d_wgrad(const void* x, const void* dy, float* dw, float accumulate, const acg_conv_desc* d,
                          int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
-  ACG_REQUIRE_F32(dtype);
-  return run(ACG_CONV_WGRAD, (const float*)x, (const float*)dy, dw, accumulate, d, ws, wsb, s, "conv2d_wgrad");
+  return run(ACG_CONV_WGRAD, (const float*)x, (const float*)dy, dw, accumulate, d, dtype, ws, wsb, s, "conv2d_wgrad");
 }
 int32_t acg_deconv2d_fwd(const void* x, const void* w, void* y, const acg_conv_desc* adj, int32_t dtype, void* ws,
                          size_t wsb, acg_stream_t s) {
-  ACG_REQUIRE_F32(dtype);
-  return run(ACG_CONV_DGRAD, (const float*)x, (const float*)w, (float*)y, 0.f, adj, ws, wsb, s, "deconv2d_fwd");
+  return run(ACG_CONV_DGRAD, (const float*)x, (const float*)w, (float*)y, 0.f, adj, dtype, ws, wsb, s, "deconv2d_fwd");
 }
 int32_t acg_deconv2d_dgrad(const void* dy, const void* w, void* dx, const acg_conv_desc* adj, int32_t dtype, void* ws,
                            size_t wsb, acg_stream_t s) {
-  ACG_REQUIRE_F32(dtype);
-  return run(ACG_CONV_FWD, (const float*)dy, (const float*)w, (float*)dx, 0.f, adj, ws, wsb, s, "deconv2d_dgrad");
+  return run(ACG_CONV_FWD, (const float*)dy, (const float*)w, (float*)dx, 0.f, adj, dtype, ws, wsb, s, "deconv2d_dgrad");
 }
 int32_t acg_deconv2d_wgrad(const void* x, const void* dy, float* dw, float accumulate, const acg_conv_desc* adj,
                            int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
-  ACG_REQUIRE_F32(dtype);
   // roles exchanged: the deconv's output gradient is the adjoint conv's input
-  return run(ACG_CONV_WGRAD, (const float*)dy, (const float*)x, dw, accumulate, adj, ws, wsb, s, "deconv2d_wgrad");
+  return run(ACG_CONV_WGRAD, (const float*)dy, (const float*)x, dw, accumulate, adj, dtype, ws, wsb, s, "deconv2d_wgrad");
 }
 
 }  // extern "C"

@@ -14,6 +14,8 @@ namespace acgconv {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned 16-byte global load
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
 constexpr int BK = 32;  // k per K-step = 8 quads
@@ -82,15 +84,19 @@ __device__ __forceinline__ float guarded_scalar(__amdgpu_buffer_rsrc_t rs, int e
 
 // RAGGED: gathered channel count not a multiple of 4; NVEC: dense operand rows are float4-loadable (N % 4 == 0).
 // Both are compile-time so that the slow variants never share registers (and waits) with the fast one.
-template <int MODE, int BM, int BN, int WM, int WN, bool RAGGED, bool NVEC>
+// BF16: operands are rounded to bf16 (RNE) as they are staged into LDS and contracted by v_mfma_f32_32x32x16_bf16
+// (fp32 accumulate); tensors stay fp32 in memory.  LDS then holds 8-k "octs": quad kq lands in half (kq&1) of
+// oct kq>>1, and lane half h feeds oct 2t+h of both tiles to MFMA t (2 MFMAs per 32-deep K-step instead of 16).
+template <int MODE, int BM, int BN, int WM, int WN, bool RAGGED, bool NVEC, bool BF16>
 __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int TA = BM / (32 * WM), TB = BN / (32 * WN);
   constexpr int QA = BM / 32, QB = BN / 32;  // quads per thread per K-step
   constexpr int NROW = (MODE == MODE_WGRAD) ? BK : BM;
 
-  __shared__ f4 As[8 * BM];
-  __shared__ f4 Bs[8 * BN];
+  constexpr int KSLOTS = BF16 ? 4 : 8;   // 16-byte k-slots per tile column: 8 quads (fp32) or 4 octs (bf16)
+  __shared__ f4 As[KSLOTS * BM];
+  __shared__ f4 Bs[KSLOTS * BN];
   __shared__ RowInfo rows[NROW];
   __shared__ int tapA[kMaxTaps];
   __shared__ int tapB[kMaxTaps];
@@ -336,6 +342,17 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
     return ((col & ~31) | (e << 3) | (j ^ ((e >> 1) << 2))) ^ kq;
   };
 
+  // write quad `kq` of tile column `col`: a 16-byte slot (fp32) or one half of the column's oct (bf16)
+  auto put = [&](f4* tile, int width, int kq, int col, const f4& q) {
+    if constexpr (BF16) {
+      const int oct = kq >> 1;
+      char* dst = reinterpret_cast<char*>(tile + oct * width + pcol(col, oct)) + (kq & 1) * 8;
+      *reinterpret_cast<bf4*>(dst) = bf4{(__bf16)q[0], (__bf16)q[1], (__bf16)q[2], (__bf16)q[3]};
+    } else {
+      tile[kq * width + pcol(col, kq)] = q;
+    }
+  };
+
   auto store_tiles = [&](auto stage) {
     constexpr int ST = decltype(stage)::value;
     if constexpr (MODE == MODE_WGRAD) {
@@ -343,15 +360,15 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
         f4 q[4];
         transpose_into(q, ra[ST]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) As[kqa * BM + pcol(4 * ja + i, kqa)] = q[i];
+        for (int i = 0; i < 4; ++i) put(As, BM, kqa, 4 * ja + i, q[i]);
       }
     } else {
       const int kq = tid & 7, rg = tid >> 3;
 #pragma unroll
-      for (int u = 0; u < QA; ++u) As[kq * BM + pcol(rg + 32 * u, kq)] = ra[ST][u];
+      for (int u = 0; u < QA; ++u) put(As, BM, kq, rg + 32 * u, ra[ST][u]);
       if constexpr (MODE == MODE_DGRAD) {
 #pragma unroll
-        for (int u = 0; u < QB; ++u) Bs[kq * BN + pcol(rg + 32 * u, kq)] = rb[ST][u];
+        for (int u = 0; u < QB; ++u) put(Bs, BN, kq, rg + 32 * u, rb[ST][u]);
       }
     }
     if constexpr (MODE != MODE_DGRAD) {
@@ -360,13 +377,13 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
           f4 q[4];
           transpose_into(q, rb[ST]);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) Bs[kqb * BN + pcol(4 * jb + i, kqb)] = q[i];
+          for (int i = 0; i < 4; ++i) put(Bs, BN, kqb, 4 * jb + i, q[i]);
         }
       } else {
         constexpr int stepB = 256 / BN;
         const int nb = tid % BN, kq0 = tid / BN;
 #pragma unroll
-        for (int u = 0; u < QB; ++u) { const int kq = kq0 + stepB * u; Bs[kq * BN + pcol(nb, kq)] = rb[ST][u]; }
+        for (int u = 0; u < QB; ++u) put(Bs, BN, kq0 + stepB * u, nb, rb[ST][u]);
       }
     }
   };
@@ -385,6 +402,22 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
   const int lrow = lane & 31, lk = lane >> 5;
 
   auto compute = [&]() {
+    if constexpr (BF16) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int oct = 2 * t + lk;  // lane half h holds k = 8h..8h+7 of the 16-deep MFMA: oct 2t+h of BOTH tiles
+        bf8 av[TA], bv[TB];
+#pragma unroll
+        for (int a = 0; a < TA; ++a) av[a] = *reinterpret_cast<const bf8*>(&As[oct * BM + pcol(wm0 + 32 * a + lrow, oct)]);
+#pragma unroll
+        for (int b = 0; b < TB; ++b) bv[b] = *reinterpret_cast<const bf8*>(&Bs[oct * BN + pcol(wn0 + 32 * b + lrow, oct)]);
+#pragma unroll
+        for (int a = 0; a < TA; ++a)
+#pragma unroll
+          for (int b = 0; b < TB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[a], bv[b], acc[a][b], 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int kq = 2 * t + lk;  // lane half h consumes quad 2t+h of BOTH tiles: same k on both sides
@@ -479,34 +512,39 @@ struct Plan {
   int bm, bn;
   long long M, N;  // per class (class 0 = largest) GEMM extents (M padded per tap for WGRAD)
   int classes, nk, splits;
-  bool ragged, nvec;
+  bool ragged, nvec, bf16;
   long long tiles, out_numel;
 };
 
 template <int MODE>
 int launch_mode(const Plan& pl, const ConvArgs& a, hipStream_t st);
 
-template <int MODE, bool RAGGED, bool NVEC>
+template <int MODE, bool RAGGED, bool NVEC, bool BF16>
 static inline void launch_cfg(const Plan& pl, const ConvArgs& a, hipStream_t st) {
   const dim3 grid((unsigned)(acg::ceil_div(pl.M, pl.bm) * acg::ceil_div(pl.N, pl.bn)), (unsigned)pl.classes, (unsigned)pl.splits);
   switch (pl.cfg) {
-    case 0: hipLaunchKernelGGL((conv_mfma_f32<MODE, 128, 128, 2, 2, RAGGED, NVEC>), grid, dim3(256), 0, st, a); break;
-    case 1: hipLaunchKernelGGL((conv_mfma_f32<MODE, 128, 64, 2, 2, RAGGED, NVEC>), grid, dim3(256), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((conv_mfma_f32<MODE, 128, 32, 4, 1, RAGGED, NVEC>), grid, dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((conv_mfma_f32<MODE, 64, 64, 2, 2, RAGGED, NVEC>), grid, dim3(256), 0, st, a); break;
+    case 0: hipLaunchKernelGGL((conv_mfma_f32<MODE, 128, 128, 2, 2, RAGGED, NVEC, BF16>), grid, dim3(256), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((conv_mfma_f32<MODE, 128, 64, 2, 2, RAGGED, NVEC, BF16>), grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((conv_mfma_f32<MODE, 128, 32, 4, 1, RAGGED, NVEC, BF16>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((conv_mfma_f32<MODE, 64, 64, 2, 2, RAGGED, NVEC, BF16>), grid, dim3(256), 0, st, a); break;
+  }
+}
+template <int MODE, bool BF16>
+static inline void launch_variant(const Plan& pl, const ConvArgs& a, hipStream_t st) {
+  if (pl.ragged) {
+    if (pl.nvec) launch_cfg<MODE, true, true, BF16>(pl, a, st);
+    else launch_cfg<MODE, true, false, BF16>(pl, a, st);
+  } else {
+    if (pl.nvec) launch_cfg<MODE, false, true, BF16>(pl, a, st);
+    else launch_cfg<MODE, false, false, BF16>(pl, a, st);
   }
 }
 
 #define ACG_DEFINE_CONV_LAUNCH(MODE)                                                    \
   template <>                                                                           \
   int launch_mode<MODE>(const Plan& pl, const ConvArgs& a, hipStream_t st) {            \
-    if (pl.ragged) {                                                                    \
-      if (pl.nvec) launch_cfg<MODE, true, true>(pl, a, st);                             \
-      else launch_cfg<MODE, true, false>(pl, a, st);                                    \
-    } else {                                                                            \
-      if (pl.nvec) launch_cfg<MODE, false, true>(pl, a, st);                            \
-      else launch_cfg<MODE, false, false>(pl, a, st);                                   \
-    }                                                                                   \
+    if (pl.bf16) launch_variant<MODE, true>(pl, a, st);                                 \
+    else launch_variant<MODE, false>(pl, a, st);                                        \
     return acg::check_launch("conv_mfma_f32");                                          \
   }
 

@@ -295,8 +295,9 @@ class _Program:
 class Runtime:
     """What an Op needs to bind itself: the kernel library, the device, buffers, process group."""
 
-    def __init__(self, lib, device, world_size=1, rank=0, process_group=None):
+    def __init__(self, lib, device, world_size=1, rank=0, process_group=None, conv_dtype=0):
         self.lib, self.device = lib, torch.device(device)
+        self.conv_dtype = conv_dtype          # ACG_F32 / ACG_BF16 for the conv contractions
         self.world_size, self.rank, self.process_group = world_size, rank, process_group
         self.is_cuda = self.device.type == 'cuda'
         self.comm_stream = torch.cuda.Stream(self.device) if self.is_cuda else None
@@ -318,7 +319,7 @@ class Session:
     """``tf.Session`` stand-in bound to one GPU (one process per GPU)."""
 
     def __init__(self, device='cuda:0', graph=None, use_hip_graphs=True, lib=None,
-                 world_size=1, rank=0, process_group=None, overlap_wgrad=False):
+                 world_size=1, rank=0, process_group=None, overlap_wgrad=False, dtype='f32'):
         self.graph = graph or get_default_graph()
         dev = torch.device(device)
         if lib is None:
@@ -327,7 +328,9 @@ class Session:
                 raise RuntimeError('the HIP library runs on a GPU device, got %s' % dev)
             if not torch.cuda.is_available():
                 raise RuntimeError('no GPU visible: the HIP path cannot run and there is no CPU fallback')
-        self.rt = Runtime(lib, dev, world_size, rank, process_group)
+        if dtype not in ('f32', 'bf16'):
+            raise ValueError("dtype must be 'f32' or 'bf16' (bf16 matrix-core operands, fp32 storage and accumulation)")
+        self.rt = Runtime(lib, dev, world_size, rank, process_group, _lib.ACG_BF16 if dtype == 'bf16' else _lib.ACG_F32)
         if dev.type == 'cuda':
             torch.cuda.set_device(dev)
         self.use_hip_graphs = use_hip_graphs and dev.type == 'cuda'

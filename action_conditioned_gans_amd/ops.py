@@ -152,10 +152,10 @@ class _ConvBase(G.Op):
         ws, n = rt.workspace(lib.conv2d_workspace_bytes(ctypes.byref(d), self.which, ACG_F32))
         self._keep = (ws, d)
         fn = getattr(lib, entry)
-        pa, pb, po, dref, pws = _p(a.buf), _p(b.buf), _p(out.buf), ctypes.byref(d), _p(ws)
+        pa, pb, po, dref, pws, dt = _p(a.buf), _p(b.buf), _p(out.buf), ctypes.byref(d), _p(ws), rt.conv_dtype
         if accumulate is None:
-            return lambda s: fn(pa, pb, po, dref, ACG_F32, pws, n, s)
-        return lambda s: fn(pa, pb, po, accumulate, dref, ACG_F32, pws, n, s)
+            return lambda s: fn(pa, pb, po, dref, dt, pws, n, s)
+        return lambda s: fn(pa, pb, po, accumulate, dref, dt, pws, n, s)
 
 
 class Conv2dOp(_ConvBase):

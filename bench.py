@@ -29,6 +29,7 @@ import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md chip table
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense
 PEAK_HBM_GBS = 8000.0
 
 
@@ -46,6 +47,7 @@ def parse():
     ap.add_argument('--plain', action='store_true', help='plain generator instead of DNA')
     ap.add_argument('--no-adv', action='store_true')
     ap.add_argument('--no-graphs', action='store_true', help='eager launches instead of HIP-graph replay')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='conv arithmetic: exact fp32 MFMA (BASELINE config 2) or bf16 MFMA operands with fp32 storage/accumulation (configs 3, 5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-repeats', type=int, default=3)
     ap.add_argument('--cpu-steps', type=int, default=20)
@@ -108,7 +110,7 @@ def main():
     n_critic = 5 if args.loss == 'wass' else 1
     G.reset_default_graph()
     optim.set_data_parallel(world)
-    sess = G.Session(device=device, use_hip_graphs=not args.no_graphs, world_size=world, rank=rank, process_group=pg)
+    sess = G.Session(device=device, use_hip_graphs=not args.no_graphs, world_size=world, rank=rank, process_group=pg, dtype=args.dtype)
     tr = T.Trainer(sess, adv, args.loss, args.opt, dna, batch_size=B, img_size=S, ksize=args.ksize, seed=0)
     sess.run(G.global_variables_initializer())
 
@@ -176,8 +178,9 @@ def main():
                 dna_bytes += b * h * w * (op.ksize * op.ksize + 2 * c) * 4.0
         if conv_ms > 0:
             ach = conv_fl / (conv_ms * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+            peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == 'bf16' else PEAK_F32_MFMA_TFLOPS
+            roof = {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': peak, 'unit': 'TFLOP/s',
+                    'frac': round(ach / peak, 4), 'traffic': None,
                     'kernel': 'conv_mfma_f32<*> (+splitk_reduce): %d conv/deconv fwd+dgrad+wgrad launches per step' % n_conv,
                     'algorithmic_gflop_per_step': round(conv_fl / 1e9, 2), 'ms_per_step_in_kernel': round(conv_ms, 4),
                     'avg_launch_us': round(conv_ms * 1e3 / max(n_conv, 1), 2)}
@@ -196,10 +199,10 @@ def main():
         'metric': 'GAN train steps/sec (G+D) on 64x64x3xT=8 push seq', 'value': round(world * args.steps / elapsed, 3),
         'unit': 'steps/s (batch-%d G+D steps, all ranks)' % B, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'BASELINE config 2 per GPU: batch=%d %dx%dx3 T=%d %s--loss %s %s(k=%d) --opt %s fp32'
+        'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': 'BASELINE config 2 per GPU: batch=%d %dx%dx3 T=%d %s--loss %s %s(k=%d) --opt %s %s'
                                % (B, S, S, args.seq_len, '--adv ' if adv else '', args.loss, '--dna ' if dna else 'plain-G ',
-                                  args.ksize, args.opt),
+                                  args.ksize, args.opt, 'fp32' if args.dtype == 'f32' else 'bf16-MFMA/fp32-accumulate'),
                    'global_batch': B * world, 'n_critic': n_critic, 'parallelism': 'dp%d' % world,
                    'hip_graphs': not args.no_graphs, 'sequences_per_s': round(world * B * args.steps / elapsed, 1)},
         'roofline': roof, 'roofline_dna': roof_dna, 'cpu_baseline': cpu,

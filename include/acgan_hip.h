@@ -16,8 +16,10 @@
  *     safe to capture into a hipGraph.
  *   - Return 0 (ACG_OK) on success, an ACG_ERR_* code otherwise; the message is available
  *     from acg_last_error() (thread-local).  No global mutable state besides that.
- *   - `dtype` selects the storage type of activations/filters (ACG_F32, ACG_BF16); per-channel
- *     parameters, statistics, loss scalars and optimizer state are always float32.
+ *   - `dtype` selects the arithmetic of the conv contractions: ACG_F32 = exact fp32 matrix cores;
+ *     ACG_BF16 = operands rounded to bfloat16 (round-to-nearest-even) as they are staged for the bf16
+ *     matrix cores, float32 accumulation.  Tensors are float32 in memory in both cases; every other
+ *     entry point accepts ACG_F32 only.
  */
 #ifndef ACGAN_HIP_H
 #define ACGAN_HIP_H

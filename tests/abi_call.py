@@ -15,8 +15,8 @@ def _p(t):
 
 
 class Abi:
-    def __init__(self, lib, device):
-        self.lib, self.device = lib, torch.device(device)
+    def __init__(self, lib, device, conv_dtype=L.ACG_F32):
+        self.lib, self.device, self.conv_dtype = lib, torch.device(device), conv_dtype
 
     # ---- plumbing
     def stream(self):
@@ -48,7 +48,7 @@ class Abi:
         d = self.desc(b, h, wd, w.shape[2], w.shape[0], w.shape[1], w.shape[3], stride, padding, pitch)
         y = self.empty(b, d.out_h, d.out_w, d.out_c)
         ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_FWD, L.ACG_F32))
-        self.lib.conv2d_fwd(_p(x), _p(w), _p(y), ctypes.byref(d), L.ACG_F32, _p(ws), n, self.stream())
+        self.lib.conv2d_fwd(_p(x), _p(w), _p(y), ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
         return y
 
     def conv2d_dgrad(self, dy, w, x_shape, stride, padding):
@@ -57,7 +57,7 @@ class Abi:
         d = self.desc(b, h, wd, w.shape[2], w.shape[0], w.shape[1], w.shape[3], stride, padding, pitch)
         dx = torch.zeros(*x_shape, device=self.device)
         ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_DGRAD, L.ACG_F32))
-        self.lib.conv2d_dgrad(_p(dy), _p(w), _p(dx), ctypes.byref(d), L.ACG_F32, _p(ws), n, self.stream())
+        self.lib.conv2d_dgrad(_p(dy), _p(w), _p(dx), ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
         return dx
 
     def conv2d_wgrad(self, x, dy, w_shape, stride, padding, dw=None, accumulate=0.0):
@@ -67,7 +67,7 @@ class Abi:
         if dw is None:
             dw = self.empty(*w_shape)
         ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_WGRAD, L.ACG_F32))
-        self.lib.conv2d_wgrad(_p(x), _p(dy), _p(dw), accumulate, ctypes.byref(d), L.ACG_F32, _p(ws), n, self.stream())
+        self.lib.conv2d_wgrad(_p(x), _p(dy), _p(dw), accumulate, ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
         return dw
 
     # ---- deconv family (x NHWC [B,IH,IW,Cin], w [kh,kw,Cout,Cin]); SAME only
@@ -82,14 +82,14 @@ class Abi:
         d = self._adj(x.shape, w.shape, stride)
         y = self.empty(d.batch, d.in_h, d.in_w, d.in_c)
         ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_DGRAD, L.ACG_F32))
-        self.lib.deconv2d_fwd(_p(x), _p(w), _p(y), ctypes.byref(d), L.ACG_F32, _p(ws), n, self.stream())
+        self.lib.deconv2d_fwd(_p(x), _p(w), _p(y), ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
         return y
 
     def deconv2d_dgrad(self, dy, w, x_shape, stride):
         d = self._adj(x_shape, w.shape, stride)
         dx = torch.zeros(*x_shape, device=self.device)
         ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_FWD, L.ACG_F32))
-        self.lib.deconv2d_dgrad(_p(dy), _p(w), _p(dx), ctypes.byref(d), L.ACG_F32, _p(ws), n, self.stream())
+        self.lib.deconv2d_dgrad(_p(dy), _p(w), _p(dx), ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
         return dx
 
     def deconv2d_wgrad(self, x, dy, w_shape, stride, dw=None, accumulate=0.0):
@@ -97,7 +97,7 @@ class Abi:
         if dw is None:
             dw = self.empty(*w_shape)
         ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_WGRAD, L.ACG_F32))
-        self.lib.deconv2d_wgrad(_p(x), _p(dy), _p(dw), accumulate, ctypes.byref(d), L.ACG_F32, _p(ws), n, self.stream())
+        self.lib.deconv2d_wgrad(_p(x), _p(dy), _p(dw), accumulate, ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
         return dw
 
     # ---- bn / bias

@@ -83,6 +83,38 @@ def case_conv(abi, shape, tol, seed=0):
     close(got, 0.5 * dw0.double().cpu() + dw_ref, tol, tag + ' wgrad accumulate')
 
 
+def case_conv_bf16(abi, shape, tol, seed=0, transposed=False):
+    """ACG_BF16: operands rounded to bfloat16 (RNE), products exact, fp32 accumulation - so the reference is the
+    fp64 conv of the bf16-rounded operands and the bar stays at accumulation-order level."""
+    r16 = lambda t: t.bfloat16().float()
+    if transposed:
+        b, ih, iw, cin, cout, k, s = shape
+        x, wt = uniform((b, ih, iw, cin), seed), randn((k, k, cout, cin), seed + 1, 0.1)
+        fwd = lambda xx, ww: T.conv2d_transpose(xx, ww, s, 'SAME')
+    else:
+        b, h, w, cin, cout, k, s, pad = shape
+        x, wt = uniform((b, h, w, cin), seed), randn((k, k, cin, cout), seed + 1, 0.1)
+        fwd = lambda xx, ww: T.conv2d(xx, ww, s, pad)
+    y_shape = tuple(fwd(x.double(), wt.double()).shape)
+    dy = randn(y_shape, seed + 2)
+    xr, wr, dyr = r16(x).double(), r16(wt).double(), r16(dy).double()
+    y_ref = fwd(xr, wr)
+    xg_, wg_ = xr.clone().requires_grad_(True), wr.clone().requires_grad_(True)
+    dx_ref, = torch.autograd.grad(fwd(xg_, wr), [xg_], dyr)          # dgrad uses rounded dy and w
+    dw_ref, = torch.autograd.grad(fwd(xr, wg_), [wg_], dyr)          # wgrad uses rounded x and dy
+    dev = abi.device
+    xg, wg, dyg = x.to(dev), wt.to(dev), dy.to(dev)
+    tag = 'bf16 %s%s' % ('deconv' if transposed else 'conv', shape)
+    if transposed:
+        close(abi.deconv2d_fwd(xg, wg, s), y_ref, tol, tag + ' fwd')
+        close(abi.deconv2d_dgrad(dyg, wg, tuple(x.shape), s), dx_ref, tol, tag + ' dgrad')
+        close(abi.deconv2d_wgrad(xg, dyg, tuple(wt.shape), s), dw_ref, tol, tag + ' wgrad')
+    else:
+        close(abi.conv2d_fwd(xg, wg, s, pad), y_ref, tol, tag + ' fwd')
+        close(abi.conv2d_dgrad(dyg, wg, tuple(x.shape), s, pad), dx_ref, tol, tag + ' dgrad')
+        close(abi.conv2d_wgrad(xg, dyg, tuple(wt.shape), s, pad), dw_ref, tol, tag + ' wgrad')
+
+
 def case_conv_pitched(abi, tol, seed=0):
     """3- and 6-channel inputs stored with a channel pitch of 4 / 8 (in_pitch): same results as the dense tensor,
     pad channels of dx untouched."""

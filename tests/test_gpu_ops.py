@@ -16,6 +16,24 @@ def test_conv(hip_abi, shape):
     C.case_conv(hip_abi, shape, TOL_CONV)
 
 
+@pytest.fixture(scope='module')
+def hip_abi_bf16(hip_abi):
+    from abi_call import Abi
+    from action_conditioned_gans_amd import _lib
+    return Abi(hip_abi.lib, 'cuda:0', conv_dtype=_lib.ACG_BF16)
+
+
+@pytest.mark.parametrize('shape', [C.CONV_SHAPES[i] for i in (0, 1, 2, 4, 5, 9, 11)] + [(32, 16, 16, 128, 128, 5, 2, 'SAME')], ids=str)
+def test_conv_bf16(hip_abi_bf16, shape):
+    """dtype=ACG_BF16 (BASELINE configs 3 and 5): bf16 matrix-core operands, fp32 storage and accumulation."""
+    C.case_conv_bf16(hip_abi_bf16, shape, TOL_CONV)
+
+
+@pytest.mark.parametrize('shape', [C.DECONV_SHAPES[i] for i in (0, 2, 5)] + [(8, 32, 32, 128, 25, 5, 2)], ids=str)
+def test_deconv_bf16(hip_abi_bf16, shape):
+    C.case_conv_bf16(hip_abi_bf16, shape, TOL_CONV, transposed=True)
+
+
 def test_deconv_pitched(hip_abi):
     C.case_deconv_pitched(hip_abi, TOL_CONV)
 

@@ -149,7 +149,7 @@ class _ConvBase(G.Op):
 
     def _bind(self, rt, entry, a, b, out, accumulate=None):
         lib, d = rt.lib, self.desc
-        ws, n = rt.workspace(lib.conv2d_workspace_bytes(ctypes.byref(d), self.which, ACG_F32))
+        ws, n = rt.workspace(lib.conv2d_workspace_bytes(ctypes.byref(d), self.which, rt.conv_dtype))
         self._keep = (ws, d)
         fn = getattr(lib, entry)
         pa, pb, po, dref, pws, dt = _p(a.buf), _p(b.buf), _p(out.buf), ctypes.byref(d), _p(ws), rt.conv_dtype

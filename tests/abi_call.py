@@ -47,7 +47,7 @@ class Abi:
         pitch = c if c != w.shape[2] else 0            # x carries pad channels beyond the filter's Cin
         d = self.desc(b, h, wd, w.shape[2], w.shape[0], w.shape[1], w.shape[3], stride, padding, pitch)
         y = self.empty(b, d.out_h, d.out_w, d.out_c)
-        ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_FWD, L.ACG_F32))
+        ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_FWD, self.conv_dtype))
         self.lib.conv2d_fwd(_p(x), _p(w), _p(y), ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
         return y
 
@@ -56,7 +56,7 @@ class Abi:
         pitch = c if c != w.shape[2] else 0
         d = self.desc(b, h, wd, w.shape[2], w.shape[0], w.shape[1], w.shape[3], stride, padding, pitch)
         dx = torch.zeros(*x_shape, device=self.device)
-        ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_DGRAD, L.ACG_F32))
+        ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_DGRAD, self.conv_dtype))
         self.lib.conv2d_dgrad(_p(dy), _p(w), _p(dx), ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
         return dx
 
@@ -66,7 +66,7 @@ class Abi:
         d = self.desc(b, h, wd, w_shape[2], w_shape[0], w_shape[1], w_shape[3], stride, padding, pitch)
         if dw is None:
             dw = self.empty(*w_shape)
-        ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_WGRAD, L.ACG_F32))
+        ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_WGRAD, self.conv_dtype))
         self.lib.conv2d_wgrad(_p(x), _p(dy), _p(dw), accumulate, ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
         return dw
 
@@ -81,14 +81,14 @@ class Abi:
     def deconv2d_fwd(self, x, w, stride):
         d = self._adj(x.shape, w.shape, stride)
         y = self.empty(d.batch, d.in_h, d.in_w, d.in_c)
-        ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_DGRAD, L.ACG_F32))
+        ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_DGRAD, self.conv_dtype))
         self.lib.deconv2d_fwd(_p(x), _p(w), _p(y), ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
         return y
 
     def deconv2d_dgrad(self, dy, w, x_shape, stride):
         d = self._adj(x_shape, w.shape, stride)
         dx = torch.zeros(*x_shape, device=self.device)
-        ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_FWD, L.ACG_F32))
+        ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_FWD, self.conv_dtype))
         self.lib.deconv2d_dgrad(_p(dy), _p(w), _p(dx), ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
         return dx
 
@@ -96,7 +96,7 @@ class Abi:
         d = self._adj(x.shape, w_shape, stride)
         if dw is None:
             dw = self.empty(*w_shape)
-        ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_WGRAD, L.ACG_F32))
+        ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_WGRAD, self.conv_dtype))
         self.lib.deconv2d_wgrad(_p(x), _p(dy), _p(dw), accumulate, ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
         return dw
 

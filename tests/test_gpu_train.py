@@ -118,3 +118,33 @@ def test_training_loop_runs_wass_rmsprop_n_critic():
         assert torch.isfinite(val).all() and val.abs().max().item() <= 0.01 + 1e-7, v.name
     for v in tr.g_vars:
         assert torch.isfinite(tr.sess.get_value(v)).all(), v.name
+
+
+def test_bf16_mode_tracks_fp32():
+    """Session(dtype='bf16') (BASELINE configs 3/5 arithmetic: bf16 matrix-core operands, fp32 storage and
+    accumulation, fp32 master weights).  Declared tolerance for this mode: generated frames within 3e-2 of the
+    fp32 path relative to the frame scale, losses within 2e-2, per-variable gradients at cosine >= 0.95
+    (the first layers accumulate the rounding of everything behind them; measured minimum 0.975)."""
+    x, y, a, s = TC.MG.inputs(2)
+    out = {}
+    for dtype in ('f32', 'bf16'):
+        sess, tr = TC.build_trainer(gpu_session, 'dna_k6_bce_rmsprop', dtype=dtype)
+        frame, state, summ = tr.test(x, y, a)
+        dsumm = tr.train_d(x, y, a, summarize=True)
+        res = sess.run([tr.g_opt_op, tr.g_loss], tr._feed(x, y, a, s))
+        g = G.get_default_graph()
+        offs, _, _ = g.layout('g')
+        flat = tr.g_opt_op.inputs[1].buf.detach().double().cpu()
+        grads = {n: flat[o:o + g.variables[n].numel].clone() for n, o in offs.items()}
+        out[dtype] = (frame, state, dsumm['discriminator_loss'], float(res[1][0]), grads)
+    f32, b16 = out['f32'], out['bf16']
+    assert TC.rel(b16[0], f32[0]) <= 3e-2, TC.rel(b16[0], f32[0])
+    assert TC.rel(b16[1], f32[1]) <= 3e-2
+    assert abs(b16[2] - f32[2]) <= 2e-2 * max(abs(f32[2]), 1.0)
+    assert abs(b16[3] - f32[3]) <= 2e-2 * abs(f32[3])
+    assert not np.array_equal(b16[0], f32[0])                       # the bf16 kernels really ran
+    for n, gref in f32[4].items():
+        gb = b16[4][n]
+        if gref.norm() > 1e-6 * max(v.norm() for v in f32[4].values()):
+            cos = float((gref * gb).sum() / (gref.norm() * gb.norm()))
+            assert cos >= 0.95, (n, cos)

@@ -29,12 +29,18 @@ def _f32(v):
 class DataParallel:
     """Per-graph data-parallel configuration (one process per GPU; RCCL via torch.distributed)."""
 
-    def __init__(self, world_size=1, n_buckets=3):
-        self.world_size, self.n_buckets = int(world_size), int(n_buckets)
+    def __init__(self, world_size=1, n_buckets=3, force=False):
+        self.world_size, self.n_buckets, self.force = int(world_size), int(n_buckets), bool(force)
+
+    @property
+    def active(self):
+        return self.world_size > 1 or self.force
 
 
-def set_data_parallel(world_size, n_buckets=3, graph=None):
-    (graph or G.get_default_graph()).collections['data_parallel'] = DataParallel(world_size, n_buckets)
+def set_data_parallel(world_size, n_buckets=3, graph=None, force=False):
+    """``force`` inserts the bucketed all-reduce even at world_size 1 (a one-rank communicator): lets a single GPU
+    exercise the collective / side-stream / graph-segment machinery the multi-GPU runs depend on."""
+    (graph or G.get_default_graph()).collections['data_parallel'] = DataParallel(world_size, n_buckets, force)
 
 
 def _dp(graph):
@@ -154,7 +160,7 @@ class Optimizer:
         writers = [op for ops_ in ctx.writers.values() for op in ops_]
         deps = list(writers)
         dp = _dp(g)
-        if dp.world_size > 1:
+        if dp.active:
             reduces = self._insert_allreduce(g, dp, var_list, ctx, flat_grad, offsets, total)
             deps.append(AllReduceWaitOp(g, reduces, self.name + '/allreduce_wait'))
         slots = self._make_slots(g, total)

@@ -51,6 +51,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-repeats', type=int, default=3)
     ap.add_argument('--cpu-steps', type=int, default=20)
+    ap.add_argument('--buckets', type=int, default=3, help='gradient all-reduce buckets per optimizer (data parallel)')
+    ap.add_argument('--force-dp', action='store_true', help='run the data-parallel machinery (RCCL all-reduce buckets, graph segments) even on one rank')
     return ap.parse_args()
 
 
@@ -100,8 +102,10 @@ def main():
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
     pg = None
-    if world > 1:
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
+        if args.force_dp and 'MASTER_ADDR' not in os.environ:
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29531', RANK='0', WORLD_SIZE='1')
         dist.init_process_group('nccl', device_id=device)
 
     from action_conditioned_gans_amd import graph as G, ops as O, optim, train as T
@@ -109,7 +113,7 @@ def main():
     B, S, dna, adv = args.batch, args.img, not args.plain, not args.no_adv
     n_critic = 5 if args.loss == 'wass' else 1
     G.reset_default_graph()
-    optim.set_data_parallel(world)
+    optim.set_data_parallel(world, n_buckets=args.buckets, force=args.force_dp)
     sess = G.Session(device=device, use_hip_graphs=not args.no_graphs, world_size=world, rank=rank, process_group=pg, dtype=args.dtype)
     tr = T.Trainer(sess, adv, args.loss, args.opt, dna, batch_size=B, img_size=S, ksize=args.ksize, seed=0)
     sess.run(G.global_variables_initializer())
@@ -190,6 +194,9 @@ def main():
                         'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': None, 'kernel': 'dna_kernel<K,TY,fwd>',
                         'algorithmic_mb_per_step': round(dna_bytes / 1e6, 2), 'ms_per_step_in_kernel': round(dna_ms, 4)}
 
+    if world > 1 or args.force_dp:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
     if rank != 0:
         return
     cpu = None

@@ -118,6 +118,10 @@ def get():
     """The process-wide HIP library; raises if it was not built."""
     global _LIB
     if _LIB is None:
+        path = os.environ.get('ACG_HIP_LIB', LIB_PATH)     # kernel experiments: an alternative build of the same ABI
+        if path != LIB_PATH:
+            _LIB = Library(path)
+            return _LIB
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 '%s not found: the HIP kernels are not built and there is no fallback path. '

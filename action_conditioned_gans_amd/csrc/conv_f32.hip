@@ -102,21 +102,17 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
   pl.nk = (int)((K + BK - 1) / BK);
   if (pl.nk < 1) pl.nk = 1;
   auto tiles_for = [&](int bm, int bn) { return acg::ceil_div(pl.M, bm) * acg::ceil_div(pl.N, bn) * pl.classes; };
-  static const int kBM[4] = {128, 128, 128, 64}, kBN[4] = {128, 64, 32, 64};
-  // Planner (evidence: profiles/r1 tuning sweeps).  fp32 MFMA is slow enough that LDS/L2 reuse of a big tile
-  // buys little, while small tiles keep >= 3 blocks per CU resident and even out the DGRAD parity classes;
-  // only weight gradients with a large [taps*Cin, Cout] face prefer the 128x128 tile + heavy split-K.
-  if (pl.N <= 32) pl.cfg = 2;
-  // (bf16 shares the fp32 plan: preferring larger tiles for it measured slower, 377 vs 392 steps/s)
-  else if (which == ACG_CONV_WGRAD && tiles_for(128, 128) >= 128) pl.cfg = 1;
-  else if (which == ACG_CONV_WGRAD && tiles_for(128, 128) >= 16) pl.cfg = 0;
-  else pl.cfg = 3;
-  if (g_force_cfg >= 0 && g_force_cfg < 4) pl.cfg = g_force_cfg;
-  pl.bm = kBM[pl.cfg]; pl.bn = kBN[pl.cfg];
+  // Planner (evidence: profiles/r1 tuning sweeps, tools/fit_planner.py).  A wave's loader instructions do not overlap
+  // its own MFMAs on this part (tools/micro/mfma_overlap.hip), so the matrix pipe is kept busy by OTHER resident
+  // blocks: split K until ~1 block per CU for FWD/DGRAD and ~2 per CU for WGRAD (whose K = B*OH*OW is long and whose
+  // loaders are heavier), but keep >= 4 K-steps per block so the slab reduction does not take over.
+  pl.cfg = pl.N <= 32 ? 2 : 3;
+  if (g_force_cfg >= 0 && g_force_cfg < 4) pl.cfg = g_force_cfg <= 2 ? 2 : 3;
+  pl.bm = pl.cfg == 2 ? 128 : 64; pl.bn = pl.cfg == 2 ? 32 : 64;
   pl.tiles = tiles_for(pl.bm, pl.bn);
-  const long long target = 448;   // ~2 resident blocks per CU; more splits only grow the slab reduction
-  long long s = (target + pl.tiles / 2) / pl.tiles;
-  s = std::min<long long>(s, std::max(1, pl.nk / 6));
+  const long long target = which == ACG_CONV_WGRAD ? 512 : 256;
+  long long s = target / pl.tiles;
+  s = std::min<long long>(s, std::max(1, pl.nk / 4));
   s = std::min<long long>(s, 64);
   if (g_force_splits >= 1) s = std::min<long long>(g_force_splits, pl.nk);
   pl.splits = (int)std::max<long long>(s, 1);
@@ -146,6 +142,8 @@ int run(int which, const float* gsrc, const float* dense, float* out, float accu
   a.batch = d->batch; a.H = d->in_h; a.W = d->in_w; a.C = d->in_c; a.OH = d->out_h; a.OW = d->out_w; a.K = d->out_c;
   a.KH = d->kh; a.KW = d->kw; a.sh = d->stride_h; a.sw = d->stride_w; a.pt = d->pad_top; a.pl = d->pad_left;
   a.splits = pl.splits;
+  { const FastDiv fw = fast_div(d->out_w), fh = fast_div(d->out_h); a.mg_ow = fw.magic; a.sh_ow = fw.shift; a.mg_oh = fh.magic; a.sh_oh = fh.shift;
+    const FastDiv fc = fast_div(((which == ACG_CONV_DGRAD ? d->out_c : d->in_c) + 3) & ~3); a.mg_cp = fc.magic; a.sh_cp = fc.shift; }
   hipStream_t st = acg::to_stream(stream);
   int rc;
   if (which == ACG_CONV_FWD) rc = launch_mode<MODE_FWD>(pl, a, st);

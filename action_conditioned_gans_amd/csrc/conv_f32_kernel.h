@@ -14,10 +14,31 @@ namespace acgconv {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned 16-byte global load
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
+
+// f(0), f(1), ... f(N-1) while f returns true; false as soon as one call does
+template <int I, int N, class F>
+__device__ __forceinline__ bool run_unrolled(F&& f) {
+  if constexpr (I < N) {
+    if (!f(std::integral_constant<int, I>{})) return false;
+    return run_unrolled<I + 1, N>(f);
+  } else {
+    return true;
+  }
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 constexpr int BK = 32;  // k per K-step = 8 quads
 constexpr int kMaxTaps = 64;
 
@@ -32,7 +53,22 @@ struct ConvArgs {
   int Cx;              // channel pitch of x / dx in memory (>= C)
   int Ky;              // channel pitch of y / dy in memory (>= K)
   int splits;
+  unsigned mg_ow, mg_oh, mg_cp;   // magic multipliers: r / OW = (r * mg_ow) >> sh_ow for 0 <= r < 2^31 (host: fast_div)
+  int sh_ow, sh_oh, sh_cp;        // _cp: division by the gathered channel count padded to a multiple of 4
 };
+
+// Division by a launch-constant through multiply-high (Granlund-Montgomery, N = 31): a runtime integer division is
+// ~40 VALU instructions on this ISA, and WGRAD derives 32 gather rows per K-step.
+struct FastDiv { unsigned magic; int shift; };
+static inline FastDiv fast_div(int d) {
+  int s = 0;
+  while ((1ll << s) < d) ++s;
+  const unsigned long long num = 1ull << (31 + s);
+  return FastDiv{(unsigned)((num + (unsigned long long)d - 1) / (unsigned long long)d), 31 + s};
+}
+__device__ __forceinline__ int div_fast(int r, unsigned magic, int shift) {
+  return (int)(((unsigned long long)(unsigned)r * magic) >> shift);
+}
 
 struct alignas(16) RowInfo {
   int base;            // element offset of the row's (tap 0, channel 0) source element (may be virtual)
@@ -49,9 +85,11 @@ __device__ __forceinline__ unsigned long long tap_mask(int lo_a, int hi_a, int l
   return m;
 }
 
+// 32-bit operations only: 64-bit shifts and compares are quarter-rate on the VALU, and a wave's VALU work does NOT
+// hide behind its own MFMAs (tools/conv_kloop.py experiments in profiles/), so every instruction in the K-loop counts
 __device__ __forceinline__ bool tap_ok(const RowInfo& ri, int t) {
-  const unsigned long long mk = ((unsigned long long)ri.mask_hi << 32) | ri.mask_lo;
-  return (mk >> t) & 1ull;
+  const unsigned w = t < 32 ? ri.mask_lo : ri.mask_hi;
+  return (w >> (t & 31)) & 1u;
 }
 
 // Branch-free guarded loads through buffer descriptors.  A divergent `if (ok) load` makes hipcc wait for every
@@ -87,16 +125,35 @@ __device__ __forceinline__ float guarded_scalar(__amdgpu_buffer_rsrc_t rs, int e
 // BF16: operands are rounded to bf16 (RNE) as they are staged into LDS and contracted by v_mfma_f32_32x32x16_bf16
 // (fp32 accumulate); tensors stay fp32 in memory.  LDS then holds 8-k "octs": quad kq lands in half (kq&1) of
 // oct kq>>1, and lane half h feeds oct 2t+h of both tiles to MFMA t (2 MFMAs per 32-deep K-step instead of 16).
+//
+// Pipeline (one barrier per K-step): LDS holds TWO K-steps of both tiles.  In iteration ks a wave (1) drains the
+// register stage of step ks+1 into the other LDS buffer, (2) runs the MFMAs of step ks out of the current buffer and
+// (3) issues the global loads of step ks+NST into the stage that was drained one iteration earlier.
+// What the measurements behind this shape say (tools/conv_kloop.py, tools/micro/*.hip, profiles/r1):
+//  * a wave's VALU / LDS / VMEM instructions do NOT overlap its own MFMAs on this part - slot time is the SUM of the
+//    MFMA passes and everything issued between two MFMAs - so only OTHER waves of the SIMD can keep the matrix pipe
+//    busy during the loaders.  Hence: small blocks (several resident per CU, planner in conv_f32.hip) and a loader
+//    that costs as few issue cycles as possible (running offsets instead of divisions and multiplies, 32-bit mask
+//    tests, LDS lookups fetched once per iteration, row infos in registers);
+//  * the loop body must be ONE basic block with a single predecessor per unrolled copy, every load predicated by an
+//    out-of-range offset instead of a branch: only then does hipcc count outstanding loads exactly (vmcnt(N), N > 0)
+//    and the loads really run NST-1 K-steps ahead;
+//  * a chain of dependent MFMAs through one accumulator already issues every 68-74 cycles (no extra sets needed).
 template <int MODE, int BM, int BN, int WM, int WN, bool RAGGED, bool NVEC, bool BF16>
 __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int TA = BM / (32 * WM), TB = BN / (32 * WN);
   constexpr int QA = BM / 32, QB = BN / 32;  // quads per thread per K-step
-  constexpr int NROW = (MODE == MODE_WGRAD) ? BK : BM;
+  constexpr int NROW = (MODE == MODE_WGRAD) ? 2 * 256 : BM;  // WGRAD: row infos of 2 x 8 K-steps (chunk parity)
+#ifndef ACG_NST
+#define ACG_NST 4
+#endif
+  constexpr int NST = ACG_NST;           // register stages: global loads run NST K-steps ahead of their MFMAs
 
   constexpr int KSLOTS = BF16 ? 4 : 8;   // 16-byte k-slots per tile column: 8 quads (fp32) or 4 octs (bf16)
-  __shared__ f4 As[KSLOTS * BM];
-  __shared__ f4 Bs[KSLOTS * BN];
+  constexpr int ASZ = KSLOTS * BM, BSZ = KSLOTS * BN;
+  __shared__ f4 As_all[2 * ASZ];
+  __shared__ f4 Bs_all[2 * BSZ];
   __shared__ RowInfo rows[NROW];
   __shared__ int tapA[kMaxTaps];
   __shared__ int tapB[kMaxTaps];
@@ -164,7 +221,8 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
   auto fill_row_fwd = [&](int r /* global row (b,p,q) */, int limit) -> RowInfo {
     RowInfo ri; ri.base = 0; ri.mask_lo = 0; ri.mask_hi = 0; ri.out_off = 0;
     if (r < limit) {
-      const int q = r % p.OW; const int t2 = r / p.OW; const int pp = t2 % p.OH; const int b = t2 / p.OH;
+      const int t2 = div_fast(r, p.mg_ow, p.sh_ow), q = r - t2 * p.OW;
+      const int b = div_fast(t2, p.mg_oh, p.sh_oh), pp = t2 - b * p.OH;
       const int y0 = pp * p.sh - p.pt, x0 = q * p.sw - p.pl;
       ri.base = ((b * p.H + y0) * p.W + x0) * p.Cx;
       const unsigned long long m = tap_mask(max(0, -y0), min(p.KH, p.H - y0), max(0, -x0), min(p.KW, p.W - x0), p.KW);
@@ -196,31 +254,25 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
   // k-fast operands (A of FWD/DGRAD, B of DGRAD) are gathered one quad per (row, k/4); the others
   // (B of FWD, A and B of WGRAD) are contiguous along the tile column, so a thread loads a 4x4 block
   // (4 k-rows x float4 of columns) and transposes it in registers into 4 quads.
-  constexpr int RA = (MODE == MODE_WGRAD) ? 4 : QA;
-  constexpr int RB = (MODE == MODE_DGRAD) ? QB : 4;
-  f4 ra[2][RA], rb[2][RB];
+  // Transposed loaders: the 32 x (BN/4) row-quads of a K-step are dealt evenly to the 256 threads - LPB = BN/32
+  // consecutive k-rows (4, 2 or 1) of one column quad each, i.e. a whole, half or quarter 4x4 block - so every
+  // thread runs the same instruction stream (no idle waves, no divergent branch in the loop) and the transposed
+  // pieces are written as 16-, 8- or 4-byte parts of the k-quads in LDS.
+  constexpr int LPA = BM / 32, LPB = BN / 32;
+  constexpr int RA = (MODE == MODE_WGRAD) ? LPA : QA;
+  constexpr int RB = (MODE == MODE_DGRAD) ? QB : (NVEC ? LPB : QB);
+  f4 ra[NST][RA], rb[NST][RB];
 
-  // running (tap, channel) of this thread's next k-fast quad: kp = ks*32 + 4*(tid&7); no divisions in the loop
-  int kt = 0, kc = 0;
-  if constexpr (MODE != MODE_WGRAD) {
-    const int kp = ks_begin * BK + 4 * (tid & 7);
-    kt = kp / Cp; kc = kp - kt * Cp;
-  }
+  // (tap, channel) of a k index by multiply-high: the loaders are straight-line code (no running state, no loops)
+  auto tap_of = [&](int kp, int& t, int& c) { t = div_fast(kp, p.mg_cp, p.sh_cp); c = kp - t * Cp; };
   // transposed loaders: thread -> (column quad jn, k quad kq); active while kq < 8
-  const int jb = tid % (BN / 4), kqb = tid / (BN / 4);
-  const bool actb = kqb < 8;
+  const int jb = tid % (BN / 4), r0b = (tid / (BN / 4)) * LPB, kqb = r0b >> 2, subb = r0b & 3;
   constexpr bool nvec = NVEC;         // dense rows are 16-byte aligned and quads never straddle N
-  int bt = 0, bc = 0;                 // FWD: running (tap, channel) of the B rows kp = ks*32 + 4*kqb
-  if constexpr (MODE == MODE_FWD) {
-    const int kp = ks_begin * BK + 4 * (nvec ? kqb : 0);
-    bt = kp / Cp; bc = kp - bt * Cp;
-  }
-  const int ja = tid % (BM / 4), kqa = tid / (BM / 4);
-  const bool acta = kqa < 8;
+  const int ja = tid % (BM / 4), r0a = (tid / (BM / 4)) * LPA, kqa = r0a >> 2, suba = r0a & 3;
   int wg_t = 0, wg_off = 0, wg_nvalid = 0;   // WGRAD: this thread's fixed (padded) output-row quad -> (tap, channel)
   if constexpr (MODE == MODE_WGRAD) {
     const int mp = m0 + 4 * ja;
-    if (acta && mp < M) {
+    if (mp < M) {
       wg_t = mp / Cp;
       const int c = mp - wg_t * Cp;
       wg_nvalid = Cs - c;            // >= 1
@@ -228,110 +280,124 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
     }
   }
 
-  auto transpose_into = [&](f4 (&dst)[4], const f4 (&l)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dst[i] = f4{l[0][i], l[1][i], l[2][i], l[3][i]};
-  };
 
   constexpr bool ragged = RAGGED;     // quads at the end of a tap are partial
 
-  auto load_tiles = [&](auto stage, int ks) {
-    constexpr int ST = decltype(stage)::value;
+  // `live` false (a step beyond this block's K range): every lane addresses out of range, the loads return zeros
+  // without touching memory - the loop body stays branch-free, so hipcc counts outstanding loads exactly
+  // (s_waitcnt vmcnt(N), N > 0) instead of draining them at every control-flow join.
+  // The loads of a K-step are NLD independent "pieces" (A pieces first, then B) so that the K-loop can deal them out
+  // between MFMAs; shared address arithmetic is written per piece and merged by the compiler.
+  constexpr int NLD = RA + RB;
+  // Everything a K-step's loads need from LDS (tap table entry, WGRAD row infos) is fetched by load_prep at the top
+  // of an iteration, so no piece waits on an LDS round trip between two MFMAs; the row infos of the k-fast gathers
+  // never change and live in registers.
+  RowInfo myrow[MODE == MODE_WGRAD ? 1 : QA];
+  if constexpr (MODE != MODE_WGRAD) {
+#pragma unroll
+    for (int u = 0; u < QA; ++u) myrow[u] = rows[(tid >> 3) + 32 * u];
+  }
+  // Running (tap, channel) state of this thread's k-fast quad and dense rows, advanced by one K-step (32 k) per
+  // load_prep call with adds and ONE conditional wrap (32 = step_t * Cp + step_c with step_c < Cp): the K-loop has
+  // no division, no multiply and no 64-bit arithmetic.  load_prep must therefore be called for consecutive ks,
+  // starting at ks_begin - which is how the pipeline below issues its loads.
+  const int step_t = BK / Cp, step_c = BK - step_t * Cp;
+  int run_kt = 0, run_kc = 0, run_bt = 0, run_bc = 0, run_boff = 0;
+  if constexpr (MODE != MODE_WGRAD) tap_of(ks_begin * BK + 4 * (tid & 7), run_kt, run_kc);
+  const int nB = n0 + 4 * jb;                       // first column of the dense-row quads (nvec)
+  if constexpr (MODE == MODE_FWD && nvec) {
+    tap_of(ks_begin * BK + 4 * kqb, run_bt, run_bc);
+    run_boff = (run_bt * Cs + run_bc + subb) * N + nB;
+  }
+  if constexpr (MODE == MODE_WGRAD && nvec) run_boff = (ks_begin * BK + r0b) * p.Ky + nB;
+  const int b_step = (step_t * Cs + step_c) * N, b_wrap = (Cp - Cs) * N;   // FWD: dense-row offset per K-step / per tap wrap
+  int nK[MODE == MODE_DGRAD ? QB : 1];                                     // DGRAD: n * K of this thread's filter rows
+  bool nOk[MODE == MODE_DGRAD ? QB : 1];
+  if constexpr (MODE == MODE_DGRAD) {
+#pragma unroll
+    for (int u = 0; u < QB; ++u) { const int n = n0 + (tid >> 3) + 32 * u; nK[u] = n * p.K; nOk[u] = n < N; }
+  }
+  struct Prep {
+    int t, kc, aoff, tb, bt, bc, boff, brow;
+    bool kv;
+    RowInfo wri[MODE == MODE_WGRAD ? LPA : 1];
+  };
+  auto load_prep = [&](int ks, bool live) {
+    Prep q{};
     if constexpr (MODE == MODE_WGRAD) {
-      if (acta) {   // raw rows now; the 4x4 transpose happens at store time so no load is waited for here
-        if constexpr (!ragged) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const RowInfo ri = rows[4 * kqa + e];
-            ra[ST][e] = guarded_quad(rs_g, ri.base + wg_off, wg_nvalid > 0 && tap_ok(ri, wg_t));
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const RowInfo ri = rows[4 * kqa + e];
-            ra[ST][e] = guarded_ragged(rs_g, ri.base + wg_off, wg_nvalid > 0 && tap_ok(ri, wg_t), wg_nvalid);
-          }
-        }
+      for (int e = 0; e < LPA; ++e) q.wri[e] = rows[((ks - ks_begin) & 15) * BK + r0a + e];
+    } else {
+      q.kc = run_kc;
+      q.kv = live && run_kt < ntaps;
+      q.t = q.kv ? run_kt : 0;
+      q.aoff = tapA[q.t] + run_kc;
+      if constexpr (MODE == MODE_DGRAD) q.tb = tapB[q.t] + run_kc;
+      run_kt += step_t; run_kc += step_c;
+      const bool wrap = run_kc >= Cp;
+      run_kc -= wrap ? Cp : 0; run_kt += wrap ? 1 : 0;
+    }
+    if constexpr (MODE == MODE_FWD && nvec) {
+      q.bt = run_bt; q.bc = run_bc + subb; q.boff = run_boff;
+      run_bt += step_t; run_bc += step_c;
+      const bool wrap = run_bc >= Cp;
+      run_bc -= wrap ? Cp : 0; run_bt += wrap ? 1 : 0;
+      run_boff += b_step - (wrap ? b_wrap : 0);
+    }
+    if constexpr (MODE == MODE_WGRAD && nvec) {
+      q.boff = run_boff; q.brow = ks * BK + r0b;
+      run_boff += BK * p.Ky;
+    }
+    return q;
+  };
+  auto load_piece = [&](auto stage, int ks, bool live, const Prep& q, auto pc) {
+    constexpr int ST = decltype(stage)::value;
+    constexpr int I = decltype(pc)::value;
+    if constexpr (I < RA) {
+      if constexpr (MODE == MODE_WGRAD) {   // raw rows now; the transpose happens at store time
+        const RowInfo ri = q.wri[I];
+        const bool ok = live && wg_nvalid > 0 && tap_ok(ri, wg_t);
+        if constexpr (!ragged) ra[ST][I] = guarded_quad(rs_g, ri.base + wg_off, ok);
+        else ra[ST][I] = guarded_ragged(rs_g, ri.base + wg_off, ok, wg_nvalid);
+      } else {
+        // k-fast gather: 8 consecutive lanes walk 8 quads (128 contiguous bytes) of one gathered row
+        const RowInfo ri = myrow[I];
+        if constexpr (!ragged) ra[ST][I] = guarded_quad(rs_g, ri.base + q.aoff, q.kv && tap_ok(ri, q.t));
+        else ra[ST][I] = guarded_ragged(rs_g, ri.base + q.aoff, q.kv && tap_ok(ri, q.t), Cs - q.kc);
       }
     } else {
-      // k-fast gather: 8 consecutive lanes walk 8 quads (128 contiguous bytes) of one gathered row
-      const int rg = tid >> 3;
-      const bool kv = kt < ntaps;
-      const int t = kv ? kt : 0;
-      const int nvalid = Cs - kc;  // >= 1
-      const int aoff = tapA[t] + kc;
-      if constexpr (!ragged) {
-#pragma unroll
-        for (int u = 0; u < QA; ++u) {
-          const RowInfo ri = rows[rg + 32 * u];
-          ra[ST][u] = guarded_quad(rs_g, ri.base + aoff, kv && tap_ok(ri, t));
-        }
-      } else {
-#pragma unroll
-        for (int u = 0; u < QA; ++u) {
-          const RowInfo ri = rows[rg + 32 * u];
-          ra[ST][u] = guarded_ragged(rs_g, ri.base + aoff, kv && tap_ok(ri, t), nvalid);
-        }
-      }
+      constexpr int U = I - RA;
       if constexpr (MODE == MODE_DGRAD) {  // B[k=(tap,o)][n=c] = W[tap][c][o], contiguous along o
-        const int boff = tapB[t] + kc;
-        if constexpr (!ragged) {
-#pragma unroll
-          for (int u = 0; u < QB; ++u) {
-            const int n = n0 + rg + 32 * u;
-            rb[ST][u] = guarded_quad(rs_d, boff + n * p.K, kv && n < N);
-          }
-        } else {
-#pragma unroll
-          for (int u = 0; u < QB; ++u) {
-            const int n = n0 + rg + 32 * u;
-            rb[ST][u] = guarded_ragged(rs_d, boff + n * p.K, kv && n < N, nvalid);
-          }
-        }
-      }
-      kc += BK;
-      while (kc >= Cp) { kc -= Cp; ++kt; }
-    }
-    if constexpr (MODE != MODE_DGRAD) {
-      // dense operand: FWD W[(tap,c)][n] rows, WGRAD dY[(b,p,q)][n] rows
-      if constexpr (nvec) {
-        if (actb) {
-          const int n = n0 + 4 * jb;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            int row;
-            bool ok;
-            if constexpr (MODE == MODE_FWD) { row = bt * Cs + bc + e; ok = bt < ntaps && bc + e < Cs; }
-            else { row = ks * BK + 4 * kqb + e; ok = row < Kdim; }
-            rb[ST][e] = guarded_quad(rs_d, row * (MODE == MODE_WGRAD ? p.Ky : N) + n, ok && n < N);   // raw row; transposed at store time
-          }
-        }
+        if constexpr (!ragged) rb[ST][U] = guarded_quad(rs_d, q.tb + nK[U], q.kv && nOk[U]);
+        else rb[ST][U] = guarded_ragged(rs_d, q.tb + nK[U], q.kv && nOk[U], Cs - q.kc);
+      } else if constexpr (nvec) {
+        // dense operand: FWD W[(tap,c)][n] rows, WGRAD dY[(b,p,q)][n] rows; raw row, transposed at store time
+        bool ok;
+        if constexpr (MODE == MODE_FWD) ok = q.bt < ntaps && q.bc + U < Cs;
+        else ok = q.brow + U < Kdim;
+        rb[ST][U] = guarded_quad(rs_d, q.boff + U * (MODE == MODE_WGRAD ? p.Ky : N), live && ok && nB < N);
       } else {  // ragged N (25, 5, 3, 1 ...): 4 k-rows of one column per quad, lanes along n
         constexpr int stepB = 256 / BN;
-        const int n = n0 + (tid % BN), kq0 = tid / BN;
+        const int n = n0 + (tid % BN), kq = tid / BN + stepB * U;
+        f4 v;
+        if constexpr (MODE == MODE_FWD) {
+          int t2, c2;
+          tap_of(ks * BK + 4 * kq, t2, c2);
 #pragma unroll
-        for (int u = 0; u < QB; ++u) {
-          const int kq = kq0 + stepB * u;
-          f4 v;
-          if constexpr (MODE == MODE_FWD) {
-            int t2 = bt, c2 = bc + 4 * kq;     // bt/bc track kp = ks*32 here (kqb term is 0 when !nvec)
-            while (c2 >= Cp) { c2 -= Cp; ++t2; }
+          for (int e = 0; e < 4; ++e)
+            v[e] = guarded_scalar(rs_d, (t2 * Cs + c2 + e) * N + n, live && t2 < ntaps && c2 + e < Cs && n < N);
+        } else {
+          const int r = ks * BK + 4 * kq;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              v[e] = guarded_scalar(rs_d, (t2 * Cs + c2 + e) * N + n, t2 < ntaps && c2 + e < Cs && n < N);
-          } else {
-            const int r = ks * BK + 4 * kq;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = guarded_scalar(rs_d, (r + e) * p.Ky + n, r + e < Kdim && n < N);
-          }
-          rb[ST][u] = v;
+          for (int e = 0; e < 4; ++e) v[e] = guarded_scalar(rs_d, (r + e) * p.Ky + n, live && r + e < Kdim && n < N);
         }
-      }
-      if constexpr (MODE == MODE_FWD) {
-        bc += BK;
-        while (bc >= Cp) { bc -= Cp; ++bt; }
+        rb[ST][U] = v;
       }
     }
+  };
+  auto load_tiles = [&](auto stage, int ks, bool live) {
+    const Prep q = load_prep(ks, live);
+    static_for<0, NLD>([&](auto pc) { load_piece(stage, ks, live, q, pc); });
   };
 
   // LDS column permutation: physical = P(col) ^ kq with P(32q + 4j + e) = 32q + 8e + (j ^ 4(e>>1)).
@@ -353,14 +419,34 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
     }
   };
 
-  auto store_tiles = [&](auto stage) {
+  // write k-rows sub..sub+L-1 of quad `kq` of tile column `col` (L = 4, 2, 1: a whole, half or quarter quad)
+  auto put_part = [&](f4* tile, int width, int kq, int sub, int col, auto lc, const float* v) {
+    constexpr int L = decltype(lc)::value;
+    if constexpr (BF16) {
+      const int oct = kq >> 1;
+      char* dst = reinterpret_cast<char*>(tile + oct * width + pcol(col, oct)) + (kq & 1) * 8 + sub * 2;
+      if constexpr (L == 4) *reinterpret_cast<bf4*>(dst) = bf4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+      else if constexpr (L == 2) *reinterpret_cast<bf2*>(dst) = bf2{(__bf16)v[0], (__bf16)v[1]};
+      else *reinterpret_cast<__bf16*>(dst) = (__bf16)v[0];
+    } else {
+      char* dst = reinterpret_cast<char*>(tile + kq * width + pcol(col, kq)) + sub * 4;
+      if constexpr (L == 4) *reinterpret_cast<f4*>(dst) = f4{v[0], v[1], v[2], v[3]};
+      else if constexpr (L == 2) *reinterpret_cast<f2*>(dst) = f2{v[0], v[1]};
+      else *reinterpret_cast<float*>(dst) = v[0];
+    }
+  };
+
+  auto store_tiles = [&](auto stage, int buf) {
     constexpr int ST = decltype(stage)::value;
+    f4* const As = As_all + buf * ASZ;
+    f4* const Bs = Bs_all + buf * BSZ;
     if constexpr (MODE == MODE_WGRAD) {
-      if (acta) {
-        f4 q[4];
-        transpose_into(q, ra[ST]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) put(As, BM, kqa, 4 * ja + i, q[i]);
+      for (int i = 0; i < 4; ++i) {
+        float v[LPA];
+#pragma unroll
+        for (int e = 0; e < LPA; ++e) v[e] = ra[ST][e][i];
+        put_part(As, BM, kqa, suba, 4 * ja + i, std::integral_constant<int, LPA>{}, v);
       }
     } else {
       const int kq = tid & 7, rg = tid >> 3;
@@ -373,11 +459,12 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
     }
     if constexpr (MODE != MODE_DGRAD) {
       if constexpr (nvec) {
-        if (actb) {
-          f4 q[4];
-          transpose_into(q, rb[ST]);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) put(Bs, BN, kqb, 4 * jb + i, q[i]);
+        for (int i = 0; i < 4; ++i) {
+          float v[LPB];
+#pragma unroll
+          for (int e = 0; e < LPB; ++e) v[e] = rb[ST][e][i];
+          put_part(Bs, BN, kqb, subb, 4 * jb + i, std::integral_constant<int, LPB>{}, v);
         }
       } else {
         constexpr int stepB = 256 / BN;
@@ -389,85 +476,122 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
   };
 
   // ---- main loop ----------------------------------------------------------------------------------
-  f32x16 acc[TA][TB];
+  // Accumulator sets rotated by k within a K-step (summed in the epilogue).  Measured (tools/micro/mfma_rate.hip):
+  // a chain of dependent v_mfma_f32_32x32x2_f32 through ONE accumulator already issues every 68-74 cycles, so one
+  // set is enough; the knob stays for experiments.
+#ifndef ACG_NSET
+#define ACG_NSET 1
+#endif
+  constexpr int NSET = (TA * TB >= 4) ? 1 : ACG_NSET;
+  f32x16 accs[NSET][TA][TB];
+  auto& acc = accs[0];
 #pragma unroll
   for (int a = 0; a < TA; ++a)
 #pragma unroll
     for (int b = 0; b < TB; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int z = 0; z < NSET; ++z) accs[z][a][b][r] = 0.f;
+      }
 
   const int wr = wave / WN, wc = wave - wr * WN;
   const int wm0 = wr * (BM / WM), wn0 = wc * (BN / WN);
   const int lrow = lane & 31, lk = lane >> 5;
 
-  auto compute = [&]() {
+  // MFMA work of one K-step as NM single instructions in NT groups (a group = one k-slot per lane half): group t
+  // reads quad (fp32) / oct (bf16) 2t+h of BOTH tiles for lane half h - the MFMA contracts slot (lane>>5) of A with
+  // the same slot of B, so the k order inside a K-step is free - and feeds it to GM MFMAs.
+  constexpr int NT = BF16 ? 2 : 4, GM = (BF16 ? 1 : 4) * TA * TB, NM = NT * GM;
+  f4 av[2][TA], bv[2][TB];        // operand fragments of group t live in av[t & 1] (bf16: 8 values in the 16 bytes)
+  auto frag_read = [&](int buf, auto tc) {
+    constexpr int T = decltype(tc)::value;
+    const f4* const As = As_all + buf * ASZ;
+    const f4* const Bs = Bs_all + buf * BSZ;
+    const int kq = 2 * T + lk;
+#pragma unroll
+    for (int a = 0; a < TA; ++a) av[T & 1][a] = As[kq * BM + pcol(wm0 + 32 * a + lrow, kq)];
+#pragma unroll
+    for (int b = 0; b < TB; ++b) bv[T & 1][b] = Bs[kq * BN + pcol(wn0 + 32 * b + lrow, kq)];
+  };
+  auto mfma = [&](auto ic) {
+    constexpr int I = decltype(ic)::value;
+    constexpr int T = I / GM, R = I % GM, AB = R % (TA * TB), A = AB / TB, B = AB % TB;
     if constexpr (BF16) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int oct = 2 * t + lk;  // lane half h holds k = 8h..8h+7 of the 16-deep MFMA: oct 2t+h of BOTH tiles
-        bf8 av[TA], bv[TB];
-#pragma unroll
-        for (int a = 0; a < TA; ++a) av[a] = *reinterpret_cast<const bf8*>(&As[oct * BM + pcol(wm0 + 32 * a + lrow, oct)]);
-#pragma unroll
-        for (int b = 0; b < TB; ++b) bv[b] = *reinterpret_cast<const bf8*>(&Bs[oct * BN + pcol(wn0 + 32 * b + lrow, oct)]);
-#pragma unroll
-        for (int a = 0; a < TA; ++a)
-#pragma unroll
-          for (int b = 0; b < TB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[a], bv[b], acc[a][b], 0, 0, 0);
-      }
-      return;
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int kq = 2 * t + lk;  // lane half h consumes quad 2t+h of BOTH tiles: same k on both sides
-      f4 av[TA], bv[TB];
-#pragma unroll
-      for (int a = 0; a < TA; ++a) av[a] = As[kq * BM + pcol(wm0 + 32 * a + lrow, kq)];
-#pragma unroll
-      for (int b = 0; b < TB; ++b) bv[b] = Bs[kq * BN + pcol(wn0 + 32 * b + lrow, kq)];
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int a = 0; a < TA; ++a)
-#pragma unroll
-          for (int b = 0; b < TB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][e], bv[b][e], acc[a][b], 0, 0, 0);
+      accs[T % NSET][A][B] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, av[T & 1][A]), __builtin_bit_cast(bf8, bv[T & 1][B]), accs[T % NSET][A][B], 0, 0, 0);
+    } else {
+      constexpr int E = R / (TA * TB);
+      accs[E % NSET][A][B] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[T & 1][A][E], bv[T & 1][B][E], accs[E % NSET][A][B], 0, 0, 0);
     }
   };
 
-  // WGRAD gathers along the reduction: its 32 row infos change every K-step and must be in LDS
-  // (behind a barrier) before the loads of that step are issued.
-  auto wgrad_rows = [&](int ks) {
-    if constexpr (MODE == MODE_WGRAD) {
-      if (tid < BK) rows[tid] = fill_row_fwd(ks * BK + tid, Kdim);
-    }
+  // WGRAD gathers along the reduction: the row infos change every K-step.  They are derived 8 K-steps (256 rows,
+  // one per thread) at a time into the half of `rows` selected by the chunk parity, one barrier ahead of their
+  // first use, so the K-loop itself carries no divergent "first 32 threads" section.
+  auto wgrad_rows = [&](int chunk) {
+    if constexpr (MODE == MODE_WGRAD) rows[(chunk & 1) * 256 + tid] = fill_row_fwd((ks_begin + 8 * chunk) * BK + tid, Kdim);
   };
 
-  using S0 = std::integral_constant<int, 0>;
-  using S1 = std::integral_constant<int, 1>;
-
+  // prologue: stages 0..NST-1 <- steps ks_begin..+NST-1; step ks_begin -> LDS buffer 0
   if (ks_begin < ks_end) {
-    if constexpr (MODE == MODE_WGRAD) { wgrad_rows(ks_begin); __syncthreads(); }
-    load_tiles(S0{}, ks_begin);
-    if (ks_begin + 1 < ks_end) {
-      if constexpr (MODE == MODE_WGRAD) { __syncthreads(); wgrad_rows(ks_begin + 1); __syncthreads(); }
-      load_tiles(S1{}, ks_begin + 1);
-    }
-    if constexpr (MODE == MODE_WGRAD) __syncthreads();
-  }
-  auto iterate = [&](auto stage, int ks) {
-    store_tiles(stage);                  // K-step ks: registers -> LDS
-    if (ks + 2 < ks_end) wgrad_rows(ks + 2);
+    if constexpr (MODE == MODE_WGRAD) { wgrad_rows(0); __syncthreads(); }
+    static_for<0, NST>([&](auto jc) {
+      constexpr int J = decltype(jc)::value;
+      load_tiles(jc, ks_begin + J, ks_begin + J < ks_end);
+    });
+    store_tiles(std::integral_constant<int, 0>{}, 0);
     __syncthreads();
-    if (ks + 2 < ks_end) load_tiles(stage, ks + 2);   // runs two K-steps ahead of the MFMAs
-    compute();
+  }
+  // iteration ks: LDS[buf] holds step ks; stage J (its source) is free; stage J+1 holds step ks+1.
+  // The loads of the step NST ahead are dealt out between the MFMAs and the order is pinned with sched_barrier: it
+  // keeps the fragment reads of group t+1 in front of the MFMAs of group t and spreads the VMEM issue over the K-step.
+  auto iterate = [&](auto jc, int ks, int buf) {
+    constexpr int J = decltype(jc)::value;
+    using SN = std::integral_constant<int, (J + 1) % NST>;
+    const bool live = ks + NST < ks_end;
+    frag_read(buf, std::integral_constant<int, 0>{});
+    const Prep q = load_prep(ks + NST, live);
+    store_tiles(SN{}, buf ^ 1);       // overlaps the LDS latency of the first fragments and of the lookups
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, NM>([&](auto ic) {
+      constexpr int I = decltype(ic)::value;
+      mfma(ic);
+      if constexpr (I % GM == 0 && I / GM + 1 < NT) frag_read(buf, std::integral_constant<int, I / GM + 1>{});
+      static_for<0, NLD>([&](auto pc) {
+        constexpr int P = decltype(pc)::value;
+        if constexpr ((P * NM) / NLD == I) load_piece(jc, ks + NST, live, q, pc);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if constexpr (MODE == MODE_WGRAD) {
+      const int rel = ks - ks_begin + NST + 1;      // first step whose loads are issued in the NEXT iteration
+      if ((rel & 7) == 0 && ks + NST + 1 < ks_end) wgrad_rows(rel >> 3);
+    }
     __syncthreads();
   };
-  for (int ks = ks_begin; ks < ks_end; ks += 2) {
-    iterate(S0{}, ks);
-    if (ks + 1 < ks_end) iterate(S1{}, ks + 1);
+  // (stage, LDS buffer) repeat with period UNR = lcm(NST, 2); every unrolled iteration has exactly ONE predecessor
+  // besides the loop entry, so the compiler's outstanding-load bookkeeping stays exact (chained `if (ks+j < end)`
+  // do not: each skipped iteration is a second path into the next one and the merge drains vmcnt to 0)
+  if (ks_begin < ks_end) {
+    constexpr int UNR = (NST % 2 == 0) ? NST : 2 * NST;
+    int ks = ks_begin;
+    while (run_unrolled<0, UNR>([&](auto ic) {
+      constexpr int I = decltype(ic)::value;
+      iterate(std::integral_constant<int, I % NST>{}, ks, I & 1);
+      return ++ks < ks_end;
+    })) {
+    }
   }
 
+  if constexpr (NSET > 1) {
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+      for (int b = 0; b < TB; ++b) {
+        if constexpr (NSET == 4) acc[a][b] = (accs[0][a][b] + accs[1][a][b]) + (accs[2][a][b] + accs[3][a][b]);
+        else acc[a][b] = accs[0][a][b] + accs[NSET - 1][a][b];
+      }
+  }
   // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) --------------
   float* outp = p.out + (p.splits > 1 ? (long long)blockIdx.z * p.out_numel : 0ll);
 #pragma unroll
@@ -508,7 +632,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
 
 
 struct Plan {
-  int cfg;       // 0: 128x128, 1: 128x64, 2: 128x32, 3: 64x64
+  int cfg;       // 2: 128x32, 3: 64x64 (0 and 1 were the retired 128x128 / 128x64 tiles)
   int bm, bn;
   long long M, N;  // per class (class 0 = largest) GEMM extents (M padded per tap for WGRAD)
   int classes, nk, splits;
@@ -522,12 +646,10 @@ int launch_mode(const Plan& pl, const ConvArgs& a, hipStream_t st);
 template <int MODE, bool RAGGED, bool NVEC, bool BF16>
 static inline void launch_cfg(const Plan& pl, const ConvArgs& a, hipStream_t st) {
   const dim3 grid((unsigned)(acg::ceil_div(pl.M, pl.bm) * acg::ceil_div(pl.N, pl.bn)), (unsigned)pl.classes, (unsigned)pl.splits);
-  switch (pl.cfg) {
-    case 0: hipLaunchKernelGGL((conv_mfma_f32<MODE, 128, 128, 2, 2, RAGGED, NVEC, BF16>), grid, dim3(256), 0, st, a); break;
-    case 1: hipLaunchKernelGGL((conv_mfma_f32<MODE, 128, 64, 2, 2, RAGGED, NVEC, BF16>), grid, dim3(256), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((conv_mfma_f32<MODE, 128, 32, 4, 1, RAGGED, NVEC, BF16>), grid, dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((conv_mfma_f32<MODE, 64, 64, 2, 2, RAGGED, NVEC, BF16>), grid, dim3(256), 0, st, a); break;
-  }
+  // two tile shapes: 128x32 for narrow N, 64x64 otherwise.  128x128 / 128x64 variants existed through v4; with the
+  // one-barrier pipeline they lost every layer of the tuning sweep (profiles/r1) and were dropped.
+  if (pl.cfg == 2) hipLaunchKernelGGL((conv_mfma_f32<MODE, 128, 32, 4, 1, RAGGED, NVEC, BF16>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_mfma_f32<MODE, 64, 64, 2, 2, RAGGED, NVEC, BF16>), grid, dim3(256), 0, st, a);
 }
 template <int MODE, bool BF16>
 static inline void launch_variant(const Plan& pl, const ConvArgs& a, hipStream_t st) {

@@ -194,10 +194,8 @@ def main():
                         'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': None, 'kernel': 'dna_kernel<K,TY,fwd>',
                         'algorithmic_mb_per_step': round(dna_bytes / 1e6, 2), 'ms_per_step_in_kernel': round(dna_ms, 4)}
 
-    if world > 1 or args.force_dp:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
     if rank != 0:
+        _leave_distributed()
         return
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
@@ -215,7 +213,22 @@ def main():
         'roofline': roof, 'roofline_dna': roof_dna, 'cpu_baseline': cpu,
         'op_ms_per_step': {k: round(v, 4) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])},
     }
-    print(json.dumps(line))
+    print(json.dumps(line), flush=True)
+    if world > 1 or args.force_dp:
+        _leave_distributed()
+
+
+def _leave_distributed():
+    """All ranks meet once more, then leave WITHOUT communicator teardown: the result line is already out, and an RCCL
+    destroy that aborts (seen once on the GPU box inside a long-lived process) must not turn a finished run into a
+    failed one."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        torch.cuda.synchronize()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == '__main__':

@@ -1,0 +1,47 @@
+"""Child process of test_gpu_train.py::test_data_parallel_machinery_on_one_rank (needs a GPU)."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from action_conditioned_gans_amd import graph as G, optim, train as T   # noqa: E402
+from oracle import models as OM   # noqa: E402
+import train_cases as TC   # noqa: E402
+
+
+def main():
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    x, y, a, s = TC.MG.inputs(2)
+    finals = []
+    for force in (False, True):
+        adv, loss, opt, dna, batch, ksize = TC.MG.CASES['c4_dna_wass_rmsprop']
+        G.reset_default_graph()
+        optim.set_data_parallel(1, force=force)
+        sess = G.Session(device='cuda:0')
+        tr = T.Trainer(sess, True, 'bce', 'rmsprop', dna, batch_size=batch, ksize=ksize)
+        sess.run(G.global_variables_initializer())
+        params = OM.init_params(dna, batch=batch, ksize=ksize, seed=TC.MG.PARAM_SEED, dtype=torch.float32)
+        for n, v in G.get_default_graph().variables.items():
+            sess.set_value(v, params[n])
+        for _ in range(4):                  # eager, capture, replay, replay
+            tr.train_d(x, y, a)
+            tr.train_g(x, y, a, s)
+        torch.cuda.synchronize()
+        finals.append({n: sess.get_value(v) for n, v in G.get_default_graph().variables.items()})
+        if force:
+            kinds = [type(o).__name__ for o in G.get_default_graph().ops]
+            assert kinds.count('AllReduceOp') >= 4, kinds.count('AllReduceOp')
+            progs = [p for p in sess._programs.values() if any(k == 'host' for k, _ in p.segments)]
+            assert progs and all(any(g is not None for g in p.graphs) for p in progs if p.runs >= 2)
+    for n in finals[0]:
+        assert torch.equal(finals[0][n], finals[1][n]), n
+    print('DP_ONE_RANK_OK', flush=True)
+    os._exit(0)     # leave without communicator teardown
+
+
+if __name__ == '__main__':
+    main()

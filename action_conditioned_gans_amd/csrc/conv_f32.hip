@@ -102,10 +102,9 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
   pl.nk = (int)((K + BK - 1) / BK);
   if (pl.nk < 1) pl.nk = 1;
   auto tiles_for = [&](int bm, int bn) { return acg::ceil_div(pl.M, bm) * acg::ceil_div(pl.N, bn) * pl.classes; };
-  // Planner (evidence: profiles/r1 tuning sweeps, tools/fit_planner.py).  A wave's loader instructions do not overlap
-  // its own MFMAs on this part (tools/micro/mfma_overlap.hip), so the matrix pipe is kept busy by OTHER resident
-  // blocks: split K until ~1 block per CU for FWD/DGRAD and ~2 per CU for WGRAD (whose K = B*OH*OW is long and whose
-  // loaders are heavier), but keep >= 4 K-steps per block so the slab reduction does not take over.
+  // Planner (evidence: profiles/r1 tuning sweeps, tools/fit_planner.py).  Split K until ~1 block per CU for
+  // FWD/DGRAD and ~2 per CU for WGRAD (long K = B*OH*OW, heavier loaders: a second resident block hides its
+  // latencies), but keep >= 4 K-steps per block so the slab reduction does not take over.
   pl.cfg = pl.N <= 32 ? 2 : 3;
   if (g_force_cfg >= 0 && g_force_cfg < 4) pl.cfg = g_force_cfg <= 2 ? 2 : 3;
   pl.bm = pl.cfg == 2 ? 128 : 64; pl.bn = pl.cfg == 2 ? 32 : 64;

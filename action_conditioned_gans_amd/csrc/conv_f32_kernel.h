@@ -130,11 +130,12 @@ __device__ __forceinline__ float guarded_scalar(__amdgpu_buffer_rsrc_t rs, int e
 // register stage of step ks+1 into the other LDS buffer, (2) runs the MFMAs of step ks out of the current buffer and
 // (3) issues the global loads of step ks+NST into the stage that was drained one iteration earlier.
 // What the measurements behind this shape say (tools/conv_kloop.py, tools/micro/*.hip, profiles/r1):
-//  * a wave's VALU / LDS / VMEM instructions do NOT overlap its own MFMAs on this part - slot time is the SUM of the
-//    MFMA passes and everything issued between two MFMAs - so only OTHER waves of the SIMD can keep the matrix pipe
-//    busy during the loaders.  Hence: small blocks (several resident per CU, planner in conv_f32.hip) and a loader
-//    that costs as few issue cycles as possible (running offsets instead of divisions and multiplies, 32-bit mask
-//    tests, LDS lookups fetched once per iteration, row infos in registers);
+//  * v_mfma_f32_32x32x2_f32 runs on the SIMD's fp32 vector ALUs (MI355X quotes the same 157.3 TFLOP/s for fp32
+//    vector and fp32 matrix): VALU instructions of ANY wave on the SIMD do not overlap it - SIMD time per K-step is
+//    the SUM of the MFMA passes and every VALU instruction issued, whatever the occupancy; LDS instructions overlap
+//    only partly (tools/micro/mfma_overlap.hip with 1, 2 and 4 waves per SIMD).  More resident blocks hide latency,
+//    not issue cycles.  Hence a loader that costs as few VALU instructions as possible: running offsets instead of
+//    divisions and multiplies, 32-bit mask tests, LDS lookups fetched once per iteration, row infos in registers;
 //  * the loop body must be ONE basic block with a single predecessor per unrolled copy, every load predicated by an
 //    out-of-range offset instead of a branch: only then does hipcc count outstanding loads exactly (vmcnt(N), N > 0)
 //    and the loads really run NST-1 K-steps ahead;

@@ -45,6 +45,7 @@ def main():
     ap.add_argument('--dtype', type=int, default=0)
     ap.add_argument('--cfg', type=int, default=3)
     ap.add_argument('--modes', default='fwd,dgrad,wgrad')
+    ap.add_argument('--data', default='randn', help='randn | zeros | ones | small (randn * 1e-3): operand values (the MFMA rate turned out to depend on them)')
     args = ap.parse_args()
     lib = _lib.get()
     dev = torch.device('cuda:0')
@@ -59,6 +60,14 @@ def main():
                 lib.conv_desc_init(ctypes.byref(d), batch, hw, hw, cin, 5, 5, cout, 2, 1)
                 nx, ny, nw = batch * hw * hw * cin, batch * d.out_h * d.out_w * cout, 25 * cin * cout
                 x, y, w = (torch.randn(n, device=dev) for n in (nx, ny, nw))
+                if args.data != 'randn':
+                    for t_ in (x, y, w):
+                        if args.data == 'zeros':
+                            t_.zero_()
+                        elif args.data == 'ones':
+                            t_.fill_(1.0)
+                        else:
+                            t_.mul_(1e-3)
                 lib.debug_conv_plan(args.cfg, 1)
                 stream_of = lambda: ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)   # noqa: E731
                 px, py, pw = (ctypes.c_void_p(t.data_ptr()) for t in (x, y, w))

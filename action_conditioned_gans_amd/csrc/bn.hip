@@ -112,12 +112,18 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
     for (int j = 0; j < V; ++j) { s1[j] = 0.f; s2[j] = 0.f; pv[j] = 0.f; }
     if (m.active && cv < m.Cv) {
       ldv<V>(xg + c, pv);   // shift by the group's first row: E[d^2]-E[d]^2 cannot cancel catastrophically
-#pragma unroll 4
-      for (long long r = r0 + m.rsub; r < r1; r += m.RPP) {
-        float v[V];
-        ldv<V>(xg + r * C + c, v);
+      // batches of 4 row passes, all loads of a batch issued before the first use (rows beyond r1 re-read
+      // the last valid row with weight 0), so a block's few passes cost ~one memory round trip
+      for (long long r = r0 + m.rsub; r < r1; r += 4 * m.RPP) {
+        float v[4][V];
 #pragma unroll
-        for (int j = 0; j < V; ++j) { const float d = v[j] - pv[j]; s1[j] += d; s2[j] += d * d; }
+        for (int u = 0; u < 4; ++u) ldv<V>(xg + min(r + u * m.RPP, r1 - 1) * C + c, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float w = r + u * m.RPP < r1 ? 1.f : 0.f;
+#pragma unroll
+          for (int j = 0; j < V; ++j) { const float d = (v[u][j] - pv[j]) * w; s1[j] += d; s2[j] += d * d; }
+        }
       }
     }
     reduce_rsub_v<V>(m, s1, s2, sh);
@@ -224,15 +230,22 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
     if (m.active && cv < m.Cv) {
       float mean[V], rstd[V], bt[V];
       ldv<V>(save_mean + g * C + c, mean); ldv<V>(save_rstd + g * C + c, rstd); ldv<V>(beta + c, bt);
-#pragma unroll 4
-      for (long long r = r0 + m.rsub; r < r1; r += m.RPP) {
-        float xv[V], dv[V];
-        ldv<V>(xg + r * C + c, xv); ldv<V>(dyg + r * C + c, dv);
+      for (long long r = r0 + m.rsub; r < r1; r += 4 * m.RPP) {   // batched like bn_stats_partial
+        float xv[4][V], dv[4][V];
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-          const float xh = (xv[j] - mean[j]) * rstd[j];
-          const float dp = dv[j] * acg::act_deriv_pre(act, xh + bt[j], leak);
-          s1[j] += dp; s2[j] += dp * xh;
+        for (int u = 0; u < 4; ++u) {
+          const long long rr = min(r + u * m.RPP, r1 - 1);
+          ldv<V>(xg + rr * C + c, xv[u]); ldv<V>(dyg + rr * C + c, dv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float w = r + u * m.RPP < r1 ? 1.f : 0.f;
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            const float xh = (xv[u][j] - mean[j]) * rstd[j];
+            const float dp = w * dv[u][j] * acg::act_deriv_pre(act, xh + bt[j], leak);
+            s1[j] += dp; s2[j] += dp * xh;
+          }
         }
       }
     }
@@ -368,9 +381,12 @@ int apply_blocks(long long R, int C) {
   return (int)n;
 }
 // vectorised variants: columns are C/V wide
-int vpartial_blocks(long long R, int C, int V) {
+// Rows per partial block: the partial kernels are latency-bound on small tensors (a thread's iterations are serial
+// round trips to L2/HBM), so a block takes only `iters` row passes - all of them in flight at once - until the block
+// count reaches kMaxPartialBlocks (profiles/r1: bn_bwd_partial took ~12.5 us at ANY size with 16 passes per block).
+int vpartial_blocks(long long R, int C, int V, int iters = 16) {
   const int Cv = C / V, Cb = Cv < 256 ? Cv : 256, RPP = 256 / Cb;
-  long long n = acg::ceil_div(R, (long long)RPP * 16);
+  long long n = acg::ceil_div(R, (long long)RPP * iters);
   if (n < 1) n = 1;
   if (n > kMaxPartialBlocks) n = kMaxPartialBlocks;
   return (int)n;
@@ -429,7 +445,7 @@ int32_t acg_bn_act_fwd(const void* x, const float* beta, void* y, float* save_me
   float* part = (float*)ws;
   const bool v4 = vec4_ok(C, x, y, beta) && vec4_ok(C, save_mean, save_rstd, ws);
   const int V = v4 ? 4 : 1;
-  const int nblk = vpartial_blocks(R, C, V);
+  const int nblk = vpartial_blocks(R, C, V, 8);
   if (v4) hipLaunchKernelGGL(bn_stats_partial<4>, dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk);
   else hipLaunchKernelGGL(bn_stats_partial<1>, dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk);
   if (int rc = acg::check_launch("bn_stats_partial")) return rc;
@@ -454,7 +470,7 @@ int32_t acg_bn_act_bwd(const void* x, const void* dy, const float* beta, const f
   float* part = (float*)ws;
   const bool v4 = vec4_ok(C, x, dy, dx) && vec4_ok(C, save_mean, save_rstd, ws) && vec4_ok(C, beta, dbeta, ws);
   const int V = v4 ? 4 : 1;
-  const int nblk = vpartial_blocks(R, C, V);
+  const int nblk = vpartial_blocks(R, C, V, 4);
   if (v4) hipLaunchKernelGGL(bn_bwd_partial<4>, dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak);
   else hipLaunchKernelGGL(bn_bwd_partial<1>, dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak);
   if (int rc = acg::check_launch("bn_bwd_partial")) return rc;

@@ -39,13 +39,15 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ s
   const long long n4 = al ? numel / 4 : 0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     f4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < splits; ++z) s += reinterpret_cast<const f4*>(slabs + (long long)z * numel)[i];
+#pragma unroll 8
+    for (int z = 0; z < splits; ++z) s += reinterpret_cast<const f4*>(slabs + (long long)z * numel)[i];   // 8 loads in flight, summed in z order
     f4* o = reinterpret_cast<f4*>(out) + i;
     if (accumulate != 0.f) s += accumulate * *o;
     *o = s;
   }
   for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride) {
     float s = 0.f;
+#pragma unroll 8
     for (int z = 0; z < splits; ++z) s += slabs[(long long)z * numel + i];
     out[i] = (accumulate != 0.f ? accumulate * out[i] : 0.f) + s;
   }
@@ -150,7 +152,7 @@ int run(int which, const float* gsrc, const float* dense, float* out, float accu
   else rc = launch_mode<MODE_WGRAD>(pl, a, st);
   if (rc) return rc;
   if (pl.splits > 1) {
-    const int blocks = (int)std::min<long long>(acg::ceil_div(pl.out_numel, 1024), 2048);
+    const int blocks = (int)std::min<long long>(acg::ceil_div(pl.out_numel, 256 * 4), 2048);
     hipLaunchKernelGGL(splitk_reduce, dim3(std::max(blocks, 1)), dim3(256), 0, st, (const float*)ws, out, pl.out_numel, pl.splits,
                        which == ACG_CONV_WGRAD ? accumulate : 0.f);
     return acg::check_launch("splitk_reduce");

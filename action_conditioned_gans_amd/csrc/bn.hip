@@ -346,10 +346,23 @@ __global__ __launch_bounds__(256) void bias_act_bwd_partial(const float* __restr
     const int c = ch * m.Cb + m.cl;
     float s1 = 0.f, s2 = 0.f;
     if (m.active && c < C) {
-      for (long long r = r0 + m.rsub; r < r1; r += m.RPP) {
-        const float gq = dy[r * C + c] * acg::act_deriv_out(act, y[r * C + c], leak);
-        if (dx) dx[r * C + c] = gq;
-        s1 += gq;
+      // batches of 4 row passes with all loads in flight; y is not read at all for the identity activation
+      for (long long r = r0 + m.rsub; r < r1; r += 4 * m.RPP) {
+        float g[4], yv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long long rr = min(r + u * m.RPP, r1 - 1);
+          g[u] = dy[rr * C + c];
+          yv[u] = act != ACG_ACT_NONE ? y[rr * C + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (r + u * m.RPP < r1) {
+            const float gq = g[u] * acg::act_deriv_out(act, yv[u], leak);
+            if (dx) dx[(r + u * m.RPP) * C + c] = gq;
+            s1 += gq;
+          }
+        }
       }
     }
     reduce_rsub(m, s1, s2, sh);
@@ -357,11 +370,21 @@ __global__ __launch_bounds__(256) void bias_act_bwd_partial(const float* __restr
   }
 }
 
+// out[c] = out_acc * out[c] + sum_b part[b][c]; a block owns 32 channels, 8 row lanes per channel walk the partials
 __global__ __launch_bounds__(256) void colsum_finalize(const float* __restrict__ part, float* __restrict__ out,
                                                        float out_acc, int C, int nblk) {
-  for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += part[(long long)b * C + c];
+  __shared__ double sh[256];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+  double s = 0.0;
+  if (c < C) {
+#pragma unroll 4
+    for (int b = rl; b < nblk; b += 8) s += part[(long long)b * C + c];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+#pragma unroll
+    for (int r = 1; r < 8; ++r) s += sh[r * 32 + cl];
     out[c] = (out_acc != 0.f ? out_acc * out[c] : 0.f) + (float)s;
   }
 }
@@ -510,7 +533,7 @@ int32_t acg_bias_act_bwd(const void* y, const void* dy, void* dx, float* dbias, 
                      dbias ? (float*)ws : (float*)nullptr, (long long)rows, C, nblk, act, leak);
   if (int rc = acg::check_launch("bias_act_bwd_partial")) return rc;
   if (!dbias) return ACG_OK;
-  hipLaunchKernelGGL(colsum_finalize, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)ws, dbias, dbias_acc, C, nblk);
+  hipLaunchKernelGGL(colsum_finalize, dim3((C + 31) / 32), dim3(256), 0, st, (const float*)ws, dbias, dbias_acc, C, nblk);
   return acg::check_launch("colsum_finalize");
 }
 

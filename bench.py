@@ -158,6 +158,24 @@ def main():
         elapsed = float(t.item())
     assert torch.isfinite(frames).all(), 'generated frames are not finite'
 
+    # ---- eval rollout: Trainer.test_sequence, T-1 recursive G-only steps through the
+    # reference's numpy-in / numpy-out API (train.py:157-176), after the timed region ---------------------------
+    rollout = None
+    if rank == 0 and dna:
+        r_img = rng.uniform(-1, 1, (B, args.seq_len, S, S, 3)).astype(np.float32)
+        r_act = rng.standard_normal((B, args.seq_len, 10)).astype(np.float32)
+        for _ in range(3):
+            tr.test_sequence(r_img, r_img, r_act)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            pred, _ = tr.test_sequence(r_img, r_img, r_act)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / reps
+        rollout = {'frames_per_s': round(B * (args.seq_len - 1) / dt, 1), 'ms_per_rollout': round(dt * 1e3, 3),
+                   'steps': args.seq_len - 1, 'batch': B, 'api': 'numpy in / numpy out per step, as the reference'}
+
     # ---- per-kernel event timing (instrumented eager pass, after the timed region) --------------
     roof, roof_dna, kernel_ms = None, None, {}
     if rank == 0:
@@ -210,7 +228,7 @@ def main():
                                   args.ksize, args.opt, 'fp32' if args.dtype == 'f32' else 'bf16-MFMA/fp32-accumulate'),
                    'global_batch': B * world, 'n_critic': n_critic, 'parallelism': 'dp%d' % world,
                    'hip_graphs': not args.no_graphs, 'sequences_per_s': round(world * B * args.steps / elapsed, 1)},
-        'roofline': roof, 'roofline_dna': roof_dna, 'cpu_baseline': cpu,
+        'roofline': roof, 'roofline_dna': roof_dna, 'cpu_baseline': cpu, 'eval_rollout': rollout,
         'op_ms_per_step': {k: round(v, 4) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])},
     }
     print(json.dumps(line), flush=True)

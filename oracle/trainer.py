@@ -146,3 +146,19 @@ class OracleTrainer:
         with torch.no_grad():
             frame, st = self._g(self.p, img, actions)
             return frame, st, T.psnr(next_frame, frame)
+
+    def test_sequence(self, frames, next_frames, actions, steps=None):
+        """Recursive rollout (reference train.py:157-176 / the eval block at :285-298): the predicted frame and the
+        predicted state are fed back in; the commanded action of step j comes from the data.
+        frames, next_frames: [B,T,H,W,3]; actions: [B,T,10] (action 0:5, state 5:10).  Returns [B,steps,H,W,3], PSNRs."""
+        steps = steps if steps is not None else next_frames.shape[1] - 1
+        cur, state = frames[:, 0], actions[:, 0, 5:]
+        out, psnrs = [], []
+        for j in range(steps):
+            acs = torch.cat([actions[:, j, :5], state], dim=1)
+            frame, st, ps = self.test(cur, next_frames[:, j + 1], acs)
+            out.append(frame)
+            psnrs.append(float(ps))
+            cur = frame
+            state = st if st is not None else actions[:, j + 1, 5:]
+        return torch.stack(out, dim=1), psnrs

@@ -107,6 +107,30 @@ def test_config5_shapes_128x128_k11_match_oracle():
         assert (got - want).abs().max().item() <= 1e-3 * max(want.abs().max().item(), 1e-3) + 2e-6, n
 
 
+@pytest.mark.parametrize('name', ['c2_dna_bce_adam', 'plain_adv_bce_rmsprop'])
+def test_rollout_matches_oracle(name):
+    """the recursive multi-step rollout (Trainer.test_sequence, train.py:157-176 and the eval
+    block at :285-298) - prediction and predicted state fed back for T-1 steps - against the fp64 oracle's rollout.
+    Errors compound through the recursion, so the bar is the north_star 1e-3 on the LAST frame as well."""
+    from oracle.trainer import OracleTrainer
+    from oracle import models as OM
+    adv, loss, opt, dna, batch, ksize = TC.MG.CASES[name]
+    sess, tr = TC.build_trainer(gpu_session, name)
+    rng = np.random.default_rng(5)
+    T_ = 5
+    frames = rng.uniform(-1, 1, (batch, T_, 64, 64, 3)).astype(np.float32)
+    acts = rng.standard_normal((batch, T_, 10)).astype(np.float32)
+    pred, summ = tr.test_sequence(frames, frames, acts)
+    params = OM.init_params(dna, batch=batch, ksize=ksize, seed=TC.MG.PARAM_SEED, dtype=torch.float32)
+    ot = OracleTrainer({k: v.double() for k, v in params.items()}, adv, loss, opt, dna, ksize)
+    want, psnrs = ot.test_sequence(torch.from_numpy(frames).double(), torch.from_numpy(frames).double(),
+                                   torch.from_numpy(acts).double())
+    assert pred.shape == (batch, T_ - 1, 64, 64, 3)
+    for j in range(T_ - 1):
+        assert TC.rel(pred[:, j], want[:, j].numpy()) <= 1e-3, j
+    assert abs(summ['g_psnr'] - psnrs[0]) <= 1e-3 * abs(psnrs[0])
+
+
 def test_training_loop_runs_wass_rmsprop_n_critic():
     """train() end to end on synthetic sequences: pretrain iterations, then n_critic=5 D steps per G step
     (train.py:217-263) with weight clip; weights stay finite and inside the clip range."""

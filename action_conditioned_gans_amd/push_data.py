@@ -1,0 +1,339 @@
+"""The on-disk format on the input side of the hot path: the BAIR/Google "push" TFRecords, read without TensorFlow.
+
+Restates ``build_tfrecord_input`` (reference ops.py:140-223): every record is a ``tf.train.Example`` holding, for the
+frames 6, 8, ..., 18 of a push (7 frames), a 512x640 JPEG (``move/<i>/image/encoded``), the commanded pose
+(``move/<i>/commanded_pose/vec_pitch_yaw``, 5 floats) and the end-effector pose
+(``move/<i>/endeffector/vec_pitch_yaw``, 5 floats).  A frame is decoded, centre-cropped to 512x512
+(``resize_image_with_crop_or_pad``), area-resized to 64x64 (``tf.image.resize_area``; exactly the mean of 8x8 boxes at
+this ratio), and mapped to [-1, 1] by ``x / 127.5 - 1``.  A batch is ``images [B, 7, 64, 64, 3]`` and
+``action_state [B, 7, 10]`` (action 0:5, state 5:10), the two arrays ``get_batch`` (ops.py:15-17) hands the Trainer.
+
+Pieces (all host code; numpy + PIL for the JPEG):
+  * TFRecord framing: ``uint64 length | uint32 masked_crc32c(length) | data | uint32 masked_crc32c(data)``;
+  * a minimal protobuf reader / writer for ``Example { Features { map<string, Feature> } }`` with ``BytesList`` (1),
+    ``FloatList`` (2, packed or not) and ``Int64List`` (3);
+  * ``resize_area`` for arbitrary ratios (box filter with fractional overlaps, as TF defines it);
+  * ``PushDataset`` - file split by ``train_val_split`` as the reference does, shuffled record stream, batches;
+  * ``write_push_tfrecord`` - the inverse, used by the tests and for making small synthetic shards.
+"""
+import glob
+import io
+import os
+import struct
+
+import numpy as np
+
+ORIGINAL_WIDTH, ORIGINAL_HEIGHT, COLOR_CHAN = 640, 512, 3      # ops.py:129-131
+IMG_WIDTH = IMG_HEIGHT = 64                                    # ops.py:134-135
+STATE_DIM = 5                                                  # ops.py:138
+FRAME_IDS = tuple(range(6, 20, 2))                             # ops.py:171
+
+
+# ---- CRC32C (Castagnoli), masked as TFRecord does -------------------------------------------------------------
+def _crc_table():
+    poly, table = 0x82F63B78, []
+    for n in range(256):
+        c = n
+        for _ in range(8):
+            c = (c >> 1) ^ poly if c & 1 else c >> 1
+        table.append(c)
+    return table
+
+
+_TABLE = _crc_table()
+
+
+def crc32c(data):
+    c = 0xFFFFFFFF
+    for b in data:
+        c = _TABLE[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def masked_crc32c(data):
+    c = crc32c(data)
+    return ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+# ---- TFRecord framing -----------------------------------------------------------------------------------------
+def read_records(path, verify_crc=False):
+    """Yield the payload of every record of a TFRecord file.  ``verify_crc`` checks both checksums (pure Python: slow
+    on multi-megabyte records, meant for tests and for diagnosing a damaged shard)."""
+    with open(path, 'rb') as f:
+        while True:
+            head = f.read(12)
+            if not head:
+                return
+            if len(head) < 12:
+                raise IOError('%s: truncated record header' % path)
+            (length,), (lcrc,) = struct.unpack('<Q', head[:8]), struct.unpack('<I', head[8:])
+            if verify_crc and masked_crc32c(head[:8]) != lcrc:
+                raise IOError('%s: corrupted record length' % path)
+            data = f.read(length)
+            tail = f.read(4)
+            if len(data) < length or len(tail) < 4:
+                raise IOError('%s: truncated record' % path)
+            if verify_crc and masked_crc32c(data) != struct.unpack('<I', tail)[0]:
+                raise IOError('%s: corrupted record data' % path)
+            yield data
+
+
+def write_records(path, payloads):
+    with open(path, 'wb') as f:
+        for data in payloads:
+            head = struct.pack('<Q', len(data))
+            f.write(head + struct.pack('<I', masked_crc32c(head)) + data + struct.pack('<I', masked_crc32c(data)))
+
+
+# ---- protobuf (only what tf.train.Example needs) ----------------------------------------------------------------
+def _varint(buf, pos):
+    shift = value = 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        value |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return value, pos
+        shift += 7
+        if shift > 63:
+            raise ValueError('malformed varint')
+
+
+def _fields(buf):
+    """Yield (field number, wire type, value) of one message; length-delimited values as memoryviews."""
+    buf = memoryview(buf)
+    pos, end = 0, len(buf)
+    while pos < end:
+        key, pos = _varint(buf, pos)
+        num, wt = key >> 3, key & 7
+        if wt == 0:
+            val, pos = _varint(buf, pos)
+        elif wt == 1:
+            val, pos = bytes(buf[pos:pos + 8]), pos + 8
+        elif wt == 2:
+            n, pos = _varint(buf, pos)
+            val, pos = buf[pos:pos + n], pos + n
+        elif wt == 5:
+            val, pos = bytes(buf[pos:pos + 4]), pos + 4
+        else:
+            raise ValueError('unsupported protobuf wire type %d' % wt)
+        if pos > end:
+            raise ValueError('truncated protobuf message')
+        yield num, wt, val
+
+
+def _parse_feature(buf):
+    for num, wt, val in _fields(buf):
+        if num == 1:                                   # BytesList { repeated bytes value = 1 }
+            return [bytes(v) for n, w, v in _fields(val) if n == 1]
+        if num == 2:                                   # FloatList { repeated float value = 1 [packed] }
+            out = []
+            for n, w, v in _fields(val):
+                if n == 1:
+                    out.append(np.frombuffer(bytes(v), '<f4') if w == 2 else np.frombuffer(v, '<f4'))
+            return np.concatenate(out) if out else np.zeros(0, np.float32)
+        if num == 3:                                   # Int64List { repeated int64 value = 1 [packed] }
+            out = []
+            for n, w, v in _fields(val):
+                if n != 1:
+                    continue
+                if w == 2:
+                    p, v = 0, bytes(v)
+                    while p < len(v):
+                        x, p = _varint(v, p)
+                        out.append(x - (1 << 64) if x >> 63 else x)
+                else:
+                    out.append(v - (1 << 64) if v >> 63 else v)
+            return np.array(out, np.int64)
+    return None
+
+
+def parse_example(buf, keys=None):
+    """tf.train.Example bytes -> {feature name: list of bytes | float32 array | int64 array}; ``keys`` limits the
+    features that are decoded (the push records carry 30 frames and more, the reference reads 7)."""
+    out = {}
+    for num, wt, features in _fields(buf):
+        if num != 1:
+            continue
+        for fnum, fwt, entry in _fields(features):     # map<string, Feature> feature = 1
+            if fnum != 1:
+                continue
+            name = value = None
+            for enum_, ewt, ev in _fields(entry):
+                if enum_ == 1:
+                    name = bytes(ev).decode('utf-8')
+                elif enum_ == 2:
+                    value = ev
+            if name is not None and value is not None and (keys is None or name in keys):
+                out[name] = _parse_feature(value)
+    return out
+
+
+def _enc_varint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _ld(num, payload):
+    return _enc_varint((num << 3) | 2) + _enc_varint(len(payload)) + payload
+
+
+def serialize_example(features):
+    """{name: bytes | sequence of floats} -> tf.train.Example bytes (floats packed, as TensorFlow writes them)."""
+    entries = b''
+    for name in sorted(features):
+        v = features[name]
+        if isinstance(v, (bytes, bytearray)):
+            feat = _ld(1, _ld(1, bytes(v)))
+        else:
+            feat = _ld(2, _ld(1, np.asarray(v, '<f4').tobytes()))
+        entries += _ld(1, _ld(1, name.encode('utf-8')) + _ld(2, feat))
+    return _ld(1, entries)
+
+
+# ---- image ops ----------------------------------------------------------------------------------------------------
+def crop_or_pad_center(img, th, tw):
+    """tf.image.resize_image_with_crop_or_pad: centred crop and / or zero pad to th x tw."""
+    h, w = img.shape[:2]
+    if h > th:
+        o = (h - th) // 2
+        img = img[o:o + th]
+    if w > tw:
+        o = (w - tw) // 2
+        img = img[:, o:o + tw]
+    h, w = img.shape[:2]
+    if h < th or w < tw:
+        out = np.zeros((th, tw) + img.shape[2:], img.dtype)
+        oh, ow = (th - h) // 2, (tw - w) // 2
+        out[oh:oh + h, ow:ow + w] = img
+        img = out
+    return img
+
+
+def _area_weights(n_in, n_out):
+    """[n_out, n_in] box-filter weights of tf.image.resize_area along one axis (rows sum to 1)."""
+    scale = n_in / float(n_out)
+    w = np.zeros((n_out, n_in), np.float64)
+    for o in range(n_out):
+        lo, hi = o * scale, (o + 1) * scale
+        for i in range(int(np.floor(lo)), min(int(np.ceil(hi)), n_in)):
+            w[o, i] = max(0.0, min(hi, i + 1) - max(lo, i))
+        w[o] /= scale
+    return w
+
+
+def resize_area(img, oh, ow):
+    """tf.image.resize_area of an HxWxC image to oh x ow, float32."""
+    h, w = img.shape[:2]
+    x = img.astype(np.float32)
+    if h % oh == 0 and w % ow == 0:                    # integer ratio: plain box means (the push pipeline: 512 -> 64)
+        return x.reshape(oh, h // oh, ow, w // ow, -1).mean(axis=(1, 3), dtype=np.float32)
+    wh, ww = _area_weights(h, oh).astype(np.float32), _area_weights(w, ow).astype(np.float32)
+    return np.einsum('oh,hwc,pw->opc', wh, x, ww)
+
+
+def decode_frame(jpeg_bytes, img_size=IMG_HEIGHT):
+    """ops.py:184-196: decode (3 channels), centre-crop to the short side, area-resize, scale to [-1, 1]."""
+    from PIL import Image
+    img = np.asarray(Image.open(io.BytesIO(jpeg_bytes)).convert('RGB'))
+    crop = min(img.shape[0], img.shape[1])
+    img = crop_or_pad_center(img, crop, crop)
+    return resize_area(img, img_size, img_size) / np.float32(255.0 / 2.0) - np.float32(1.0)
+
+
+def decode_example(buf, use_state=True, img_size=IMG_HEIGHT):
+    """One record -> (images [7, S, S, 3], action [7, 5], state [7, 5]) (zeros for the vectors without use_state)."""
+    keys = set()
+    for i in FRAME_IDS:
+        keys.add('move/%d/image/encoded' % i)
+        if use_state:
+            keys.add('move/%d/commanded_pose/vec_pitch_yaw' % i)
+            keys.add('move/%d/endeffector/vec_pitch_yaw' % i)
+    feats = parse_example(buf, keys)
+    missing = sorted(keys - set(feats))
+    if missing:
+        raise KeyError('record lacks features %s' % missing[:3])
+    imgs, acts, states = [], [], []
+    for i in FRAME_IDS:
+        enc = feats['move/%d/image/encoded' % i]
+        if len(enc) != 1:
+            raise ValueError('move/%d/image/encoded: expected one JPEG, got %d' % (i, len(enc)))
+        imgs.append(decode_frame(enc[0], img_size))
+        if use_state:
+            a, s = feats['move/%d/commanded_pose/vec_pitch_yaw' % i], feats['move/%d/endeffector/vec_pitch_yaw' % i]
+            if a.shape != (STATE_DIM,) or s.shape != (STATE_DIM,):
+                raise ValueError('move/%d: pose vectors must have %d floats' % (i, STATE_DIM))
+            acts.append(a)
+            states.append(s)
+    n = len(FRAME_IDS)
+    acts = np.stack(acts).astype(np.float32) if use_state else np.zeros((n, STATE_DIM), np.float32)
+    states = np.stack(states).astype(np.float32) if use_state else np.zeros((n, STATE_DIM), np.float32)
+    return np.stack(imgs).astype(np.float32), acts, states
+
+
+class PushDataset:
+    """``build_tfrecord_input`` + ``get_batch`` (ops.py:140-223, 15-17) as an iterator of numpy batches.
+
+    Files are split by ``train_val_split`` exactly as the reference does (first ``floor(split * n)`` files train, the
+    rest validation; sorted here so the split is reproducible); records are streamed file by file in a shuffled file
+    order (``string_input_producer(shuffle=True)``), forever.  ``rank`` / ``world_size`` give every data-parallel
+    process its own interleaved share of the record stream.
+    """
+
+    def __init__(self, data_dir, batch_size, train_val_split=0.95, use_state=True, training=True, img_size=IMG_HEIGHT,
+                 seed=7, rank=0, world_size=1, verify_crc=False):
+        files = sorted(glob.glob(os.path.join(data_dir, '*')))
+        if not files:
+            raise RuntimeError('No data files found.')                          # ops.py:159
+        index = int(np.floor(train_val_split * len(files)))
+        self.files = files[:index] if training else files[index:]
+        if not self.files:
+            raise RuntimeError('No data files found for the %s split.' % ('training' if training else 'validation'))
+        self.batch_size, self.use_state, self.img_size = batch_size, use_state, img_size
+        self.rng = np.random.default_rng(seed)
+        self.rank, self.world_size, self.verify_crc = rank, world_size, verify_crc
+        self.seq_len = len(FRAME_IDS)
+        self._stream = self._records()
+
+    def _records(self):
+        n = 0
+        while True:
+            seen = False
+            for k in self.rng.permutation(len(self.files)):
+                for rec in read_records(self.files[k], self.verify_crc):
+                    seen = True
+                    if n % self.world_size == self.rank:
+                        yield rec
+                    n += 1
+            if not seen:
+                raise RuntimeError('the data files hold no records')
+
+    def get_batch(self):
+        """-> (frames, frames, action||state [B,T,10], state [B,T,5]), the tuple the training loop consumes."""
+        imgs, acts, states = zip(*(decode_example(next(self._stream), self.use_state, self.img_size)
+                                   for _ in range(self.batch_size)))
+        img = np.stack(imgs)
+        action_state = np.concatenate([np.stack(acts), np.stack(states)], axis=2)
+        return img, img, action_state, action_state[:, :, STATE_DIM:].copy()
+
+
+def write_push_tfrecord(path, sequences, quality=95):
+    """Write records in the push format.  ``sequences``: iterable of (frames uint8 [7, H, W, 3], action [7, 5],
+    state [7, 5]).  Used by the tests and to make small synthetic shards."""
+    from PIL import Image
+    payloads = []
+    for frames, action, state in sequences:
+        feats = {}
+        for j, i in enumerate(FRAME_IDS):
+            b = io.BytesIO()
+            Image.fromarray(np.asarray(frames[j], np.uint8)).save(b, format='JPEG', quality=quality)
+            feats['move/%d/image/encoded' % i] = b.getvalue()
+            feats['move/%d/commanded_pose/vec_pitch_yaw' % i] = np.asarray(action[j], np.float32)
+            feats['move/%d/endeffector/vec_pitch_yaw' % i] = np.asarray(state[j], np.float32)
+        payloads.append(serialize_example(feats))
+    write_records(path, payloads)

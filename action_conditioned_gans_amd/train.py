@@ -200,12 +200,16 @@ def train(input_path, output_path, test_output_path, log_dir, model_dir, arg_adv
           batch_size=64, img_size=64, seq_len=8, ksize=5, train_iter=TRAIN_ITER, pretrain_iter=PRETRAIN_ITER,
           n_critic=None, device='cuda:0', world_size=1, rank=0, process_group=None, log_every=100, quiet=False,
           eval_every=500, resume=None):
-    """Training loop of train.py:179-309 on synthetic sequences (the TFRecord pipeline is out of scope)."""
-    if input_path not in (None, '', 'synthetic'):
-        raise ValueError('only synthetic input is supported (input_path="synthetic"); the push-dataset TFRecord '
-                         'pipeline of ops.py:122-223 is outside the hot path')
+    """Training loop of train.py:179-309.  ``input_path``: 'synthetic' (seeded random sequences) or a directory of
+    push-dataset TFRecords, read by push_data.PushDataset (the reference's build_tfrecord_input, ops.py:140-223)."""
     np.random.seed(7)                                           # train.py:14
-    data = SyntheticPush(batch_size, seq_len, img_size, rank=rank)
+    synthetic = input_path in (None, '', 'synthetic')
+    if synthetic:
+        data = SyntheticPush(batch_size, seq_len, img_size, rank=rank)
+    else:
+        from .push_data import PushDataset
+        data = PushDataset(input_path, batch_size, training=True, img_size=img_size, rank=rank, world_size=world_size)
+        seq_len = data.seq_len
     boolean_mask = build_all_mask(seq_len)
     G.reset_default_graph()
     optim.set_data_parallel(world_size)
@@ -215,7 +219,13 @@ def train(input_path, output_path, test_output_path, log_dir, model_dir, arg_adv
         saver = Saver()                                                           # train.py:215
         if resume:
             saver.restore(sess, resume)
-        eval_data = SyntheticPush(batch_size, seq_len, img_size, seed=1007, rank=rank)
+        if synthetic:
+            eval_data = SyntheticPush(batch_size, seq_len, img_size, seed=1007, rank=rank)
+        else:
+            try:                                                                  # validation files: the tail of the split
+                eval_data = PushDataset(input_path, batch_size, training=False, img_size=img_size, seed=1007)
+            except RuntimeError:
+                eval_data = PushDataset(input_path, batch_size, training=True, img_size=img_size, seed=1007)
         D_per_G = n_critic if n_critic else (5 if arg_loss == 'wass' else 1)      # train.py:217-220
         log_file = os.path.join(log_dir, 'train.jsonl') if log_dir else None
         t0 = time.time()

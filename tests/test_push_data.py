@@ -1,0 +1,162 @@
+"""Host-side input format of the path: push-dataset TFRecords read without TensorFlow."""
+import io
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from action_conditioned_gans_amd import push_data as P
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def smooth_frames(rng, n=7, h=P.ORIGINAL_HEIGHT, w=P.ORIGINAL_WIDTH):
+    """low-frequency images: JPEG keeps them almost exactly"""
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    out = []
+    for _ in range(n):
+        a, b, c = rng.uniform(0.002, 0.01, 3)
+        img = np.stack([127 + 100 * np.sin(a * xx + b * yy), 127 + 100 * np.cos(b * xx), 127 + 100 * np.sin(c * yy)], -1)
+        out.append(np.clip(img, 0, 255).astype(np.uint8))
+    return np.stack(out)
+
+
+def make_shard(path, rng, n_records):
+    seqs = [(smooth_frames(rng), rng.standard_normal((7, 5)).astype(np.float32), rng.standard_normal((7, 5)).astype(np.float32))
+            for _ in range(n_records)]
+    P.write_push_tfrecord(path, seqs, quality=95)
+    return seqs
+
+
+def test_crc32c_known_answers():
+    assert P.crc32c(b'123456789') == 0xE3069283          # the CRC-32C check value
+    assert P.crc32c(b'') == 0
+    assert P.crc32c(bytes(32)) == 0x8A9136AA             # RFC 3720 B.4: 32 bytes of zeros
+    assert P.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43    # RFC 3720 B.4: 32 bytes of ones
+
+
+def test_record_framing_and_corruption(tmp_path):
+    path = str(tmp_path / 'a.tfrecord')
+    payloads = [b'', b'x', os.urandom(1000)]
+    P.write_records(path, payloads)
+    assert list(P.read_records(path, verify_crc=True)) == payloads
+    raw = bytearray(open(path, 'rb').read())
+    raw[-10] ^= 0x40                                     # flip a bit inside the last payload
+    open(path, 'wb').write(raw)
+    assert len(list(P.read_records(path))) == 3          # unchecked read still frames correctly
+    with pytest.raises(IOError):
+        list(P.read_records(path, verify_crc=True))
+    open(path, 'wb').write(raw[:-3])
+    with pytest.raises(IOError):
+        list(P.read_records(path))
+
+
+def test_example_round_trip_and_unpacked_floats():
+    feats = {'a/b': b'\x00\x01jpeg', 'v': np.array([1.5, -2.0, 3.25], np.float32)}
+    got = P.parse_example(P.serialize_example(feats))
+    assert got['a/b'] == [b'\x00\x01jpeg'] and np.array_equal(got['v'], feats['v'])
+    assert P.parse_example(P.serialize_example(feats), keys={'v'}).keys() == {'v'}
+    # FloatList written UNPACKED (wire type 5 per element) and an Int64List, as other writers may emit them
+    fl = b''.join(P._enc_varint((1 << 3) | 5) + struct.pack('<f', x) for x in (0.5, 7.0))
+    il = P._ld(1, P._enc_varint(3) + P._enc_varint((1 << 64) - 2))        # packed [3, -2]
+    ex = P._ld(1, P._ld(1, P._ld(1, b'f') + P._ld(2, P._ld(2, fl))) + P._ld(1, P._ld(1, b'i') + P._ld(2, P._ld(3, il))))
+    got = P.parse_example(ex)
+    assert np.array_equal(got['f'], np.array([0.5, 7.0], np.float32)) and np.array_equal(got['i'], np.array([3, -2]))
+
+
+def test_resize_area_matches_box_integration():
+    rng = np.random.default_rng(0)
+    img = rng.uniform(0, 255, (10, 14, 3)).astype(np.float32)
+    got = P.resize_area(img, 4, 6)                       # non-integer ratios 2.5 and 2.333
+    want = np.zeros((4, 6, 3))
+    for o in range(4):
+        for p in range(6):
+            y0, y1, x0, x1 = o * 2.5, (o + 1) * 2.5, p * 14 / 6.0, (p + 1) * 14 / 6.0
+            acc = 0.0
+            for y in range(10):
+                for x in range(14):
+                    wy = max(0.0, min(y1, y + 1) - max(y0, y))
+                    wx = max(0.0, min(x1, x + 1) - max(x0, x))
+                    acc = acc + wy * wx * img[y, x].astype(np.float64)
+            want[o, p] = acc / ((y1 - y0) * (x1 - x0))
+    assert np.abs(got - want).max() < 1e-3
+    box = P.resize_area(img[:8, :12], 4, 6)              # integer ratio: plain 2x2 means
+    assert np.allclose(box, img[:8, :12].reshape(4, 2, 6, 2, 3).mean((1, 3)), atol=1e-4)
+
+
+def test_crop_or_pad_center():
+    img = np.arange(6 * 10 * 1).reshape(6, 10, 1)
+    assert np.array_equal(P.crop_or_pad_center(img, 6, 6), img[:, 2:8])
+    out = P.crop_or_pad_center(img, 8, 6)
+    assert out.shape == (8, 6, 1) and np.array_equal(out[1:7], img[:, 2:8]) and not out[0].any() and not out[7].any()
+
+
+def test_decode_frame_is_crop_then_8x8_means():
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    frame = smooth_frames(rng, 1)[0]
+    b = io.BytesIO()
+    Image.fromarray(frame).save(b, format='JPEG', quality=95)
+    dec = np.asarray(Image.open(io.BytesIO(b.getvalue())).convert('RGB')).astype(np.float64)
+    got = P.decode_frame(b.getvalue())
+    assert got.shape == (64, 64, 3) and got.dtype == np.float32 and -1.0 <= got.min() and got.max() <= 1.0
+    for (p, q) in ((0, 0), (63, 63), (10, 50), (31, 32)):
+        want = dec[8 * p:8 * p + 8, 64 + 8 * q:64 + 8 * q + 8].mean((0, 1)) / 127.5 - 1.0    # 640 -> centre 512: offset 64
+        assert np.abs(got[p, q] - want).max() < 1e-5
+    assert np.abs(got - (P.resize_area(frame[:, 64:576], 64, 64) / 127.5 - 1)).max() < 0.03      # JPEG is near-lossless here
+
+
+def test_push_dataset_batches_split_and_ranks(tmp_path):
+    rng = np.random.default_rng(2)
+    seqs = []
+    for k in range(4):
+        seqs.append(make_shard(str(tmp_path / ('push_%02d.tfrecord' % k)), rng, 2))
+    ds = P.PushDataset(str(tmp_path), batch_size=3, train_val_split=0.75, training=True, verify_crc=True)
+    assert [os.path.basename(f) for f in ds.files] == ['push_00.tfrecord', 'push_01.tfrecord', 'push_02.tfrecord']
+    val = P.PushDataset(str(tmp_path), batch_size=1, train_val_split=0.75, training=False)
+    assert [os.path.basename(f) for f in val.files] == ['push_03.tfrecord']
+    img, img2, acts, states = ds.get_batch()
+    assert img.shape == (3, 7, 64, 64, 3) and img is img2 and acts.shape == (3, 7, 10) and states.shape == (3, 7, 5)
+    assert np.array_equal(acts[:, :, 5:], states) and img.dtype == np.float32
+    # every record of the batch is one of the written sequences, vectors bit-exact
+    written = {tuple(np.round(a[0], 5)): (a, s) for shard in seqs for (_, a, s) in shard}
+    for b in range(3):
+        a, s = written[tuple(np.round(acts[b, 0, :5], 5))]
+        assert np.array_equal(acts[b, :, :5], a) and np.array_equal(acts[b, :, 5:], s)
+    # two ranks see disjoint halves of the same stream
+    r0 = P.PushDataset(str(tmp_path), 3, train_val_split=1.0, rank=0, world_size=2)
+    r1 = P.PushDataset(str(tmp_path), 3, train_val_split=1.0, rank=1, world_size=2)
+    k0 = {tuple(np.round(v, 5)) for v in r0.get_batch()[2][:, 0, :5]}
+    k1 = {tuple(np.round(v, 5)) for v in r1.get_batch()[2][:, 0, :5]}
+    assert len(k0) == 3 and len(k1) == 3 and not (k0 & k1)
+    no_state = P.PushDataset(str(tmp_path), 2, use_state=False, train_val_split=1.0)
+    assert not no_state.get_batch()[2].any()
+    with pytest.raises(RuntimeError, match='No data files found'):
+        P.PushDataset(str(tmp_path / 'missing'), 2)
+
+
+def test_committed_fixture_decodes_to_pinned_values():
+    """tests/golden/push_tiny.tfrecord (+ make_push_fixture.py) pins the on-disk format and the decode arithmetic."""
+    exp = np.load(os.path.join(HERE, 'golden', 'push_tiny_expected.npz'))
+    recs = list(P.read_records(os.path.join(HERE, 'golden', 'push_tiny.tfrecord'), verify_crc=True))
+    assert len(recs) == 1
+    img, act, state = P.decode_example(recs[0])
+    assert np.abs(img - exp['images']).max() <= 2e-2      # libjpeg builds may differ by a level or two
+    assert np.array_equal(act, exp['action']) and np.array_equal(state, exp['state'])
+    with pytest.raises(KeyError):
+        P.decode_example(P.serialize_example({'move/6/image/encoded': b'x'}))
+
+
+@pytest.mark.gpu
+def test_training_loop_reads_tfrecords(tmp_path):
+    """train() end to end from a directory of push TFRecords (2 iterations) on the GPU."""
+    import torch
+    from action_conditioned_gans_amd import train as T
+    rng = np.random.default_rng(3)
+    for k in range(2):
+        make_shard(str(tmp_path / ('push_%02d.tfrecord' % k)), rng, 2)
+    tr = T.train(str(tmp_path), None, None, None, None, True, 'bce', 'adam', True, batch_size=2, train_iter=3,
+                 pretrain_iter=1, device='cuda:0', quiet=True, eval_every=2)
+    for v in tr.g_vars + tr.d_vars:
+        assert torch.isfinite(tr.sess.get_value(v)).all(), v.name

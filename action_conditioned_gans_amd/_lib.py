@@ -57,6 +57,9 @@ SIGNATURES = {
                                    _P, c_size_t, _P]),
     'acg_dna_fwd': (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     'acg_dna_bwd': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
+    'acg_cdna_workspace_bytes': (c_size_t, [c_int32] * 6),
+    'acg_cdna_fwd': (c_int32, [_P, _P, _P, _P] + [c_int32] * 6 + [c_float, c_int32, _P]),
+    'acg_cdna_bwd': (c_int32, [_P, _P, _P, _P, _P, _P] + [c_int32] * 6 + [c_float, c_int32, _P, c_size_t, _P]),
     'acg_concat_actions_fwd': (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     'acg_concat_channels_fwd': (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P]),
     'acg_slice_channels': (c_int32, [_P, _P, c_float, c_int64, c_int32, c_int32, c_int32, c_int32, _P]),

@@ -351,6 +351,66 @@ class DnaBwdOp(G.Op):
         return lambda s: fn(*args, s)
 
 
+class CdnaOp(G.Op):
+    """cdna_transformation after its fully-connected layer (reference ops.py:77-98): normalise the per-sample kernels
+    and apply them as a depthwise SAME correlation.  Outputs: the M transformed images (windows of one [M,B,H,W,C]
+    buffer the kernel writes in one launch), then the buffer itself and the normalised kernels (saved for backward)."""
+
+    def __init__(self, params, image, masks, ksize, relu_shift, name):
+        b, h, w, c = image.shape
+        self.masks, self.ksize, self.relu_shift = int(masks), int(ksize), float(relu_shift)
+        self.whole = _new((self.masks, b, h, w, c), name + ':whole')
+        self.kern_norm = _new((b, self.ksize * self.ksize * self.masks), name + ':kern_norm')
+        plane = b * h * w * c
+        pieces = [self.whole.view(j * plane, (b, h, w, c), name='%s:%d' % (name, j)) for j in range(self.masks)]
+        super().__init__(G.get_default_graph(), name, [params, image], pieces + [self.whole, self.kern_norm])
+
+    def bind(self, rt):
+        par, img = self.inputs
+        b, h, w, c = img.shape
+        args = (_p(par.buf), _p(img.buf), _p(self.whole.buf), _p(self.kern_norm.buf), b, h, w, c, self.masks, self.ksize,
+                self.relu_shift, ACG_F32)
+        fn = rt.lib.cdna_fwd
+        return lambda s: fn(*args, s)
+
+    def grad(self, gouts, needs, ctx):
+        g = CdnaBwdOp(self, gouts[:self.masks], needs[1], self.name + '/bwd')
+        return [g.outputs[0] if needs[0] else None, g.outputs[1] if needs[1] else None]
+
+
+class CdnaBwdOp(G.Op):
+    """Packs the M piece gradients into one [M,B,H,W,C] buffer (pieces nobody differentiated stay zero) and runs the
+    backward kernels: d params through the normalisation and the relu, d image on request."""
+
+    def __init__(self, fwd, gpieces, want_dimage, name):
+        self.fwd, self.want_dimage = fwd, bool(want_dimage)
+        par, img = fwd.inputs
+        g = G.get_default_graph()
+        self.packed = g.new_state(fwd.whole.shape, 0.0, name + '/packed')
+        self.present = [(j, t) for j, t in enumerate(gpieces) if t is not None]
+        super().__init__(g, name, [par, img, fwd.kern_norm] + [t for _, t in self.present],
+                         [_new(par.shape, name + ':dparams'), _new(img.shape, name + ':dimage')])
+
+    def bind(self, rt):
+        par, img, kn = self.inputs[:3]
+        b, h, w, c = img.shape
+        m, k = self.fwd.masks, self.fwd.ksize
+        plane = b * h * w * c
+        nbytes = rt.lib.cdna_workspace_bytes(b, h, w, c, m, k)
+        ws, nbytes = rt.workspace(nbytes)
+        copies = [(_p(t.buf), ctypes.c_void_p(self.packed.buf.data_ptr() + 4 * j * plane)) for j, t in self.present]
+        dimg = _p(self.outputs[1].buf) if self.want_dimage else None
+        args = (_p(par.buf), _p(kn.buf), _p(img.buf), _p(self.packed.buf), _p(self.outputs[0].buf), dimg, b, h, w, c, m, k,
+                self.fwd.relu_shift, ACG_F32, _p(ws), nbytes)
+        copy, bwd = rt.lib.slice_channels, rt.lib.cdna_bwd
+
+        def launch(s):
+            for src, dst in copies:
+                copy(src, dst, 0.0, b * h * w, c, 0, c, ACG_F32, s)
+            bwd(*args, s)
+        return launch
+
+
 class ConcatActionsOp(G.Op):
     """tf.tile([B,1,1,A] -> [B,h,w,A]) + tf.concat(axis=3) in one pass (train.py:48-50; models.py:16,38,84).
     The result is stored at a channel pitch rounded up to 4 (138 -> 140, 266 -> 268; zero pad channels) so that
@@ -605,6 +665,36 @@ def dna_gather(logits, image, ksize=DNA_KERN_SIZE, name='dna'):
     if not 1 <= image.shape[3] <= 4:
         raise ValueError('dna_gather: image channels outside 1..4')
     return DnaOp(logits, image, ksize, _scope_name(name)).outputs[0]
+
+
+RELU_SHIFT = 1e-12                                                # ops.py:13
+
+
+def fully_connected(inputs, num_outputs, activation_fn=None, scope=None, reuse=None):
+    """slim.layers.fully_connected on [B, F] (ops.py:70-74): a 1x1 convolution over a 1x1 map - weights
+    ``scope/weights`` [1,1,F,out] (slim's [F,out] with two unit axes), ``scope/biases`` [out]."""
+    if len(inputs.shape) != 2:
+        raise ValueError('fully_connected expects [batch, features], got %s' % (inputs.shape,))
+    b, f = inputs.shape
+    y = conv2d(inputs.reshape((b, 1, 1, f)), num_outputs, [1, 1], stride=1, padding='SAME', activation_fn=activation_fn,
+               normalizer_fn=None, scope=scope, reuse=reuse)
+    return y.reshape((b, num_outputs))
+
+
+def cdna_transformation(prev_image, cdna_input, num_masks, color_channels, ksize=DNA_KERN_SIZE, reuse=None):
+    """Reference ops.py:52-98: predict ``num_masks`` k x k kernels per sample from ``cdna_input`` [B, F] with a linear
+    layer (scope ``cdna_params``), normalise them and transform ``prev_image`` with each; returns the list of
+    ``num_masks`` images [B,H,W,C] (the reference's channel split of the c-major depthwise output, kept as written)."""
+    _check_nhwc(prev_image, 'cdna_transformation')
+    if prev_image.shape[3] != color_channels:
+        raise ValueError('cdna_transformation: color_channels %r does not match image %s' % (color_channels, prev_image.shape))
+    if len(cdna_input.shape) != 2 or cdna_input.shape[0] != prev_image.shape[0]:
+        raise ValueError('cdna_transformation: cdna_input must be [batch, features], got %s' % (cdna_input.shape,))
+    if ksize not in (3, 5, 7) or not 1 <= num_masks <= 32 or not 1 <= color_channels <= 4:
+        raise ValueError('cdna_transformation: supports ksize 3/5/7, 1..32 masks, 1..4 colour channels')
+    params = fully_connected(cdna_input, ksize * ksize * num_masks, activation_fn=None, scope='cdna_params', reuse=reuse)
+    op = CdnaOp(params, prev_image, num_masks, ksize, RELU_SHIFT, _scope_name('cdna'))
+    return list(op.outputs[:num_masks])
 
 
 def concat_actions(x, actions, name='concat_actions'):

@@ -137,6 +137,25 @@ int32_t acg_dna_bwd(const void* logits, const void* image, const void* dout, voi
                     int32_t h, int32_t w, int32_t c, int32_t ksize, int32_t dtype, acg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * CDNA transformation (reference ops.py:52-98, the unused sibling of the DNA tail).
+ *   params [B, k*k*M]: the raw kernel parameters of `masks` = M kernels per sample (the output of the reference's
+ *   `cdna_params` fully-connected layer), read as [B,k,k,1,M].
+ *   n[b,u,v,m] = (relu(p - relu_shift) + relu_shift) / sum_{u,v}(...)                      (ops.py:79-81)
+ *   depthwise SAME correlation of image[b] (C colours) with n[b,:,:,m]; the [B,H,W,C*M] result (channel q = c*M+m,
+ *   tf.nn.depthwise_conv2d) is split into M pieces of C channels along the channel axis (ops.py:94-96), so piece j,
+ *   channel i is q = j*C + i, i.e. colour q/M under mask q%M - reproduced as written.
+ *   out [M,B,H,W,C] (the list of M images); kern_norm [B,k*k*M] receives n (input of bwd; may be NULL in fwd).
+ * bwd: dparams [B,k*k*M] (through normalisation and relu), dimage [B,H,W,C] or NULL.  k in {3,5,7}, C<=4, M<=32.
+ * ---------------------------------------------------------------------------------------- */
+size_t acg_cdna_workspace_bytes(int32_t batch, int32_t h, int32_t w, int32_t c, int32_t masks, int32_t ksize);
+int32_t acg_cdna_fwd(const void* params, const void* image, void* out, float* kern_norm, int32_t batch, int32_t h,
+                     int32_t w, int32_t c, int32_t masks, int32_t ksize, float relu_shift, int32_t dtype,
+                     acg_stream_t stream);
+int32_t acg_cdna_bwd(const void* params, const float* kern_norm, const void* image, const void* dout, void* dparams,
+                     void* dimage, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t masks, int32_t ksize,
+                     float relu_shift, int32_t dtype, void* workspace, size_t workspace_bytes, acg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Channel plumbing: tf.tile + tf.concat at train.py:48-50,64,68 and models.py:16,38,84.
  * ---------------------------------------------------------------------------------------- */
 /* y[b,s,0:c] = x[b,s,:],  y[b,s,c:c+a] = actions[b,:]   for s in [0,hw); y rows are y_pitch floats apart

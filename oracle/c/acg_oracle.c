@@ -209,6 +209,75 @@ int32_t acg_bias_act_bwd(const void* yv, const void* dyv, void* dxv, float* dbia
   return ACG_OK;
 }
 
+/* ---- CDNA transformation: ops.py:52-98 (normalised per-sample kernels, depthwise SAME correlation, split into M
+ * pieces of C channels of the c-major depthwise output) */
+static int cdna_check(int C, int M, int k) { return C >= 1 && C <= 4 && M >= 1 && M <= 32 && (k == 3 || k == 5 || k == 7); }
+size_t acg_cdna_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t C, int32_t M, int32_t k) {
+  if (B <= 0 || H <= 0 || W <= 0 || !cdna_check(C, M, k)) return 0;
+  return (size_t)B * ((H + 15) / 16) * ((W + 15) / 16) * k * k * M * sizeof(float);
+}
+static void cdna_norm(const float* p, int kk, int M, double shift, double* n, double* S) {
+  for (int m = 0; m < M; m++) {
+    double s = 0;
+    for (int t = 0; t < kk; t++) { double v = p[t * M + m] - shift; v = (v > 0 ? v : 0) + shift; n[t * M + m] = v; s += v; }
+    S[m] = s;
+    for (int t = 0; t < kk; t++) n[t * M + m] /= s;
+  }
+}
+int32_t acg_cdna_fwd(const void* pv, const void* iv, void* ov, float* kern_norm, int32_t B, int32_t H, int32_t W,
+                     int32_t C, int32_t M, int32_t k, float shift, int32_t dtype, acg_stream_t s) {
+  (void)s; REQUIRE_F32(dtype);
+  if (B <= 0 || H <= 0 || W <= 0 || !cdna_check(C, M, k)) return fail(ACG_ERR_INVALID_ARG, "cdna: need c<=4, masks<=32, ksize in {3,5,7}");
+  const float* par = pv; const float* img = iv; float* out = ov; int kk = k * k, pad = (k - 1) / 2;
+  size_t plane = (size_t)B * H * W * C;
+  double n[49 * 32], S[32];
+  for (int b = 0; b < B; b++) {
+    cdna_norm(par + (size_t)b * kk * M, kk, M, shift, n, S);
+    if (kern_norm) for (int i = 0; i < kk * M; i++) kern_norm[(size_t)b * kk * M + i] = (float)n[i];
+    for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) for (int c = 0; c < C; c++) for (int m = 0; m < M; m++) {
+      double acc = 0;
+      for (int u = 0; u < k; u++) for (int v = 0; v < k; v++) {
+        int yy = y + u - pad, xx = x + v - pad; if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        acc += n[(u * k + v) * M + m] * img[(((size_t)b * H + yy) * W + xx) * C + c];
+      }
+      int q = c * M + m;
+      out[(size_t)(q / C) * plane + (((size_t)b * H + y) * W + x) * C + q % C] = (float)acc;
+    }
+  }
+  return ACG_OK;
+}
+int32_t acg_cdna_bwd(const void* pv, const float* kern_norm, const void* iv, const void* dov, void* dpv, void* div,
+                     int32_t B, int32_t H, int32_t W, int32_t C, int32_t M, int32_t k, float shift, int32_t dtype,
+                     void* ws, size_t wsb, acg_stream_t s) {
+  (void)s; (void)ws; (void)wsb; (void)kern_norm; REQUIRE_F32(dtype);
+  if (B <= 0 || H <= 0 || W <= 0 || !cdna_check(C, M, k)) return fail(ACG_ERR_INVALID_ARG, "cdna: need c<=4, masks<=32, ksize in {3,5,7}");
+  const float* par = pv; const float* img = iv; const float* dout = dov; float* dpar = dpv; float* dimg = div;
+  int kk = k * k, pad = (k - 1) / 2; size_t plane = (size_t)B * H * W * C;
+  double n[49 * 32], S[32], dn[49 * 32];
+  for (int b = 0; b < B; b++) {
+    cdna_norm(par + (size_t)b * kk * M, kk, M, shift, n, S);
+    for (int i = 0; i < kk * M; i++) dn[i] = 0;
+    if (dimg) for (size_t i = 0; i < (size_t)H * W * C; i++) dimg[(size_t)b * H * W * C + i] = 0.f;
+    for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) for (int c = 0; c < C; c++) for (int m = 0; m < M; m++) {
+      int q = c * M + m;
+      double g = dout[(size_t)(q / C) * plane + (((size_t)b * H + y) * W + x) * C + q % C];
+      for (int u = 0; u < k; u++) for (int v = 0; v < k; v++) {
+        int yy = y + u - pad, xx = x + v - pad; if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        size_t ii = (((size_t)b * H + yy) * W + xx) * C + c;
+        dn[(u * k + v) * M + m] += g * img[ii];
+        if (dimg) dimg[ii] += (float)(g * n[(u * k + v) * M + m]);
+      }
+    }
+    for (int m = 0; m < M; m++) {
+      double dot = 0;
+      for (int t = 0; t < kk; t++) dot += dn[t * M + m] * n[t * M + m];
+      for (int t = 0; t < kk; t++)
+        dpar[(size_t)b * kk * M + t * M + m] = par[(size_t)b * kk * M + t * M + m] - shift > 0 ? (float)((dn[t * M + m] - dot) / S[m]) : 0.f;
+    }
+  }
+  return ACG_OK;
+}
+
 /* ---- DNA tail: models.py:60-72, SURVEY A.7 */
 static int dna_check(int c, int k) { return c >= 1 && c <= 4 && k >= 1 && k <= 15; }
 int32_t acg_dna_fwd(const void* lv, const void* iv, void* ov, int32_t B, int32_t H, int32_t W, int32_t C,

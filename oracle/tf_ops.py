@@ -111,6 +111,29 @@ def extract_image_patches(img, ksize):
     return out.permute(0, 3, 4, 1, 2).contiguous()      # [B, H, W, k*k, C]
 
 
+def cdna_transform(params, img, num_masks, ksize=5, relu_shift=1e-12):
+    """cdna_transformation after its fully-connected layer (reference ops.py:77-98): params [B, k*k*M] read as
+    [B,k,k,1,M]; k = relu(p - shift) + shift, normalised over (k, k, 1); per-sample depthwise SAME correlation
+    (tf.nn.depthwise_conv2d: output channel c*M + m); concatenated over the batch and split into M pieces of C
+    channels along the channel axis.  Returns the list of M tensors [B,H,W,C]."""
+    B, H, W, C = img.shape
+    M, k = num_masks, ksize
+    kern = params.reshape(B, k, k, 1, M)
+    kern = torch.relu(kern - relu_shift) + relu_shift
+    kern = kern / kern.sum(dim=(1, 2, 3), keepdim=True)
+    pad = (k - 1) // 2
+    outs = []
+    for b in range(B):
+        w = kern[b, :, :, 0, :].permute(2, 0, 1)                                    # [M,k,k]
+        w = w.unsqueeze(0).expand(C, M, k, k).reshape(C * M, 1, k, k)               # group c, multiplier m -> channel c*M+m
+        x = img[b].permute(2, 0, 1).unsqueeze(0)                                    # [1,C,H,W]
+        x = F.pad(x, (pad, k - 1 - pad, pad, k - 1 - pad))
+        y = F.conv2d(x, w, groups=C)                                                # [1,C*M,H,W]
+        outs.append(y[0].permute(1, 2, 0))                                          # [H,W,C*M]
+    t = torch.stack(outs)                                                           # [B,H,W,C*M]
+    return [t[..., j * C:(j + 1) * C] for j in range(M)]
+
+
 def dna_gather(logits, img, ksize):
     """models.py:60-72: softmax over k*k logits, per-pixel weighted sum of the k x k window."""
     m = torch.softmax(logits, dim=-1)

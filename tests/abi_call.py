@@ -138,6 +138,24 @@ class Abi:
                               self.stream())
         return dx, dbias
 
+    # ---- cdna
+    def cdna_fwd(self, params, img, masks, k, shift=1e-12):
+        b, h, w, c = img.shape
+        out = torch.empty((masks, b, h, w, c), dtype=torch.float32, device=self.device)
+        kn = torch.empty((b, k * k * masks), dtype=torch.float32, device=self.device)
+        self.lib.cdna_fwd(_p(params), _p(img), _p(out), _p(kn), b, h, w, c, masks, k, shift, L.ACG_F32, self.stream())
+        return out, kn
+
+    def cdna_bwd(self, params, kn, img, dout, masks, k, shift=1e-12, want_dimg=True):
+        b, h, w, c = img.shape
+        dpar = torch.empty_like(params)
+        dimg = torch.empty_like(img) if want_dimg else None
+        nb = self.lib.cdna_workspace_bytes(b, h, w, c, masks, k)
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=self.device)
+        self.lib.cdna_bwd(_p(params), _p(kn), _p(img), _p(dout), _p(dpar), _p(dimg) if want_dimg else None, b, h, w, c,
+                          masks, k, shift, L.ACG_F32, _p(ws), nb, self.stream())
+        return dpar, dimg
+
     # ---- dna
     def dna_fwd(self, logits, img, k):
         b, h, w, c = img.shape

@@ -239,6 +239,28 @@ def case_bias(abi, tol, seed=0):
 DNA_SHAPES = [(2, 64, 64, 3, 5), (1, 16, 16, 3, 6), (1, 24, 20, 3, 11), (2, 7, 5, 3, 5), (1, 3, 3, 1, 5), (1, 8, 8, 4, 3)]
 
 
+def case_cdna(abi, shape, tol, seed=0):
+    """shape = (B, H, W, C, masks, k).  Forward pieces and both gradients against autograd on the torch restatement;
+    some raw parameters are negative (clamped by the relu: zero gradient there)."""
+    b, h, w, c, m, k = shape
+    g = torch.Generator().manual_seed(seed)
+    params = (torch.randn(b, k * k * m, generator=g) * 0.7 + 0.3).float()
+    img = (torch.rand(b, h, w, c, generator=g) * 2 - 1).float()
+    dout = torch.randn(m, b, h, w, c, generator=g).float()
+    pd, im = params.double().requires_grad_(True), img.double().requires_grad_(True)
+    pieces = T.cdna_transform(pd, im, m, k)
+    ref = torch.stack(pieces)
+    (ref * dout.double()).sum().backward()
+    dev = abi.device
+    tag = 'cdna%s' % (shape,)
+    out, kn = abi.cdna_fwd(params.to(dev), img.to(dev), m, k)
+    close(out, ref.detach(), tol, tag + ' fwd')
+    dpar, dimg = abi.cdna_bwd(params.to(dev), kn, img.to(dev), dout.to(dev), m, k)
+    close(dimg, im.grad, tol * 4, tag + ' dimg')
+    close(dpar, pd.grad, tol * 8, tag + ' dparams')
+    assert (dpar.cpu()[params <= 1e-12] == 0).all(), tag + ' clamped parameters must have zero gradient'
+
+
 def case_dna(abi, shape, tol, seed=0):
     b, h, w, c, k = shape
     logits = randn((b, h, w, k * k), seed, 2.0)

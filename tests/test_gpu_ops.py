@@ -77,6 +77,12 @@ def test_dna(hip_abi, shape):
     C.case_dna(hip_abi, shape, TOL)
 
 
+@pytest.mark.parametrize('shape', [(2, 9, 7, 3, 4, 5), (1, 16, 16, 1, 1, 3), (2, 20, 17, 3, 10, 5), (1, 8, 8, 4, 3, 7),
+                                   (4, 64, 64, 3, 10, 5)])
+def test_cdna(hip_abi, shape):
+    C.case_cdna(hip_abi, shape, TOL)
+
+
 def test_dna_extreme(hip_abi):
     C.case_dna_extreme_logits(hip_abi, TOL)
 

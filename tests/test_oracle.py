@@ -44,6 +44,11 @@ def test_dna(oracle_abi, shape):
     C.case_dna(oracle_abi, shape, TOL)
 
 
+@pytest.mark.parametrize('shape', [(2, 9, 7, 3, 4, 5), (1, 16, 16, 1, 1, 3), (2, 20, 17, 3, 10, 5), (1, 8, 8, 4, 3, 7)])
+def test_cdna(oracle_abi, shape):
+    C.case_cdna(oracle_abi, shape, TOL)
+
+
 def test_dna_extreme(oracle_abi):
     C.case_dna_extreme_logits(oracle_abi, TOL)
 

@@ -191,3 +191,44 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(hip, name), 'libacgan_hip.so lacks ' + name
     assert _lib.get().version() == _lib.ABI_VERSION
     assert cbind.load().version() == _lib.ABI_VERSION
+
+
+def test_cdna_transformation_layer_and_gradients():
+    """ops.cdna_transformation (reference ops.py:52-98) - linear layer `cdna_params`, kernel
+    normalisation, per-sample depthwise transform, M outputs - and its gradients into the layer's weights, against
+    autograd on the torch restatement.  Only pieces 0 and 2 enter the loss: piece 1's gradient is the zero window."""
+    from oracle import tf_ops as OT
+    B, H, W, C, F, M, K = 2, 10, 9, 3, 6, 3, 5
+    rng = np.random.default_rng(4)
+    img = rng.uniform(-1, 1, (B, H, W, C)).astype(np.float32)
+    feat = rng.standard_normal((B, F)).astype(np.float32)
+    tgt = rng.uniform(-1, 1, (B, H, W, C)).astype(np.float32)
+    G.reset_default_graph()
+    optim.set_data_parallel(1)
+    sess = cpu_session()
+    img_ph, feat_ph, tgt_ph = G.placeholder((B, H, W, C), 'img'), G.placeholder((B, F), 'feat'), G.placeholder((B, H, W, C), 'tgt')
+    with O.variable_scope('g'):
+        pieces = O.cdna_transformation(img_ph, feat_ph, M, C, ksize=K)
+    assert len(pieces) == M and all(p.shape == (B, H, W, C) for p in pieces)
+    loss = O.l2_norm(pieces[0], tgt_ph) + O.l1_norm(pieces[2], tgt_ph) * 0.5
+    step = optim.RMSPropOptimizer(1e-3).minimize(loss, G.get_default_graph().trainable_variables('g'))
+    sess.run(G.global_variables_initializer())
+    g = G.get_default_graph()
+    wv, bv = g.variables['g/cdna_params/weights'], g.variables['g/cdna_params/biases']
+    assert wv.shape == (1, 1, F, K * K * M) and bv.shape == (K * K * M,)
+    w0 = (torch.from_numpy(rng.standard_normal((F, K * K * M)).astype(np.float32)) * 0.5)
+    b0 = torch.from_numpy(rng.standard_normal(K * K * M).astype(np.float32) * 0.5 + 0.5)
+    sess.set_value(wv, w0.reshape(wv.shape))
+    sess.set_value(bv, b0)
+    fd = {img_ph: img, feat_ph: feat, tgt_ph: tgt}
+    got = sess.run(pieces, fd)
+    wd, bd = w0.double().requires_grad_(True), b0.double().requires_grad_(True)
+    ref = OT.cdna_transform(torch.from_numpy(feat).double() @ wd + bd, torch.from_numpy(img).double(), M, K)
+    for j in range(M):
+        assert TC.rel(got[j], ref[j].detach().numpy()) <= 1e-5, j
+    t = torch.from_numpy(tgt).double()
+    ((ref[0] - t).pow(2).sum().sqrt() + 0.5 * (ref[2] - t).abs().sum()).backward()
+    sess.run([step], fd)
+    norms = TC.flat_grad_norms(sess, step)
+    assert abs(norms['g/cdna_params/weights'] - float(wd.grad.norm())) <= 1e-4 * float(wd.grad.norm())
+    assert abs(norms['g/cdna_params/biases'] - float(bd.grad.norm())) <= 1e-4 * float(bd.grad.norm())

@@ -21,11 +21,39 @@ def main():
     ap.add_argument('--img', type=int, default=64)
     ap.add_argument('--ksize', type=int, default=5)
     ap.add_argument('--reps', type=int, default=50)
+    ap.add_argument('--cdna', action='store_true', help='time the CDNA transformation (10 masks, k=5) instead')
     args = ap.parse_args()
     lib, dev = _lib.get(), torch.device('cuda:0')
     k, S, C = args.ksize, args.img, 3
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
+    if args.cdna:
+        M = 10
+        for B in [int(b) for b in args.batches.split(',')]:
+            par = torch.randn(B, k * k * M, device=dev)
+            img = torch.rand(B, S, S, C, device=dev) * 2 - 1
+            out = torch.empty(M, B, S, S, C, device=dev)
+            kn = torch.empty(B, k * k * M, device=dev)
+            dout = torch.randn_like(out)
+            dpar, dimg = torch.empty_like(par), torch.empty_like(img)
+            nb = lib.cdna_workspace_bytes(B, S, S, C, M, k)
+            ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+            img_b = B * S * S * C * 4
+            for name, fn, nbytes in (
+                    ('fwd', lambda: lib.cdna_fwd(p(par), p(img), p(out), p(kn), B, S, S, C, M, k, 1e-12, 0, stream), (1 + M) * img_b),
+                    ('bwd', lambda: lib.cdna_bwd(p(par), p(kn), p(img), p(dout), p(dpar), p(dimg), B, S, S, C, M, k, 1e-12, 0, p(ws), nb, stream), (2 + M) * img_b)):
+                for _ in range(5):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.reps):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / args.reps
+                print('cdna_%s k=%d masks=%d B=%-5d %7.2f MB  %8.2f us  %7.1f GB/s  (%.1f%% of 8 TB/s)' % (
+                    name, k, M, B, nbytes / 1e6, us, nbytes / us / 1e3, 100 * nbytes / us / 1e3 / 8000))
+        return
     for B in [int(b) for b in args.batches.split(',')]:
         logits = torch.randn(B, S, S, k * k, device=dev)
         img = torch.rand(B, S, S, C, device=dev) * 2 - 1

@@ -8,6 +8,12 @@ import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
 
+# torch FIRST: it carries its own copy of the HIP runtime, and the process must end up with ONE.  Loaded after torch,
+# libacgan_hip.so binds to the runtime torch has already mapped (streams, device memory and graphs are then shared);
+# loaded before it, the library would initialise the system runtime and torch a second one, and the first kernel
+# launch from here fails with "no ROCm-capable device is detected" (seen in build() -> smoke() in one process).
+import torch  # noqa: F401  (import order is the point)
+
 ACG_F32, ACG_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 0, 1, 2

@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""Per-conv-op table of one G+D step on the GPU: time (20 launches captured in a HIP graph and replayed: the in-graph cost of a launch), algorithmic
+FLOPs, TFLOP/s and the time above a 90 TFLOP/s line - where the conv time of a step goes.
+  python tools/conv_table.py [--batch 32] > gpurun_out/conv_table.txt"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from action_conditioned_gans_amd import graph as G, ops as O, optim, train as T   # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=32)
+    args = ap.parse_args()
+    B = args.batch
+    G.reset_default_graph()
+    optim.set_data_parallel(1)
+    sess = G.Session(device='cuda:0')
+    tr = T.Trainer(sess, True, 'bce', 'adam', True, batch_size=B)
+    sess.run(G.global_variables_initializer())
+    rng = np.random.default_rng(0)
+    x, y = (rng.uniform(-1, 1, (B, 64, 64, 3)).astype(np.float32) for _ in range(2))
+    a, s = rng.standard_normal((B, 10)).astype(np.float32), rng.standard_normal((B, 5)).astype(np.float32)
+    import ctypes
+    rows = []
+    for tag, fetch, feed in (('D', [tr.d_opt_op, tr.clip_d], tr._feed(x, y, a, np.zeros((B, 5), np.float32))),
+                             ('G', [tr.g_opt_op, tr.g_next_frame], tr._feed(x, y, a, s))):
+        sess.run(fetch, feed)
+        key = [k for k in sess._programs][-1]
+        prog = sess._programs[key]
+        for kind, seg in prog.segments:
+            if kind == 'host':
+                continue
+            for op, fn in seg:
+                if not isinstance(op, O._ConvBase):
+                    continue
+                # 20 launches of the op captured in a HIP graph: the in-graph cost of one launch (kernel + reduce + gaps)
+                torch.cuda.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+                    for _ in range(20):
+                        fn(sp)
+                gr.replay()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    gr.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                d = op.desc
+                fl = 2.0 * d.batch * d.out_h * d.out_w * d.kh * d.kw * d.in_c * d.out_c
+                rows.append((tag, op.name, type(op).__name__, fl, e0.elapsed_time(e1) * 1e3 / 60))
+    tot_us = sum(r[4] for r in rows)
+    tot_fl = sum(r[3] for r in rows)
+    print('# %d conv ops, %.1f us, %.2f GFLOP, %.1f TFLOP/s average' % (len(rows), tot_us, tot_fl / 1e9, tot_fl / tot_us / 1e6))
+    print('# step op kind GFLOP us TFLOP/s us_above_90TF')
+    for tag, name, kind, fl, us in sorted(rows, key=lambda r: -(r[4] - r[3] / 90e6)):
+        print('%s %-38s %-12s %6.2f %7.1f %6.1f %7.1f' % (tag, name[:38], kind, fl / 1e9, us, fl / us / 1e6, us - fl / 90e6))
+
+
+if __name__ == '__main__':
+    main()

@@ -114,7 +114,7 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
   const long long target = which == ACG_CONV_WGRAD ? 512 : 256;
   long long s = target / pl.tiles;
   s = std::min<long long>(s, std::max(1, pl.nk / 4));
-  s = std::min<long long>(s, 64);
+  s = std::min<long long>(s, 128);
   if (g_force_splits >= 1) s = std::min<long long>(g_force_splits, pl.nk);
   pl.splits = (int)std::max<long long>(s, 1);
   return pl;

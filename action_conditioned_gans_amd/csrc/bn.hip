@@ -199,13 +199,20 @@ __global__ __launch_bounds__(256) void bn_apply_fwd(const float* __restrict__ x,
     rstd[j] = (float)(1.0 / sqrt(var + (double)eps));
   }
   if (blockIdx.x == 0 && rl == 0) { stv<V>(save_mean + g * C + c, mean); stv<V>(save_rstd + g * C + c, rstd); }
-#pragma unroll 4
-  for (long long r = (long long)blockIdx.x * 32 + rl; r < R; r += (long long)gridDim.x * 32) {
-    float v[V];
-    ldv<V>(xg + r * C + c, v);
+  // batches of 4 row passes with the loads issued together (a block walks ~4 passes: one memory round trip)
+  const long long rstep = (long long)gridDim.x * 32;
+  for (long long r = (long long)blockIdx.x * 32 + rl; r < R; r += 4 * rstep) {
+    float v[4][V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) v[j] = acg::act_apply(act, (v[j] - mean[j]) * rstd[j] + bt[j], leak);
-    stv<V>(yg + r * C + c, v);
+    for (int u = 0; u < 4; ++u) ldv<V>(xg + min(r + u * rstep, R - 1) * C + c, v[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (r + u * rstep < R) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[u][j] = acg::act_apply(act, (v[u][j] - mean[j]) * rstd[j] + bt[j], leak);
+        stv<V>(yg + (r + u * rstep) * C + c, v[u]);
+      }
+    }
   }
 }
 
@@ -305,17 +312,26 @@ __global__ __launch_bounds__(256) void bn_apply_bwd(const float* __restrict__ x,
   const float invR = 1.f / (float)R;
 #pragma unroll
   for (int j = 0; j < V; ++j) { m1[j] = s1[j] * invR; m2[j] = s2[j] * invR; }
-#pragma unroll 4
-  for (long long r = (long long)blockIdx.x * 32 + rl; r < R; r += (long long)gridDim.x * 32) {
-    float xv[V], dv[V];
-    ldv<V>(xg + r * C + c, xv); ldv<V>(dyg + r * C + c, dv);
+  const long long rstep = (long long)gridDim.x * 32;
+  for (long long r = (long long)blockIdx.x * 32 + rl; r < R; r += 4 * rstep) {    // batched like bn_apply_fwd
+    float xv[4][V], dv[4][V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-      const float xh = (xv[j] - mean[j]) * rstd[j];
-      const float dp = dv[j] * acg::act_deriv_pre(act, xh + bt[j], leak);
-      dv[j] = rstd[j] * (dp - m1[j] - xh * m2[j]);
+    for (int u = 0; u < 4; ++u) {
+      const long long rr = min(r + u * rstep, R - 1);
+      ldv<V>(xg + rr * C + c, xv[u]); ldv<V>(dyg + rr * C + c, dv[u]);
     }
-    stv<V>(dxg + r * C + c, dv);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (r + u * rstep < R) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const float xh = (xv[u][j] - mean[j]) * rstd[j];
+          const float dp = dv[u][j] * acg::act_deriv_pre(act, xh + bt[j], leak);
+          dv[u][j] = rstd[j] * (dp - m1[j] - xh * m2[j]);
+        }
+        stv<V>(dxg + (r + u * rstep) * C + c, dv[u]);
+      }
+    }
   }
 }
 

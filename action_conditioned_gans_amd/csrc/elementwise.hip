@@ -43,6 +43,14 @@ __global__ __launch_bounds__(256) void concat_k(const float* __restrict__ a, con
                                                 int pitch) {
   const int cy = ca + cb;
   const long long n = rows * cy, stride = (long long)gridDim.x * 256;
+  if (n < (1ll << 31)) {   // 32-bit index arithmetic: a 64-bit division per element costs more than the copy
+    const unsigned n32 = (unsigned)n, st32 = (unsigned)stride, ucy = (unsigned)cy, urpb = (unsigned)rows_per_b;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n32; i += st32) {
+      const unsigned r = i / ucy, c = i - r * ucy;
+      y[(size_t)r * pitch + c] = c < (unsigned)ca ? a[(size_t)r * ca + c] : b[(size_t)(r / urpb) * cb + (c - ca)];
+    }
+    return;
+  }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     const long long r = i / cy;
     const int c = (int)(i - r * cy);
@@ -53,6 +61,15 @@ __global__ __launch_bounds__(256) void concat_k(const float* __restrict__ a, con
 __global__ __launch_bounds__(256) void slice_k(const float* __restrict__ src, float* __restrict__ dst, float acc,
                                                long long rows, int c_src, int c_off, int c_dst) {
   const long long n = rows * c_dst, stride = (long long)gridDim.x * 256;
+  if (n < (1ll << 31) && rows * c_src < (1ll << 31)) {
+    const unsigned n32 = (unsigned)n, st32 = (unsigned)stride, ud = (unsigned)c_dst;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n32; i += st32) {
+      const unsigned r = i / ud, c = i - r * ud;
+      const float v = src[r * (unsigned)c_src + c_off + c];
+      dst[i] = acc != 0.f ? acc * dst[i] + v : v;
+    }
+    return;
+  }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     const long long r = i / c_dst;
     const int c = (int)(i - r * c_dst);

@@ -9,6 +9,8 @@
 // The backward pass overwrites the staged logits in place with dlogits and streams them back coalesced.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -140,8 +142,138 @@ __global__ __launch_bounds__(TX* TY) void dna_kernel(const float* __restrict__ l
   }
 }
 
+// Larger kernels (K >= 6; config 5 uses 11x11 = 121 taps, 484 B of logits per pixel): a thread per pixel would need the
+// whole tile's logits in LDS (31 KB per 64 pixels: a handful of waves per CU, measured 12 % of the HBM peak).  Here a
+// 16-lane ROW of a wave owns one pixel and the lanes split its taps (t = lane16 + 16 r): logits are read straight
+// from global memory in 64-byte runs, stay in registers for both softmax passes, and the per-pixel maximum, sum and
+// channel sums are 4-step butterflies inside the 16-lane row.  A block (4 waves) walks 64 consecutive pixels of one
+// image row, 16 at a time; only the image window (11 x 74 x C floats) goes through LDS.
+// CC: compile-time channel count (3 = RGB) or 0 = runtime C (kept small: its channel loops stay rolled).
+template <int K, bool BWD, int CC>
+__global__ __launch_bounds__(256) void dna_rows_kernel(const float* __restrict__ logits, const float* __restrict__ img,
+                                                       const float* __restrict__ dout, float* __restrict__ out,
+                                                       int H, int W, int Crt) {
+  constexpr int KK = K * K, P = (K - 1) / 2, R = (KK + 15) / 16, WW = 64 + K - 1;
+  const int C = CC ? CC : Crt;
+  __shared__ float win[K * WW * 4];
+  const int tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;        // 16 pixel groups per block
+  const int x0 = blockIdx.x * 64, y = blockIdx.y, b = blockIdx.z;
+  for (int i = tid; i < K * WW * C; i += 256) {
+    const int c = i % C, p = i / C, wx = p % WW, wy = p / WW;
+    const int gy = y - P + wy, gx = x0 - P + wx;
+    win[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(((long long)b * H + gy) * W + gx) * C + c] : 0.f;
+  }
+  __syncthreads();
+  // all-reduce inside a 16-lane DPP row: xor 1, xor 2 (quad permutes), then the two mirror steps - four VALU
+  // instructions with a DPP operand instead of four LDS-permute round trips
+  auto dpp = [](float v, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, false));
+  };
+  using QP1 = std::integral_constant<int, 0xB1>;      // quad_perm [1,0,3,2]
+  using QP2 = std::integral_constant<int, 0x4E>;      // quad_perm [2,3,0,1]
+  using RHM = std::integral_constant<int, 0x141>;     // row_half_mirror
+  using RM = std::integral_constant<int, 0x140>;      // row_mirror
+  auto row_max = [&](float v) {
+    v = fmaxf(v, dpp(v, QP1{})); v = fmaxf(v, dpp(v, QP2{})); v = fmaxf(v, dpp(v, RHM{})); v = fmaxf(v, dpp(v, RM{}));
+    return v;
+  };
+  auto row_sum = [&](float v) {
+    v += dpp(v, QP1{}); v += dpp(v, QP2{}); v += dpp(v, RHM{}); v += dpp(v, RM{});
+    return v;
+  };
+  int woff[R];                                                        // window offset of this lane's taps (pixel 0 of the tile)
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int t = l16 + 16 * r, i = t / K, j = t - i * K;
+    woff[r] = (i * WW + j) * C;
+  }
+  // the logits of all four pixels of this 16-lane row are requested up front (4 x R loads in flight per lane): the
+  // per-pixel work below is a dependent chain (max -> exp -> sums) that would otherwise sit behind each round trip
+  float lall[4][R];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int x = x0 + it * 16 + grp;
+    const float* lp = logits + (((long long)b * H + y) * W + min(x, W - 1)) * KK;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int t = l16 + 16 * r;
+      lall[it][r] = t < KK ? lp[t] : -3.0e38f;
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int px = it * 16 + grp, x = x0 + px;
+    if (x >= W) continue;                                             // uniform per 16-lane row: the DPP steps stay inside it
+    const long long pix = ((long long)b * H + y) * W + x;
+    float l[R];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      l[r] = lall[it][r];
+      mx = fmaxf(mx, l[r]);
+    }
+    mx = row_max(mx);
+    float den = 0.f, a[4] = {0.f, 0.f, 0.f, 0.f}, d[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BWD) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) d[c] = c < C ? dout[pix * C + c] : 0.f;
+    }
+    float g[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int t = l16 + 16 * r;
+      const float e = t < KK ? __expf(l[r] - mx) : 0.f;
+      const float* wp = win + woff[r] + px * C;
+      den += e;
+      if constexpr (!BWD) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < C) a[c] += e * (t < KK ? wp[c] : 0.f);
+      } else {
+        float gg = 0.f;
+        if (t < KK) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (c < C) gg += d[c] * wp[c];
+        }
+        g[r] = gg;
+        a[0] += e * gg;                                               // numerator of dot = sum_t m_t g_t
+      }
+      l[r] = e;
+    }
+    den = row_sum(den);
+    const float inv = 1.f / den;
+    if constexpr (!BWD) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c < C) {
+          const float v = row_sum(a[c]);
+          if (l16 == c) out[pix * C + c] = v * inv;
+        }
+      }
+    } else {
+      const float dot = row_sum(a[0]) * inv;
+      float* op = out + pix * KK;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int t = l16 + 16 * r;
+        if (t < KK) op[t] = l[r] * inv * (g[r] - dot);
+      }
+    }
+  }
+}
+
 template <int K, bool BWD>
 int launch_k(const float* logits, const float* img, const float* dout, float* out, int B, int H, int W, int C, hipStream_t st) {
+#ifndef ACG_DNA_ROWS_MIN
+#define ACG_DNA_ROWS_MIN 6      // measured (profiles/r1/c_dna_microbench.txt): the row kernel wins from k = 6 (~2x), loses at 5
+#endif
+  if constexpr (K >= ACG_DNA_ROWS_MIN) {
+    const dim3 grid((W + 63) / 64, H, B);
+    if (C == 3) hipLaunchKernelGGL((dna_rows_kernel<K, BWD, 3>), grid, dim3(256), 0, st, logits, img, dout, out, H, W, C);
+    else hipLaunchKernelGGL((dna_rows_kernel<K, BWD, 0>), grid, dim3(256), 0, st, logits, img, dout, out, H, W, C);
+    return acg::check_launch(BWD ? "dna_bwd" : "dna_fwd");
+  }
   constexpr int TY = K <= 6 ? 4 : 1;
   const dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, B);
   if (C == 3) hipLaunchKernelGGL((dna_kernel<K, TY, BWD, 3>), grid, dim3(TX * TY), 0, st, logits, img, dout, out, H, W, C);
@@ -163,7 +295,7 @@ int dispatch(int k, const float* logits, const float* img, const float* dout, fl
 int check(const char* who, int B, int H, int W, int C, int k) {
   ACG_REQUIRE(B > 0 && H > 0 && W > 0, ACG_ERR_INVALID_ARG, "%s: non-positive size", who);
   ACG_REQUIRE(C >= 1 && C <= 4, ACG_ERR_INVALID_ARG, "%s: channels %d outside 1..4", who, C);
-  ACG_REQUIRE(B <= 65535 && (H + 0) <= 65535 * 4, ACG_ERR_UNSUPPORTED, "%s: grid too large", who);
+  ACG_REQUIRE(B <= 65535 && H <= 65535, ACG_ERR_UNSUPPORTED, "%s: grid too large", who);
   ACG_REQUIRE((long long)B * H * W * k * k < 2147483647ll, ACG_ERR_UNSUPPORTED, "%s: tensor exceeds 2^31 elements", who);
   return ACG_OK;
 }

@@ -183,7 +183,8 @@ def main():
     roof, roof_dna, kernel_ms = None, None, {}
     # EVERY rank runs the instrumented pass: with world > 1 the programs contain gradient all-reduces, and a
     # collective issued by rank 0 alone would never complete.  Only rank 0 reports.
-    if True:
+    every_rank_profiles = True
+    if every_rank_profiles:
         x, y, a, s = pool[0]
         zero_state = torch.zeros(B, 5, device=device)
         recs = []

@@ -236,7 +236,9 @@ def case_bias(abi, tol, seed=0):
             close(db2, db_ref, tol * 4, 'bias none dbias (dx NULL)')
 
 
-DNA_SHAPES = [(2, 64, 64, 3, 5), (1, 16, 16, 3, 6), (1, 24, 20, 3, 11), (2, 7, 5, 3, 5), (1, 3, 3, 1, 5), (1, 8, 8, 4, 3)]
+DNA_SHAPES = [(2, 64, 64, 3, 5), (1, 16, 16, 3, 6), (1, 24, 20, 3, 11), (2, 7, 5, 3, 5), (1, 3, 3, 1, 5), (1, 8, 8, 4, 3),
+              # the 16-lane-row kernel (k >= 6): widths beyond / not a multiple of its 64-pixel block, C != 3
+              (1, 9, 70, 3, 7), (2, 5, 130, 1, 6), (1, 6, 33, 4, 9), (1, 4, 4, 2, 8)]
 
 
 def case_cdna(abi, shape, tol, seed=0):

@@ -237,13 +237,16 @@ def main():
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, n_critic)
+    is_config2 = (B == 32 and S == 64 and args.seq_len == 8 and adv and args.loss == 'bce' and dna and args.ksize == 5
+                  and args.opt == 'adam' and args.dtype == 'f32')
     line = {
         'metric': 'GAN train steps/sec (G+D) on 64x64x3xT=8 push seq', 'value': round(world * args.steps / elapsed, 3),
         'unit': 'steps/s (batch-%d G+D steps, all ranks)' % B, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-        'config': {'workload': 'BASELINE config 2 per GPU: batch=%d %dx%dx3 T=%d %s--loss %s %s(k=%d) --opt %s %s'
-                               % (B, S, S, args.seq_len, '--adv ' if adv else '', args.loss, '--dna ' if dna else 'plain-G ',
+        'config': {'workload': '%s per GPU: batch=%d %dx%dx3 T=%d %s--loss %s %s(k=%d) --opt %s %s'
+                               % ('BASELINE config 2' if is_config2 else 'variant of BASELINE config 2',
+                                  B, S, S, args.seq_len, '--adv ' if adv else '', args.loss, '--dna ' if dna else 'plain-G ',
                                   args.ksize, args.opt, 'fp32' if args.dtype == 'f32' else 'bf16-MFMA/fp32-accumulate'),
                    'global_batch': B * world, 'n_critic': n_critic, 'parallelism': 'dp%d' % world,
                    'hip_graphs': not args.no_graphs, 'sequences_per_s': round(world * B * args.steps / elapsed, 1)},

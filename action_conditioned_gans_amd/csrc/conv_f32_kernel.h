@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
   constexpr int QA = BM / 32, QB = BN / 32;  // quads per thread per K-step
   constexpr int NROW = (MODE == MODE_WGRAD) ? 2 * 256 : BM;  // WGRAD: row infos of 2 x 8 K-steps (chunk parity)
 #ifndef ACG_NST
-#define ACG_NST 4
+#define ACG_NST 3      // whole-step sweep: 2 -> 339.5, 3 -> 349, 4 -> 344, 5 -> 340 steps/s
 #endif
   constexpr int NST = ACG_NST;           // register stages: global loads run NST K-steps ahead of their MFMAs
 

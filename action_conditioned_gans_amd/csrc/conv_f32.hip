@@ -25,6 +25,8 @@
 // block hides memory latency on its own even when the grid is too small for many blocks per CU.  Small
 // grids are filled by split-K over blockIdx.z into workspace slabs that a second kernel sums in fixed
 // order (deterministic; no float atomics).
+#include <stdlib.h>
+
 #include "conv_f32_kernel.h"
 
 using namespace acgconv;
@@ -77,6 +79,11 @@ int validate(const acg_conv_desc* d, const char* who) {
 // Tuning hook (acg_debug_conv_plan): force a tile configuration / split-K factor; -1 = heuristic.
 int g_force_cfg = -1, g_force_splits = -1;
 
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
 Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
   Plan pl{};
   pl.bf16 = bf16;
@@ -111,9 +118,11 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
   if (g_force_cfg >= 0 && g_force_cfg < 4) pl.cfg = g_force_cfg <= 2 ? 2 : 3;
   pl.bm = pl.cfg == 2 ? 128 : 64; pl.bn = pl.cfg == 2 ? 32 : 64;
   pl.tiles = tiles_for(pl.bm, pl.bn);
-  const long long target = which == ACG_CONV_WGRAD ? 512 : 256;
+  // tuning hooks (whole-step sweeps): ACG_PLAN_TARGET_FD / _W / ACG_PLAN_MIN_STEPS override the constants below
+  static const int t_fd = env_int("ACG_PLAN_TARGET_FD", 256), t_w = env_int("ACG_PLAN_TARGET_W", 512), min_steps = env_int("ACG_PLAN_MIN_STEPS", 4);
+  const long long target = which == ACG_CONV_WGRAD ? t_w : t_fd;
   long long s = target / pl.tiles;
-  s = std::min<long long>(s, std::max(1, pl.nk / 4));
+  s = std::min<long long>(s, std::max(1, pl.nk / min_steps));
   s = std::min<long long>(s, 128);
   if (g_force_splits >= 1) s = std::min<long long>(g_force_splits, pl.nk);
   pl.splits = (int)std::max<long long>(s, 1);

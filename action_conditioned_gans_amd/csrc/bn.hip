@@ -10,6 +10,8 @@
 // deterministic.
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "common.h"
@@ -17,6 +19,11 @@
 namespace {
 
 constexpr int kMaxPartialBlocks = 512;
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
 constexpr int kMaxC = 1024;
 
 struct ColMap {
@@ -441,7 +448,8 @@ int vapply_blocks(long long R, int C, int V) {
 // row-chunk count of the tiled apply kernels: ~4 passes of 32 rows per block, total blocks capped
 int tile_row_blocks(long long R, int C, int V) {
   const long long cchunks = (C + 8 * V - 1) / (8 * V);
-  long long n = acg::ceil_div(R, 32 * 4);
+  static const int passes = env_int("ACG_BN_APPLY_PASSES", 4);      // tuning hook
+  long long n = acg::ceil_div(R, 32 * passes);
   const long long cap = std::max<long long>(1, 4096 / cchunks);
   if (n > cap) n = cap;
   if (n < 1) n = 1;
@@ -484,7 +492,8 @@ int32_t acg_bn_act_fwd(const void* x, const float* beta, void* y, float* save_me
   float* part = (float*)ws;
   const bool v4 = vec4_ok(C, x, y, beta) && vec4_ok(C, save_mean, save_rstd, ws);
   const int V = v4 ? 4 : 1;
-  const int nblk = vpartial_blocks(R, C, V, 8);
+  static const int stats_iters = env_int("ACG_BN_STATS_ITERS", 8);  // tuning hook
+  const int nblk = vpartial_blocks(R, C, V, stats_iters);
   if (v4) hipLaunchKernelGGL(bn_stats_partial<4>, dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk);
   else hipLaunchKernelGGL(bn_stats_partial<1>, dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk);
   if (int rc = acg::check_launch("bn_stats_partial")) return rc;
@@ -509,7 +518,8 @@ int32_t acg_bn_act_bwd(const void* x, const void* dy, const float* beta, const f
   float* part = (float*)ws;
   const bool v4 = vec4_ok(C, x, dy, dx) && vec4_ok(C, save_mean, save_rstd, ws) && vec4_ok(C, beta, dbeta, ws);
   const int V = v4 ? 4 : 1;
-  const int nblk = vpartial_blocks(R, C, V, 4);
+  static const int bwd_iters = env_int("ACG_BN_BWD_ITERS", 4);      // tuning hook
+  const int nblk = vpartial_blocks(R, C, V, bwd_iters);
   if (v4) hipLaunchKernelGGL(bn_bwd_partial<4>, dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak);
   else hipLaunchKernelGGL(bn_bwd_partial<1>, dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak);
   if (int rc = acg::check_launch("bn_bwd_partial")) return rc;

@@ -494,12 +494,12 @@ int32_t acg_bn_act_fwd(const void* x, const float* beta, void* y, float* save_me
   const int V = v4 ? 4 : 1;
   static const int stats_iters = env_int("ACG_BN_STATS_ITERS", 8);  // tuning hook
   const int nblk = vpartial_blocks(R, C, V, stats_iters);
-  if (v4) hipLaunchKernelGGL(bn_stats_partial<4>, dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk);
-  else hipLaunchKernelGGL(bn_stats_partial<1>, dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk);
+  if (v4) ACG_LAUNCH(bn_stats_partial<4>, dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk);
+  else ACG_LAUNCH(bn_stats_partial<1>, dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk);
   if (int rc = acg::check_launch("bn_stats_partial")) return rc;
   const dim3 ag(tile_row_blocks(R, C, V), (C + 8 * V - 1) / (8 * V), groups);
-  if (v4) hipLaunchKernelGGL(bn_apply_fwd<4>, ag, dim3(256), 0, st, xf, beta, (const float*)part, (float*)y, save_mean, save_rstd, R, C, nblk, eps, act, leak);
-  else hipLaunchKernelGGL(bn_apply_fwd<1>, ag, dim3(256), 0, st, xf, beta, (const float*)part, (float*)y, save_mean, save_rstd, R, C, nblk, eps, act, leak);
+  if (v4) ACG_LAUNCH(bn_apply_fwd<4>, ag, dim3(256), 0, st, xf, beta, (const float*)part, (float*)y, save_mean, save_rstd, R, C, nblk, eps, act, leak);
+  else ACG_LAUNCH(bn_apply_fwd<1>, ag, dim3(256), 0, st, xf, beta, (const float*)part, (float*)y, save_mean, save_rstd, R, C, nblk, eps, act, leak);
   return acg::check_launch("bn_apply_fwd");
 }
 
@@ -520,12 +520,12 @@ int32_t acg_bn_act_bwd(const void* x, const void* dy, const float* beta, const f
   const int V = v4 ? 4 : 1;
   static const int bwd_iters = env_int("ACG_BN_BWD_ITERS", 4);      // tuning hook
   const int nblk = vpartial_blocks(R, C, V, bwd_iters);
-  if (v4) hipLaunchKernelGGL(bn_bwd_partial<4>, dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak);
-  else hipLaunchKernelGGL(bn_bwd_partial<1>, dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak);
+  if (v4) ACG_LAUNCH(bn_bwd_partial<4>, dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak);
+  else ACG_LAUNCH(bn_bwd_partial<1>, dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak);
   if (int rc = acg::check_launch("bn_bwd_partial")) return rc;
   const dim3 ag(tile_row_blocks(R, C, V), (C + 8 * V - 1) / (8 * V), groups);
-  if (v4) hipLaunchKernelGGL(bn_apply_bwd<4>, ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)part, (float*)dx, dbeta, dbeta_acc, R, C, groups, nblk, act, leak);
-  else hipLaunchKernelGGL(bn_apply_bwd<1>, ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)part, (float*)dx, dbeta, dbeta_acc, R, C, groups, nblk, act, leak);
+  if (v4) ACG_LAUNCH(bn_apply_bwd<4>, ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)part, (float*)dx, dbeta, dbeta_acc, R, C, groups, nblk, act, leak);
+  else ACG_LAUNCH(bn_apply_bwd<1>, ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)part, (float*)dx, dbeta, dbeta_acc, R, C, groups, nblk, act, leak);
   return acg::check_launch("bn_apply_bwd");
 }
 
@@ -540,7 +540,7 @@ int32_t acg_bias_act_fwd(const void* x, const float* bias, void* y, int64_t rows
   ACG_REQUIRE(rows > 0 && C > 0, ACG_ERR_INVALID_ARG, "bias_act_fwd: non-positive size");
   ACG_REQUIRE(x && y, ACG_ERR_INVALID_ARG, "bias_act_fwd: null pointer");
   ACG_REQUIRE(act >= ACG_ACT_NONE && act <= ACG_ACT_TANH, ACG_ERR_INVALID_ARG, "bias_act_fwd: activation %d", act);
-  hipLaunchKernelGGL(bias_act_fwd_k, dim3(apply_blocks(rows, C)), dim3(256), 0, acg::to_stream(stream), (const float*)x,
+  ACG_LAUNCH(bias_act_fwd_k, dim3(apply_blocks(rows, C)), dim3(256), 0, acg::to_stream(stream), (const float*)x,
                      bias, (float*)y, (long long)rows, C, act, leak);
   return acg::check_launch("bias_act_fwd");
 }
@@ -555,11 +555,11 @@ int32_t acg_bias_act_bwd(const void* y, const void* dy, void* dx, float* dbias, 
   ACG_REQUIRE(!dbias || (ws && wsb >= acg_bias_workspace_bytes(rows, C)), ACG_ERR_WORKSPACE, "bias_act_bwd: workspace too small");
   const int nblk = partial_blocks(rows, C);
   hipStream_t st = acg::to_stream(stream);
-  hipLaunchKernelGGL(bias_act_bwd_partial, dim3(nblk), dim3(256), 0, st, (const float*)y, (const float*)dy, (float*)dx,
+  ACG_LAUNCH(bias_act_bwd_partial, dim3(nblk), dim3(256), 0, st, (const float*)y, (const float*)dy, (float*)dx,
                      dbias ? (float*)ws : (float*)nullptr, (long long)rows, C, nblk, act, leak);
   if (int rc = acg::check_launch("bias_act_bwd_partial")) return rc;
   if (!dbias) return ACG_OK;
-  hipLaunchKernelGGL(colsum_finalize, dim3((C + 31) / 32), dim3(256), 0, st, (const float*)ws, dbias, dbias_acc, C, nblk);
+  ACG_LAUNCH(colsum_finalize, dim3((C + 31) / 32), dim3(256), 0, st, (const float*)ws, dbias, dbias_acc, C, nblk);
   return acg::check_launch("colsum_finalize");
 }
 

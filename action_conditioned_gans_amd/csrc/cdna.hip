@@ -235,9 +235,9 @@ int32_t acg_cdna_fwd(const void* params, const void* image, void* out, float* ke
   const dim3 grid(g.tiles_x, g.tiles_y, B);
   hipStream_t st = acg::to_stream(stream);
   const float *pp = (const float*)params, *im = (const float*)image;
-  if (K == 3) hipLaunchKernelGGL(cdna_fwd_k<3>, grid, dim3(256), 0, st, pp, im, (float*)out, kern_norm, g, relu_shift);
-  else if (K == 5) hipLaunchKernelGGL(cdna_fwd_k<5>, grid, dim3(256), 0, st, pp, im, (float*)out, kern_norm, g, relu_shift);
-  else hipLaunchKernelGGL(cdna_fwd_k<7>, grid, dim3(256), 0, st, pp, im, (float*)out, kern_norm, g, relu_shift);
+  if (K == 3) ACG_LAUNCH(cdna_fwd_k<3>, grid, dim3(256), 0, st, pp, im, (float*)out, kern_norm, g, relu_shift);
+  else if (K == 5) ACG_LAUNCH(cdna_fwd_k<5>, grid, dim3(256), 0, st, pp, im, (float*)out, kern_norm, g, relu_shift);
+  else ACG_LAUNCH(cdna_fwd_k<7>, grid, dim3(256), 0, st, pp, im, (float*)out, kern_norm, g, relu_shift);
   return acg::check_launch("cdna_fwd");
 }
 
@@ -252,12 +252,12 @@ int32_t acg_cdna_bwd(const void* params, const float* kern_norm, const void* ima
   hipStream_t st = acg::to_stream(stream);
   const dim3 grid(g.tiles_x, g.tiles_y, B);
   if (dimage) {
-    hipLaunchKernelGGL(cdna_bwd_img_k, grid, dim3(256), 0, st, kern_norm, (const float*)dout, (float*)dimage, g);
+    ACG_LAUNCH(cdna_bwd_img_k, grid, dim3(256), 0, st, kern_norm, (const float*)dout, (float*)dimage, g);
     if (int rc = acg::check_launch("cdna_bwd_img")) return rc;
   }
-  hipLaunchKernelGGL(cdna_bwd_kern_partial_k, grid, dim3(256), 0, st, (const float*)image, (const float*)dout, (float*)ws, g);
+  ACG_LAUNCH(cdna_bwd_kern_partial_k, grid, dim3(256), 0, st, (const float*)image, (const float*)dout, (float*)ws, g);
   if (int rc = acg::check_launch("cdna_bwd_kern_partial")) return rc;
-  hipLaunchKernelGGL(cdna_bwd_kern_final_k, dim3(B), dim3(256), 0, st, (const float*)params, kern_norm, (const float*)ws,
+  ACG_LAUNCH(cdna_bwd_kern_final_k, dim3(B), dim3(256), 0, st, (const float*)params, kern_norm, (const float*)ws,
                      (float*)dparams, g, relu_shift);
   return acg::check_launch("cdna_bwd_kern_final");
 }

@@ -14,6 +14,15 @@ int check_launch(const char* what);
 
 static inline hipStream_t to_stream(acg_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Every launch first drops whatever error an unrelated HIP call left behind on this thread (torch and RCCL make
+// calls whose benign failures stay "last error" until somebody reads them, e.g. peer access already enabled), so that
+// check_launch reports the launch it follows and nothing else.
+#define ACG_LAUNCH(...)                \
+  do {                                 \
+    (void)hipGetLastError();           \
+    hipLaunchKernelGGL(__VA_ARGS__);   \
+  } while (0)
+
 constexpr int kWave = 64;  // CDNA wavefront
 
 // ---- device-side reductions -----------------------------------------------------------------

@@ -162,7 +162,7 @@ int run(int which, const float* gsrc, const float* dense, float* out, float accu
   if (rc) return rc;
   if (pl.splits > 1) {
     const int blocks = (int)std::min<long long>(acg::ceil_div(pl.out_numel, 256 * 4), 2048);
-    hipLaunchKernelGGL(splitk_reduce, dim3(std::max(blocks, 1)), dim3(256), 0, st, (const float*)ws, out, pl.out_numel, pl.splits,
+    ACG_LAUNCH(splitk_reduce, dim3(std::max(blocks, 1)), dim3(256), 0, st, (const float*)ws, out, pl.out_numel, pl.splits,
                        which == ACG_CONV_WGRAD ? accumulate : 0.f);
     return acg::check_launch("splitk_reduce");
   }

@@ -649,8 +649,8 @@ static inline void launch_cfg(const Plan& pl, const ConvArgs& a, hipStream_t st)
   const dim3 grid((unsigned)(acg::ceil_div(pl.M, pl.bm) * acg::ceil_div(pl.N, pl.bn)), (unsigned)pl.classes, (unsigned)pl.splits);
   // two tile shapes: 128x32 for narrow N, 64x64 otherwise.  128x128 / 128x64 variants existed through v4; with the
   // one-barrier pipeline they lost every layer of the tuning sweep (profiles/r1) and were dropped.
-  if (pl.cfg == 2) hipLaunchKernelGGL((conv_mfma_f32<MODE, 128, 32, 4, 1, RAGGED, NVEC, BF16>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((conv_mfma_f32<MODE, 64, 64, 2, 2, RAGGED, NVEC, BF16>), grid, dim3(256), 0, st, a);
+  if (pl.cfg == 2) ACG_LAUNCH((conv_mfma_f32<MODE, 128, 32, 4, 1, RAGGED, NVEC, BF16>), grid, dim3(256), 0, st, a);
+  else ACG_LAUNCH((conv_mfma_f32<MODE, 64, 64, 2, 2, RAGGED, NVEC, BF16>), grid, dim3(256), 0, st, a);
 }
 template <int MODE, bool BF16>
 static inline void launch_variant(const Plan& pl, const ConvArgs& a, hipStream_t st) {

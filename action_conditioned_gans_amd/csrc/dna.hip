@@ -270,14 +270,14 @@ int launch_k(const float* logits, const float* img, const float* dout, float* ou
 #endif
   if constexpr (K >= ACG_DNA_ROWS_MIN) {
     const dim3 grid((W + 63) / 64, H, B);
-    if (C == 3) hipLaunchKernelGGL((dna_rows_kernel<K, BWD, 3>), grid, dim3(256), 0, st, logits, img, dout, out, H, W, C);
-    else hipLaunchKernelGGL((dna_rows_kernel<K, BWD, 0>), grid, dim3(256), 0, st, logits, img, dout, out, H, W, C);
+    if (C == 3) ACG_LAUNCH((dna_rows_kernel<K, BWD, 3>), grid, dim3(256), 0, st, logits, img, dout, out, H, W, C);
+    else ACG_LAUNCH((dna_rows_kernel<K, BWD, 0>), grid, dim3(256), 0, st, logits, img, dout, out, H, W, C);
     return acg::check_launch(BWD ? "dna_bwd" : "dna_fwd");
   }
   constexpr int TY = K <= 6 ? 4 : 1;
   const dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, B);
-  if (C == 3) hipLaunchKernelGGL((dna_kernel<K, TY, BWD, 3>), grid, dim3(TX * TY), 0, st, logits, img, dout, out, H, W, C);
-  else hipLaunchKernelGGL((dna_kernel<K, TY, BWD, 0>), grid, dim3(TX * TY), 0, st, logits, img, dout, out, H, W, C);
+  if (C == 3) ACG_LAUNCH((dna_kernel<K, TY, BWD, 3>), grid, dim3(TX * TY), 0, st, logits, img, dout, out, H, W, C);
+  else ACG_LAUNCH((dna_kernel<K, TY, BWD, 0>), grid, dim3(TX * TY), 0, st, logits, img, dout, out, H, W, C);
   return acg::check_launch(BWD ? "dna_bwd" : "dna_fwd");
 }
 

@@ -108,7 +108,7 @@ int32_t acg_concat_actions_fwd(const void* x, const float* actions, void* y, int
   const int pitch = y_pitch > 0 ? y_pitch : c + a;
   ACG_REQUIRE(pitch >= c + a, ACG_ERR_INVALID_ARG, "concat_actions_fwd: pitch smaller than the row");
   const long long rows = (long long)B * hw;
-  hipLaunchKernelGGL(concat_k, dim3(grid_for(rows * (c + a))), dim3(256), 0, acg::to_stream(stream), (const float*)x,
+  ACG_LAUNCH(concat_k, dim3(grid_for(rows * (c + a))), dim3(256), 0, acg::to_stream(stream), (const float*)x,
                      actions, (float*)y, rows, c, a, hw, pitch);
   return acg::check_launch("concat_actions_fwd");
 }
@@ -120,7 +120,7 @@ int32_t acg_concat_channels_fwd(const void* a, const void* b, void* y, int64_t r
   ACG_REQUIRE(a && (b || cb == 0) && y, ACG_ERR_INVALID_ARG, "concat_channels_fwd: null pointer");
   const int pitch = y_pitch > 0 ? y_pitch : ca + cb;
   ACG_REQUIRE(pitch >= ca + cb, ACG_ERR_INVALID_ARG, "concat_channels_fwd: pitch smaller than the row");
-  hipLaunchKernelGGL(concat_k, dim3(grid_for(rows * (ca + cb))), dim3(256), 0, acg::to_stream(stream), (const float*)a,
+  ACG_LAUNCH(concat_k, dim3(grid_for(rows * (ca + cb))), dim3(256), 0, acg::to_stream(stream), (const float*)a,
                      (const float*)b, (float*)y, (long long)rows, ca, cb, 1, pitch);
   return acg::check_launch("concat_channels_fwd");
 }
@@ -131,7 +131,7 @@ int32_t acg_slice_channels(const void* src, void* dst, float accumulate, int64_t
   ACG_REQUIRE(rows > 0 && c_src > 0 && c_dst > 0, ACG_ERR_INVALID_ARG, "slice_channels: non-positive size");
   ACG_REQUIRE(c_off >= 0 && c_off + c_dst <= c_src, ACG_ERR_INVALID_ARG, "slice_channels: range outside source");
   ACG_REQUIRE(src && dst, ACG_ERR_INVALID_ARG, "slice_channels: null pointer");
-  hipLaunchKernelGGL(slice_k, dim3(grid_for(rows * c_dst)), dim3(256), 0, acg::to_stream(stream), (const float*)src,
+  ACG_LAUNCH(slice_k, dim3(grid_for(rows * c_dst)), dim3(256), 0, acg::to_stream(stream), (const float*)src,
                      (float*)dst, accumulate, (long long)rows, c_src, c_off, c_dst);
   return acg::check_launch("slice_channels");
 }
@@ -139,7 +139,7 @@ int32_t acg_slice_channels(const void* src, void* dst, float accumulate, int64_t
 int32_t acg_add(const void* a, const void* b, void* y, int64_t n, int32_t dtype, acg_stream_t stream) {
   ACG_REQUIRE_F32(dtype);
   ACG_REQUIRE(n > 0 && a && b && y, ACG_ERR_INVALID_ARG, "add: bad argument");
-  hipLaunchKernelGGL(add_k, dim3(grid_for(n / 4 + 1)), dim3(256), 0, acg::to_stream(stream), (const float*)a,
+  ACG_LAUNCH(add_k, dim3(grid_for(n / 4 + 1)), dim3(256), 0, acg::to_stream(stream), (const float*)a,
                      (const float*)b, (float*)y, (long long)n);
   return acg::check_launch("add");
 }

@@ -146,31 +146,31 @@ int32_t acg_frame_loss(const void* gen, const void* gt, float* out2, void* dgen,
   const long long n = (long long)B * H * W * C;
   const int nblk = blocks_for(n);
   hipStream_t st = acg::to_stream(stream);
-  hipLaunchKernelGGL(frame_loss_k, dim3(nblk), dim3(256), 0, st, (const float*)gen, (const float*)gt, (float*)ws,
+  ACG_LAUNCH(frame_loss_k, dim3(nblk), dim3(256), 0, st, (const float*)gen, (const float*)gt, (float*)ws,
                      (float*)dgen, n, H, W, C, w_l1, w_gdl);
   if (int rc = acg::check_launch("frame_loss")) return rc;
-  hipLaunchKernelGGL(finalize_k, dim3(1), dim3(256), 0, st, (const float*)ws, out2, nblk, 2, 0, 1.0);
+  ACG_LAUNCH(finalize_k, dim3(1), dim3(256), 0, st, (const float*)ws, out2, nblk, 2, 0, 1.0);
   return acg::check_launch("frame_loss finalize");
 }
 
 int32_t acg_l2norm_loss(const float* pred, const float* gt, float* out, float* dpred, int64_t n, float scale, acg_stream_t stream) {
   ACG_REQUIRE(n > 0 && n <= 65536, ACG_ERR_INVALID_ARG, "l2norm_loss: n outside 1..65536");
   ACG_REQUIRE(pred && gt && out, ACG_ERR_INVALID_ARG, "l2norm_loss: null pointer");
-  hipLaunchKernelGGL(l2norm_loss_k, dim3(1), dim3(1024), 0, acg::to_stream(stream), pred, gt, out, dpred, (int)n, scale);
+  ACG_LAUNCH(l2norm_loss_k, dim3(1), dim3(1024), 0, acg::to_stream(stream), pred, gt, out, dpred, (int)n, scale);
   return acg::check_launch("l2norm_loss");
 }
 
 int32_t acg_sigmoid_ce_loss(const float* logits, float label, float* out, float* dlogits, int64_t n, float scale, acg_stream_t stream) {
   ACG_REQUIRE(n > 0 && n <= 65536, ACG_ERR_INVALID_ARG, "sigmoid_ce_loss: n outside 1..65536");
   ACG_REQUIRE(logits && out, ACG_ERR_INVALID_ARG, "sigmoid_ce_loss: null pointer");
-  hipLaunchKernelGGL(sigmoid_ce_loss_k, dim3(1), dim3(1024), 0, acg::to_stream(stream), logits, label, out, dlogits, (int)n, scale);
+  ACG_LAUNCH(sigmoid_ce_loss_k, dim3(1), dim3(1024), 0, acg::to_stream(stream), logits, label, out, dlogits, (int)n, scale);
   return acg::check_launch("sigmoid_ce_loss");
 }
 
 int32_t acg_mean_loss(const float* x, float* out, float* dx, int64_t n, float scale, acg_stream_t stream) {
   ACG_REQUIRE(n > 0 && n <= 65536, ACG_ERR_INVALID_ARG, "mean_loss: n outside 1..65536");
   ACG_REQUIRE(x && out, ACG_ERR_INVALID_ARG, "mean_loss: null pointer");
-  hipLaunchKernelGGL(mean_loss_k, dim3(1), dim3(1024), 0, acg::to_stream(stream), x, out, dx, (int)n, scale);
+  ACG_LAUNCH(mean_loss_k, dim3(1), dim3(1024), 0, acg::to_stream(stream), x, out, dx, (int)n, scale);
   return acg::check_launch("mean_loss");
 }
 
@@ -180,16 +180,16 @@ int32_t acg_psnr(const void* a, const void* b, float* out, int64_t n, int32_t dt
   ACG_REQUIRE(ws && wsb >= kPartialBytes, ACG_ERR_WORKSPACE, "psnr: workspace too small");
   const int nblk = blocks_for(n);
   hipStream_t st = acg::to_stream(stream);
-  hipLaunchKernelGGL(sqdiff_partial_k, dim3(nblk), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)ws, (long long)n);
+  ACG_LAUNCH(sqdiff_partial_k, dim3(nblk), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)ws, (long long)n);
   if (int rc = acg::check_launch("psnr partial")) return rc;
-  hipLaunchKernelGGL(finalize_k, dim3(1), dim3(256), 0, st, (const float*)ws, out, nblk, 1, 1, (double)n);
+  ACG_LAUNCH(finalize_k, dim3(1), dim3(256), 0, st, (const float*)ws, out, nblk, 1, 1, (double)n);
   return acg::check_launch("psnr finalize");
 }
 
 int32_t acg_scalar_combine(float* out, const float* i0, float w0, const float* i1, float w1, const float* i2, float w2,
                            const float* i3, float w3, acg_stream_t stream) {
   ACG_REQUIRE(out, ACG_ERR_INVALID_ARG, "scalar_combine: null output");
-  hipLaunchKernelGGL(scalar_combine_k, dim3(1), dim3(1), 0, acg::to_stream(stream), out, i0, w0, i1, w1, i2, w2, i3, w3);
+  ACG_LAUNCH(scalar_combine_k, dim3(1), dim3(1), 0, acg::to_stream(stream), out, i0, w0, i1, w1, i2, w2, i3, w3);
   return acg::check_launch("scalar_combine");
 }
 

@@ -89,7 +89,7 @@ int32_t acg_adam_step(float* param, const float* grad, float* m, float* v, const
                       float beta1, float beta2, float eps, float grad_scale, int32_t use_clip, float clip_lo, float clip_hi,
                       acg_stream_t stream) {
   ACG_REQUIRE(n > 0 && param && grad && m && v && step_dev, ACG_ERR_INVALID_ARG, "adam_step: bad argument");
-  hipLaunchKernelGGL(adam_k, dim3(grid_for(n / 4 + 1)), dim3(256), 0, acg::to_stream(stream), param, grad, m, v, step_dev,
+  ACG_LAUNCH(adam_k, dim3(grid_for(n / 4 + 1)), dim3(256), 0, acg::to_stream(stream), param, grad, m, v, step_dev,
                      (long long)n, lr, beta1, beta2, eps, grad_scale, use_clip, clip_lo, clip_hi);
   return acg::check_launch("adam_step");
 }
@@ -97,20 +97,20 @@ int32_t acg_adam_step(float* param, const float* grad, float* m, float* v, const
 int32_t acg_rmsprop_step(float* param, const float* grad, float* ms, int64_t n, float lr, float decay, float eps,
                          float grad_scale, int32_t use_clip, float clip_lo, float clip_hi, acg_stream_t stream) {
   ACG_REQUIRE(n > 0 && param && grad && ms, ACG_ERR_INVALID_ARG, "rmsprop_step: bad argument");
-  hipLaunchKernelGGL(rmsprop_k, dim3(grid_for(n / 4 + 1)), dim3(256), 0, acg::to_stream(stream), param, grad, ms,
+  ACG_LAUNCH(rmsprop_k, dim3(grid_for(n / 4 + 1)), dim3(256), 0, acg::to_stream(stream), param, grad, ms,
                      (long long)n, lr, decay, eps, grad_scale, use_clip, clip_lo, clip_hi);
   return acg::check_launch("rmsprop_step");
 }
 
 int32_t acg_clip(float* param, int64_t n, float lo, float hi, acg_stream_t stream) {
   ACG_REQUIRE(n > 0 && param, ACG_ERR_INVALID_ARG, "clip: bad argument");
-  hipLaunchKernelGGL(clip_k, dim3(grid_for(n)), dim3(256), 0, acg::to_stream(stream), param, (long long)n, lo, hi);
+  ACG_LAUNCH(clip_k, dim3(grid_for(n)), dim3(256), 0, acg::to_stream(stream), param, (long long)n, lo, hi);
   return acg::check_launch("clip");
 }
 
 int32_t acg_step_inc(int32_t* step_dev, acg_stream_t stream) {
   ACG_REQUIRE(step_dev, ACG_ERR_INVALID_ARG, "step_inc: null counter");
-  hipLaunchKernelGGL(step_inc_k, dim3(1), dim3(1), 0, acg::to_stream(stream), step_dev);
+  ACG_LAUNCH(step_inc_k, dim3(1), dim3(1), 0, acg::to_stream(stream), step_dev);
   return acg::check_launch("step_inc");
 }
 

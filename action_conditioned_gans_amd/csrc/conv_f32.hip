@@ -119,8 +119,10 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
   pl.bm = pl.cfg == 2 ? 128 : 64; pl.bn = pl.cfg == 2 ? 32 : 64;
   pl.tiles = tiles_for(pl.bm, pl.bn);
   // tuning hooks (whole-step sweeps): ACG_PLAN_TARGET_FD / _W / ACG_PLAN_MIN_STEPS override the constants below
-  static const int t_fd = env_int("ACG_PLAN_TARGET_FD", 256), t_w = env_int("ACG_PLAN_TARGET_W", 512), min_steps = env_int("ACG_PLAN_MIN_STEPS", 4);
-  const long long target = which == ACG_CONV_WGRAD ? t_w : t_fd;
+  static const int t_fd = env_int("ACG_PLAN_TARGET_FD", 0), t_w = env_int("ACG_PLAN_TARGET_W", 512), min_steps = env_int("ACG_PLAN_MIN_STEPS", 4);
+  // bf16 K-steps are ~2x cheaper (matrix cores, loader-bound): two resident blocks per CU pay off there as well
+  // (whole-step sweep: 507 vs 500 steps/s)
+  const long long target = which == ACG_CONV_WGRAD ? t_w : (t_fd > 0 ? t_fd : (bf16 ? 512 : 256));
   long long s = target / pl.tiles;
   s = std::min<long long>(s, std::max(1, pl.nk / min_steps));
   s = std::min<long long>(s, 128);

@@ -6,7 +6,7 @@
 // pass 1 leaves per-block partial sums (shifted by the group's first row, so E[x^2]-E[x]^2 cannot
 // cancel catastrophically) in the workspace; pass 2 is tiled rows x 32 channels, re-derives the statistics
 // of its own channels from the partials (fp64 combine) and applies normalise + activation.  Two launches per
-// direction (a trivial launch costs ~4.7 us on this part - more than the few redundant L2 reads), no atomics,
+// direction (a launch costs more than the few redundant L2 reads of the partials), no atomics,
 // deterministic.
 #include <hip/hip_runtime.h>
 

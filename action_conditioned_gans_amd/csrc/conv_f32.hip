@@ -20,11 +20,10 @@
 // inside a K-step is free: lane half h reads quad 2t+h of both tiles and feeds its four floats to four
 // consecutive MFMAs - one ds_read_b128 per 32x32 tile per 8 k.
 //
-// Tiling: 256 threads = 4 waves, block tile BM x BN x 32, wave tile (BM/WM) x (BN/WN) built from 32x32
-// MFMA tiles.  Global loads run TWO K-steps ahead of the MFMAs in registers (two named stages), so a
-// block hides memory latency on its own even when the grid is too small for many blocks per CU.  Small
-// grids are filled by split-K over blockIdx.z into workspace slabs that a second kernel sums in fixed
-// order (deterministic; no float atomics).
+// Tiling: 256 threads = 4 waves, block tile 64 x 64 x 32 (128 x 32 for N <= 32), wave tile 32 x 32.  Global loads
+// run NST-1 K-steps ahead of the MFMAs through NST register stages and a double-buffered LDS tile (one barrier per
+// K-step; pipeline notes in conv_f32_kernel.h).  Small grids are filled by split-K over blockIdx.z into workspace
+// slabs that a second kernel sums in fixed order (deterministic; no float atomics).
 #include <stdlib.h>
 
 #include "conv_f32_kernel.h"

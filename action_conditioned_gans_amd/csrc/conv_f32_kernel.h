@@ -13,7 +13,6 @@ namespace acgconv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f4 __attribute__((ext_vector_type(4)));
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned 16-byte global load
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
@@ -97,7 +96,7 @@ __device__ __forceinline__ bool tap_ok(const RowInfo& ri, int t) {
 // drags the wait up to the load as well.  Instead each operand tensor is addressed through a raw buffer
 // resource (base + 32-bit byte offset, hardware range check): a masked lane gets an offset beyond the buffer
 // and the load returns zeros without touching memory.  One v_cndmask on a 32-bit offset per load, no 64-bit
-// pointer arithmetic, and every load of a stage issues back to back; the first wait is two K-steps later.
+// pointer arithmetic, and every load of a stage issues back to back; the first wait is NST-1 K-steps later.
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kOob = 0xFFFFFF00u;   // >= any num_records (tensors are < 2^30 elements)
 
@@ -251,7 +250,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
   }
   __syncthreads();
 
-  // ---- loaders: two register stages ---------------------------------------------------------------
+  // ---- loaders: NST register stages ---------------------------------------------------------------
   // k-fast operands (A of FWD/DGRAD, B of DGRAD) are gathered one quad per (row, k/4); the others
   // (B of FWD, A and B of WGRAD) are contiguous along the tile column, so a thread loads a 4x4 block
   // (4 k-rows x float4 of columns) and transposes it in registers into 4 quads.

@@ -33,6 +33,12 @@ class ConvDesc(ctypes.Structure):
         return tuple(getattr(self, n) for n, _ in self._fields_)
 
 
+class CopyList(ctypes.Structure):
+    """struct acg_copy_list (ACG_COPY_MAX = 8 segments)."""
+    _fields_ = [('src', c_void_p * 8), ('dst', c_void_p * 8), ('rows', c_int64 * 8), ('cols', c_int32 * 8),
+                ('dst_pitch', c_int32 * 8)]
+
+
 _P = c_void_p
 _D = ctypes.POINTER(ConvDesc)
 _conv = [_P, _P, _P, _D, c_int32, _P, c_size_t, _P]
@@ -69,6 +75,7 @@ SIGNATURES = {
     'acg_concat_actions_fwd': (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     'acg_concat_channels_fwd': (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P]),
     'acg_slice_channels': (c_int32, [_P, _P, c_float, c_int64, c_int32, c_int32, c_int32, c_int32, _P]),
+    'acg_copy_many': (c_int32, [ctypes.POINTER(CopyList), c_int32, c_int32, _P]),
     'acg_add': (c_int32, [_P, _P, _P, c_int64, c_int32, _P]),
     'acg_frame_loss_workspace_bytes': (c_size_t, [c_int64]),
     'acg_frame_loss': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_int32,
@@ -85,6 +92,9 @@ SIGNATURES = {
     'acg_clip': (c_int32, [_P, c_int64, c_float, c_float, _P]),
     'acg_step_inc': (c_int32, [_P, _P]),
 }
+
+
+COPY_MAX = 8
 
 
 class AcgError(RuntimeError):

@@ -5,6 +5,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace acg {
@@ -92,6 +94,33 @@ __global__ __launch_bounds__(256) void add_k(const float* __restrict__ a, const 
   for (long long i = n4 * 4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] = a[i] + b[i];
 }
 
+struct CopyList {
+  const float* src[ACG_COPY_MAX];
+  float* dst[ACG_COPY_MAX];
+  long long rows[ACG_COPY_MAX];
+  int cols[ACG_COPY_MAX], pitch[ACG_COPY_MAX];
+};
+
+// blockIdx.y = segment; float4 when the segment is dense and aligned, else one float per thread with 32-bit row math
+__global__ __launch_bounds__(256) void copy_many_k(const CopyList l) {
+  const int sgm = blockIdx.y;
+  const float* __restrict__ src = l.src[sgm];
+  float* __restrict__ dst = l.dst[sgm];
+  const long long rows = l.rows[sgm];
+  const int cols = l.cols[sgm], pitch = l.pitch[sgm];
+  const long long n = rows * cols, stride = (long long)gridDim.x * 256;
+  if (pitch == cols && (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += stride) d4[i] = s4[i];
+    return;
+  }
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const long long r = i / cols;
+    dst[r * pitch + (i - r * cols)] = src[i];
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -134,6 +163,23 @@ int32_t acg_slice_channels(const void* src, void* dst, float accumulate, int64_t
   ACG_LAUNCH(slice_k, dim3(grid_for(rows * c_dst)), dim3(256), 0, acg::to_stream(stream), (const float*)src,
                      (float*)dst, accumulate, (long long)rows, c_src, c_off, c_dst);
   return acg::check_launch("slice_channels");
+}
+
+int32_t acg_copy_many(const acg_copy_list* list, int32_t count, int32_t dtype, acg_stream_t stream) {
+  ACG_REQUIRE_F32(dtype);
+  ACG_REQUIRE(list && count >= 1 && count <= ACG_COPY_MAX, ACG_ERR_INVALID_ARG, "copy_many: 1..%d segments", ACG_COPY_MAX);
+  CopyList l{};
+  long long most = 0;
+  for (int i = 0; i < count; ++i) {
+    ACG_REQUIRE(list->src[i] && list->dst[i] && list->rows[i] > 0 && list->cols[i] > 0, ACG_ERR_INVALID_ARG, "copy_many: bad segment %d", i);
+    const int pitch = list->dst_pitch[i] > 0 ? list->dst_pitch[i] : list->cols[i];
+    ACG_REQUIRE(pitch >= list->cols[i], ACG_ERR_INVALID_ARG, "copy_many: segment %d pitch smaller than its row", i);
+    l.src[i] = (const float*)list->src[i]; l.dst[i] = (float*)list->dst[i];
+    l.rows[i] = list->rows[i]; l.cols[i] = list->cols[i]; l.pitch[i] = pitch;
+    most = std::max<long long>(most, list->rows[i] * list->cols[i]);
+  }
+  ACG_LAUNCH(copy_many_k, dim3(grid_for(most / 4 + 1), count), dim3(256), 0, acg::to_stream(stream), l);
+  return acg::check_launch("copy_many");
 }
 
 int32_t acg_add(const void* a, const void* b, void* y, int64_t n, int32_t dtype, acg_stream_t stream) {

@@ -482,12 +482,24 @@ class Session:
         if prog is None:
             prog = self._compile(flat, list(feed_dict.keys()))
             self._programs[key] = prog
+        fused = []
         for ph, val in feed_dict.items():
             src = val if torch.is_tensor(val) else torch.from_numpy(np.ascontiguousarray(val))
             dst = ph.buf if ph.valid_c is None else ph.buf[..., :ph.valid_c]     # pad channels stay zero
             if tuple(src.shape) != tuple(dst.shape):
                 raise ValueError('Cannot feed value of shape %s for %r' % (tuple(src.shape), ph))
-            dst.copy_(src.to(ph.dtype), non_blocking=True)
+            if (self.rt.is_cuda and src.is_cuda and src.device == ph.buf.device and src.dtype == torch.float32
+                    and ph.dtype == torch.float32 and src.is_contiguous() and len(fused) < _lib.COPY_MAX):
+                fused.append((src, ph))          # device-resident feeds: one launch for all of them (below)
+            else:
+                dst.copy_(src.to(ph.dtype), non_blocking=True)
+        if fused:
+            cl = _lib.CopyList()
+            for i, (src, ph) in enumerate(fused):
+                cols = ph.valid_c if ph.valid_c is not None else ph.shape[-1]
+                cl.src[i], cl.dst[i] = src.data_ptr(), ph.buf.data_ptr()
+                cl.rows[i], cl.cols[i], cl.dst_pitch[i] = src.numel() // cols, cols, ph.shape[-1]
+            self.rt.lib.copy_many(ctypes.byref(cl), len(fused), _lib.ACG_F32, self.rt.stream_ptr())
         self._execute(prog)
         results = []
         for t in prog.fetch_tensors:

@@ -169,6 +169,18 @@ int32_t acg_concat_channels_fwd(const void* a, const void* b, void* y, int64_t r
 /* dst[r,:] = accumulate * dst[r,:] + src[r, c_off : c_off + c_dst] */
 int32_t acg_slice_channels(const void* src, void* dst, float accumulate, int64_t rows, int32_t c_src,
                            int32_t c_off, int32_t c_dst, int32_t dtype, acg_stream_t stream);
+/* Up to ACG_COPY_MAX row-block copies in ONE launch: the feed_dict of a sess.run (train.py:115-154) lands in the
+ * placeholders with a single kernel.  Segment i copies rows[i] x cols[i] floats from src[i] (dense rows) to dst[i] whose
+ * rows are dst_pitch[i] floats apart (0 = dense; pad channels are not written). */
+#define ACG_COPY_MAX 8
+typedef struct acg_copy_list {
+  const void* src[ACG_COPY_MAX];
+  void* dst[ACG_COPY_MAX];
+  int64_t rows[ACG_COPY_MAX];
+  int32_t cols[ACG_COPY_MAX];
+  int32_t dst_pitch[ACG_COPY_MAX];
+} acg_copy_list;
+int32_t acg_copy_many(const acg_copy_list* list, int32_t count, int32_t dtype, acg_stream_t stream);
 /* y = a + b (gradient fan-in where one tensor feeds two consumers, models.py:40-53) */
 int32_t acg_add(const void* a, const void* b, void* y, int64_t n, int32_t dtype, acg_stream_t stream);
 

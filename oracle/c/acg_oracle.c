@@ -355,6 +355,18 @@ int32_t acg_slice_channels(const void* sv, void* dv, float acc, int64_t rows, in
     dst[r * c_dst + c] = (acc != 0.f ? acc * dst[r * c_dst + c] : 0.f) + src[r * c_src + c_off + c];
   return ACG_OK;
 }
+int32_t acg_copy_many(const acg_copy_list* l, int32_t count, int32_t dtype, acg_stream_t s) {
+  (void)s; REQUIRE_F32(dtype);
+  if (!l || count < 1 || count > ACG_COPY_MAX) return fail(ACG_ERR_INVALID_ARG, "copy_many: 1..8 segments");
+  for (int i = 0; i < count; i++) {
+    if (!l->src[i] || !l->dst[i] || l->rows[i] <= 0 || l->cols[i] <= 0) return fail(ACG_ERR_INVALID_ARG, "copy_many: bad segment");
+    int pitch = l->dst_pitch[i] > 0 ? l->dst_pitch[i] : l->cols[i];
+    if (pitch < l->cols[i]) return fail(ACG_ERR_INVALID_ARG, "copy_many: pitch smaller than the row");
+    const float* src = l->src[i]; float* dst = l->dst[i];
+    for (int64_t r = 0; r < l->rows[i]; r++) for (int c = 0; c < l->cols[i]; c++) dst[r * pitch + c] = src[r * l->cols[i] + c];
+  }
+  return ACG_OK;
+}
 int32_t acg_add(const void* av, const void* bv, void* yv, int64_t n, int32_t dtype, acg_stream_t s) {
   (void)s; REQUIRE_F32(dtype);
   const float* a = av; const float* b = bv; float* y = yv;

@@ -190,6 +190,14 @@ class Abi:
         self.lib.slice_channels(_p(src), _p(dst), accumulate, src.numel() // cs, cs, off, cdst, L.ACG_F32, self.stream())
         return dst
 
+    def copy_many(self, pairs):
+        """pairs: [(src [rows, cols] dense, dst [rows, pitch])]; copies every src into the first cols channels of dst."""
+        cl = L.CopyList()
+        for i, (src, dst) in enumerate(pairs):
+            cl.src[i], cl.dst[i] = src.data_ptr(), dst.data_ptr()
+            cl.rows[i], cl.cols[i], cl.dst_pitch[i] = src.shape[0], src.shape[1], dst.shape[1]
+        self.lib.copy_many(ctypes.byref(cl), len(pairs), L.ACG_F32, self.stream())
+
     def add(self, a, b):
         y = torch.empty_like(a)
         self.lib.add(_p(a), _p(b), _p(y), a.numel(), L.ACG_F32, self.stream())

@@ -241,6 +241,25 @@ DNA_SHAPES = [(2, 64, 64, 3, 5), (1, 16, 16, 3, 6), (1, 24, 20, 3, 11), (2, 7, 5
               (1, 9, 70, 3, 7), (2, 5, 130, 1, 6), (1, 6, 33, 4, 9), (1, 4, 4, 2, 8)]
 
 
+def case_copy_many(abi):
+    """acg_copy_many: eight segments of different sizes in one launch - dense float4-able, dense ragged, pitched."""
+    g = torch.Generator().manual_seed(3)
+    dev = abi.device
+    specs = [(64, 64, 64), (7, 10, 10), (1, 5, 5), (33, 3, 4), (129, 6, 8), (2, 138, 140), (1000, 1, 1), (16, 12, 12)]
+    pairs, want = [], []
+    for rows, cols, pitch in specs:
+        src = torch.randn(rows, cols, generator=g).to(dev)
+        dst = torch.full((rows, pitch), -7.0, device=dev)
+        pairs.append((src, dst))
+        ref = torch.full((rows, pitch), -7.0)
+        ref[:, :cols] = src.cpu()
+        want.append(ref)
+    abi.copy_many(pairs)
+    abi.sync()
+    for (src, dst), ref in zip(pairs, want):
+        assert torch.equal(dst.cpu(), ref), (tuple(src.shape), tuple(dst.shape))
+
+
 def case_cdna(abi, shape, tol, seed=0):
     """shape = (B, H, W, C, masks, k).  Forward pieces and both gradients against autograd on the torch restatement;
     some raw parameters are negative (clamped by the relu: zero gradient there)."""

@@ -83,6 +83,10 @@ def test_cdna(hip_abi, shape):
     C.case_cdna(hip_abi, shape, TOL)
 
 
+def test_copy_many(hip_abi):
+    C.case_copy_many(hip_abi)
+
+
 def test_dna_extreme(hip_abi):
     C.case_dna_extreme_logits(hip_abi, TOL)
 

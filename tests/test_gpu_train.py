@@ -131,6 +131,17 @@ def test_rollout_matches_oracle(name):
     assert abs(summ['g_psnr'] - psnrs[0]) <= 1e-3 * abs(psnrs[0])
 
 
+def test_device_resident_feeds_equal_host_feeds():
+    """sess.run fed with CUDA tensors (one fused copy launch, incl. the channel-padded image placeholder) must give
+    exactly what the same values give when fed as numpy arrays."""
+    x, y, a, s = TC.MG.inputs(2)
+    sess, tr = TC.build_trainer(gpu_session, 'c2_dna_bce_adam')
+    host = sess.run([tr.g_next_frame, tr.g_loss], tr._feed(x, y, a, s))
+    dev = lambda t: torch.from_numpy(t).cuda()
+    devr = sess.run([tr.g_next_frame, tr.g_loss], tr._feed(dev(x), dev(y), dev(a), dev(s)))
+    assert np.array_equal(host[0], devr[0]) and np.array_equal(host[1], devr[1])
+
+
 def test_training_loop_runs_wass_rmsprop_n_critic():
     """train() end to end on synthetic sequences: pretrain iterations, then n_critic=5 D steps per G step
     (train.py:217-263) with weight clip; weights stay finite and inside the clip range."""

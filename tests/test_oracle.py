@@ -49,6 +49,10 @@ def test_cdna(oracle_abi, shape):
     C.case_cdna(oracle_abi, shape, TOL)
 
 
+def test_copy_many(oracle_abi):
+    C.case_copy_many(oracle_abi)
+
+
 def test_dna_extreme(oracle_abi):
     C.case_dna_extreme_logits(oracle_abi, TOL)
 

@@ -456,6 +456,72 @@ int tile_row_blocks(long long R, int C, int V) {
   return (int)n;
 }
 
+// ---- synchronised BatchNorm (optional data-parallel mode; plain elementwise kernels, nothing tuned) -----------
+// moments / sums from the per-block partials: one thread per (group, channel), fp64 combine
+__global__ __launch_bounds__(256) void bn_moments_finalize(const float* __restrict__ part, const float* __restrict__ x,
+                                                           float* __restrict__ moments, long long R, int C, int groups, int nblk) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= groups * C) return;
+  const int g = i / C, c = i - g * C;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s1 += part[((long long)g * nblk + b) * 2 * C + c];
+    s2 += part[((long long)g * nblk + b) * 2 * C + C + c];
+  }
+  const double shift = x[(long long)g * R * C + c], dm = s1 / (double)R;
+  double var = s2 / (double)R - dm * dm;
+  moments[(g * 2 + 0) * C + c] = (float)(shift + dm);
+  moments[(g * 2 + 1) * C + c] = (float)(var > 0.0 ? var : 0.0);
+}
+__global__ __launch_bounds__(256) void bn_sums_finalize(const float* __restrict__ part, float* __restrict__ sums, int C,
+                                                        int groups, int nblk) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= groups * C) return;
+  const int g = i / C, c = i - g * C;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s1 += part[((long long)g * nblk + b) * 2 * C + c];
+    s2 += part[((long long)g * nblk + b) * 2 * C + C + c];
+  }
+  sums[(g * 2 + 0) * C + c] = (float)s1;
+  sums[(g * 2 + 1) * C + c] = (float)s2;
+}
+__global__ __launch_bounds__(256) void bn_fwd_moments_k(const float* __restrict__ x, const float* __restrict__ beta,
+                                                        const float* __restrict__ moments, float* __restrict__ y,
+                                                        float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                        long long R, int C, int groups, float eps, int act, float leak) {
+  const long long n = (long long)groups * R * C, stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const long long row = i / C;
+    const int c = (int)(i - row * C), g = (int)(row / R);
+    const float mean = moments[(g * 2 + 0) * C + c], rstd = 1.0f / sqrtf(moments[(g * 2 + 1) * C + c] + eps);
+    y[i] = acg::act_apply(act, (x[i] - mean) * rstd + beta[c], leak);
+    if (row == (long long)g * R) { save_mean[g * C + c] = mean; save_rstd[g * C + c] = rstd; }
+  }
+}
+__global__ __launch_bounds__(256) void bn_bwd_sums_k(const float* __restrict__ x, const float* __restrict__ dy,
+                                                     const float* __restrict__ beta, const float* __restrict__ save_mean,
+                                                     const float* __restrict__ save_rstd, const float* __restrict__ sums,
+                                                     float* __restrict__ dx, long long R, int C, int groups, float inv_total,
+                                                     int act, float leak) {
+  const long long n = (long long)groups * R * C, stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const long long row = i / C;
+    const int c = (int)(i - row * C), g = (int)(row / R);
+    const float rstd = save_rstd[g * C + c], xh = (x[i] - save_mean[g * C + c]) * rstd;
+    const float dp = dy[i] * acg::act_deriv_pre(act, xh + beta[c], leak);
+    dx[i] = rstd * (dp - sums[(g * 2 + 0) * C + c] * inv_total - xh * sums[(g * 2 + 1) * C + c] * inv_total);
+  }
+}
+__global__ __launch_bounds__(256) void bn_dbeta_local_k(const float* __restrict__ local_sums, float* __restrict__ dbeta,
+                                                        float acc, int C, int groups) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int g = 0; g < groups; ++g) s += local_sums[(g * 2 + 0) * C + c];
+  dbeta[c] = (acc != 0.f ? acc * dbeta[c] : 0.f) + s;
+}
+
 int check_bn(const char* who, long long rows, int C, int groups) {
   ACG_REQUIRE(rows > 0 && C > 0 && groups > 0, ACG_ERR_INVALID_ARG, "%s: non-positive size", who);
   ACG_REQUIRE(rows % groups == 0, ACG_ERR_INVALID_ARG, "%s: rows (%lld) not divisible by groups (%d)", who, rows, groups);
@@ -527,6 +593,71 @@ int32_t acg_bn_act_bwd(const void* x, const void* dy, const float* beta, const f
   if (v4) ACG_LAUNCH(bn_apply_bwd<4>, ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)part, (float*)dx, dbeta, dbeta_acc, R, C, groups, nblk, act, leak);
   else ACG_LAUNCH(bn_apply_bwd<1>, ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)part, (float*)dx, dbeta, dbeta_acc, R, C, groups, nblk, act, leak);
   return acg::check_launch("bn_apply_bwd");
+}
+
+int32_t acg_bn_moments(const void* x, float* moments, int64_t rows, int32_t C, int32_t groups, int32_t dtype, void* ws,
+                       size_t wsb, acg_stream_t stream) {
+  ACG_REQUIRE_F32(dtype);
+  if (int rc = check_bn("bn_moments", rows, C, groups)) return rc;
+  ACG_REQUIRE(x && moments, ACG_ERR_INVALID_ARG, "bn_moments: null pointer");
+  ACG_REQUIRE(ws && wsb >= acg_bn_workspace_bytes(rows, C, groups), ACG_ERR_WORKSPACE, "bn_moments: workspace too small");
+  const long long R = rows / groups;
+  hipStream_t st = acg::to_stream(stream);
+  const bool v4 = vec4_ok(C, x, x, ws);
+  const int V = v4 ? 4 : 1, nblk = vpartial_blocks(R, C, V, 8);
+  if (v4) ACG_LAUNCH(bn_stats_partial<4>, dim3(nblk, groups), dim3(256), 0, st, (const float*)x, (float*)ws, R, C, nblk);
+  else ACG_LAUNCH(bn_stats_partial<1>, dim3(nblk, groups), dim3(256), 0, st, (const float*)x, (float*)ws, R, C, nblk);
+  if (int rc = acg::check_launch("bn_stats_partial")) return rc;
+  ACG_LAUNCH(bn_moments_finalize, dim3((groups * C + 255) / 256), dim3(256), 0, st, (const float*)ws, (const float*)x, moments, R, C, groups, nblk);
+  return acg::check_launch("bn_moments_finalize");
+}
+
+int32_t acg_bn_act_fwd_moments(const void* x, const float* beta, const float* moments, void* y, float* save_mean,
+                               float* save_rstd, int64_t rows, int32_t C, int32_t groups, float eps, int32_t act, float leak,
+                               int32_t dtype, acg_stream_t stream) {
+  ACG_REQUIRE_F32(dtype);
+  if (int rc = check_bn("bn_act_fwd_moments", rows, C, groups)) return rc;
+  ACG_REQUIRE(x && beta && moments && y && save_mean && save_rstd, ACG_ERR_INVALID_ARG, "bn_act_fwd_moments: null pointer");
+  ACG_REQUIRE(act == ACG_ACT_NONE || act == ACG_ACT_RELU || act == ACG_ACT_LRELU, ACG_ERR_UNSUPPORTED, "bn_act_fwd_moments: activation %d", act);
+  const long long n = rows * (long long)C;
+  ACG_LAUNCH(bn_fwd_moments_k, dim3((int)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, acg::to_stream(stream),
+             (const float*)x, beta, moments, (float*)y, save_mean, save_rstd, rows / groups, C, groups, eps, act, leak);
+  return acg::check_launch("bn_act_fwd_moments");
+}
+
+int32_t acg_bn_bwd_sums(const void* x, const void* dy, const float* beta, const float* save_mean, const float* save_rstd,
+                        float* sums, int64_t rows, int32_t C, int32_t groups, int32_t act, float leak, int32_t dtype, void* ws,
+                        size_t wsb, acg_stream_t stream) {
+  ACG_REQUIRE_F32(dtype);
+  if (int rc = check_bn("bn_bwd_sums", rows, C, groups)) return rc;
+  ACG_REQUIRE(x && dy && beta && save_mean && save_rstd && sums, ACG_ERR_INVALID_ARG, "bn_bwd_sums: null pointer");
+  ACG_REQUIRE(ws && wsb >= acg_bn_workspace_bytes(rows, C, groups), ACG_ERR_WORKSPACE, "bn_bwd_sums: workspace too small");
+  const long long R = rows / groups;
+  hipStream_t st = acg::to_stream(stream);
+  const bool v4 = vec4_ok(C, x, dy, ws) && vec4_ok(C, save_mean, save_rstd, beta);
+  const int V = v4 ? 4 : 1, nblk = vpartial_blocks(R, C, V, 4);
+  if (v4) ACG_LAUNCH(bn_bwd_partial<4>, dim3(nblk, groups), dim3(256), 0, st, (const float*)x, (const float*)dy, beta, save_mean, save_rstd, (float*)ws, R, C, nblk, act, leak);
+  else ACG_LAUNCH(bn_bwd_partial<1>, dim3(nblk, groups), dim3(256), 0, st, (const float*)x, (const float*)dy, beta, save_mean, save_rstd, (float*)ws, R, C, nblk, act, leak);
+  if (int rc = acg::check_launch("bn_bwd_partial")) return rc;
+  ACG_LAUNCH(bn_sums_finalize, dim3((groups * C + 255) / 256), dim3(256), 0, st, (const float*)ws, sums, C, groups, nblk);
+  return acg::check_launch("bn_sums_finalize");
+}
+
+int32_t acg_bn_act_bwd_sums(const void* x, const void* dy, const float* beta, const float* save_mean, const float* save_rstd,
+                            const float* sums, const float* local_sums, int64_t total_rows, void* dx, float* dbeta,
+                            float dbeta_acc, int64_t rows, int32_t C, int32_t groups, int32_t act, float leak, int32_t dtype,
+                            acg_stream_t stream) {
+  ACG_REQUIRE_F32(dtype);
+  if (int rc = check_bn("bn_act_bwd_sums", rows, C, groups)) return rc;
+  ACG_REQUIRE(x && dy && beta && save_mean && save_rstd && sums && local_sums && dx && dbeta, ACG_ERR_INVALID_ARG, "bn_act_bwd_sums: null pointer");
+  ACG_REQUIRE(total_rows >= rows / groups, ACG_ERR_INVALID_ARG, "bn_act_bwd_sums: total_rows smaller than this rank's rows");
+  hipStream_t st = acg::to_stream(stream);
+  const long long n = rows * (long long)C;
+  ACG_LAUNCH(bn_bwd_sums_k, dim3((int)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, st, (const float*)x, (const float*)dy,
+             beta, save_mean, save_rstd, sums, (float*)dx, rows / groups, C, groups, 1.0f / (float)total_rows, act, leak);
+  if (int rc = acg::check_launch("bn_bwd_sums_k")) return rc;
+  ACG_LAUNCH(bn_dbeta_local_k, dim3((C + 255) / 256), dim3(256), 0, st, local_sums, dbeta, dbeta_acc, C, groups);
+  return acg::check_launch("bn_dbeta_local_k");
 }
 
 size_t acg_bias_workspace_bytes(int64_t rows, int32_t channels) {

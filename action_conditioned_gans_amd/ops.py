@@ -264,6 +264,132 @@ class BnActBwdOp(G.Op):
         return lambda s: fn(*args, s)
 
 
+# ---- synchronised BatchNorm (optional data-parallel mode: statistics of the GLOBAL batch, SURVEY 8(e) caveat 1) -------
+class BnMomentsOp(G.Op):
+    """This rank's per-group mean / biased variance (acg_bn_moments)."""
+
+    def __init__(self, x, groups, name):
+        c = x.shape[-1]
+        self.rows, self.c, self.groups = x.numel // c, c, int(groups)
+        super().__init__(G.get_default_graph(), name, [x], [_new((groups * 2 * c,), name + ':0')])
+
+    def bind(self, rt):
+        lib = rt.lib
+        ws, n = rt.workspace(lib.bn_workspace_bytes(self.rows, self.c, self.groups))
+        self._keep = ws
+        args = (_p(self.inputs[0].buf), _p(self.outputs[0].buf), self.rows, self.c, self.groups, ACG_F32, _p(ws), n)
+        fn = lib.bn_moments
+        return lambda s: fn(*args, s)
+
+
+class BnMomentsAllReduceOp(G.Op):
+    """Host op: combines the ranks' (mean, var) into the moments of the global batch (equal row counts per rank):
+    mean = avg(mean_r), var = avg(var_r + mean_r^2) - mean^2.  One small all-reduce per BatchNorm layer."""
+    host = True
+
+    def __init__(self, moments, groups, c, name):
+        self.groups, self.c = groups, c
+        super().__init__(G.get_default_graph(), name, [moments], [_new(moments.shape, name + ':0')])
+
+    def bind(self, rt):
+        import torch.distributed as dist
+        src, dst, g, c = self.inputs[0], self.outputs[0], self.groups, self.c
+
+        def run():
+            m = src.buf.view(g, 2, c)
+            t = torch.stack([m[:, 0], m[:, 1] + m[:, 0] * m[:, 0]], dim=1).contiguous()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=rt.process_group)
+            t /= rt.world_size
+            out = dst.buf.view(g, 2, c)
+            out[:, 0] = t[:, 0]
+            out[:, 1] = (t[:, 1] - t[:, 0] * t[:, 0]).clamp_(min=0.0)
+        return run
+
+
+class BnApplyMomentsOp(G.Op):
+    """y = act((x - mean) * rstd + beta) with GIVEN (global) moments; saves mean / rstd for backward."""
+
+    def __init__(self, x, beta, gmoments, act, leak, eps, groups, name):
+        c = x.shape[-1]
+        self.act, self.leak, self.eps, self.groups = act, float(leak), float(eps), int(groups)
+        self.rows, self.c = x.numel // c, c
+        self.mean, self.rstd = _new((groups * c,), name + '/mean'), _new((groups * c,), name + '/rstd')
+        super().__init__(G.get_default_graph(), name, [x, beta, gmoments], [_new(x.shape, name + ':0'), self.mean, self.rstd])
+
+    def bind(self, rt):
+        x, beta, gm = self.inputs
+        y, mean, rstd = self.outputs
+        args = (_p(x.buf), _p(beta.buf), _p(gm.buf), _p(y.buf), _p(mean.buf), _p(rstd.buf), self.rows, self.c, self.groups,
+                self.eps, _ACT_CODE[self.act], self.leak, ACG_F32)
+        fn = rt.lib.bn_act_fwd_moments
+        return lambda s: fn(*args, s)
+
+    def grad(self, gouts, needs, ctx):
+        x, beta, _ = self.inputs
+        name = self.name + '/bwd'
+        sums = BnBwdSumsOp(self, gouts[0], name + '/sums').outputs[0]
+        red = BnSumsAllReduceOp(sums, name + '/allreduce')
+        dst, acc = ctx.slot(beta) if (needs[1] and ctx.wants(beta)) else (None, 0.0)
+        op = BnBwdApplySumsOp(self, gouts[0], red.outputs[0], red.outputs[1], dst, acc, name)
+        if dst is not None:
+            ctx.wrote(beta, op)
+        return [op.outputs[0] if needs[0] else None, None, None]     # the moments' dependence on x is inside dx
+
+
+class BnBwdSumsOp(G.Op):
+    def __init__(self, fwd, dy, name):
+        self.fwd = fwd
+        x, beta, _ = fwd.inputs
+        super().__init__(G.get_default_graph(), name, [x, dy, beta, fwd.mean, fwd.rstd], [_new((fwd.groups * 2 * fwd.c,), name + ':0')])
+
+    def bind(self, rt):
+        lib, f = rt.lib, self.fwd
+        ws, n = rt.workspace(lib.bn_workspace_bytes(f.rows, f.c, f.groups))
+        self._keep = ws
+        x, dy, beta, mean, rstd = self.inputs
+        args = (_p(x.buf), _p(dy.buf), _p(beta.buf), _p(mean.buf), _p(rstd.buf), _p(self.outputs[0].buf), f.rows, f.c, f.groups,
+                _ACT_CODE[f.act], f.leak, ACG_F32, _p(ws), n)
+        fn = lib.bn_bwd_sums
+        return lambda s: fn(*args, s)
+
+
+class BnSumsAllReduceOp(G.Op):
+    """Host op: keeps this rank's sums (its dbeta share) and all-reduces the sums of dp, dp*xhat over the ranks."""
+    host = True
+
+    def __init__(self, sums, name):
+        super().__init__(G.get_default_graph(), name, [sums], [_new(sums.shape, name + ':global'), _new(sums.shape, name + ':local')])
+
+    def bind(self, rt):
+        import torch.distributed as dist
+        src, glob, loc = self.inputs[0], self.outputs[0], self.outputs[1]
+
+        def run():
+            loc.buf.copy_(src.buf)
+            glob.buf.copy_(src.buf)
+            dist.all_reduce(glob.buf, op=dist.ReduceOp.SUM, group=rt.process_group)
+        return run
+
+
+class BnBwdApplySumsOp(G.Op):
+    def __init__(self, fwd, dy, gsums, lsums, dbeta_dst, accumulate, name):
+        self.fwd, self.accumulate = fwd, float(accumulate)
+        x, beta, _ = fwd.inputs
+        if dbeta_dst is None:
+            dbeta_dst = _new((fwd.c,), name + '/dbeta_scratch')
+        super().__init__(G.get_default_graph(), name, [x, dy, beta, fwd.mean, fwd.rstd, gsums, lsums], [_new(x.shape, name + ':0'), dbeta_dst])
+
+    def bind(self, rt):
+        f = self.fwd
+        x, dy, beta, mean, rstd, gs, ls = self.inputs
+        dx, dbeta = self.outputs
+        total = (f.rows // f.groups) * rt.world_size
+        args = (_p(x.buf), _p(dy.buf), _p(beta.buf), _p(mean.buf), _p(rstd.buf), _p(gs.buf), _p(ls.buf), total, _p(dx.buf),
+                _p(dbeta.buf), self.accumulate, f.rows, f.c, f.groups, _ACT_CODE[f.act], f.leak, ACG_F32)
+        fn = rt.lib.bn_act_bwd_sums
+        return lambda s: fn(*args, s)
+
+
 class BiasActOp(G.Op):
     """y = act(x + bias); bias None gives the bare activation."""
 
@@ -592,7 +718,14 @@ def batch_norm(inputs, decay=0.999, center=True, scale=False, epsilon=0.001, act
         beta = G.get_default_graph().get_variable(_scope_name('beta'), (c,), zeros_initializer(), _scope_reuse())
         name = _scope_name()
     fused = act if act is not None else (None, 0.0)
-    out = BnActOp(inputs, beta, fused[0], fused[1], epsilon, groups, name).outputs[0]
+    dp = G.get_default_graph().collections.get('data_parallel')
+    if dp is not None and getattr(dp, 'sync_bn', False) and dp.active:
+        # statistics of the global batch: moments -> all-reduce (host) -> apply (SURVEY 8(e) caveat 1)
+        mom = BnMomentsOp(inputs, groups, name + '/moments').outputs[0]
+        gmom = BnMomentsAllReduceOp(mom, groups, c, name + '/moments_allreduce').outputs[0]
+        out = BnApplyMomentsOp(inputs, beta, gmom, fused[0], fused[1], epsilon, groups, name).outputs[0]
+    else:
+        out = BnActOp(inputs, beta, fused[0], fused[1], epsilon, groups, name).outputs[0]
     return out if act is not None else activation_fn(out)
 
 

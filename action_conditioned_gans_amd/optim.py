@@ -29,18 +29,19 @@ def _f32(v):
 class DataParallel:
     """Per-graph data-parallel configuration (one process per GPU; RCCL via torch.distributed)."""
 
-    def __init__(self, world_size=1, n_buckets=3, force=False):
+    def __init__(self, world_size=1, n_buckets=3, force=False, sync_bn=False):
         self.world_size, self.n_buckets, self.force = int(world_size), int(n_buckets), bool(force)
+        self.sync_bn = bool(sync_bn)      # BatchNorm over the GLOBAL batch (ops.batch_norm; one small all-reduce per layer)
 
     @property
     def active(self):
         return self.world_size > 1 or self.force
 
 
-def set_data_parallel(world_size, n_buckets=3, graph=None, force=False):
+def set_data_parallel(world_size, n_buckets=3, graph=None, force=False, sync_bn=False):
     """``force`` inserts the bucketed all-reduce even at world_size 1 (a one-rank communicator): lets a single GPU
     exercise the collective / side-stream / graph-segment machinery the multi-GPU runs depend on."""
-    (graph or G.get_default_graph()).collections['data_parallel'] = DataParallel(world_size, n_buckets, force)
+    (graph or G.get_default_graph()).collections['data_parallel'] = DataParallel(world_size, n_buckets, force, sync_bn)
 
 
 def _dp(graph):

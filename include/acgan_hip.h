@@ -98,6 +98,32 @@ int32_t acg_deconv2d_wgrad(const void* x, const void* dy, float* dw, float accum
                            int32_t dtype, void* workspace, size_t workspace_bytes, acg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Synchronised BatchNorm for data parallel runs (SURVEY 8(e) caveat 1; optional, no reference counterpart: the
+ * reference is single-device).  The statistics are those of the GLOBAL batch: each direction is two calls with
+ * one collective between them, issued by the caller.
+ *   fwd:  acg_bn_moments            moments[g][0][c] = mean, moments[g][1][c] = biased variance of THIS rank's rows
+ *         (caller: all-gather, combine into global moments - equal row counts per rank)
+ *         acg_bn_act_fwd_moments    y = act((x - mean) * rsqrt(var + eps) + beta) with the GIVEN moments; saves mean, rstd
+ *   bwd:  acg_bn_bwd_sums           sums[g][0][c] = sum dp, sums[g][1][c] = sum dp * xhat over this rank's rows
+ *         (caller: keeps a copy as local_sums, all-reduces sums)
+ *         acg_bn_act_bwd_sums       dx with the global sums and total_rows (global rows per group);
+ *                                   dbeta = dbeta_acc * dbeta + sum_g local_sums[g][0][c]  (this rank's share; the
+ *                                   gradient all-reduce averages it like every other parameter gradient)
+ * ---------------------------------------------------------------------------------------- */
+int32_t acg_bn_moments(const void* x, float* moments, int64_t rows, int32_t channels, int32_t groups, int32_t dtype,
+                       void* workspace, size_t workspace_bytes, acg_stream_t stream);
+int32_t acg_bn_act_fwd_moments(const void* x, const float* beta, const float* moments, void* y, float* save_mean,
+                               float* save_rstd, int64_t rows, int32_t channels, int32_t groups, float eps, int32_t act,
+                               float leak, int32_t dtype, acg_stream_t stream);
+int32_t acg_bn_bwd_sums(const void* x, const void* dy, const float* beta, const float* save_mean, const float* save_rstd,
+                        float* sums, int64_t rows, int32_t channels, int32_t groups, int32_t act, float leak, int32_t dtype,
+                        void* workspace, size_t workspace_bytes, acg_stream_t stream);
+int32_t acg_bn_act_bwd_sums(const void* x, const void* dy, const float* beta, const float* save_mean,
+                            const float* save_rstd, const float* sums, const float* local_sums, int64_t total_rows,
+                            void* dx, float* dbeta, float dbeta_acc, int64_t rows, int32_t channels, int32_t groups,
+                            int32_t act, float leak, int32_t dtype, acg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * slim.batch_norm (training mode, scale=False, center=True) fused with the layer activation:
  * implicit via argscope at models.py:10-11,31-32,80-81; lrelu is ops.py:22-26.
  * x is viewed as [rows, channels]; `groups` splits the rows into equal contiguous chunks that

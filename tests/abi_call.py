@@ -122,6 +122,41 @@ class Abi:
                             groups, ACT[act], leak, L.ACG_F32, _p(ws), n, self.stream())
         return dx, dbeta
 
+    # ---- synchronised BatchNorm entries (statistics supplied by the caller)
+    def bn_moments(self, x, groups=1):
+        c = x.shape[-1]
+        rows = x.numel() // c
+        mom = self.empty(groups * 2 * c)
+        ws, n = self.ws(self.lib.bn_workspace_bytes(rows, c, groups))
+        self.lib.bn_moments(_p(x), _p(mom), rows, c, groups, L.ACG_F32, _p(ws), n, self.stream())
+        return mom
+
+    def bn_act_fwd_moments(self, x, beta, moments, act, groups=1, eps=1e-3, leak=0.2):
+        c = x.shape[-1]
+        rows = x.numel() // c
+        y = torch.empty_like(x)
+        mean, rstd = self.empty(groups * c), self.empty(groups * c)
+        self.lib.bn_act_fwd_moments(_p(x), _p(beta), _p(moments), _p(y), _p(mean), _p(rstd), rows, c, groups, eps, ACT[act], leak,
+                                    L.ACG_F32, self.stream())
+        return y, mean, rstd
+
+    def bn_bwd_sums(self, x, dy, beta, mean, rstd, act, groups=1, leak=0.2):
+        c = x.shape[-1]
+        rows = x.numel() // c
+        sums = self.empty(groups * 2 * c)
+        ws, n = self.ws(self.lib.bn_workspace_bytes(rows, c, groups))
+        self.lib.bn_bwd_sums(_p(x), _p(dy), _p(beta), _p(mean), _p(rstd), _p(sums), rows, c, groups, ACT[act], leak, L.ACG_F32,
+                             _p(ws), n, self.stream())
+        return sums
+
+    def bn_act_bwd_sums(self, x, dy, beta, mean, rstd, sums, local_sums, total_rows, act, groups=1, leak=0.2):
+        c = x.shape[-1]
+        rows = x.numel() // c
+        dx, dbeta = torch.empty_like(x), self.empty(c)
+        self.lib.bn_act_bwd_sums(_p(x), _p(dy), _p(beta), _p(mean), _p(rstd), _p(sums), _p(local_sums), total_rows, _p(dx),
+                                 _p(dbeta), 0.0, rows, c, groups, ACT[act], leak, L.ACG_F32, self.stream())
+        return dx, dbeta
+
     def bias_act_fwd(self, x, bias, act, leak=0.2):
         c = x.shape[-1]
         y = torch.empty_like(x)

@@ -39,6 +39,26 @@ def main():
             assert progs and all(any(g is not None for g in p.graphs) for p in progs if p.runs >= 2)
     for n in finals[0]:
         assert torch.equal(finals[0][n], finals[1][n]), n
+    # synchronised BatchNorm on the one-rank communicator: global statistics = local ones, so the run must track the
+    # plain one (different kernels: compared at 1e-4 of the weight scale after the same four steps)
+    adv, loss, opt, dna, batch, ksize = TC.MG.CASES['c4_dna_wass_rmsprop']
+    G.reset_default_graph()
+    optim.set_data_parallel(1, force=True, sync_bn=True)
+    sess = G.Session(device='cuda:0')
+    tr = T.Trainer(sess, True, 'bce', 'rmsprop', dna, batch_size=batch, ksize=ksize)
+    sess.run(G.global_variables_initializer())
+    params = OM.init_params(dna, batch=batch, ksize=ksize, seed=TC.MG.PARAM_SEED, dtype=torch.float32)
+    for n, v in G.get_default_graph().variables.items():
+        sess.set_value(v, params[n])
+    for _ in range(4):
+        tr.train_d(x, y, a)
+        tr.train_g(x, y, a, s)
+    torch.cuda.synchronize()
+    kinds = [type(o).__name__ for o in G.get_default_graph().ops]
+    assert kinds.count('BnMomentsAllReduceOp') >= 15 and kinds.count('BnSumsAllReduceOp') >= 15
+    for n, v in G.get_default_graph().variables.items():
+        got, want = sess.get_value(v).double(), finals[0][n].double()
+        assert (got - want).abs().max().item() <= 1e-4 * max(want.abs().max().item(), 1e-3) + 1e-6, n
     print('DP_ONE_RANK_OK', flush=True)
     os._exit(0)     # leave without communicator teardown
 

@@ -241,6 +241,29 @@ DNA_SHAPES = [(2, 64, 64, 3, 5), (1, 16, 16, 3, 6), (1, 24, 20, 3, 11), (2, 7, 5
               (1, 9, 70, 3, 7), (2, 5, 130, 1, 6), (1, 6, 33, 4, 9), (1, 4, 4, 2, 8)]
 
 
+def case_sync_bn_entries(abi, shape, act, groups, tol):
+    """The four synchronised-BatchNorm entries on ONE rank (global = local) must reproduce acg_bn_act_fwd / _bwd, and
+    with doubled total_rows and sums of two identical halves they must give the two-rank answer for identical shards."""
+    g = torch.Generator().manual_seed(9)
+    dev = abi.device
+    x = (torch.randn(*shape, generator=g) * 2 + 0.5).to(dev)
+    dy = torch.randn(*shape, generator=g).to(dev)
+    beta = torch.randn(shape[-1], generator=g).to(dev)
+    y_ref, mean_ref, rstd_ref = abi.bn_act_fwd(x, beta, act, groups=groups)
+    dx_ref, dbeta_ref = abi.bn_act_bwd(x, dy, beta, mean_ref, rstd_ref, act, groups=groups)
+    mom = abi.bn_moments(x, groups=groups)
+    y, mean, rstd = abi.bn_act_fwd_moments(x, beta, mom, act, groups=groups)
+    tag = 'sync_bn%s %s g%d' % (shape, act, groups)
+    close(mean, mean_ref, tol, tag + ' mean'); close(rstd, rstd_ref, tol * 4, tag + ' rstd'); close(y, y_ref, tol * 4, tag + ' y')
+    sums = abi.bn_bwd_sums(x, dy, beta, mean_ref, rstd_ref, act, groups=groups)
+    rows_per_group = x.numel() // shape[-1] // groups
+    dx, dbeta = abi.bn_act_bwd_sums(x, dy, beta, mean_ref, rstd_ref, sums, sums, rows_per_group, act, groups=groups)
+    close(dx, dx_ref, tol * 8, tag + ' dx'); close(dbeta, dbeta_ref, tol * 8, tag + ' dbeta')
+    # two ranks holding the SAME shard: global sums double, total rows double -> dx unchanged, dbeta still the local sum
+    dx2, dbeta2 = abi.bn_act_bwd_sums(x, dy, beta, mean_ref, rstd_ref, sums * 2, sums, 2 * rows_per_group, act, groups=groups)
+    close(dx2, dx_ref, tol * 8, tag + ' dx (two identical ranks)'); close(dbeta2, dbeta_ref, tol * 8, tag + ' dbeta (two identical ranks)')
+
+
 def case_copy_many(abi):
     """acg_copy_many: eight segments of different sizes in one launch - dense float4-able, dense ragged, pitched."""
     g = torch.Generator().manual_seed(3)

@@ -97,3 +97,61 @@ def test_two_rank_allreduce_matches_mean_gradient_update():
 
 def _single(_, rank, outdir):
     _worker(rank, 1, 0, outdir)
+
+
+# ---- synchronised BatchNorm: two ranks x batch 2 == one process x batch 4 -------------------------------------------
+SYNC_CASE = 'c1_plain_l1'       # plain generator, L1 only: the loss is a per-sample mean, so with global-batch BatchNorm
+                                # statistics data parallel must reproduce the single-process global batch exactly
+
+
+def _global_inputs():
+    rng = np.random.default_rng(77)
+    return (rng.uniform(-1, 1, (4, 64, 64, 3)).astype(np.float32), rng.uniform(-1, 1, (4, 64, 64, 3)).astype(np.float32),
+            rng.standard_normal((4, 10)).astype(np.float32), rng.standard_normal((4, 5)).astype(np.float32))
+
+
+def _sync_worker(rank, world, port, outdir):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(2)
+    import train_cases as TC
+    from oracle import cbind
+    from action_conditioned_gans_amd import graph as G
+    if world > 1:
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    sess, tr = TC.build_trainer(lambda **kw: G.Session(device='cpu', lib=cbind.load(), world_size=world, rank=rank, **kw),
+                                SYNC_CASE, world_size=world, sync_bn=True, batch=4 // world)
+    lo, hi = rank * (4 // world), (rank + 1) * (4 // world)
+    x, y, a, s = (t[lo:hi] for t in _global_inputs())
+    frame = sess.run(tr.g_next_frame, tr._feed(x, y, a, s))
+    tr.pretrain_g(x, y, a, s)
+    out = {'frame': frame, 'grad': _flat(tr.g_pretrain_opt_op.inputs[1]), 'param': _flat(tr.g_pretrain_opt_op.inputs[0])}
+    if world > 1:
+        kinds = [type(o).__name__ for o in G.get_default_graph().ops]
+        out['n_moment_reduces'] = np.array(kinds.count('BnMomentsAllReduceOp'))
+        out['n_sum_reduces'] = np.array(kinds.count('BnSumsAllReduceOp'))
+    np.savez(os.path.join(outdir, 'sync_w%d_r%d.npz' % (world, rank)), **out)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_sync_batchnorm_reproduces_the_global_batch():
+    """SURVEY 8(e) caveat 1: with set_data_parallel(..., sync_bn=True) every BatchNorm uses the statistics of the
+    global batch (one small all-reduce per layer and direction).  Two ranks with two samples each must then give the
+    frames, the (averaged) gradient and the updated weights of ONE process running all four samples."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_sync_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        mp.spawn(_sync_worker, args=(1, 0, d), nprocs=1, join=True)
+        dp = [dict(np.load(os.path.join(d, 'sync_w2_r%d.npz' % r))) for r in (0, 1)]
+        ref = dict(np.load(os.path.join(d, 'sync_w1_r0.npz')))
+    assert dp[0]['n_moment_reduces'] >= 7 and dp[0]['n_sum_reduces'] >= 7          # the plain generator has 7 BatchNorm layers
+    frames = np.concatenate([dp[0]['frame'], dp[1]['frame']])
+    assert np.abs(frames - ref['frame']).max() <= 2e-5 * max(np.abs(ref['frame']).max(), 1.0)
+    mean_grad = dp[0]['grad'].astype(np.float64) / 2.0                              # the buffer holds the SUM over ranks
+    assert np.array_equal(dp[0]['grad'], dp[1]['grad'])
+    scale = np.abs(ref['grad']).max()
+    assert np.abs(mean_grad - ref['grad']).max() <= 2e-4 * scale, np.abs(mean_grad - ref['grad']).max() / scale
+    assert np.array_equal(dp[0]['param'], dp[1]['param'])

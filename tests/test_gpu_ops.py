@@ -83,6 +83,12 @@ def test_cdna(hip_abi, shape):
     C.case_cdna(hip_abi, shape, TOL)
 
 
+@pytest.mark.parametrize('shape,act,groups', [((4, 6, 5, 8), 'relu', 1), ((6, 3, 3, 12), 'lrelu', 2), ((2, 5, 7, 3), None, 1),
+                                              ((32, 16, 16, 128), 'relu', 1), ((64, 8, 8, 256), 'lrelu', 2)])
+def test_sync_bn_entries(hip_abi, shape, act, groups):
+    C.case_sync_bn_entries(hip_abi, shape, act, groups, TOL)
+
+
 def test_copy_many(hip_abi):
     C.case_copy_many(hip_abi)
 

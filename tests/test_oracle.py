@@ -49,6 +49,11 @@ def test_cdna(oracle_abi, shape):
     C.case_cdna(oracle_abi, shape, TOL)
 
 
+@pytest.mark.parametrize('shape,act,groups', [((4, 6, 5, 8), 'relu', 1), ((6, 3, 3, 12), 'lrelu', 2), ((2, 5, 7, 3), None, 1)])
+def test_sync_bn_entries(oracle_abi, shape, act, groups):
+    C.case_sync_bn_entries(oracle_abi, shape, act, groups, TOL)
+
+
 def test_copy_many(oracle_abi):
     C.case_copy_many(oracle_abi)
 

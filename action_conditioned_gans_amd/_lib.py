@@ -86,6 +86,8 @@ SIGNATURES = {
     'acg_frame_loss': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_int32,
                                  _P, c_size_t, _P]),
     'acg_l2norm_loss': (c_int32, [_P, _P, _P, _P, c_int64, c_float, _P]),
+    'acg_sumsq_diff': (c_int32, [_P, _P, _P, c_int64, _P]),
+    'acg_l2norm_loss_global': (c_int32, [_P, _P, _P, _P, _P, c_int64, c_float, _P]),
     'acg_sigmoid_ce_loss': (c_int32, [_P, c_float, _P, _P, c_int64, c_float, _P]),
     'acg_mean_loss': (c_int32, [_P, _P, _P, c_int64, c_float, _P]),
     'acg_psnr': (c_int32, [_P, _P, _P, c_int64, c_int32, _P, c_size_t, _P]),

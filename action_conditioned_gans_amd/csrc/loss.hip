@@ -77,14 +77,21 @@ __global__ __launch_bounds__(256) void sqdiff_partial_k(const float* __restrict_
 }
 
 // ---- small heads: one 1024-thread block, n <= 65536 ---------------------------------------------------
+// gss: sum of squares of the GLOBAL batch (data parallel, all-reduced by the caller) to take the norm from instead of
+// this rank's own; sumsq_only: out[0] = this rank's sum of squares, nothing else
 __global__ __launch_bounds__(1024) void l2norm_loss_k(const float* __restrict__ p, const float* __restrict__ g,
-                                                      float* __restrict__ out, float* __restrict__ dp, int n, float scale) {
+                                                      float* __restrict__ out, float* __restrict__ dp, int n, float scale,
+                                                      const float* __restrict__ gss, int sumsq_only) {
   __shared__ double scratch[16];
   __shared__ double s_norm;
   double ss = 0.0;
   for (int i = threadIdx.x; i < n; i += 1024) { const double e = (double)p[i] - (double)g[i]; ss += e * e; }
   ss = acg::block_sum(ss, scratch);
-  if (threadIdx.x == 0) { s_norm = sqrt(ss); out[0] = (float)s_norm; }
+  if (sumsq_only) {
+    if (threadIdx.x == 0) out[0] = (float)ss;
+    return;
+  }
+  if (threadIdx.x == 0) { s_norm = sqrt(gss ? (double)gss[0] : ss); out[0] = (float)s_norm; }
   __syncthreads();
   if (dp) {
     const double nrm = s_norm;
@@ -156,8 +163,23 @@ int32_t acg_frame_loss(const void* gen, const void* gt, float* out2, void* dgen,
 int32_t acg_l2norm_loss(const float* pred, const float* gt, float* out, float* dpred, int64_t n, float scale, acg_stream_t stream) {
   ACG_REQUIRE(n > 0 && n <= 65536, ACG_ERR_INVALID_ARG, "l2norm_loss: n outside 1..65536");
   ACG_REQUIRE(pred && gt && out, ACG_ERR_INVALID_ARG, "l2norm_loss: null pointer");
-  ACG_LAUNCH(l2norm_loss_k, dim3(1), dim3(1024), 0, acg::to_stream(stream), pred, gt, out, dpred, (int)n, scale);
+  ACG_LAUNCH(l2norm_loss_k, dim3(1), dim3(1024), 0, acg::to_stream(stream), pred, gt, out, dpred, (int)n, scale, (const float*)nullptr, 0);
   return acg::check_launch("l2norm_loss");
+}
+
+int32_t acg_sumsq_diff(const float* pred, const float* gt, float* out, int64_t n, acg_stream_t stream) {
+  ACG_REQUIRE(n > 0 && n <= 65536, ACG_ERR_INVALID_ARG, "sumsq_diff: n outside 1..65536");
+  ACG_REQUIRE(pred && gt && out, ACG_ERR_INVALID_ARG, "sumsq_diff: null pointer");
+  ACG_LAUNCH(l2norm_loss_k, dim3(1), dim3(1024), 0, acg::to_stream(stream), pred, gt, out, (float*)nullptr, (int)n, 0.f, (const float*)nullptr, 1);
+  return acg::check_launch("sumsq_diff");
+}
+
+int32_t acg_l2norm_loss_global(const float* pred, const float* gt, const float* global_sumsq, float* out, float* dpred, int64_t n,
+                               float scale, acg_stream_t stream) {
+  ACG_REQUIRE(n > 0 && n <= 65536, ACG_ERR_INVALID_ARG, "l2norm_loss_global: n outside 1..65536");
+  ACG_REQUIRE(pred && gt && global_sumsq && out, ACG_ERR_INVALID_ARG, "l2norm_loss_global: null pointer");
+  ACG_LAUNCH(l2norm_loss_k, dim3(1), dim3(1024), 0, acg::to_stream(stream), pred, gt, out, dpred, (int)n, scale, global_sumsq, 0);
+  return acg::check_launch("l2norm_loss_global");
 }
 
 int32_t acg_sigmoid_ce_loss(const float* logits, float label, float* out, float* dlogits, int64_t n, float scale, acg_stream_t stream) {

@@ -986,8 +986,55 @@ class SmallLossOp(LossHead):
             if needs[0]:
                 raise NotImplementedError('l2norm: gradient w.r.t. both arguments')
             a, b = b, a                    # ||a-b|| is symmetric
+        dp = G.get_default_graph().collections.get('data_parallel')
+        if self.kind == 'l2norm' and dp is not None and getattr(dp, 'exact_global_batch', False) and dp.active:
+            # ||.||_2 over the GLOBAL batch: this rank's sum of squares -> all-reduce -> gradient with the global norm
+            ss = SumSqDiffOp(a, b, self.name + '/sumsq').outputs[0]
+            gss = ScalarAllReduceOp(ss, self.name + '/sumsq_allreduce').outputs[0]
+            op = L2GlobalGradOp(a, b, gss, sign * weights.get(0, 0.0), self.name + '/grad')
+            return [(a, op.dx)]
         op = SmallLossOp(self.kind, a, b, self.label, sign * weights.get(0, 0.0), self.name + '/grad')
         return [(a, op.dx)]
+
+
+class SumSqDiffOp(G.Op):
+    def __init__(self, a, b, name):
+        super().__init__(G.get_default_graph(), name, [a, b], [_new((1,), name + ':0')])
+
+    def bind(self, rt):
+        a, b = self.inputs
+        args, fn = (_p(a.buf), _p(b.buf), _p(self.outputs[0].buf), a.numel), rt.lib.sumsq_diff
+        return lambda s: fn(*args, s)
+
+
+class ScalarAllReduceOp(G.Op):
+    """Host op: sum of a small tensor over the ranks."""
+    host = True
+
+    def __init__(self, x, name):
+        super().__init__(G.get_default_graph(), name, [x], [_new(x.shape, name + ':0')])
+
+    def bind(self, rt):
+        import torch.distributed as dist
+        src, dst = self.inputs[0], self.outputs[0]
+
+        def run():
+            dst.buf.copy_(src.buf)
+            dist.all_reduce(dst.buf, op=dist.ReduceOp.SUM, group=rt.process_group)
+        return run
+
+
+class L2GlobalGradOp(G.Op):
+    def __init__(self, a, b, gss, grad_scale, name):
+        self.grad_scale = float(grad_scale)
+        self.dx = _new(a.shape, name + '/dx')
+        super().__init__(G.get_default_graph(), name, [a, b, gss], [_new((1,), name + ':0'), self.dx])
+
+    def bind(self, rt):
+        a, b, gss = self.inputs
+        args = (_p(a.buf), _p(b.buf), _p(gss.buf), _p(self.outputs[0].buf), _p(self.dx.buf), a.numel, self.grad_scale)
+        fn = rt.lib.l2norm_loss_global
+        return lambda s: fn(*args, s)
 
 
 class PairedLossOp(LossHead):
@@ -1107,7 +1154,11 @@ def frame_losses(g_out, next_frames):
     head = cache.get(key)
     if head is None:
         head = cache[key] = FrameLossOp(g_out, next_frames)
-    return Scalar([(head, 0, 1.0)]), Scalar([(head, 1, 1.0)])
+    # the GDL is a SUM over the batch (ops.py:120): averaging the ranks' gradients divides it by the world size relative
+    # to one device at the global batch; the exact-global-batch mode scales it back (SURVEY 8(e) caveat 2)
+    dp = G.get_default_graph().collections.get('data_parallel')
+    gdl_w = float(dp.world_size) if (dp is not None and getattr(dp, 'exact_global_batch', False) and dp.active) else 1.0
+    return Scalar([(head, 0, 1.0)]), Scalar([(head, 1, gdl_w)])
 
 
 def build_gdl(g_out, next_frames, alpha=1):

@@ -29,19 +29,22 @@ def _f32(v):
 class DataParallel:
     """Per-graph data-parallel configuration (one process per GPU; RCCL via torch.distributed)."""
 
-    def __init__(self, world_size=1, n_buckets=3, force=False, sync_bn=False):
+    def __init__(self, world_size=1, n_buckets=3, force=False, sync_bn=False, exact_global_batch=False):
         self.world_size, self.n_buckets, self.force = int(world_size), int(n_buckets), bool(force)
-        self.sync_bn = bool(sync_bn)      # BatchNorm over the GLOBAL batch (ops.batch_norm; one small all-reduce per layer)
+        # exact_global_batch: the run reproduces ONE device at the global batch - BatchNorm over the global batch,
+        # the GDL sum scaled by the world size, the state-loss norm taken over all ranks (SURVEY 8(e) caveats 1-3)
+        self.exact_global_batch = bool(exact_global_batch)
+        self.sync_bn = bool(sync_bn) or self.exact_global_batch   # BatchNorm over the GLOBAL batch (ops.batch_norm)
 
     @property
     def active(self):
         return self.world_size > 1 or self.force
 
 
-def set_data_parallel(world_size, n_buckets=3, graph=None, force=False, sync_bn=False):
+def set_data_parallel(world_size, n_buckets=3, graph=None, force=False, sync_bn=False, exact_global_batch=False):
     """``force`` inserts the bucketed all-reduce even at world_size 1 (a one-rank communicator): lets a single GPU
     exercise the collective / side-stream / graph-segment machinery the multi-GPU runs depend on."""
-    (graph or G.get_default_graph()).collections['data_parallel'] = DataParallel(world_size, n_buckets, force, sync_bn)
+    (graph or G.get_default_graph()).collections['data_parallel'] = DataParallel(world_size, n_buckets, force, sync_bn, exact_global_batch)
 
 
 def _dp(graph):

@@ -53,6 +53,7 @@ def parse():
     ap.add_argument('--cpu-steps', type=int, default=20)
     ap.add_argument('--overlap-wgrad', action='store_true', help='experiment: weight gradients on a second HIP stream')
     ap.add_argument('--buckets', type=int, default=3, help='gradient all-reduce buckets per optimizer (data parallel)')
+    ap.add_argument('--exact-global-batch', action='store_true', help='data parallel that reproduces one device at the global batch: SyncBN + GDL scaling + global state-loss norm')
     ap.add_argument('--sync-bn', action='store_true', help='data parallel with BatchNorm statistics of the global batch (one small all-reduce per BatchNorm layer and direction)')
     ap.add_argument('--force-dp', action='store_true', help='run the data-parallel machinery (RCCL all-reduce buckets, graph segments) even on one rank')
     return ap.parse_args()
@@ -117,7 +118,7 @@ def main():
     B, S, dna, adv = args.batch, args.img, not args.plain, not args.no_adv
     n_critic = 5 if args.loss == 'wass' else 1
     G.reset_default_graph()
-    optim.set_data_parallel(world, n_buckets=args.buckets, force=args.force_dp, sync_bn=args.sync_bn)
+    optim.set_data_parallel(world, n_buckets=args.buckets, force=args.force_dp, sync_bn=args.sync_bn, exact_global_batch=args.exact_global_batch)
     sess = G.Session(device=device, overlap_wgrad=args.overlap_wgrad, use_hip_graphs=not args.no_graphs, world_size=world, rank=rank, process_group=pg, dtype=args.dtype)
     tr = T.Trainer(sess, adv, args.loss, args.opt, dna, batch_size=B, img_size=S, ksize=args.ksize, seed=0)
     sess.run(G.global_variables_initializer())

@@ -223,6 +223,12 @@ int32_t acg_frame_loss(const void* gen, const void* gt, float* out2, void* dgen,
 /* out[0] = ||pred-gt||_2 (tf.norm ord=2, train.py:77); dpred = scale*(pred-gt)/norm (0 if norm==0). n <= 65536 */
 int32_t acg_l2norm_loss(const float* pred, const float* gt, float* out, float* dpred, int64_t n, float scale,
                         acg_stream_t stream);
+/* The same loss over a GLOBAL batch in a data-parallel run (SURVEY 8(e) caveat 3: the square root does not decompose over
+ * ranks): acg_sumsq_diff gives this rank's sum (pred-gt)^2, the caller all-reduces it, acg_l2norm_loss_global takes
+ * the norm from that global sum: out[0] = sqrt(global_sumsq[0]); dpred = scale*(pred-gt)/out[0]. */
+int32_t acg_sumsq_diff(const float* pred, const float* gt, float* out, int64_t n, acg_stream_t stream);
+int32_t acg_l2norm_loss_global(const float* pred, const float* gt, const float* global_sumsq, float* out, float* dpred,
+                               int64_t n, float scale, acg_stream_t stream);
 /* out[0] = mean(max(x,0) - x*label + log1p(exp(-|x|)))  (tf.losses.sigmoid_cross_entropy, ops.py:30-31,39-42);
  * dlogits = scale*(sigmoid(x)-label)/n.  n <= 65536 */
 int32_t acg_sigmoid_ce_loss(const float* logits, float label, float* out, float* dlogits, int64_t n, float scale,

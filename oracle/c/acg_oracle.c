@@ -475,6 +475,17 @@ int32_t acg_l2norm_loss(const float* p, const float* g, float* out, float* dp, i
   if (dp) for (int64_t i = 0; i < n; i++) dp[i] = nrm > 0 ? (float)(scale * ((double)p[i] - g[i]) / nrm) : 0.f;
   return ACG_OK;
 }
+int32_t acg_sumsq_diff(const float* p, const float* g, float* out, int64_t n, acg_stream_t s) {
+  (void)s; double ss = 0;
+  for (int64_t i = 0; i < n; i++) { double e = (double)p[i] - g[i]; ss += e * e; }
+  out[0] = (float)ss;
+  return ACG_OK;
+}
+int32_t acg_l2norm_loss_global(const float* p, const float* g, const float* gss, float* out, float* dp, int64_t n, float scale, acg_stream_t s) {
+  (void)s; double nrm = sqrt((double)gss[0]); out[0] = (float)nrm;
+  if (dp) for (int64_t i = 0; i < n; i++) dp[i] = nrm > 0 ? (float)(scale * ((double)p[i] - g[i]) / nrm) : 0.f;
+  return ACG_OK;
+}
 int32_t acg_sigmoid_ce_loss(const float* x, float label, float* out, float* dx, int64_t n, float scale, acg_stream_t s) {
   (void)s; double sum = 0;
   for (int64_t i = 0; i < n; i++) { double v = x[i];

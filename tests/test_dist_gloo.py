@@ -155,3 +155,59 @@ def test_sync_batchnorm_reproduces_the_global_batch():
     scale = np.abs(ref['grad']).max()
     assert np.abs(mean_grad - ref['grad']).max() <= 2e-4 * scale, np.abs(mean_grad - ref['grad']).max() / scale
     assert np.array_equal(dp[0]['param'], dp[1]['param'])
+
+
+# ---- exact global batch: SyncBN + GDL scaling + global state-loss norm, the full adversarial DNA step ----------------
+EXACT_CASE = 'dna_k6_bce_rmsprop'
+
+
+def _exact_worker(rank, world, port, outdir, exact=True):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(2)
+    import train_cases as TC
+    from oracle import cbind
+    from action_conditioned_gans_amd import graph as G
+    if world > 1:
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    sess, tr = TC.build_trainer(lambda **kw: G.Session(device='cpu', lib=cbind.load(), world_size=world, rank=rank, **kw),
+                                EXACT_CASE, world_size=world, exact=exact, batch=4 // world)
+    lo, hi = rank * (4 // world), (rank + 1) * (4 // world)
+    x, y, a, s = (t[lo:hi] for t in _global_inputs())
+    tr.train_d(x, y, a)
+    out = {'d_grad': _flat(tr.d_opt_op.inputs[1]), 'd_param': _flat(tr.d_opt_op.inputs[0])}
+    tr.train_g(x, y, a, s)
+    out['g_grad'] = _flat(tr.g_opt_op.inputs[1])
+    out['g_param'] = _flat(tr.g_opt_op.inputs[0])
+    np.savez(os.path.join(outdir, 'exact%d_w%d_r%d.npz' % (int(exact), world, rank)), **out)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_exact_global_batch_mode_reproduces_one_device():
+    """SURVEY 8(e) caveats 1-3 together (set_data_parallel(..., exact_global_batch=True)): BatchNorm over the global
+    batch, the GDL sum scaled by the world size, the state-loss norm over all ranks.  One adversarial D step + G step of
+    the DNA model on two ranks x two samples must match ONE process on the four samples: averaged gradients and
+    RMSProp-updated weights (the D input of the G step already depends on the first update)."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_exact_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        mp.spawn(_exact_worker, args=(1, 0, d), nprocs=1, join=True)
+        mp.spawn(_exact_worker, args=(2, _free_port(), d, False), nprocs=2, join=True)      # control: conventional DP
+        dp = [dict(np.load(os.path.join(d, 'exact1_w2_r%d.npz' % r))) for r in (0, 1)]
+        ref = dict(np.load(os.path.join(d, 'exact1_w1_r0.npz')))
+        plain = dict(np.load(os.path.join(d, 'exact0_w2_r0.npz')))
+    for key in ('d_grad', 'g_grad'):
+        assert np.array_equal(dp[0][key], dp[1][key])
+        mean = dp[0][key].astype(np.float64) / 2.0
+        scale = np.abs(ref[key]).max()
+        assert np.abs(mean - ref[key]).max() <= 5e-4 * scale, (key, np.abs(mean - ref[key]).max() / scale)
+    for key in ('d_param', 'g_param'):
+        assert np.array_equal(dp[0][key], dp[1][key])
+        assert np.abs(dp[0][key] - ref[key]).max() <= 1e-5 * max(np.abs(ref[key]).max(), 1.0), key
+    # the control shows the test bites: conventional data parallel (per-replica BatchNorm, unscaled GDL, local norm) is
+    # a different, if equally legitimate, computation
+    off = np.abs(plain['g_grad'].astype(np.float64) / 2.0 - ref['g_grad']).max() / np.abs(ref['g_grad']).max()
+    assert off > 1e-2, off

@@ -43,7 +43,7 @@ def main():
     # plain one (different kernels: compared at 1e-4 of the weight scale after the same four steps)
     adv, loss, opt, dna, batch, ksize = TC.MG.CASES['c4_dna_wass_rmsprop']
     G.reset_default_graph()
-    optim.set_data_parallel(1, force=True, sync_bn=True)
+    optim.set_data_parallel(1, force=True, exact_global_batch=True)    # SyncBN + GDL scale (x1) + global state-loss norm
     sess = G.Session(device='cuda:0')
     tr = T.Trainer(sess, True, 'bce', 'rmsprop', dna, batch_size=batch, ksize=ksize)
     sess.run(G.global_variables_initializer())
@@ -56,6 +56,7 @@ def main():
     torch.cuda.synchronize()
     kinds = [type(o).__name__ for o in G.get_default_graph().ops]
     assert kinds.count('BnMomentsAllReduceOp') >= 15 and kinds.count('BnSumsAllReduceOp') >= 15
+    assert kinds.count('L2GlobalGradOp') >= 1 and kinds.count('ScalarAllReduceOp') >= 1
     for n, v in G.get_default_graph().variables.items():
         got, want = sess.get_value(v).double(), finals[0][n].double()
         assert (got - want).abs().max().item() <= 1e-4 * max(want.abs().max().item(), 1e-3) + 1e-6, n

@@ -51,6 +51,15 @@ def _dp(graph):
     return graph.collections.get('data_parallel') or DataParallel(1)
 
 
+def _capture_collectives():
+    """ACG_CAPTURE_COLLECTIVES=1 (experimental, off): the gradient all-reduces become ordinary stream-ordered device
+    ops, so they are captured INTO the step's HIP graph instead of cutting it (no cut cost, but no overlap with
+    backward either).  RCCL supports capture on this stack (tools/micro/rccl_capture_probe.py); validated here on one
+    rank only, hence opt-in until a multi-GPU run has measured it."""
+    import os
+    return os.environ.get('ACG_CAPTURE_COLLECTIVES') == '1'
+
+
 class AllReduceOp(G.Op):
     """Sum-all-reduce of one contiguous gradient bucket on the communication stream."""
     host = True
@@ -60,10 +69,13 @@ class AllReduceOp(G.Op):
         self.flat_grad, self.start, self.end = flat_grad, start, end
         self.index = max(o.index for o in after) + 0.5     # right behind the op that completes the bucket
         self.work = None
+        self.host = not _capture_collectives()
 
     def bind(self, rt):
         view = self.flat_grad.buf[self.start:self.end]
         op = self
+        if not self.host:          # captured: in stream order on whatever stream the segment is being enqueued on
+            return lambda s: dist.all_reduce(view, op=dist.ReduceOp.SUM, group=rt.process_group)
 
         def launch():
             if rt.is_cuda:
@@ -84,9 +96,12 @@ class AllReduceWaitOp(G.Op):
     def __init__(self, graph, reduces, name):
         super().__init__(graph, name, [], [], control_inputs=reduces)
         self.reduces = reduces
+        self.host = not _capture_collectives()
 
     def bind(self, rt):
         reduces = self.reduces
+        if not self.host:
+            return None            # stream order already serialises the captured all-reduces before the update
 
         def wait():
             for r in reduces:

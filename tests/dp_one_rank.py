@@ -60,6 +60,27 @@ def main():
     for n, v in G.get_default_graph().variables.items():
         got, want = sess.get_value(v).double(), finals[0][n].double()
         assert (got - want).abs().max().item() <= 1e-4 * max(want.abs().max().item(), 1e-3) + 1e-6, n
+    # experimental: all-reduces captured into the HIP graph (ACG_CAPTURE_COLLECTIVES=1) - one graph per program again,
+    # weights bit-identical to the plain run
+    os.environ['ACG_CAPTURE_COLLECTIVES'] = '1'
+    try:
+        G.reset_default_graph()
+        optim.set_data_parallel(1, force=True)
+        sess = G.Session(device='cuda:0')
+        tr = T.Trainer(sess, True, 'bce', 'rmsprop', dna, batch_size=batch, ksize=ksize)
+        sess.run(G.global_variables_initializer())
+        for n, v in G.get_default_graph().variables.items():
+            sess.set_value(v, params[n])
+        for _ in range(4):
+            tr.train_d(x, y, a)
+            tr.train_g(x, y, a, s)
+        torch.cuda.synchronize()
+        progs = [p for p in sess._programs.values() if p.runs >= 2 and p.graphs is not None]
+        assert progs and all(len(p.segments) == 1 for p in progs), [len(p.segments) for p in progs]
+        for n, v in G.get_default_graph().variables.items():
+            assert torch.equal(sess.get_value(v), finals[0][n]), n
+    finally:
+        del os.environ['ACG_CAPTURE_COLLECTIVES']
     print('DP_ONE_RANK_OK', flush=True)
     os._exit(0)     # leave without communicator teardown
 

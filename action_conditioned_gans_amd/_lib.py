@@ -33,6 +33,12 @@ class ConvDesc(ctypes.Structure):
         return tuple(getattr(self, n) for n, _ in self._fields_)
 
 
+class ReduceList(ctypes.Structure):
+    """struct acg_reduce_list (ACG_REDUCE_MAX = 32 entries)."""
+    _fields_ = [('slabs', c_void_p * 32), ('out', c_void_p * 32), ('numel', c_int64 * 32), ('splits', c_int32 * 32),
+                ('accumulate', c_float * 32)]
+
+
 class CopyList(ctypes.Structure):
     """struct acg_copy_list (ACG_COPY_MAX = 8 segments)."""
     _fields_ = [('src', c_void_p * 8), ('dst', c_void_p * 8), ('rows', c_int64 * 8), ('cols', c_int32 * 8),
@@ -55,6 +61,10 @@ SIGNATURES = {
     'acg_conv2d_fwd': (c_int32, _conv),
     'acg_conv2d_dgrad': (c_int32, _conv),
     'acg_conv2d_wgrad': (c_int32, _wgrad),
+    'acg_conv2d_splits': (c_int32, [_D, c_int32, c_int32]),
+    'acg_conv2d_wgrad_slabs': (c_int32, [_P, _P, _D, c_int32, _P, c_size_t, _P]),
+    'acg_deconv2d_wgrad_slabs': (c_int32, [_P, _P, _D, c_int32, _P, c_size_t, _P]),
+    'acg_splitk_reduce_many': (c_int32, [ctypes.POINTER(ReduceList), c_int32, _P]),
     'acg_deconv2d_fwd': (c_int32, _conv),
     'acg_deconv2d_dgrad': (c_int32, _conv),
     'acg_deconv2d_wgrad': (c_int32, _wgrad),
@@ -102,6 +112,8 @@ SIGNATURES = {
 
 
 COPY_MAX = 8
+REDUCE_MAX = 32
+VALUE_RETURNING = ('acg_version', 'acg_conv2d_splits')     # int32 results that are not status codes
 
 
 class AcgError(RuntimeError):
@@ -120,7 +132,7 @@ class Library:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(self._cdll, name)
             fn.restype, fn.argtypes = res, args
-            if res is c_int32 and name != 'acg_version':
+            if res is c_int32 and name not in VALUE_RETURNING:
                 fn = self._checked(name, fn)
             setattr(self, name[4:], fn)
         if self.version() != ABI_VERSION:

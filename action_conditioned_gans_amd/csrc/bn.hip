@@ -8,6 +8,8 @@
 // of its own channels from the partials (fp64 combine) and applies normalise + activation.  Two launches per
 // direction (a launch costs more than the few redundant L2 reads of the partials), no atomics,
 // deterministic.
+// Tensors of <= 2048 rows per group take ONE launch instead: a block keeps its channels' rows in registers
+// (bn_resident_fwd / _bwd below).
 #include <hip/hip_runtime.h>
 
 #include <stdlib.h>
@@ -342,6 +344,150 @@ __global__ __launch_bounds__(256) void bn_apply_bwd(const float* __restrict__ x,
   }
 }
 
+// ---- register-resident BatchNorm for small tensors (R <= 256 * NR rows per group) ------------------------------
+// The two-launch path above costs ~7.5-10 us at ANY size below ~1 MB (two dependent launches, each a memory round
+// trip: profiles/r1/q_non_conv_ops.txt); half of the BatchNorm'd tensors of the models are that small.  Here a block owns V
+// channels of one group, keeps all R rows of them in registers (NR rows per thread), reduces through LDS and writes
+// the result: one launch, every element read once.  Loads are 16 bytes per row (V = 4) - a poor use of cache lines,
+// irrelevant at these sizes: the tensor was just written by the conv and sits in L2 / the memory-side cache.
+template <int N>
+__device__ __forceinline__ void block_sum(float (&v)[N], float* sh /* 4 * N floats */) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[j] += __shfl_xor(v[j], off, 64);
+  }
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) sh[wave * N + j] = v[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < N; ++j) v[j] = sh[j] + sh[N + j] + sh[2 * N + j] + sh[3 * N + j];
+}
+
+template <int V, int NR>
+__global__ __launch_bounds__(256) void bn_resident_fwd(const float* __restrict__ x, const float* __restrict__ beta,
+                                                       float* __restrict__ y, float* __restrict__ save_mean,
+                                                       float* __restrict__ save_rstd, int R, int C, float eps, int act, float leak) {
+  __shared__ float sh[4 * 2 * V];
+  const int c = blockIdx.x * V, g = blockIdx.y;
+  const float* xg = x + (long long)g * R * C + c;
+  float* yg = y + (long long)g * R * C + c;
+  float v[NR][V], pv[V], bt[V];
+#pragma unroll
+  for (int u = 0; u < NR; ++u) ldv<V>(xg + min((int)threadIdx.x + u * 256, R - 1) * C, v[u]);
+  ldv<V>(xg, pv);      // shift by the group's first row, as in bn_stats_partial
+  ldv<V>(beta + c, bt);
+  float s[2 * V];
+#pragma unroll
+  for (int j = 0; j < 2 * V; ++j) s[j] = 0.f;
+#pragma unroll
+  for (int u = 0; u < NR; ++u) {
+    const float w = (int)threadIdx.x + u * 256 < R ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < V; ++j) { const float d = (v[u][j] - pv[j]) * w; s[j] += d; s[V + j] += d * d; }
+  }
+  block_sum<2 * V>(s, sh);
+  float mean[V], rstd[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const double inv = 1.0 / (double)R, dm = (double)s[j] * inv;
+    double var = (double)s[V + j] * inv - dm * dm;
+    var = var > 0.0 ? var : 0.0;
+    mean[j] = (float)((double)pv[j] + dm);
+    rstd[j] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  if (threadIdx.x == 0) { stv<V>(save_mean + g * C + c, mean); stv<V>(save_rstd + g * C + c, rstd); }
+#pragma unroll
+  for (int u = 0; u < NR; ++u) {
+    const int r = (int)threadIdx.x + u * 256;
+    if (r < R) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[u][j] = acg::act_apply(act, (v[u][j] - mean[j]) * rstd[j] + bt[j], leak);
+      stv<V>(yg + r * C, v[u]);
+    }
+  }
+}
+
+// One block per V channels walks the groups in turn (dbeta is the sum over groups of its first reduction).
+template <int V, int NR>
+__global__ __launch_bounds__(256) void bn_resident_bwd(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       const float* __restrict__ beta, const float* __restrict__ save_mean,
+                                                       const float* __restrict__ save_rstd, float* __restrict__ dx,
+                                                       float* __restrict__ dbeta, float dbeta_acc, int R, int C, int groups,
+                                                       int act, float leak) {
+  __shared__ float sh[4 * 2 * V];
+  const int c = blockIdx.x * V;
+  float bt[V], tot[V];
+  ldv<V>(beta + c, bt);
+#pragma unroll
+  for (int j = 0; j < V; ++j) tot[j] = 0.f;
+  for (int g = 0; g < groups; ++g) {
+    const long long base = (long long)g * R * C + c;
+    float xv[NR][V], dv[NR][V], mean[V], rstd[V];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+      const int rr = min((int)threadIdx.x + u * 256, R - 1) * C;
+      ldv<V>(x + base + rr, xv[u]); ldv<V>(dy + base + rr, dv[u]);
+    }
+    ldv<V>(save_mean + g * C + c, mean); ldv<V>(save_rstd + g * C + c, rstd);
+    float s[2 * V];
+#pragma unroll
+    for (int j = 0; j < 2 * V; ++j) s[j] = 0.f;
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+      const float w = (int)threadIdx.x + u * 256 < R ? 1.f : 0.f;
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float xh = (xv[u][j] - mean[j]) * rstd[j];
+        const float dp = w * dv[u][j] * acg::act_deriv_pre(act, xh + bt[j], leak);
+        xv[u][j] = xh; dv[u][j] = dp;
+        s[j] += dp; s[V + j] += dp * xh;
+      }
+    }
+    block_sum<2 * V>(s, sh);
+    const float invR = 1.f / (float)R;
+#pragma unroll
+    for (int j = 0; j < V; ++j) tot[j] += s[j];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+      const int r = (int)threadIdx.x + u * 256;
+      if (r < R) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) dv[u][j] = rstd[j] * (dv[u][j] - s[j] * invR - xv[u][j] * (s[V + j] * invR));
+        stv<V>(dx + base + r * C, dv[u]);
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    float d[V];
+    if (dbeta_acc != 0.f) {
+      ldv<V>(dbeta + c, d);
+#pragma unroll
+      for (int j = 0; j < V; ++j) d[j] = dbeta_acc * d[j] + tot[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) d[j] = tot[j];
+    }
+    stv<V>(dbeta + c, d);
+  }
+}
+
+// Rows per thread of the resident kernels, 0 = two-launch path.  `R` = rows a block walks (fwd: one group; bwd: all
+// groups in turn).  A block pulls one cache line per row through its CU's L1, ~2R cycles: measured break-even
+// against the two-launch path is ~2048 rows (profiles/r1/q_non_conv_ops.txt: 512 rows 3.9 vs 7.5 us, 2048 rows 6.1
+// vs 7.7 us, 4096 rows 20.9 vs 9.5 us, 8192 rows 23.5 vs 9.3 us).
+int resident_nr(long long R, int max_nr) {
+  static const int lim = env_int("ACG_BN_RESIDENT_ROWS", 2048);     // tuning hook; 0 disables the resident kernels
+  if (R > lim) return 0;
+  for (int nr = 1; nr <= max_nr; nr *= 2)
+    if (R <= 256ll * nr) return nr;
+  return 0;
+}
+
 // ---- bias + activation --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bias_act_fwd_k(const float* __restrict__ x, const float* __restrict__ bias,
                                                       float* __restrict__ y, long long R, int C, int act, float leak) {
@@ -558,6 +704,22 @@ int32_t acg_bn_act_fwd(const void* x, const float* beta, void* y, float* save_me
   float* part = (float*)ws;
   const bool v4 = vec4_ok(C, x, y, beta) && vec4_ok(C, save_mean, save_rstd, ws);
   const int V = v4 ? 4 : 1;
+  if (const int nr = resident_nr(R, 32)) {
+    const dim3 rg(C / V, groups);
+#define ACG_BN_RES_FWD(VV, NN) ACG_LAUNCH((bn_resident_fwd<VV, NN>), rg, dim3(256), 0, st, xf, beta, (float*)y, save_mean, save_rstd, (int)R, C, eps, act, leak)
+#define ACG_BN_RES_FWD_V(NN) do { if (v4) ACG_BN_RES_FWD(4, NN); else ACG_BN_RES_FWD(1, NN); } while (0)
+    switch (nr) {
+      case 1: ACG_BN_RES_FWD_V(1); break;
+      case 2: ACG_BN_RES_FWD_V(2); break;
+      case 4: ACG_BN_RES_FWD_V(4); break;
+      case 8: ACG_BN_RES_FWD_V(8); break;
+      case 16: ACG_BN_RES_FWD_V(16); break;
+      default: ACG_BN_RES_FWD_V(32); break;
+    }
+#undef ACG_BN_RES_FWD_V
+#undef ACG_BN_RES_FWD
+    return acg::check_launch("bn_resident_fwd");
+  }
   static const int stats_iters = env_int("ACG_BN_STATS_ITERS", 8);  // tuning hook
   const int nblk = vpartial_blocks(R, C, V, stats_iters);
   if (v4) ACG_LAUNCH(bn_stats_partial<4>, dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk);
@@ -584,6 +746,21 @@ int32_t acg_bn_act_bwd(const void* x, const void* dy, const float* beta, const f
   float* part = (float*)ws;
   const bool v4 = vec4_ok(C, x, dy, dx) && vec4_ok(C, save_mean, save_rstd, ws) && vec4_ok(C, beta, dbeta, ws);
   const int V = v4 ? 4 : 1;
+  if (const int nr = resident_nr(R * groups, 16) ? resident_nr(R, 16) : 0) {
+    const dim3 rg(C / V);
+#define ACG_BN_RES_BWD(VV, NN) ACG_LAUNCH((bn_resident_bwd<VV, NN>), rg, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (float*)dx, dbeta, dbeta_acc, (int)R, C, groups, act, leak)
+#define ACG_BN_RES_BWD_V(NN) do { if (v4) ACG_BN_RES_BWD(4, NN); else ACG_BN_RES_BWD(1, NN); } while (0)
+    switch (nr) {
+      case 1: ACG_BN_RES_BWD_V(1); break;
+      case 2: ACG_BN_RES_BWD_V(2); break;
+      case 4: ACG_BN_RES_BWD_V(4); break;
+      case 8: ACG_BN_RES_BWD_V(8); break;
+      default: ACG_BN_RES_BWD_V(16); break;
+    }
+#undef ACG_BN_RES_BWD_V
+#undef ACG_BN_RES_BWD
+    return acg::check_launch("bn_resident_bwd");
+  }
   static const int bwd_iters = env_int("ACG_BN_BWD_ITERS", 4);      // tuning hook
   const int nblk = vpartial_blocks(R, C, V, bwd_iters);
   if (v4) ACG_LAUNCH(bn_bwd_partial<4>, dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak);

@@ -32,13 +32,13 @@ using namespace acgconv;
 
 namespace {
 
-// out[i] = accumulate * out[i] + sum_z slabs[z][i]   (fixed summation order)
-__global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ slabs, float* __restrict__ out,
-                                                     long long numel, int splits, float accumulate) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
+// out[i] = accumulate * out[i] + sum_z slabs[z][i]   (fixed summation order); `block` of `nblocks` 256-thread blocks
+__device__ __forceinline__ void reduce_slabs(const float* __restrict__ slabs, float* __restrict__ out, long long numel,
+                                             int splits, float accumulate, int block, int nblocks) {
+  const long long stride = (long long)nblocks * 256;
   const bool al = ((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && (numel & 3) == 0;
   const long long n4 = al ? numel / 4 : 0;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+  for (long long i = (long long)block * 256 + threadIdx.x; i < n4; i += stride) {
     f4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
     for (int z = 0; z < splits; ++z) s += reinterpret_cast<const f4*>(slabs + (long long)z * numel)[i];   // 8 loads in flight, summed in z order
@@ -46,13 +46,38 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ s
     if (accumulate != 0.f) s += accumulate * *o;
     *o = s;
   }
-  for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride) {
+  for (long long i = n4 * 4 + (long long)block * 256 + threadIdx.x; i < numel; i += stride) {
     float s = 0.f;
 #pragma unroll 8
     for (int z = 0; z < splits; ++z) s += slabs[(long long)z * numel + i];
     out[i] = (accumulate != 0.f ? accumulate * out[i] : 0.f) + s;
   }
 }
+
+__global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ slabs, float* __restrict__ out,
+                                                     long long numel, int splits, float accumulate) {
+  reduce_slabs(slabs, out, numel, splits, accumulate, blockIdx.x, gridDim.x);
+}
+
+// The slab reductions of several weight gradients in ONE launch (acg_splitk_reduce_many): a launch costs ~4-5 us in
+// the step's HIP graph whatever its size, and nothing reads a weight gradient before the optimizer (or the
+// all-reduce of its bucket).  Entry e owns blocks [first_block[e], first_block[e+1]); same arithmetic as above.
+struct ReduceList {
+  const float* slabs[ACG_REDUCE_MAX];
+  float* out[ACG_REDUCE_MAX];
+  long long numel[ACG_REDUCE_MAX];
+  int splits[ACG_REDUCE_MAX];
+  float accumulate[ACG_REDUCE_MAX];
+  int first_block[ACG_REDUCE_MAX + 1];
+};
+__global__ __launch_bounds__(256) void splitk_reduce_many(const ReduceList l, int count) {
+  int e = 0;
+  while (e + 1 < count && (int)blockIdx.x >= l.first_block[e + 1]) ++e;      // block-uniform scan of <= 32 entries
+  reduce_slabs(l.slabs[e], l.out[e], l.numel[e], l.splits[e], l.accumulate[e], (int)blockIdx.x - l.first_block[e],
+               l.first_block[e + 1] - l.first_block[e]);
+}
+
+int reduce_blocks(long long numel) { return (int)std::max<long long>(1, std::min<long long>(acg::ceil_div(numel, 256 * 4), 2048)); }
 
 // ---- host-side planning ------------------------------------------------------------------------------
 
@@ -130,12 +155,15 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
   return pl;
 }
 
+// slabs_only (weight gradients whose reduction is deferred to acg_splitk_reduce_many): the contraction leaves its
+// `splits` partial slabs in the workspace and `out` is not touched.
 int run(int which, const float* gsrc, const float* dense, float* out, float accumulate, const acg_conv_desc* d, int dtype,
-        void* ws, size_t ws_bytes, acg_stream_t stream, const char* who) {
+        void* ws, size_t ws_bytes, acg_stream_t stream, const char* who, bool slabs_only = false) {
   ACG_REQUIRE(dtype == ACG_F32 || dtype == ACG_BF16, ACG_ERR_UNSUPPORTED, "%s: dtype %d", who, dtype);
   if (int rc = validate(d, who)) return rc;
-  ACG_REQUIRE(gsrc && dense && out, ACG_ERR_INVALID_ARG, "%s: null tensor pointer", who);
+  ACG_REQUIRE(gsrc && dense && (out || slabs_only), ACG_ERR_INVALID_ARG, "%s: null tensor pointer", who);
   const Plan pl = make_plan(*d, which, dtype == ACG_BF16);
+  ACG_REQUIRE(!slabs_only || pl.splits > 1, ACG_ERR_INVALID_ARG, "%s: this shape is not split (acg_conv2d_splits == 1): call the plain entry", who);
   const size_t need = pl.splits > 1 ? (size_t)pl.splits * (size_t)pl.out_numel * sizeof(float) : 0;
   ACG_REQUIRE(ws_bytes >= need && (need == 0 || ws != nullptr), ACG_ERR_WORKSPACE, "%s: workspace %zu bytes < required %zu", who, ws_bytes, need);
   ConvArgs a{};
@@ -161,9 +189,8 @@ int run(int which, const float* gsrc, const float* dense, float* out, float accu
   else if (which == ACG_CONV_DGRAD) rc = launch_mode<MODE_DGRAD>(pl, a, st);
   else rc = launch_mode<MODE_WGRAD>(pl, a, st);
   if (rc) return rc;
-  if (pl.splits > 1) {
-    const int blocks = (int)std::min<long long>(acg::ceil_div(pl.out_numel, 256 * 4), 2048);
-    ACG_LAUNCH(splitk_reduce, dim3(std::max(blocks, 1)), dim3(256), 0, st, (const float*)ws, out, pl.out_numel, pl.splits,
+  if (pl.splits > 1 && !slabs_only) {
+    ACG_LAUNCH(splitk_reduce, dim3(reduce_blocks(pl.out_numel)), dim3(256), 0, st, (const float*)ws, out, pl.out_numel, pl.splits,
                        which == ACG_CONV_WGRAD ? accumulate : 0.f);
     return acg::check_launch("splitk_reduce");
   }
@@ -201,6 +228,39 @@ size_t acg_conv2d_workspace_bytes(const acg_conv_desc* d, int32_t which, int32_t
   if (!d || validate(d, "conv2d_workspace_bytes") != ACG_OK || which < 0 || which > 2) return 0;
   const Plan pl = make_plan(*d, which, dtype == ACG_BF16);
   return pl.splits > 1 ? (size_t)pl.splits * (size_t)pl.out_numel * sizeof(float) : 0;
+}
+
+int32_t acg_conv2d_splits(const acg_conv_desc* d, int32_t which, int32_t dtype) {
+  if (!d || validate(d, "conv2d_splits") != ACG_OK || which < 0 || which > 2) return 0;
+  return make_plan(*d, which, dtype == ACG_BF16).splits;
+}
+
+int32_t acg_conv2d_wgrad_slabs(const void* x, const void* dy, const acg_conv_desc* d, int32_t dtype, void* ws, size_t wsb,
+                               acg_stream_t s) {
+  return run(ACG_CONV_WGRAD, (const float*)x, (const float*)dy, nullptr, 0.f, d, dtype, ws, wsb, s, "conv2d_wgrad_slabs", true);
+}
+int32_t acg_deconv2d_wgrad_slabs(const void* x, const void* dy, const acg_conv_desc* adj, int32_t dtype, void* ws, size_t wsb,
+                                 acg_stream_t s) {
+  return run(ACG_CONV_WGRAD, (const float*)dy, (const float*)x, nullptr, 0.f, adj, dtype, ws, wsb, s, "deconv2d_wgrad_slabs", true);
+}
+
+int32_t acg_splitk_reduce_many(const acg_reduce_list* list, int32_t count, acg_stream_t stream) {
+  ACG_REQUIRE(list && count >= 1 && count <= ACG_REDUCE_MAX, ACG_ERR_INVALID_ARG, "splitk_reduce_many: 1..%d entries", ACG_REDUCE_MAX);
+  ReduceList l{};
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    ACG_REQUIRE(list->slabs[i] && list->out[i] && list->numel[i] > 0 && list->splits[i] >= 1, ACG_ERR_INVALID_ARG,
+                "splitk_reduce_many: bad entry %d", i);
+    for (int j = 0; j < i; ++j)
+      ACG_REQUIRE(list->out[j] != list->out[i], ACG_ERR_INVALID_ARG, "splitk_reduce_many: entries %d and %d share an output", j, i);
+    l.slabs[i] = (const float*)list->slabs[i]; l.out[i] = (float*)list->out[i]; l.numel[i] = list->numel[i];
+    l.splits[i] = list->splits[i]; l.accumulate[i] = list->accumulate[i];
+    l.first_block[i] = blocks;
+    blocks += reduce_blocks(list->numel[i]);
+  }
+  l.first_block[count] = blocks;
+  ACG_LAUNCH(splitk_reduce_many, dim3(blocks), dim3(256), 0, acg::to_stream(stream), l, (int)count);
+  return acg::check_launch("splitk_reduce_many");
 }
 
 int32_t acg_conv2d_fwd(const void* x, const void* w, void* y, const acg_conv_desc* d, int32_t dtype, void* ws,

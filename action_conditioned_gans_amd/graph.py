@@ -305,9 +305,13 @@ class Runtime:
         self._scratch = {}
 
     def workspace(self, nbytes):
-        """A private zero-initialised scratch buffer (never shared: ops may overlap across streams)."""
+        """A private zero-initialised scratch buffer (never shared: ops may overlap across streams).  It lives as long
+        as the runtime: the launch closures of EVERY compiled program hold its raw address, also after the op is
+        bound again for another fetch signature."""
         n = max(int(nbytes), 16)
-        return torch.zeros(n, dtype=torch.uint8, device=self.device), n
+        buf = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        self._scratch.setdefault('workspaces', []).append(buf)
+        return buf, n
 
     def stream_ptr(self):
         if self.is_cuda:

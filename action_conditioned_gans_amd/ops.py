@@ -202,12 +202,56 @@ class ConvWgradOp(_ConvBase):
 
     def __init__(self, x, dy, dst, accumulate, desc, transposed, name):
         self.desc, self.transposed, self.accumulate = desc, transposed, float(accumulate)
+        self.deferred_to = None     # a WgradReduceOp: this op leaves its split-K slabs for that op's single launch
         super().__init__(G.get_default_graph(), name, [x, dy], [dst])
 
     def bind(self, rt):
         x, dy = self.inputs
+        lib, d = rt.lib, self.desc
+        if self.deferred_to is not None:
+            splits = lib.conv2d_splits(ctypes.byref(d), CONV_WGRAD, rt.conv_dtype)
+            if splits > 1:
+                ws, n = rt.workspace(lib.conv2d_workspace_bytes(ctypes.byref(d), CONV_WGRAD, rt.conv_dtype))
+                self._keep = (ws, d)
+                self.deferred_to.pending.append((ws, self.outputs[0], splits, self.accumulate))
+                fn = lib.deconv2d_wgrad_slabs if self.transposed else lib.conv2d_wgrad_slabs
+                pa, pb, dref, pws, dt = _p(x.buf), _p(dy.buf), ctypes.byref(d), _p(ws), rt.conv_dtype
+                return lambda s: fn(pa, pb, dref, dt, pws, n, s)
         return self._bind(rt, 'deconv2d_wgrad' if self.transposed else 'conv2d_wgrad', x, dy, self.outputs[0],
                           accumulate=self.accumulate)
+
+
+class WgradReduceOp(G.Op):
+    """ONE launch that finishes the split-K weight gradients of several layers (acg_splitk_reduce_many): nothing reads
+    a weight gradient before the optimizer update (or the all-reduce of its bucket), and a launch costs ~4-5 us in the
+    step's HIP graph whatever its size.  Bit-identical to the per-layer reductions it replaces."""
+
+    def __init__(self, wgrads, name):
+        g = G.get_default_graph()
+        super().__init__(g, name, [], [], control_inputs=wgrads)
+        self.index = max(o.index for o in wgrads) + 0.25      # right behind the last of its layers
+        self.pending = []                                     # filled by the ConvWgradOps as they are bound
+        for o in wgrads:
+            o.deferred_to = self
+
+    def bind(self, rt):
+        entries, self.pending = self.pending, []
+        if not entries:
+            return None                                       # none of the layers is split at these shapes
+        lists = []
+        for lo in range(0, len(entries), _lib.REDUCE_MAX):
+            chunk = entries[lo:lo + _lib.REDUCE_MAX]
+            rl = _lib.ReduceList()
+            for i, (ws, dst, splits, acc) in enumerate(chunk):
+                rl.slabs[i], rl.out[i], rl.numel[i], rl.splits[i], rl.accumulate[i] = ws.data_ptr(), dst.buf.data_ptr(), dst.numel, splits, acc
+            lists.append((rl, len(chunk)))
+        self._keep = lists
+        fn = rt.lib.splitk_reduce_many
+
+        def launch(s):
+            for rl, n in lists:
+                fn(ctypes.byref(rl), n, s)
+        return launch
 
 
 class BnActOp(G.Op):

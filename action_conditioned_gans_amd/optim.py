@@ -176,16 +176,19 @@ class Optimizer:
         missing = [v.name for v in var_list if v.name not in ctx.writers]
         if len(missing) == len(var_list):
             raise ValueError('No gradients provided for any variable: %s' % missing)
-        writers = [op for ops_ in ctx.writers.values() for op in ops_]
-        deps = list(writers)
         dp = _dp(g)
+        buckets = self._buckets(dp, var_list, offsets, total) if dp.active else [(0, total)]
+        self._defer_wgrad_reductions(var_list, ctx, offsets, buckets)
+        writers = [op for ops_ in ctx.writers.values() for op in ops_]
+        deps = list(dict.fromkeys(writers))
         if dp.active:
-            reduces = self._insert_allreduce(g, dp, var_list, ctx, flat_grad, offsets, total)
+            reduces = self._insert_allreduce(var_list, ctx, flat_grad, offsets, buckets)
             deps.append(AllReduceWaitOp(g, reduces, self.name + '/allreduce_wait'))
         slots = self._make_slots(g, total)
         return StepOp(self, scope, [v.name for v in var_list], flat_param, flat_grad, slots, deps, 1.0 / dp.world_size)
 
-    def _insert_allreduce(self, g, dp, var_list, ctx, flat_grad, offsets, total):
+    @staticmethod
+    def _buckets(dp, var_list, offsets, total):
         # Buckets are contiguous windows of the flat gradient buffer, cut from the END of the layout
         # (the last-created layers finish their wgrad first), each reduced as soon as its last writer ran.
         order = sorted(var_list, key=lambda v: offsets[v.name])
@@ -198,9 +201,27 @@ class Optimizer:
                 hi, acc = offsets[v.name], 0
         if hi > 0:
             buckets.append((0, hi))
+        return buckets
+
+    def _defer_wgrad_reductions(self, var_list, ctx, offsets, buckets):
+        """Per bucket (one bucket = the whole buffer without data parallelism), the conv weight gradients with a single
+        writer hand their split-K slab reduction to ONE WgradReduceOp, which becomes the gradient's writer."""
+        for k, (lo, hi) in enumerate(buckets):
+            group = [ctx.writers[v.name][0] for v in var_list
+                     if lo <= offsets[v.name] < hi and len(ctx.writers.get(v.name, ())) == 1
+                     and isinstance(ctx.writers[v.name][0], O.ConvWgradOp)]
+            if len(group) < 2:
+                continue
+            red = O.WgradReduceOp(group, '%s/wgrad_reduce_%d' % (self.name, k))
+            for v in var_list:
+                if ctx.writers.get(v.name) and ctx.writers[v.name][0] in group:
+                    ctx.writers[v.name] = [red]
+
+    def _insert_allreduce(self, var_list, ctx, flat_grad, offsets, buckets):
+        order = sorted(var_list, key=lambda v: offsets[v.name])
         reduces = []
         for k, (lo, hi_) in enumerate(buckets):
-            after = [op for v in order if lo <= offsets[v.name] < hi_ for op in ctx.writers.get(v.name, [])]
+            after = list(dict.fromkeys(op for v in order if lo <= offsets[v.name] < hi_ for op in ctx.writers.get(v.name, [])))
             if not after:
                 continue
             reduces.append(AllReduceOp(flat_grad, lo, hi_, after, '%s/allreduce_%d' % (self.name, k)))

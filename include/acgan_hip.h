@@ -97,6 +97,29 @@ int32_t acg_deconv2d_dgrad(const void* dy, const void* w, void* dx, const acg_co
 int32_t acg_deconv2d_wgrad(const void* x, const void* dy, float* dw, float accumulate, const acg_conv_desc* adj,
                            int32_t dtype, void* workspace, size_t workspace_bytes, acg_stream_t stream);
 
+/* Deferred reduction of split weight gradients.  Nothing reads a weight gradient before the optimizer update of
+ * train.py:100-102 (or, data parallel, the all-reduce of its bucket), so the per-layer slab reductions that
+ * acg_conv2d_wgrad would launch one by one can run as ONE launch per step:
+ *   acg_conv2d_splits          the split-K factor the planner picks (which = ACG_CONV_FWD/DGRAD/WGRAD); 0 on a bad desc
+ *   acg_(de)conv2d_wgrad_slabs the contraction only: `splits` partial slabs of kh*kw*in_c*out_c floats are left in the
+ *                              workspace (acg_conv2d_workspace_bytes); an error when the shape is not split
+ *   acg_splitk_reduce_many     out[i] = accumulate[i] * out[i] + sum_z slabs[i][z], z in order: bit-identical to the
+ *                              per-layer reduction.  Outputs must be distinct. */
+#define ACG_REDUCE_MAX 32
+typedef struct acg_reduce_list {
+  const void* slabs[ACG_REDUCE_MAX];
+  void* out[ACG_REDUCE_MAX];
+  int64_t numel[ACG_REDUCE_MAX];
+  int32_t splits[ACG_REDUCE_MAX];
+  float accumulate[ACG_REDUCE_MAX];
+} acg_reduce_list;
+int32_t acg_conv2d_splits(const acg_conv_desc* d, int32_t which, int32_t dtype);
+int32_t acg_conv2d_wgrad_slabs(const void* x, const void* dy, const acg_conv_desc* d, int32_t dtype, void* workspace,
+                               size_t workspace_bytes, acg_stream_t stream);
+int32_t acg_deconv2d_wgrad_slabs(const void* x, const void* dy, const acg_conv_desc* adj, int32_t dtype, void* workspace,
+                                 size_t workspace_bytes, acg_stream_t stream);
+int32_t acg_splitk_reduce_many(const acg_reduce_list* list, int32_t count, acg_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Synchronised BatchNorm for data parallel runs (SURVEY 8(e) caveat 1; optional, no reference counterpart: the
  * reference is single-device).  The statistics are those of the GLOBAL batch: each direction is two calls with

@@ -46,7 +46,17 @@ int32_t acg_conv_desc_init(acg_conv_desc* d, int32_t batch, int32_t in_h, int32_
   return ACG_OK;
 }
 
-size_t acg_conv2d_workspace_bytes(const acg_conv_desc* d, int32_t which, int32_t dtype) { (void)d; (void)which; (void)dtype; return 0; }
+/* The oracle splits only the weight-gradient contraction, over the two halves of the batch (the product's planner splits
+ * K = batch * out_h * out_w into up to 128 chunks): enough to state what the deferred-reduction entries mean. */
+int32_t acg_conv2d_splits(const acg_conv_desc* d, int32_t which, int32_t dtype) {
+  (void)dtype;
+  if (!d || which < 0 || which > 2) return 0;
+  return which == ACG_CONV_WGRAD && d->batch >= 2 ? 2 : 1;
+}
+size_t acg_conv2d_workspace_bytes(const acg_conv_desc* d, int32_t which, int32_t dtype) {
+  const int32_t sp = acg_conv2d_splits(d, which, dtype);
+  return sp > 1 ? (size_t)sp * d->kh * d->kw * d->in_c * d->out_c * sizeof(float) : 0;
+}
 int32_t acg_debug_conv_plan(int32_t cfg, int32_t splits) { (void)cfg; (void)splits; return ACG_OK; }
 
 #define XPITCH(d) ((d)->in_pitch > 0 ? (d)->in_pitch : (d)->in_c)
@@ -103,6 +113,49 @@ int32_t acg_conv2d_wgrad(const void* xv, const void* dyv, float* dw, float accum
       size_t k = WI(d, i, j, c, o);
       dw[k] = (float)((accumulate != 0.f ? (double)accumulate * dw[k] : 0.0) + acc);
     }
+  return ACG_OK;
+}
+
+/* include/acgan_hip.h "Deferred reduction of split weight gradients": slab z = the contribution of batch half z */
+int32_t acg_conv2d_wgrad_slabs(const void* xv, const void* dyv, const acg_conv_desc* d, int32_t dtype, void* ws, size_t wsb,
+                               acg_stream_t s) {
+  (void)s; REQUIRE_F32(dtype);
+  const int sp = acg_conv2d_splits(d, ACG_CONV_WGRAD, dtype);
+  if (sp < 2) return fail(ACG_ERR_INVALID_ARG, "conv2d_wgrad_slabs: this shape is not split");
+  const size_t numel = (size_t)d->kh * d->kw * d->in_c * d->out_c;
+  if (!ws || wsb < sp * numel * sizeof(float)) return fail(ACG_ERR_WORKSPACE, "conv2d_wgrad_slabs: workspace too small");
+  const float* x = xv; const float* dy = dyv; float* slabs = ws;
+  for (int z = 0; z < sp; z++) {
+    const int b0 = z * d->batch / sp, b1 = (z + 1) * d->batch / sp;
+    for (int i = 0; i < d->kh; i++) for (int j = 0; j < d->kw; j++) for (int c = 0; c < d->in_c; c++)
+      for (int o = 0; o < d->out_c; o++) {
+        double acc = 0;
+        for (int b = b0; b < b1; b++) for (int p = 0; p < d->out_h; p++) { int yy = p * d->stride_h - d->pad_top + i; if (yy < 0 || yy >= d->in_h) continue;
+          for (int q = 0; q < d->out_w; q++) { int xx = q * d->stride_w - d->pad_left + j; if (xx < 0 || xx >= d->in_w) continue;
+            acc += (double)x[XI(d, b, yy, xx, c)] * dy[YI(d, b, p, q, o)]; } }
+        slabs[z * numel + WI(d, i, j, c, o)] = (float)acc;
+      }
+  }
+  return ACG_OK;
+}
+int32_t acg_deconv2d_wgrad_slabs(const void* x, const void* dy, const acg_conv_desc* adj, int32_t dtype, void* ws, size_t wsb,
+                                 acg_stream_t s) {
+  return acg_conv2d_wgrad_slabs(dy, x, adj, dtype, ws, wsb, s); }
+int32_t acg_splitk_reduce_many(const acg_reduce_list* l, int32_t count, acg_stream_t s) {
+  (void)s;
+  if (!l || count < 1 || count > ACG_REDUCE_MAX) return fail(ACG_ERR_INVALID_ARG, "splitk_reduce_many: 1..32 entries");
+  for (int e = 0; e < count; e++) {
+    if (!l->slabs[e] || !l->out[e] || l->numel[e] <= 0 || l->splits[e] < 1) return fail(ACG_ERR_INVALID_ARG, "splitk_reduce_many: bad entry");
+    for (int f = 0; f < e; f++) if (l->out[f] == l->out[e]) return fail(ACG_ERR_INVALID_ARG, "splitk_reduce_many: entries share an output");
+  }
+  for (int e = 0; e < count; e++) {
+    const float* slabs = l->slabs[e]; float* out = l->out[e];
+    for (int64_t i = 0; i < l->numel[e]; i++) {
+      double acc = l->accumulate[e] != 0.f ? (double)l->accumulate[e] * out[i] : 0.0;
+      for (int z = 0; z < l->splits[e]; z++) acc += slabs[(size_t)z * l->numel[e] + i];
+      out[i] = (float)acc;
+    }
+  }
   return ACG_OK;
 }
 

@@ -100,6 +100,29 @@ class Abi:
         self.lib.deconv2d_wgrad(_p(x), _p(dy), _p(dw), accumulate, ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
         return dw
 
+    # ---- deferred split-K reduction of weight gradients
+    def wgrad_slabs(self, x, dy, w_shape, stride, padding=None, transposed=False):
+        """-> (slab workspace, splits), or (None, 1) when the planner does not split this shape."""
+        if transposed:
+            d = self._adj(x.shape, w_shape, stride)
+        else:
+            b, h, wd, c = x.shape
+            d = self.desc(b, h, wd, w_shape[2], w_shape[0], w_shape[1], w_shape[3], stride, padding, c if c != w_shape[2] else 0)
+        splits = self.lib.conv2d_splits(ctypes.byref(d), L.CONV_WGRAD, self.conv_dtype)
+        if splits < 2:
+            return None, splits
+        ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_WGRAD, self.conv_dtype))
+        fn = self.lib.deconv2d_wgrad_slabs if transposed else self.lib.conv2d_wgrad_slabs
+        fn(_p(x), _p(dy), ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
+        return ws, splits
+
+    def splitk_reduce_many(self, entries):
+        """entries: (slab workspace, out tensor, splits, accumulate)."""
+        rl = L.ReduceList()
+        for i, (ws, out, splits, acc) in enumerate(entries):
+            rl.slabs[i], rl.out[i], rl.numel[i], rl.splits[i], rl.accumulate[i] = ws.data_ptr(), out.data_ptr(), out.numel(), splits, acc
+        self.lib.splitk_reduce_many(ctypes.byref(rl), len(entries), self.stream())
+
     # ---- bn / bias
     def bn_act_fwd(self, x, beta, act, groups=1, eps=1e-3, leak=0.2):
         c = x.shape[-1]

@@ -2,6 +2,7 @@
 GPU suite (libacgan_hip.so vs torch-fp64 restatement).  Every case takes an ``Abi`` (tests/abi_call.py)
 and a tolerance, builds seeded inputs, and returns nothing or raises AssertionError."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import tf_ops as T
@@ -262,6 +263,46 @@ def case_sync_bn_entries(abi, shape, act, groups, tol):
     # two ranks holding the SAME shard: global sums double, total rows double -> dx unchanged, dbeta still the local sum
     dx2, dbeta2 = abi.bn_act_bwd_sums(x, dy, beta, mean_ref, rstd_ref, sums * 2, sums, 2 * rows_per_group, act, groups=groups)
     close(dx2, dx_ref, tol * 8, tag + ' dx (two identical ranks)'); close(dbeta2, dbeta_ref, tol * 8, tag + ' dbeta (two identical ranks)')
+
+
+def case_wgrad_deferred(abi, tol, exact):
+    """acg_(de)conv2d_wgrad_slabs + ONE acg_splitk_reduce_many over several layers == the per-layer acg_(de)conv2d_wgrad
+    (bit for bit on the HIP side: same slabs, same summation order), including an accumulating entry and a ragged size."""
+    dev = abi.device
+    layers = [((4, 16, 16, 8), (5, 5, 8, 16), 2, 'SAME', False), ((4, 18, 14, 3), (5, 5, 3, 5), 1, 'SAME', False),
+              ((4, 12, 12, 12), (3, 3, 12, 8), 1, 'VALID', False), ((4, 8, 8, 16), (5, 5, 8, 16), 2, None, True)]
+    entries, want, got = [], [], []
+    for i, (xs, ws_, stride, padding, transposed) in enumerate(layers):
+        x = randn(xs, 20 + i).to(dev)
+        if transposed:
+            dy = randn((xs[0], xs[1] * stride, xs[2] * stride, ws_[2]), 40 + i).to(dev)
+            plain = lambda dw, acc: abi.deconv2d_wgrad(x, dy, ws_, stride, dw=dw, accumulate=acc)    # noqa: E731
+        else:
+            d = abi.desc(xs[0], xs[1], xs[2], ws_[2], ws_[0], ws_[1], ws_[3], stride, padding)
+            dy = randn((xs[0], d.out_h, d.out_w, ws_[3]), 40 + i).to(dev)
+            plain = lambda dw, acc: abi.conv2d_wgrad(x, dy, ws_, stride, padding, dw=dw, accumulate=acc)    # noqa: E731
+        acc = 1.0 if i == 2 else 0.0                       # one entry accumulates into an existing gradient
+        init = randn(ws_, 60 + i).to(dev)
+        want.append(plain(init.clone(), acc))
+        slabs, splits = abi.wgrad_slabs(x, dy, ws_, stride, padding, transposed)
+        assert splits >= 1
+        if slabs is None:                                  # planner does not split this shape: nothing to defer
+            got.append(plain(init.clone(), acc))
+            continue
+        out = init.clone()
+        got.append(out)
+        entries.append((slabs, out, splits, acc))
+    assert len(entries) >= 2, 'the case must exercise a multi-entry launch'
+    abi.splitk_reduce_many(entries)
+    abi.sync()
+    for i, (w_, g_) in enumerate(zip(want, got)):
+        if exact:
+            assert torch.equal(w_.cpu(), g_.cpu()), 'deferred reduction of layer %d is not bit-identical' % i
+        else:
+            close(g_, w_.double().cpu(), tol, 'deferred wgrad layer %d' % i)
+    # two entries sharing an output would race: rejected
+    with pytest.raises(Exception):
+        abi.splitk_reduce_many([entries[0], (entries[1][0], entries[0][1], entries[1][2], 0.0)])
 
 
 def case_copy_many(abi):

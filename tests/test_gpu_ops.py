@@ -59,7 +59,10 @@ def test_deconv_batch32(hip_abi, shape):
     C.case_deconv(hip_abi, shape, TOL_CONV)
 
 
-@pytest.mark.parametrize('shape', C.BN_SHAPES + [((32, 32, 32), 128, 1, 'relu'), ((64, 4, 4), 512, 2, 'lrelu')], ids=str)
+@pytest.mark.parametrize('shape', C.BN_SHAPES + [((32, 32, 32), 128, 1, 'relu'), ((64, 4, 4), 512, 2, 'lrelu'),
+                                            # register-resident kernels (<= 4096 rows per group): exact fit, one row past it, ragged rows, 3 groups
+                                            ((4, 32, 32), 16, 1, 'relu'), ((1, 17, 241), 8, 1, 'lrelu'), ((3, 9, 19), 12, 3, None),
+                                            ((2, 45, 45), 4, 2, 'relu'), ((2, 30, 30), 3, 1, 'lrelu')], ids=str)
 def test_bn(hip_abi, shape):
     C.case_bn(hip_abi, shape, TOL)
 
@@ -87,6 +90,10 @@ def test_cdna(hip_abi, shape):
                                               ((32, 16, 16, 128), 'relu', 1), ((64, 8, 8, 256), 'lrelu', 2)])
 def test_sync_bn_entries(hip_abi, shape, act, groups):
     C.case_sync_bn_entries(hip_abi, shape, act, groups, TOL)
+
+
+def test_wgrad_deferred_reduction(hip_abi):
+    C.case_wgrad_deferred(hip_abi, TOL_CONV, exact=True)
 
 
 def test_copy_many(hip_abi):

@@ -78,6 +78,31 @@ def test_unbatched_d_step_matches_golden_and_accumulates_two_wgrads():
     TC.check_norms(TC.flat_grad_norms(sess, tr.d_opt_op), gold, 'dgrad_norm/', 1e-4, 'D grad (unbatched)')
 
 
+def test_weight_gradient_reductions_share_one_launch():
+    """The split-K slab reductions of the conv weight gradients are deferred to ONE op per optimizer step - per
+    all-reduce bucket under data parallelism, each bucket's all-reduce ordered behind its reduction."""
+    sess, tr = TC.build_trainer(cpu_session, 'c2_dna_bce_adam')
+    x, y, a, s = TC.MG.inputs(2)
+    ops_ = TC.program_op_names(sess, [tr.g_opt_op, tr.g_next_frame], tr._feed(x, y, a, s))
+    red = [o for o in ops_ if o[1] == 'WgradReduceOp']
+    wg = [o for o in ops_ if o[1] == 'ConvWgradOp']
+    upd = [o for o in ops_ if o[1] == 'StepOp']
+    assert len(red) == 1 and len(wg) >= 10 and len(upd) == 1
+    assert max(o[0] for o in wg) < red[0][0] < upd[0][0]
+    prog_ops = [op for kind, seg in sess._compile(sess._flatten([tr.g_opt_op]), []).segments if kind == 'dev' for op, _ in seg]
+    r = [op for op in prog_ops if isinstance(op, O.WgradReduceOp)][0]
+    assert len(r._keep) == 1 and r._keep[0][1] == len(wg)       # the oracle splits every layer at batch 2: all deferred
+    # data parallel: one reduction per bucket, the bucket's all-reduce right behind it
+    sess, tr = TC.build_trainer(cpu_session, 'c2_dna_bce_adam', world_size=2)
+    ops_ = TC.program_op_names(sess, [tr.g_opt_op, tr.g_next_frame], tr._feed(x, y, a, s))
+    red = [o for o in ops_ if o[1] == 'WgradReduceOp']
+    ar = [o for o in ops_ if o[1] == 'AllReduceOp']
+    assert 2 <= len(red) <= len(ar) == 3
+    for k, r_ in enumerate(red):
+        later = [o for o in ar if o[0] > r_[0]]
+        assert later and min(o[0] for o in later) - r_[0] == 0.5, (k, r_, ar)
+
+
 def test_clip_is_fused_after_the_update():
     """Defect D6: the reference leaves update/clip unordered; here clip follows the update in-kernel."""
     sess, tr = TC.build_trainer(cpu_session, 'c4_dna_wass_rmsprop')

@@ -17,6 +17,7 @@ from action_conditioned_gans_amd import graph as G, ops as O, optim, train as T 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--other', action='store_true', help='table of the NON-conv ops instead (time, tensor bytes moved, GB/s)')
     args = ap.parse_args()
     B = args.batch
     G.reset_default_graph()
@@ -38,7 +39,7 @@ def main():
             if kind == 'host':
                 continue
             for op, fn in seg:
-                if not isinstance(op, O._ConvBase):
+                if isinstance(op, O._ConvBase) == args.other:
                     continue
                 # 20 launches of the op captured in a HIP graph: the in-graph cost of one launch (kernel + reduce + gaps)
                 torch.cuda.synchronize()
@@ -55,10 +56,21 @@ def main():
                     gr.replay()
                 e1.record()
                 torch.cuda.synchronize()
+                if args.other:    # bytes = every input and output tensor once (the algorithmic traffic of an elementwise/reduction op)
+                    by = 4.0 * sum(t.numel for t in list(op.inputs) + list(op.outputs))
+                    shape = 'x'.join(str(v) for v in (op.inputs[0].shape if op.inputs else ()))
+                    rows.append((tag, op.name, type(op).__name__ + ' ' + shape, by, e0.elapsed_time(e1) * 1e3 / 60))
+                    continue
                 d = op.desc
                 fl = 2.0 * d.batch * d.out_h * d.out_w * d.kh * d.kw * d.in_c * d.out_c
                 rows.append((tag, op.name, type(op).__name__, fl, e0.elapsed_time(e1) * 1e3 / 60))
     tot_us = sum(r[4] for r in rows)
+    if args.other:
+        print('# %d non-conv ops, %.1f us, %.1f MB in+out tensors' % (len(rows), tot_us, sum(r[3] for r in rows) / 1e6))
+        print('# step op kind+input-shape MB us GB/s')
+        for tag, name, kind, by, us in sorted(rows, key=lambda r: -r[4]):
+            print('%s %-40s %-34s %7.2f %7.1f %7.0f' % (tag, name[:40], kind, by / 1e6, us, by / us / 1e3))
+        return
     tot_fl = sum(r[3] for r in rows)
     print('# %d conv ops, %.1f us, %.2f GFLOP, %.1f TFLOP/s average' % (len(rows), tot_us, tot_fl / 1e9, tot_fl / tot_us / 1e6))
     print('# step op kind GFLOP us TFLOP/s us_above_90TF')

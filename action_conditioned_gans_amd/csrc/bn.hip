@@ -560,9 +560,9 @@ __global__ __launch_bounds__(256) void colsum_finalize(const float* __restrict__
 
 int partial_blocks(long long R, int C) {
   const int Cb = C < 256 ? C : 256, RPP = 256 / Cb;
-  long long n = R / ((long long)RPP * 8);
+  long long n = R / ((long long)RPP * 8);   // ~8 row passes per block (two batches of loads): the kernel is latency-bound
   if (n < 1) n = 1;
-  if (n > 128) n = 128;
+  if (n > kMaxPartialBlocks) n = kMaxPartialBlocks;
   return (int)n;
 }
 int apply_blocks(long long R, int C) {

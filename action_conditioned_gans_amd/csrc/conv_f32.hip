@@ -150,6 +150,11 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
   long long s = target / pl.tiles;
   s = std::min<long long>(s, std::max(1, pl.nk / min_steps));
   s = std::min<long long>(s, 128);
+  // Long-K contractions that fill the chip with ONE block per CU (g/tconv3's dgrad: 256 tiles x 100 K-steps): a second
+  // resident block hides the first one's load latencies (0.74 -> 0.53 us per K-step) and the slab reduction is small
+  // next to a long K loop (profiles/r1/r_conv_tune_full.txt: 79.8 us unsplit, 67.1 us at 4 splits).
+  s = std::max<long long>(s, 1);
+  if (which != ACG_CONV_WGRAD && pl.tiles * s <= 256 && pl.nk / s >= 50) s *= pl.nk / s >= 100 ? 4 : 2;
   if (g_force_splits >= 1) s = std::min<long long>(g_force_splits, pl.nk);
   pl.splits = (int)std::max<long long>(s, 1);
   return pl;

@@ -204,6 +204,8 @@ def main():
                 conv_ms += ms
                 conv_fl += conv_flops(op)
                 n_conv += 1
+            elif isinstance(op, O.WgradReduceOp):      # the deferred slab reductions of the weight gradients: conv time
+                conv_ms += ms
             elif kind == 'DnaOp':
                 b, h, w, c = op.inputs[1].shape
                 dna_ms += ms
@@ -215,16 +217,16 @@ def main():
             # summary of this same workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950
             # note of MI355X_MICROARCH.md), fp32 config-2 only; null otherwise
             traffic, traffic_note = None, None
-            pmc = os.path.join(ROOT, 'profiles', 'r1', 'p_pmc_traffic_v5.json')
+            pmc = os.path.join(ROOT, 'profiles', 'r1', 'v_pmc_traffic_final.json')
             if args.dtype == 'f32' and dna and B == 32 and S == 64 and args.ksize == 5 and os.path.exists(pmc):
                 with open(pmc) as f:
                     c = json.load(f)['conv_mfma_f32']
                 traffic = round(c['fetch_bytes_per_launch'] + c['write_bytes_per_launch'])     # bytes per launch
-                traffic_note = ('HBM-side bytes per conv launch (FETCH_SIZE x2 + WRITE_SIZE) from profiles/r1/p_pmc_traffic_v5.txt, '
+                traffic_note = ('HBM-side bytes per conv launch (FETCH_SIZE x2 + WRITE_SIZE) from profiles/r1/v_pmc_traffic_final.txt, '
                                 'separate --pmc passes of this bench; algorithmic %d bytes per launch' % round(c['algorithmic_bytes_per_launch']))
             roof = {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': peak, 'unit': 'TFLOP/s',
                     'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_note': traffic_note,
-                    'kernel': 'conv_mfma_f32<*> (+splitk_reduce): %d conv/deconv fwd+dgrad+wgrad launches per step' % n_conv,
+                    'kernel': 'conv_mfma_f32<*> (+splitk_reduce, +splitk_reduce_many): %d conv/deconv fwd+dgrad+wgrad launches per step' % n_conv,
                     'algorithmic_gflop_per_step': round(conv_fl / 1e9, 2), 'ms_per_step_in_kernel': round(conv_ms, 4),
                     'avg_launch_us': round(conv_ms * 1e3 / max(n_conv, 1), 2)}
         if dna_ms > 0:

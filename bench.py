@@ -110,7 +110,11 @@ def main():
     if world > 1 or args.force_dp:
         import torch.distributed as dist
         if args.force_dp and 'MASTER_ADDR' not in os.environ:
-            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29531', RANK='0', WORLD_SIZE='1')
+            import socket
+            with socket.socket() as sk:          # a free port: back-to-back runs must not meet the previous run's socket
+                sk.bind(('127.0.0.1', 0))
+                port = sk.getsockname()[1]
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')
         dist.init_process_group('nccl', device_id=device)
 
     from action_conditioned_gans_amd import graph as G, ops as O, optim, train as T

@@ -21,6 +21,10 @@
 namespace {
 
 constexpr int kMaxPartialBlocks = 512;
+#ifndef ACG_BN_U
+#define ACG_BN_U 4
+#endif
+constexpr int kU = ACG_BN_U;   // row passes whose loads a thread keeps in flight together (two-launch BatchNorm kernels)
 
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -123,12 +127,12 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
       ldv<V>(xg + c, pv);   // shift by the group's first row: E[d^2]-E[d]^2 cannot cancel catastrophically
       // batches of 4 row passes, all loads of a batch issued before the first use (rows beyond r1 re-read
       // the last valid row with weight 0), so a block's few passes cost ~one memory round trip
-      for (long long r = r0 + m.rsub; r < r1; r += 4 * m.RPP) {
-        float v[4][V];
+      for (long long r = r0 + m.rsub; r < r1; r += kU * m.RPP) {
+        float v[kU][V];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) ldv<V>(xg + min(r + u * m.RPP, r1 - 1) * C + c, v[u]);
+        for (int u = 0; u < kU; ++u) ldv<V>(xg + min(r + u * m.RPP, r1 - 1) * C + c, v[u]);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kU; ++u) {
           const float w = r + u * m.RPP < r1 ? 1.f : 0.f;
 #pragma unroll
           for (int j = 0; j < V; ++j) { const float d = (v[u][j] - pv[j]) * w; s1[j] += d; s2[j] += d * d; }
@@ -210,12 +214,12 @@ __global__ __launch_bounds__(256) void bn_apply_fwd(const float* __restrict__ x,
   if (blockIdx.x == 0 && rl == 0) { stv<V>(save_mean + g * C + c, mean); stv<V>(save_rstd + g * C + c, rstd); }
   // batches of 4 row passes with the loads issued together (a block walks ~4 passes: one memory round trip)
   const long long rstep = (long long)gridDim.x * 32;
-  for (long long r = (long long)blockIdx.x * 32 + rl; r < R; r += 4 * rstep) {
-    float v[4][V];
+  for (long long r = (long long)blockIdx.x * 32 + rl; r < R; r += kU * rstep) {
+    float v[kU][V];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) ldv<V>(xg + min(r + u * rstep, R - 1) * C + c, v[u]);
+    for (int u = 0; u < kU; ++u) ldv<V>(xg + min(r + u * rstep, R - 1) * C + c, v[u]);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kU; ++u) {
       if (r + u * rstep < R) {
 #pragma unroll
         for (int j = 0; j < V; ++j) v[u][j] = acg::act_apply(act, (v[u][j] - mean[j]) * rstd[j] + bt[j], leak);
@@ -246,15 +250,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
     if (m.active && cv < m.Cv) {
       float mean[V], rstd[V], bt[V];
       ldv<V>(save_mean + g * C + c, mean); ldv<V>(save_rstd + g * C + c, rstd); ldv<V>(beta + c, bt);
-      for (long long r = r0 + m.rsub; r < r1; r += 4 * m.RPP) {   // batched like bn_stats_partial
-        float xv[4][V], dv[4][V];
+      for (long long r = r0 + m.rsub; r < r1; r += kU * m.RPP) {   // batched like bn_stats_partial
+        float xv[kU][V], dv[kU][V];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kU; ++u) {
           const long long rr = min(r + u * m.RPP, r1 - 1);
           ldv<V>(xg + rr * C + c, xv[u]); ldv<V>(dyg + rr * C + c, dv[u]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kU; ++u) {
           const float w = r + u * m.RPP < r1 ? 1.f : 0.f;
 #pragma unroll
           for (int j = 0; j < V; ++j) {
@@ -322,15 +326,15 @@ __global__ __launch_bounds__(256) void bn_apply_bwd(const float* __restrict__ x,
 #pragma unroll
   for (int j = 0; j < V; ++j) { m1[j] = s1[j] * invR; m2[j] = s2[j] * invR; }
   const long long rstep = (long long)gridDim.x * 32;
-  for (long long r = (long long)blockIdx.x * 32 + rl; r < R; r += 4 * rstep) {    // batched like bn_apply_fwd
-    float xv[4][V], dv[4][V];
+  for (long long r = (long long)blockIdx.x * 32 + rl; r < R; r += kU * rstep) {    // batched like bn_apply_fwd
+    float xv[kU][V], dv[kU][V];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kU; ++u) {
       const long long rr = min(r + u * rstep, R - 1);
       ldv<V>(xg + rr * C + c, xv[u]); ldv<V>(dyg + rr * C + c, dv[u]);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kU; ++u) {
       if (r + u * rstep < R) {
 #pragma unroll
         for (int j = 0; j < V; ++j) {

@@ -149,7 +149,8 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
   const long long target = which == ACG_CONV_WGRAD ? t_w : (t_fd > 0 ? t_fd : (bf16 ? 512 : 256));
   long long s = target / pl.tiles;
   s = std::min<long long>(s, std::max(1, pl.nk / min_steps));
-  s = std::min<long long>(s, 128);
+  static const int max_splits = env_int("ACG_PLAN_MAX_SPLITS", 128), max_splits_w = env_int("ACG_PLAN_MAX_SPLITS_W", 128);
+  s = std::min<long long>(s, which == ACG_CONV_WGRAD ? max_splits_w : max_splits);
   // Long-K contractions that fill the chip with ONE block per CU (g/tconv3's dgrad: 256 tiles x 100 K-steps): a second
   // resident block hides the first one's load latencies (0.74 -> 0.53 us per K-step) and the slab reduction is small
   // next to a long K loop (profiles/r1/r_conv_tune_full.txt: 79.8 us unsplit, 67.1 us at 4 splits).

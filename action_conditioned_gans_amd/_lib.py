@@ -64,6 +64,8 @@ SIGNATURES = {
     'acg_conv2d_splits': (c_int32, [_D, c_int32, c_int32]),
     'acg_conv2d_wgrad_slabs': (c_int32, [_P, _P, _D, c_int32, _P, c_size_t, _P]),
     'acg_deconv2d_wgrad_slabs': (c_int32, [_P, _P, _D, c_int32, _P, c_size_t, _P]),
+    'acg_conv2d_bwd_pair': (c_int32, [_P, _P, _P, _P, _P, c_float, _D, c_int32, _P, c_size_t, _P, c_size_t, c_int32, _P]),
+    'acg_deconv2d_bwd_pair': (c_int32, [_P, _P, _P, _P, _P, c_float, _D, c_int32, _P, c_size_t, _P, c_size_t, c_int32, _P]),
     'acg_splitk_reduce_many': (c_int32, [ctypes.POINTER(ReduceList), c_int32, _P]),
     'acg_deconv2d_fwd': (c_int32, _conv),
     'acg_deconv2d_dgrad': (c_int32, _conv),
@@ -91,6 +93,9 @@ SIGNATURES = {
     'acg_concat_channels_fwd': (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P]),
     'acg_slice_channels': (c_int32, [_P, _P, c_float, c_int64, c_int32, c_int32, c_int32, c_int32, _P]),
     'acg_copy_many': (c_int32, [ctypes.POINTER(CopyList), c_int32, c_int32, _P]),
+    'acg_stream_edge_create': (c_int32, [ctypes.POINTER(c_void_p)]),
+    'acg_stream_edge_destroy': (c_int32, [_P]),
+    'acg_stream_edge': (c_int32, [_P, _P, _P]),
     'acg_add': (c_int32, [_P, _P, _P, c_int64, c_int32, _P]),
     'acg_frame_loss_workspace_bytes': (c_size_t, [c_int64]),
     'acg_frame_loss': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_int32,

@@ -161,10 +161,21 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
   return pl;
 }
 
+// One contraction, checked and planned: everything a launch needs.
+struct Job {
+  int which;
+  Plan pl;
+  ConvArgs a;
+  void* ws;
+  float* out;
+  float accumulate;
+  bool slabs_only;
+};
+
 // slabs_only (weight gradients whose reduction is deferred to acg_splitk_reduce_many): the contraction leaves its
 // `splits` partial slabs in the workspace and `out` is not touched.
-int run(int which, const float* gsrc, const float* dense, float* out, float accumulate, const acg_conv_desc* d, int dtype,
-        void* ws, size_t ws_bytes, acg_stream_t stream, const char* who, bool slabs_only = false) {
+int prepare(Job& j, int which, const float* gsrc, const float* dense, float* out, float accumulate, const acg_conv_desc* d,
+            int dtype, void* ws, size_t ws_bytes, const char* who, bool slabs_only) {
   ACG_REQUIRE(dtype == ACG_F32 || dtype == ACG_BF16, ACG_ERR_UNSUPPORTED, "%s: dtype %d", who, dtype);
   if (int rc = validate(d, who)) return rc;
   ACG_REQUIRE(gsrc && dense && (out || slabs_only), ACG_ERR_INVALID_ARG, "%s: null tensor pointer", who);
@@ -189,18 +200,52 @@ int run(int which, const float* gsrc, const float* dense, float* out, float accu
   a.splits = pl.splits;
   { const FastDiv fw = fast_div(d->out_w), fh = fast_div(d->out_h); a.mg_ow = fw.magic; a.sh_ow = fw.shift; a.mg_oh = fh.magic; a.sh_oh = fh.shift;
     const FastDiv fc = fast_div(((which == ACG_CONV_DGRAD ? d->out_c : d->in_c) + 3) & ~3); a.mg_cp = fc.magic; a.sh_cp = fc.shift; }
-  hipStream_t st = acg::to_stream(stream);
-  int rc;
-  if (which == ACG_CONV_FWD) rc = launch_mode<MODE_FWD>(pl, a, st);
-  else if (which == ACG_CONV_DGRAD) rc = launch_mode<MODE_DGRAD>(pl, a, st);
-  else rc = launch_mode<MODE_WGRAD>(pl, a, st);
-  if (rc) return rc;
-  if (pl.splits > 1 && !slabs_only) {
-    ACG_LAUNCH(splitk_reduce, dim3(reduce_blocks(pl.out_numel)), dim3(256), 0, st, (const float*)ws, out, pl.out_numel, pl.splits,
-                       which == ACG_CONV_WGRAD ? accumulate : 0.f);
+  j.which = which; j.pl = pl; j.a = a; j.ws = ws; j.out = out; j.accumulate = accumulate; j.slabs_only = slabs_only;
+  return ACG_OK;
+}
+
+int launch(const Job& j, hipStream_t st) {
+  if (j.which == ACG_CONV_FWD) return launch_mode<MODE_FWD>(j.pl, j.a, st);
+  if (j.which == ACG_CONV_DGRAD) return launch_mode<MODE_DGRAD>(j.pl, j.a, st);
+  return launch_mode<MODE_WGRAD>(j.pl, j.a, st);
+}
+
+int reduce(const Job& j, hipStream_t st) {
+  if (j.pl.splits > 1 && !j.slabs_only) {
+    ACG_LAUNCH(splitk_reduce, dim3(reduce_blocks(j.pl.out_numel)), dim3(256), 0, st, (const float*)j.ws, j.out, j.pl.out_numel, j.pl.splits,
+               j.which == ACG_CONV_WGRAD ? j.accumulate : 0.f);
     return acg::check_launch("splitk_reduce");
   }
   return ACG_OK;
+}
+
+int run(int which, const float* gsrc, const float* dense, float* out, float accumulate, const acg_conv_desc* d, int dtype,
+        void* ws, size_t ws_bytes, acg_stream_t stream, const char* who, bool slabs_only = false) {
+  Job j;
+  if (int rc = prepare(j, which, gsrc, dense, out, accumulate, d, dtype, ws, ws_bytes, who, slabs_only)) return rc;
+  hipStream_t st = acg::to_stream(stream);
+  if (int rc = launch(j, st)) return rc;
+  return reduce(j, st);
+}
+
+// Input gradient A (whichA = DGRAD, or FWD for a transposed layer) and weight gradient B of one layer: ONE launch when
+// the pair kernel covers the shapes (conv_f32_pair.hip), two otherwise; same results either way.
+int run_pair(int whichA, const float* gsrcA, const float* denseA, float* outA, const float* gsrcB, const float* denseB, float* outB,
+             float accumulateB, const acg_conv_desc* d, int dtype, void* wsA, size_t wsbA, void* wsB, size_t wsbB, bool slabs_only_B,
+             acg_stream_t stream, const char* who) {
+  Job ja, jb;
+  if (int rc = prepare(ja, whichA, gsrcA, denseA, outA, 0.f, d, dtype, wsA, wsbA, who, false)) return rc;
+  if (int rc = prepare(jb, ACG_CONV_WGRAD, gsrcB, denseB, outB, accumulateB, d, dtype, wsB, wsbB, who, slabs_only_B)) return rc;
+  hipStream_t st = acg::to_stream(stream);
+  static const int enabled = env_int("ACG_CONV_PAIR", 1);       // 0: always two launches (A/B comparison)
+  if (enabled && g_force_cfg < 0 && pair_supported(whichA, ja.pl, jb.pl)) {
+    if (int rc = launch_pair(whichA, ja.pl, ja.a, jb.pl, jb.a, st)) return rc;
+  } else {
+    if (int rc = launch(ja, st)) return rc;
+    if (int rc = launch(jb, st)) return rc;
+  }
+  if (int rc = reduce(ja, st)) return rc;
+  return reduce(jb, st);
 }
 
 }  // namespace
@@ -248,6 +293,21 @@ int32_t acg_conv2d_wgrad_slabs(const void* x, const void* dy, const acg_conv_des
 int32_t acg_deconv2d_wgrad_slabs(const void* x, const void* dy, const acg_conv_desc* adj, int32_t dtype, void* ws, size_t wsb,
                                  acg_stream_t s) {
   return run(ACG_CONV_WGRAD, (const float*)dy, (const float*)x, nullptr, 0.f, adj, dtype, ws, wsb, s, "deconv2d_wgrad_slabs", true);
+}
+
+int32_t acg_conv2d_bwd_pair(const void* dy, const void* w, const void* x, void* dx, float* dw, float dw_accumulate,
+                            const acg_conv_desc* d, int32_t dtype, void* ws_dgrad, size_t wsb_dgrad, void* ws_wgrad, size_t wsb_wgrad,
+                            int32_t wgrad_slabs_only, acg_stream_t s) {
+  return run_pair(ACG_CONV_DGRAD, (const float*)dy, (const float*)w, (float*)dx, (const float*)x, (const float*)dy, dw, dw_accumulate,
+                  d, dtype, ws_dgrad, wsb_dgrad, ws_wgrad, wsb_wgrad, wgrad_slabs_only != 0, s, "conv2d_bwd_pair");
+}
+int32_t acg_deconv2d_bwd_pair(const void* dy, const void* w, const void* x, void* dx, float* dw, float dw_accumulate,
+                              const acg_conv_desc* adj, int32_t dtype, void* ws_dgrad, size_t wsb_dgrad, void* ws_wgrad, size_t wsb_wgrad,
+                              int32_t wgrad_slabs_only, acg_stream_t s) {
+  // transposed layer on the adjoint descriptor: its input gradient is the adjoint's FWD, its weight gradient the
+  // adjoint's WGRAD with the roles of x and dy exchanged (acg_deconv2d_dgrad / acg_deconv2d_wgrad)
+  return run_pair(ACG_CONV_FWD, (const float*)dy, (const float*)w, (float*)dx, (const float*)dy, (const float*)x, dw, dw_accumulate,
+                  adj, dtype, ws_dgrad, wsb_dgrad, ws_wgrad, wsb_wgrad, wgrad_slabs_only != 0, s, "deconv2d_bwd_pair");
 }
 
 int32_t acg_splitk_reduce_many(const acg_reduce_list* list, int32_t count, acg_stream_t stream) {

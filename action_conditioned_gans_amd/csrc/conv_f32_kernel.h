@@ -139,8 +139,17 @@ __device__ __forceinline__ float guarded_scalar(__amdgpu_buffer_rsrc_t rs, int e
 //    out-of-range offset instead of a branch: only then does hipcc count outstanding loads exactly (vmcnt(N), N > 0)
 //    and the loads really run NST-1 K-steps ahead;
 //  * a chain of dependent MFMAs through one accumulator already issues every 68-74 cycles (no extra sets needed).
+// The block program.  (bx, by, bz) / gx stand in for blockIdx / gridDim.x so that conv_pair_f32 below can run the blocks
+// of two contractions out of one 1-D grid.
+// LDS of one block program: two K-steps of both tiles, the row infos, the tap tables.
+template <int MODE, int BM, int BN, bool BF16>
+constexpr int conv_lds_bytes() {
+  return 2 * (BF16 ? 4 : 8) * (BM + BN) * (int)sizeof(f4) + ((MODE == MODE_WGRAD) ? 2 * 256 : BM) * (int)sizeof(RowInfo) +
+         2 * kMaxTaps * (int)sizeof(int);
+}
+
 template <int MODE, int BM, int BN, int WM, int WN, bool RAGGED, bool NVEC, bool BF16>
-__global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
+__device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const int by, const int bz, const int gx, char* smem) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int TA = BM / (32 * WM), TB = BN / (32 * WN);
   constexpr int QA = BM / 32, QB = BN / 32;  // quads per thread per K-step
@@ -152,11 +161,12 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
 
   constexpr int KSLOTS = BF16 ? 4 : 8;   // 16-byte k-slots per tile column: 8 quads (fp32) or 4 octs (bf16)
   constexpr int ASZ = KSLOTS * BM, BSZ = KSLOTS * BN;
-  __shared__ f4 As_all[2 * ASZ];
-  __shared__ f4 Bs_all[2 * BSZ];
-  __shared__ RowInfo rows[NROW];
-  __shared__ int tapA[kMaxTaps];
-  __shared__ int tapB[kMaxTaps];
+  static_assert(conv_lds_bytes<MODE, BM, BN, BF16>() == (2 * ASZ + 2 * BSZ) * (int)sizeof(f4) + NROW * (int)sizeof(RowInfo) + 2 * kMaxTaps * (int)sizeof(int), "LDS layout");
+  f4* const As_all = reinterpret_cast<f4*>(smem);                         // [2 * ASZ]
+  f4* const Bs_all = As_all + 2 * ASZ;                                    // [2 * BSZ]
+  RowInfo* const rows = reinterpret_cast<RowInfo*>(Bs_all + 2 * BSZ);     // [NROW]
+  int* const tapA = reinterpret_cast<int*>(rows + NROW);                  // [kMaxTaps]
+  int* const tapB = tapA + kMaxTaps;                                      // [kMaxTaps]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gsrc), 0, p.g_bytes, 0x00020000);
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
     Cs = p.C; Cp = (Cs + 3) & ~3; ntaps = p.KH * p.KW;
     M = p.batch * p.OH * p.OW; N = p.K; Kdim = ntaps * Cp;
   } else if constexpr (MODE == MODE_DGRAD) {
-    const int cls = blockIdx.y;
+    const int cls = by;
     ph = cls / p.sw; pw = cls - ph * p.sw;
     Hc = ph < p.H ? (p.H - ph + p.sh - 1) / p.sh : 0;
     Wc = pw < p.W ? (p.W - pw + p.sw - 1) / p.sw : 0;
@@ -189,9 +199,9 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
   // XCD-aware order: consecutive workgroup ids are dealt round-robin over the 8 XCDs (each with its own L2), so
   // give every XCD a CONTIGUOUS run of tiles - neighbours in the run share A rows / filter columns in that L2.
   // Bijective for any grid size; placement affects speed only.
-  int bid = blockIdx.x;
+  int bid = bx;
   {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+    const int nwg = gx, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
   }
   const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
@@ -200,7 +210,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
 
   const int nk = (Kdim + BK - 1) / BK;
   const int per = (nk + p.splits - 1) / p.splits;
-  const int ks_begin = blockIdx.z * per;
+  const int ks_begin = bz * per;
   const int ks_end = min(nk, ks_begin + per);
 
   // ---- tap tables ------------------------------------------------------------------------------
@@ -593,7 +603,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
       }
   }
   // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) --------------
-  float* outp = p.out + (p.splits > 1 ? (long long)blockIdx.z * p.out_numel : 0ll);
+  float* outp = p.out + (p.splits > 1 ? (long long)bz * p.out_numel : 0ll);
 #pragma unroll
   for (int a = 0; a < TA; ++a)
 #pragma unroll
@@ -630,6 +640,35 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
       }
 }
 
+template <int MODE, int BM, int BN, int WM, int WN, bool RAGGED, bool NVEC, bool BF16>
+__global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
+  __shared__ __align__(16) char smem[conv_lds_bytes<MODE, BM, BN, BF16>()];
+  conv_body<MODE, BM, BN, WM, WN, RAGGED, NVEC, BF16>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
+}
+
+
+// ---- two contractions in one launch -------------------------------------------------------------------------------
+// A layer's input gradient (DGRAD, or FWD on the adjoint descriptor for a transposed layer) and its weight gradient
+// both consume dy and are independent of each other.  Launched one after the other, each runs with about one block
+// per CU and pays its own launch gap, prologue and tail; out of ONE grid the blocks of the second contraction become
+// the second resident block of every CU (0.74 -> 0.53 us per K-step) and fill the first one's tail.  Two streams
+// would do the same, but a cross-stream edge costs ~18 us on this stack (profiles/r1/w_stream_edges.txt).
+// Blocks [0, nA) run contraction A with the grid (gxA, gyA, *), the rest run the weight gradient with (gxB, 1, *).
+struct PairGeom { int nA, gxA, gyA, gxB; };
+
+template <int MODE_A, int BMA, int BNA, int WMA, int WNA, int BMB, int BNB, int WMB, int WNB, bool RAGGED>
+__global__ __launch_bounds__(256) void conv_pair_f32(const ConvArgs a, const ConvArgs b, const PairGeom g) {
+  constexpr int LA = conv_lds_bytes<MODE_A, BMA, BNA, false>(), LB = conv_lds_bytes<MODE_WGRAD, BMB, BNB, false>();
+  __shared__ __align__(16) char smem[LA > LB ? LA : LB];      // one block runs one of the two programs
+  const int L = (int)blockIdx.x;
+  if (L < g.nA) {
+    const int t = L / g.gxA;
+    conv_body<MODE_A, BMA, BNA, WMA, WNA, RAGGED, true, false>(a, L - t * g.gxA, t % g.gyA, t / g.gyA, g.gxA, smem);
+  } else {
+    const int l = L - g.nA, bz = l / g.gxB;
+    conv_body<MODE_WGRAD, BMB, BNB, WMB, WNB, RAGGED, true, false>(b, l - bz * g.gxB, 0, bz, g.gxB, smem);
+  }
+}
 
 struct Plan {
   int cfg;       // 2: 128x32, 3: 64x64 (0 and 1 were the retired 128x128 / 128x64 tiles)
@@ -642,6 +681,11 @@ struct Plan {
 
 template <int MODE>
 int launch_mode(const Plan& pl, const ConvArgs& a, hipStream_t st);
+
+// conv_f32_pair.hip: A (modeA = MODE_FWD or MODE_DGRAD) and a weight gradient B in one launch; fp32, float4-able dense
+// operands, both gathers ragged or neither (pair_supported) - the caller launches the two separately otherwise.
+bool pair_supported(int modeA, const Plan& pa, const Plan& pb);
+int launch_pair(int modeA, const Plan& pa, const ConvArgs& a, const Plan& pb, const ConvArgs& b, hipStream_t st);
 
 template <int MODE, bool RAGGED, bool NVEC, bool BF16>
 static inline void launch_cfg(const Plan& pl, const ConvArgs& a, hipStream_t st) {

@@ -129,6 +129,29 @@ int32_t acg_version(void) { return ACG_ABI_VERSION; }
 const char* acg_build_info(void) { return "hip gfx950 (fp32 MFMA 32x32x2)"; }
 const char* acg_last_error(void) { return acg::g_err; }
 
+int32_t acg_stream_edge_create(acg_edge_t* edge) {
+  ACG_REQUIRE(edge != nullptr, ACG_ERR_INVALID_ARG, "stream_edge_create: null output");
+  hipEvent_t ev = nullptr;
+  const hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence);
+  ACG_REQUIRE(e == hipSuccess, ACG_ERR_LAUNCH, "stream_edge_create: %s", hipGetErrorString(e));
+  *edge = (acg_edge_t)ev;
+  return ACG_OK;
+}
+int32_t acg_stream_edge_destroy(acg_edge_t edge) {
+  ACG_REQUIRE(edge != nullptr, ACG_ERR_INVALID_ARG, "stream_edge_destroy: null edge");
+  const hipError_t e = hipEventDestroy((hipEvent_t)edge);
+  ACG_REQUIRE(e == hipSuccess, ACG_ERR_LAUNCH, "stream_edge_destroy: %s", hipGetErrorString(e));
+  return ACG_OK;
+}
+int32_t acg_stream_edge(acg_edge_t edge, acg_stream_t from, acg_stream_t to) {
+  ACG_REQUIRE(edge != nullptr, ACG_ERR_INVALID_ARG, "stream_edge: null edge");
+  hipError_t e = hipEventRecord((hipEvent_t)edge, acg::to_stream(from));
+  ACG_REQUIRE(e == hipSuccess, ACG_ERR_LAUNCH, "stream_edge (record): %s", hipGetErrorString(e));
+  e = hipStreamWaitEvent(acg::to_stream(to), (hipEvent_t)edge, 0);
+  ACG_REQUIRE(e == hipSuccess, ACG_ERR_LAUNCH, "stream_edge (wait): %s", hipGetErrorString(e));
+  return ACG_OK;
+}
+
 int32_t acg_concat_actions_fwd(const void* x, const float* actions, void* y, int32_t B, int32_t hw, int32_t c, int32_t a,
                                int32_t y_pitch, int32_t dtype, acg_stream_t stream) {
   ACG_REQUIRE_F32(dtype);

@@ -20,6 +20,7 @@ PyTorch is used for device memory, streams, graph capture and torch.distributed 
 """
 import contextlib
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -313,6 +314,16 @@ class Runtime:
         self._scratch.setdefault('workspaces', []).append(buf)
         return buf, n
 
+    def edge_pool(self, n):
+        """n reusable stream-ordering edges (acg_stream_edge: HIP events WITHOUT the system-scope fence of a default
+        event, which costs ~20 us per edge on this 8-XCD part)."""
+        pool = self._scratch.setdefault('edges', [])
+        while len(pool) < n:
+            e = ctypes.c_void_p()
+            self.lib.stream_edge_create(ctypes.byref(e))
+            pool.append(e)
+        return pool[:n]
+
     def stream_ptr(self):
         if self.is_cuda:
             return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -323,7 +334,7 @@ class Session:
     """``tf.Session`` stand-in bound to one GPU (one process per GPU)."""
 
     def __init__(self, device='cuda:0', graph=None, use_hip_graphs=True, lib=None,
-                 world_size=1, rank=0, process_group=None, overlap_wgrad=False, dtype='f32'):
+                 world_size=1, rank=0, process_group=None, overlap_wgrad=False, dtype='f32', pair_bwd=True):
         self.graph = graph or get_default_graph()
         dev = torch.device(device)
         if lib is None:
@@ -339,6 +350,8 @@ class Session:
             torch.cuda.set_device(dev)
         self.use_hip_graphs = use_hip_graphs and dev.type == 'cuda'
         self.overlap_wgrad = overlap_wgrad and dev.type == 'cuda'
+        # a layer's input gradient and weight gradient in ONE launch (acg_conv2d_bwd_pair) when they are neighbours in a program
+        self.pair_bwd = bool(pair_bwd) and not self.overlap_wgrad
         self._programs = {}
         self._initialized = False
 
@@ -428,6 +441,11 @@ class Session:
         for op in ops:
             for t in op.inputs + op.outputs:
                 self._materialize(t)
+        for k, op in enumerate(ops):           # pairing is decided per program: both ops fetched, nothing between them
+            w = getattr(op, 'pair_w', None)
+            active = self.pair_bwd and w is not None and k + 1 < len(ops) and ops[k + 1] is w
+            if w is not None:
+                op.pair_active, w.paired = active, active
         segments, cur = [], []
         for op in ops:
             fn = op.bind(self.rt)
@@ -587,17 +605,15 @@ class Session:
         sp_main = ctypes.c_void_p(main.cuda_stream)
         sp_side = ctypes.c_void_p(side.cuda_stream)
         pending = set()                 # ids of side-stream ops not yet joined into the main stream
+        edges = iter(rt.edge_pool(2 * len(seg) + 2))
+        edge = rt.lib.stream_edge
 
         def join():
-            ev = torch.cuda.Event()
-            ev.record(side)
-            main.wait_event(ev)
+            edge(next(edges), sp_side, sp_main)
             pending.clear()
         for op, fn in seg:
             if op.side_stream:
-                ev = torch.cuda.Event()
-                ev.record(main)
-                side.wait_event(ev)
+                edge(next(edges), sp_main, sp_side)
                 fn(sp_side)
                 pending.add(id(op))
             else:

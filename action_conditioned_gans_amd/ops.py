@@ -181,11 +181,17 @@ class Conv2dOp(_ConvBase):
             dx.valid_c = x.valid_c
         if needs[1] and ctx.wants(w):
             dst, acc = ctx.slot(w)
-            ctx.wrote(w, ConvWgradOp(x, dy, dst, acc, self.desc, self.transposed, self.name + '/wgrad'))
+            wg = ConvWgradOp(x, dy, dst, acc, self.desc, self.transposed, self.name + '/wgrad')
+            ctx.wrote(w, wg)
+            if dx is not None:          # both consume dy: candidates for ONE launch (Session.pair_bwd, graph._compile)
+                dx.op.pair_w = wg
         return [dx, None]
 
 
 class ConvDgradOp(_ConvBase):
+    pair_w = None          # the layer's ConvWgradOp, when both gradients are built
+    pair_active = False    # set per compiled program: this op launches both (acg_(de)conv2d_bwd_pair)
+
     def __init__(self, dy, w, x_shape, desc, transposed, name):
         self.desc, self.transposed = desc, transposed
         self.which = CONV_FWD if transposed else CONV_DGRAD
@@ -193,7 +199,25 @@ class ConvDgradOp(_ConvBase):
 
     def bind(self, rt):
         dy, w = self.inputs
-        return self._bind(rt, 'deconv2d_dgrad' if self.transposed else 'conv2d_dgrad', dy, w, self.outputs[0])
+        if not self.pair_active:
+            return self._bind(rt, 'deconv2d_dgrad' if self.transposed else 'conv2d_dgrad', dy, w, self.outputs[0])
+        # ONE launch for dx and dw: the two contractions share the CUs instead of running one grid after the other
+        wg = self.pair_w
+        x = wg.inputs[0]
+        lib, d, dt = rt.lib, self.desc, rt.conv_dtype
+        wsd, nd = rt.workspace(lib.conv2d_workspace_bytes(ctypes.byref(d), self.which, dt))
+        wsw, nw = rt.workspace(lib.conv2d_workspace_bytes(ctypes.byref(d), CONV_WGRAD, dt))
+        slabs = 0
+        if wg.deferred_to is not None:
+            splits = lib.conv2d_splits(ctypes.byref(d), CONV_WGRAD, dt)
+            if splits > 1:
+                slabs = 1
+                wg.deferred_to.pending.append((wsw, wg.outputs[0], splits, wg.accumulate))
+        self._keep = (wsd, wsw, d)
+        fn = lib.deconv2d_bwd_pair if self.transposed else lib.conv2d_bwd_pair
+        args = (_p(dy.buf), _p(w.buf), _p(x.buf), _p(self.outputs[0].buf), None if slabs else _p(wg.outputs[0].buf), wg.accumulate,
+                ctypes.byref(d), dt, _p(wsd), nd, _p(wsw), nw, slabs)
+        return lambda s: fn(*args, s)
 
 
 class ConvWgradOp(_ConvBase):
@@ -205,7 +229,11 @@ class ConvWgradOp(_ConvBase):
         self.deferred_to = None     # a WgradReduceOp: this op leaves its split-K slabs for that op's single launch
         super().__init__(G.get_default_graph(), name, [x, dy], [dst])
 
+    paired = False          # set per compiled program: the layer's ConvDgradOp launches this contraction too
+
     def bind(self, rt):
+        if self.paired:
+            return None
         x, dy = self.inputs
         lib, d = rt.lib, self.desc
         if self.deferred_to is not None:

@@ -51,6 +51,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-repeats', type=int, default=3)
     ap.add_argument('--cpu-steps', type=int, default=20)
+    ap.add_argument('--no-pair', action='store_true', help='experiment: a layer\'s dgrad and wgrad as two launches instead of one')
     ap.add_argument('--overlap-wgrad', action='store_true', help='experiment: weight gradients on a second HIP stream')
     ap.add_argument('--buckets', type=int, default=3, help='gradient all-reduce buckets per optimizer (data parallel)')
     ap.add_argument('--exact-global-batch', action='store_true', help='data parallel that reproduces one device at the global batch: SyncBN + GDL scaling + global state-loss norm')
@@ -123,7 +124,7 @@ def main():
     n_critic = 5 if args.loss == 'wass' else 1
     G.reset_default_graph()
     optim.set_data_parallel(world, n_buckets=args.buckets, force=args.force_dp, sync_bn=args.sync_bn, exact_global_batch=args.exact_global_batch)
-    sess = G.Session(device=device, overlap_wgrad=args.overlap_wgrad, use_hip_graphs=not args.no_graphs, world_size=world, rank=rank, process_group=pg, dtype=args.dtype)
+    sess = G.Session(device=device, overlap_wgrad=args.overlap_wgrad, pair_bwd=not args.no_pair, use_hip_graphs=not args.no_graphs, world_size=world, rank=rank, process_group=pg, dtype=args.dtype)
     tr = T.Trainer(sess, adv, args.loss, args.opt, dna, batch_size=B, img_size=S, ksize=args.ksize, seed=0)
     sess.run(G.global_variables_initializer())
 
@@ -208,6 +209,9 @@ def main():
                 conv_ms += ms
                 conv_fl += conv_flops(op)
                 n_conv += 1
+                if getattr(op, 'pair_active', False):      # this launch also ran the layer's weight gradient
+                    conv_fl += conv_flops(op.pair_w)
+                    n_conv += 1
             elif isinstance(op, O.WgradReduceOp):      # the deferred slab reductions of the weight gradients: conv time
                 conv_ms += ms
             elif kind == 'DnaOp':

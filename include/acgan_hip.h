@@ -120,6 +120,18 @@ int32_t acg_deconv2d_wgrad_slabs(const void* x, const void* dy, const acg_conv_d
                                  size_t workspace_bytes, acg_stream_t stream);
 int32_t acg_splitk_reduce_many(const acg_reduce_list* list, int32_t count, acg_stream_t stream);
 
+/* A layer's input gradient and weight gradient in ONE launch (both consume dy, neither reads the other's result):
+ * the same results as acg_(de)conv2d_dgrad followed by acg_(de)conv2d_wgrad - or, with wgrad_slabs_only != 0, by
+ * acg_(de)conv2d_wgrad_slabs (dw may then be NULL) - bit for bit; the blocks of the two contractions share the CUs
+ * instead of running one grid after the other.  Workspaces as for the separate entries (acg_conv2d_workspace_bytes
+ * with ACG_CONV_DGRAD / ACG_CONV_WGRAD; for the transposed layer ACG_CONV_FWD / ACG_CONV_WGRAD on the adjoint). */
+int32_t acg_conv2d_bwd_pair(const void* dy, const void* w, const void* x, void* dx, float* dw, float dw_accumulate,
+                            const acg_conv_desc* d, int32_t dtype, void* ws_dgrad, size_t ws_dgrad_bytes, void* ws_wgrad,
+                            size_t ws_wgrad_bytes, int32_t wgrad_slabs_only, acg_stream_t stream);
+int32_t acg_deconv2d_bwd_pair(const void* dy, const void* w, const void* x, void* dx, float* dw, float dw_accumulate,
+                              const acg_conv_desc* adj, int32_t dtype, void* ws_dgrad, size_t ws_dgrad_bytes, void* ws_wgrad,
+                              size_t ws_wgrad_bytes, int32_t wgrad_slabs_only, acg_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Synchronised BatchNorm for data parallel runs (SURVEY 8(e) caveat 1; optional, no reference counterpart: the
  * reference is single-device).  The statistics are those of the GLOBAL batch: each direction is two calls with
@@ -218,6 +230,17 @@ int32_t acg_concat_channels_fwd(const void* a, const void* b, void* y, int64_t r
 /* dst[r,:] = accumulate * dst[r,:] + src[r, c_off : c_off + c_dst] */
 int32_t acg_slice_channels(const void* src, void* dst, float accumulate, int64_t rows, int32_t c_src,
                            int32_t c_off, int32_t c_dst, int32_t dtype, acg_stream_t stream);
+/* Stream-ordering edge "everything enqueued on `from` so far happens before what is enqueued on `to` from now on",
+ * both streams on THIS device (no reference counterpart: TF's executor ordered its ops itself).  A default HIP event
+ * carries a system-scope fence - an L2 write-back and invalidate on all 8 XCDs, ~20 us per edge on MI355X
+ * (profiles/r1/w_stream_edges.txt); these use hipEventDisableTiming | hipEventDisableSystemFence: device memory
+ * stays coherent between the device's own queues, which is all a dgrad-chain -> weight-gradient edge needs.
+ * Not for host-visible or peer-visible data.  An edge object can be reused once per enqueue, indefinitely. */
+typedef void* acg_edge_t;
+int32_t acg_stream_edge_create(acg_edge_t* edge);
+int32_t acg_stream_edge_destroy(acg_edge_t edge);
+int32_t acg_stream_edge(acg_edge_t edge, acg_stream_t from, acg_stream_t to);
+
 /* Up to ACG_COPY_MAX row-block copies in ONE launch: the feed_dict of a sess.run (train.py:115-154) lands in the
  * placeholders with a single kernel.  Segment i copies rows[i] x cols[i] floats from src[i] (dense rows) to dst[i] whose
  * rows are dst_pitch[i] floats apart (0 = dense; pad channels are not written). */

@@ -141,6 +141,20 @@ int32_t acg_conv2d_wgrad_slabs(const void* xv, const void* dyv, const acg_conv_d
 int32_t acg_deconv2d_wgrad_slabs(const void* x, const void* dy, const acg_conv_desc* adj, int32_t dtype, void* ws, size_t wsb,
                                  acg_stream_t s) {
   return acg_conv2d_wgrad_slabs(dy, x, adj, dtype, ws, wsb, s); }
+/* paired entries: the oracle simply runs the two contractions one after the other */
+int32_t acg_conv2d_bwd_pair(const void* dy, const void* w, const void* x, void* dx, float* dw, float acc, const acg_conv_desc* d,
+                            int32_t dtype, void* wsd, size_t wsbd, void* wsw, size_t wsbw, int32_t slabs_only, acg_stream_t s) {
+  int rc = acg_conv2d_dgrad(dy, w, dx, d, dtype, wsd, wsbd, s);
+  if (rc) return rc;
+  return slabs_only ? acg_conv2d_wgrad_slabs(x, dy, d, dtype, wsw, wsbw, s) : acg_conv2d_wgrad(x, dy, dw, acc, d, dtype, wsw, wsbw, s);
+}
+int32_t acg_deconv2d_bwd_pair(const void* dy, const void* w, const void* x, void* dx, float* dw, float acc, const acg_conv_desc* adj,
+                              int32_t dtype, void* wsd, size_t wsbd, void* wsw, size_t wsbw, int32_t slabs_only, acg_stream_t s) {
+  int rc = acg_deconv2d_dgrad(dy, w, dx, adj, dtype, wsd, wsbd, s);
+  if (rc) return rc;
+  return slabs_only ? acg_deconv2d_wgrad_slabs(x, dy, adj, dtype, wsw, wsbw, s) : acg_deconv2d_wgrad(x, dy, dw, acc, adj, dtype, wsw, wsbw, s);
+}
+
 int32_t acg_splitk_reduce_many(const acg_reduce_list* l, int32_t count, acg_stream_t s) {
   (void)s;
   if (!l || count < 1 || count > ACG_REDUCE_MAX) return fail(ACG_ERR_INVALID_ARG, "splitk_reduce_many: 1..32 entries");
@@ -473,6 +487,11 @@ int32_t acg_slice_channels(const void* sv, void* dv, float acc, int64_t rows, in
     dst[r * c_dst + c] = (acc != 0.f ? acc * dst[r * c_dst + c] : 0.f) + src[r * c_src + c_off + c];
   return ACG_OK;
 }
+/* stream-ordering edges: the CPU oracle is synchronous, an edge is a no-op */
+int32_t acg_stream_edge_create(acg_edge_t* edge) { static int token; if (!edge) return fail(ACG_ERR_INVALID_ARG, "stream_edge_create: null output"); *edge = &token; return ACG_OK; }
+int32_t acg_stream_edge_destroy(acg_edge_t edge) { return edge ? ACG_OK : fail(ACG_ERR_INVALID_ARG, "stream_edge_destroy: null edge"); }
+int32_t acg_stream_edge(acg_edge_t edge, acg_stream_t from, acg_stream_t to) { (void)from; (void)to; return edge ? ACG_OK : fail(ACG_ERR_INVALID_ARG, "stream_edge: null edge"); }
+
 int32_t acg_copy_many(const acg_copy_list* l, int32_t count, int32_t dtype, acg_stream_t s) {
   (void)s; REQUIRE_F32(dtype);
   if (!l || count < 1 || count > ACG_COPY_MAX) return fail(ACG_ERR_INVALID_ARG, "copy_many: 1..8 segments");

@@ -100,6 +100,28 @@ class Abi:
         self.lib.deconv2d_wgrad(_p(x), _p(dy), _p(dw), accumulate, ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
         return dw
 
+    # ---- a layer's input gradient + weight gradient in one launch
+    def bwd_pair(self, x, dy, w, stride, padding=None, transposed=False, accumulate=0.0, dw=None, slabs_only=False):
+        """-> (dx, dw or (slab workspace, splits))."""
+        if transposed:
+            d = self._adj(x.shape, tuple(w.shape), stride)
+            which_d = L.CONV_FWD
+        else:
+            b, h, wd, c = x.shape
+            d = self.desc(b, h, wd, w.shape[2], w.shape[0], w.shape[1], w.shape[3], stride, padding, c if c != w.shape[2] else 0)
+            which_d = L.CONV_DGRAD
+        dx = torch.zeros_like(x)
+        if dw is None and not slabs_only:
+            dw = self.empty(*w.shape)
+        wsd, nd = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), which_d, self.conv_dtype))
+        wsw, nw = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_WGRAD, self.conv_dtype))
+        fn = self.lib.deconv2d_bwd_pair if transposed else self.lib.conv2d_bwd_pair
+        fn(_p(dy), _p(w), _p(x), _p(dx), None if slabs_only else _p(dw), accumulate, ctypes.byref(d), self.conv_dtype, _p(wsd), nd, _p(wsw), nw,
+           1 if slabs_only else 0, self.stream())
+        if slabs_only:
+            return dx, (wsw, self.lib.conv2d_splits(ctypes.byref(d), L.CONV_WGRAD, self.conv_dtype))
+        return dx, dw
+
     # ---- deferred split-K reduction of weight gradients
     def wgrad_slabs(self, x, dy, w_shape, stride, padding=None, transposed=False):
         """-> (slab workspace, splits), or (None, 1) when the planner does not split this shape."""

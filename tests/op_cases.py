@@ -265,6 +265,61 @@ def case_sync_bn_entries(abi, shape, act, groups, tol):
     close(dx2, dx_ref, tol * 8, tag + ' dx (two identical ranks)'); close(dbeta2, dbeta_ref, tol * 8, tag + ' dbeta (two identical ranks)')
 
 
+PAIR_LAYERS = [   # (x shape, w shape, stride, padding, transposed)
+    ((4, 16, 16, 8), (5, 5, 8, 16), 2, 'SAME', False),        # both contractions on the 128x32 tile, weight gradient split
+    ((4, 16, 16, 64), (5, 5, 64, 128), 2, 'SAME', False),     # 64x64 tiles (g/conv3-like), both split
+    ((2, 9, 7, 4), (5, 5, 4, 36), 2, 'SAME', False),          # ragged extents, mixed tiles
+    ((4, 12, 12, 12), (3, 3, 12, 8), 1, 'VALID', False),
+    ((4, 8, 8, 16), (5, 5, 8, 16), 2, None, True),            # transposed layer (adjoint FWD + WGRAD)
+    ((2, 4, 4, 128), (5, 5, 64, 128), 2, None, True),         # g/tconv2-like
+    ((2, 8, 8, 6), (5, 5, 6, 16), 2, 'SAME', False),          # Cin = 6: not float4-able -> two launches inside, same results
+    ((2, 16, 16, 32), (5, 5, 25, 32), 2, None, True),         # g/tconv4-like: 25-channel gathers (ragged variant of the pair)
+    ((2, 8, 8, 8), (3, 3, 8, 5), 1, 'SAME', False),           # Cout = 5: dense rows not float4-able -> two launches inside
+]
+
+
+def case_bwd_pair(abi, tol, exact):
+    """acg_(de)conv2d_bwd_pair == the separate dgrad and wgrad entries (bit for bit on the HIP side), with an
+    accumulating weight gradient and with the slabs-only variant feeding acg_splitk_reduce_many."""
+    dev = abi.device
+    for i, (xs, ws_, stride, padding, transposed) in enumerate(PAIR_LAYERS):
+        x = randn(xs, 70 + i).to(dev)
+        w = randn(ws_, 80 + i, 0.1).to(dev)
+        if transposed:
+            dy = randn((xs[0], xs[1] * stride, xs[2] * stride, ws_[2]), 90 + i).to(dev)
+            dx_ref = abi.deconv2d_dgrad(dy, w, tuple(xs), stride)
+            dw_plain = lambda dw, acc: abi.deconv2d_wgrad(x, dy, ws_, stride, dw=dw, accumulate=acc)    # noqa: E731
+        else:
+            d = abi.desc(xs[0], xs[1], xs[2], ws_[2], ws_[0], ws_[1], ws_[3], stride, padding)
+            dy = randn((xs[0], d.out_h, d.out_w, ws_[3]), 90 + i).to(dev)
+            dx_ref = abi.conv2d_dgrad(dy, w, tuple(xs), stride, padding)
+            dw_plain = lambda dw, acc: abi.conv2d_wgrad(x, dy, ws_, stride, padding, dw=dw, accumulate=acc)    # noqa: E731
+        init = randn(ws_, 100 + i).to(dev)
+        for acc in (0.0, 1.0):
+            dw_ref = dw_plain(init.clone(), acc)
+            dx, dw = abi.bwd_pair(x, dy, w, stride, padding, transposed, accumulate=acc, dw=init.clone())
+            abi.sync()
+            tag = 'pair layer %d acc %g' % (i, acc)
+            if exact:
+                assert torch.equal(dx.cpu(), dx_ref.cpu()), tag + ': dx differs from the separate dgrad'
+                assert torch.equal(dw.cpu(), dw_ref.cpu()), tag + ': dw differs from the separate wgrad'
+            else:
+                close(dx, dx_ref.double().cpu(), tol, tag + ' dx')
+                close(dw, dw_ref.double().cpu(), tol, tag + ' dw')
+        slabs, splits = abi.wgrad_slabs(x, dy, ws_, stride, padding, transposed)
+        if slabs is not None:                       # the weight gradient is split: slabs-only pair + deferred reduction
+            dx, (ws2, sp2) = abi.bwd_pair(x, dy, w, stride, padding, transposed, slabs_only=True)
+            assert sp2 == splits
+            out = init.clone()
+            abi.splitk_reduce_many([(ws2, out, sp2, 1.0)])
+            abi.sync()
+            dw_ref = dw_plain(init.clone(), 1.0)
+            if exact:
+                assert torch.equal(dx.cpu(), dx_ref.cpu()) and torch.equal(out.cpu(), dw_ref.cpu()), 'pair layer %d (slabs only)' % i
+            else:
+                close(out, dw_ref.double().cpu(), tol, 'pair layer %d slabs' % i)
+
+
 def case_wgrad_deferred(abi, tol, exact):
     """acg_(de)conv2d_wgrad_slabs + ONE acg_splitk_reduce_many over several layers == the per-layer acg_(de)conv2d_wgrad
     (bit for bit on the HIP side: same slabs, same summation order), including an accumulating entry and a ragged size."""

@@ -92,6 +92,10 @@ def test_sync_bn_entries(hip_abi, shape, act, groups):
     C.case_sync_bn_entries(hip_abi, shape, act, groups, TOL)
 
 
+def test_bwd_pair(hip_abi):
+    C.case_bwd_pair(hip_abi, TOL_CONV, exact=True)
+
+
 def test_wgrad_deferred_reduction(hip_abi):
     C.case_wgrad_deferred(hip_abi, TOL_CONV, exact=True)
 

@@ -54,6 +54,10 @@ def test_sync_bn_entries(oracle_abi, shape, act, groups):
     C.case_sync_bn_entries(oracle_abi, shape, act, groups, TOL)
 
 
+def test_bwd_pair(oracle_abi):
+    C.case_bwd_pair(oracle_abi, TOL, exact=False)
+
+
 def test_wgrad_deferred_reduction(oracle_abi):
     C.case_wgrad_deferred(oracle_abi, TOL, exact=False)
 

@@ -63,7 +63,9 @@ def main():
                     continue
                 d = op.desc
                 fl = 2.0 * d.batch * d.out_h * d.out_w * d.kh * d.kw * d.in_c * d.out_c
-                rows.append((tag, op.name, type(op).__name__, fl, e0.elapsed_time(e1) * 1e3 / 60))
+                paired = getattr(op, 'pair_active', False)     # this launch also ran the layer's weight gradient (same FLOPs again)
+                rows.append((tag, op.name + ('+wgrad' if paired else ''), type(op).__name__ + ('+W' if paired else ''), fl * (2 if paired else 1),
+                             e0.elapsed_time(e1) * 1e3 / 60))
     tot_us = sum(r[4] for r in rows)
     if args.other:
         print('# %d non-conv ops, %.1f us, %.1f MB in+out tensors' % (len(rows), tot_us, sum(r[3] for r in rows) / 1e6))
@@ -72,10 +74,10 @@ def main():
             print('%s %-40s %-34s %7.2f %7.1f %7.0f' % (tag, name[:40], kind, by / 1e6, us, by / us / 1e3))
         return
     tot_fl = sum(r[3] for r in rows)
-    print('# %d conv ops, %.1f us, %.2f GFLOP, %.1f TFLOP/s average' % (len(rows), tot_us, tot_fl / 1e9, tot_fl / tot_us / 1e6))
+    print('# %d conv launches (+W: input gradient and weight gradient of a layer in one launch), %.1f us, %.2f GFLOP, %.1f TFLOP/s average' % (len(rows), tot_us, tot_fl / 1e9, tot_fl / tot_us / 1e6))
     print('# step op kind GFLOP us TFLOP/s us_above_90TF')
     for tag, name, kind, fl, us in sorted(rows, key=lambda r: -(r[4] - r[3] / 90e6)):
-        print('%s %-38s %-12s %6.2f %7.1f %6.1f %7.1f' % (tag, name[:38], kind, fl / 1e9, us, fl / us / 1e6, us - fl / 90e6))
+        print('%s %-44s %-14s %6.2f %7.1f %6.1f %7.1f' % (tag, name[:44], kind, fl / 1e9, us, fl / us / 1e6, us - fl / 90e6))
 
 
 if __name__ == '__main__':

@@ -225,12 +225,12 @@ def main():
             # summary of this same workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950
             # note of MI355X_MICROARCH.md), fp32 config-2 only; null otherwise
             traffic, traffic_note = None, None
-            pmc = os.path.join(ROOT, 'profiles', 'r1', 'v_pmc_traffic_final.json')
+            pmc = os.path.join(ROOT, 'profiles', 'r1', 'zz_pmc_traffic_final.json')
             if args.dtype == 'f32' and dna and B == 32 and S == 64 and args.ksize == 5 and os.path.exists(pmc):
                 with open(pmc) as f:
                     c = json.load(f)['conv_mfma_f32']
                 traffic = round(c['fetch_bytes_per_launch'] + c['write_bytes_per_launch'])     # bytes per launch
-                traffic_note = ('HBM-side bytes per conv launch (FETCH_SIZE x2 + WRITE_SIZE) from profiles/r1/v_pmc_traffic_final.txt, '
+                traffic_note = ('HBM-side bytes per conv launch (FETCH_SIZE x2 + WRITE_SIZE) from profiles/r1/zz_pmc_traffic_final.txt, '
                                 'separate --pmc passes of this bench; algorithmic %d bytes per launch' % round(c['algorithmic_bytes_per_launch']))
             roof = {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': peak, 'unit': 'TFLOP/s',
                     'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_note': traffic_note,

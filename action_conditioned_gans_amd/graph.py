@@ -290,6 +290,7 @@ class _Program:
         self.fetch_tensors = fetch_tensors
         self.feeds = feeds
         self.graphs = None           # captured HIP graphs, one per 'dev' segment
+        self.eager = False           # always launched eagerly (contains stream-ordered collectives)
         self.runs = 0
 
 
@@ -470,7 +471,9 @@ class Session:
                 fetch_tensors.append(t)
         for ph in feeds:
             self._materialize(ph)
-        return _Program(segments, fetch_tensors, list(feeds))
+        prog = _Program(segments, fetch_tensors, list(feeds))
+        prog.eager = any(getattr(op, 'no_graph', False) for op in ops)     # stream-ordered collectives: no HIP graph
+        return prog
 
     @staticmethod
     def _fold_clips(ops):
@@ -627,7 +630,7 @@ class Session:
     def _execute(self, prog):
         rt = self.rt
         prog.runs += 1
-        if not self.use_hip_graphs or prog.runs == 1:
+        if not self.use_hip_graphs or prog.runs == 1 or prog.eager:
             # eager launch list (first run of a program is always eager: it also warms every kernel)
             for kind, seg in prog.segments:
                 if kind == 'host':

@@ -53,6 +53,7 @@ def parse():
     ap.add_argument('--cpu-steps', type=int, default=20)
     ap.add_argument('--no-pair', action='store_true', help='experiment: a layer\'s dgrad and wgrad as two launches instead of one')
     ap.add_argument('--overlap-wgrad', action='store_true', help='experiment: weight gradients on a second HIP stream')
+    ap.add_argument('--dp-collectives', default='stream', choices=['stream', 'side'], help='gradient all-reduces in stream order on the compute stream (eager launches) or on a side stream between HIP-graph segments')
     ap.add_argument('--buckets', type=int, default=3, help='gradient all-reduce buckets per optimizer (data parallel)')
     ap.add_argument('--exact-global-batch', action='store_true', help='data parallel that reproduces one device at the global batch: SyncBN + GDL scaling + global state-loss norm')
     ap.add_argument('--sync-bn', action='store_true', help='data parallel with BatchNorm statistics of the global batch (one small all-reduce per BatchNorm layer and direction)')
@@ -123,7 +124,8 @@ def main():
     B, S, dna, adv = args.batch, args.img, not args.plain, not args.no_adv
     n_critic = 5 if args.loss == 'wass' else 1
     G.reset_default_graph()
-    optim.set_data_parallel(world, n_buckets=args.buckets, force=args.force_dp, sync_bn=args.sync_bn, exact_global_batch=args.exact_global_batch)
+    optim.set_data_parallel(world, n_buckets=args.buckets, force=args.force_dp, sync_bn=args.sync_bn, exact_global_batch=args.exact_global_batch,
+                            collectives=args.dp_collectives)
     sess = G.Session(device=device, overlap_wgrad=args.overlap_wgrad, pair_bwd=not args.no_pair, use_hip_graphs=not args.no_graphs, world_size=world, rank=rank, process_group=pg, dtype=args.dtype)
     tr = T.Trainer(sess, adv, args.loss, args.opt, dna, batch_size=B, img_size=S, ksize=args.ksize, seed=0)
     sess.run(G.global_variables_initializer())
@@ -261,7 +263,8 @@ def main():
                                   B, S, S, args.seq_len, '--adv ' if adv else '', args.loss, '--dna ' if dna else 'plain-G ',
                                   args.ksize, args.opt, 'fp32' if args.dtype == 'f32' else 'bf16-MFMA/fp32-accumulate'),
                    'global_batch': B * world, 'n_critic': n_critic, 'parallelism': 'dp%d' % world,
-                   'hip_graphs': not args.no_graphs, 'sequences_per_s': round(world * B * args.steps / elapsed, 1)},
+                   'hip_graphs': (not args.no_graphs) and not ((world > 1 or args.force_dp) and args.dp_collectives == 'stream' and os.environ.get('ACG_CAPTURE_COLLECTIVES') != '1'),
+                   'dp_collectives': args.dp_collectives if (world > 1 or args.force_dp) else None, 'sequences_per_s': round(world * B * args.steps / elapsed, 1)},
         'roofline': roof, 'roofline_dna': roof_dna, 'cpu_baseline': cpu, 'eval_rollout': rollout,
         'op_ms_per_step': {k: round(v, 4) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])},
     }

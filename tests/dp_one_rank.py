@@ -17,10 +17,10 @@ def main():
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     x, y, a, s = TC.MG.inputs(2)
     finals = []
-    for force in (False, True):
+    for force, coll in ((False, 'stream'), (True, 'side'), (True, 'stream')):
         adv, loss, opt, dna, batch, ksize = TC.MG.CASES['c4_dna_wass_rmsprop']
         G.reset_default_graph()
-        optim.set_data_parallel(1, force=force)
+        optim.set_data_parallel(1, force=force, collectives=coll)
         sess = G.Session(device='cuda:0')
         tr = T.Trainer(sess, True, 'bce', 'rmsprop', dna, batch_size=batch, ksize=ksize)
         sess.run(G.global_variables_initializer())
@@ -35,10 +35,15 @@ def main():
         if force:
             kinds = [type(o).__name__ for o in G.get_default_graph().ops]
             assert kinds.count('AllReduceOp') >= 4, kinds.count('AllReduceOp')
-            progs = [p for p in sess._programs.values() if any(k == 'host' for k, _ in p.segments)]
-            assert progs and all(any(g is not None for g in p.graphs) for p in progs if p.runs >= 2)
-    for n in finals[0]:
-        assert torch.equal(finals[0][n], finals[1][n]), n
+            if coll == 'side':     # host-side collectives between HIP-graph segments
+                progs = [p for p in sess._programs.values() if any(k == 'host' for k, _ in p.segments)]
+                assert progs and all(any(g is not None for g in p.graphs) for p in progs if p.runs >= 2)
+            else:                  # stream-ordered collectives: the training programs are launched eagerly, one segment
+                progs = [p for p in sess._programs.values() if p.eager]
+                assert progs and all(p.graphs is None and len(p.segments) == 1 for p in progs), [(p.graphs, len(p.segments)) for p in progs]
+    for k in (1, 2):
+        for n in finals[0]:
+            assert torch.equal(finals[0][n], finals[k][n]), (k, n)
     # synchronised BatchNorm on the one-rank communicator: global statistics = local ones, so the run must track the
     # plain one (different kernels: compared at 1e-4 of the weight scale after the same four steps)
     adv, loss, opt, dna, batch, ksize = TC.MG.CASES['c4_dna_wass_rmsprop']

@@ -31,7 +31,7 @@ def _flat(t):
     return t.buf.detach().clone().cpu().numpy()
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, collectives='stream'):
     for p in (ROOT, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -42,7 +42,7 @@ def _worker(rank, world, port, outdir):
     if world > 1:
         dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
     sess, tr = TC.build_trainer(lambda **kw: G.Session(device='cpu', lib=cbind.load(), world_size=world, rank=rank, **kw),
-                                CASE, world_size=world)
+                                CASE, world_size=world, collectives=collectives)
     x, y, a, s = _inputs(rank)
     out = {'d_param0': _flat(tr.d_opt_op.inputs[0])}
     tr.train_d(x, y, a)
@@ -56,6 +56,7 @@ def _worker(rank, world, port, outdir):
         out['n_allreduce'] = np.array(kinds.count('AllReduceOp'))
         segs = [k for k, _ in sess._programs[next(iter(sess._programs))].segments]
         out['n_host_segments'] = np.array(segs.count('host'))
+        out['eager'] = np.array(int(sess._programs[next(iter(sess._programs))].eager))
     np.savez(os.path.join(outdir, 'w%d_r%d.npz' % (world, rank)), **out)
     if world > 1:
         dist.barrier()
@@ -69,9 +70,12 @@ def _free_port():
 
 
 @pytest.mark.timeout(900)
-def test_two_rank_allreduce_matches_mean_gradient_update():
+@pytest.mark.parametrize('collectives', ['stream', 'side'])
+def test_two_rank_allreduce_matches_mean_gradient_update(collectives):
+    """Both ways of issuing the bucketed all-reduce: in stream order (default; the step is then launched eagerly) and
+    asynchronously as a host op between program segments."""
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, _free_port(), d, collectives), nprocs=2, join=True)
         for r in (0, 1):                      # independent single-process references on each shard
             mp.spawn(_single, args=(r, d), nprocs=1, join=True)
         dp = [dict(np.load(os.path.join(d, 'w2_r%d.npz' % r))) for r in (0, 1)]
@@ -92,7 +96,11 @@ def test_two_rank_allreduce_matches_mean_gradient_update():
     # replicas stay bit-identical through the following G step
     assert np.array_equal(dp[0]['g_param1'], dp[1]['g_param1'])
     assert np.array_equal(dp[0]['g_grad'], dp[1]['g_grad'])
-    assert int(dp[0]['n_allreduce']) >= 4 and int(dp[0]['n_host_segments']) >= 2    # bucketed, several per optimizer
+    assert int(dp[0]['n_allreduce']) >= 4                                            # bucketed, several per optimizer
+    if collectives == 'side':
+        assert int(dp[0]['n_host_segments']) >= 2 and int(dp[0]['eager']) == 0
+    else:
+        assert int(dp[0]['n_host_segments']) == 0 and int(dp[0]['eager']) == 1
 
 
 def _single(_, rank, outdir):

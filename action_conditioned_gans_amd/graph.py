@@ -20,7 +20,6 @@ PyTorch is used for device memory, streams, graph capture and torch.distributed 
 """
 import contextlib
 import ctypes
-import os
 
 import numpy as np
 import torch

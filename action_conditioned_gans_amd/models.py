@@ -14,7 +14,6 @@ Deviations from the reference text, which does not run as committed (SURVEY sect
 with 16-byte loads.  Actions may be given as ``[B, A]`` (tiled and concatenated in one fused op) or already tiled
 ``[B, h, w, A]`` as the reference Trainer passes them (train.py:48-50).
 """
-from . import graph as G
 from . import ops as O
 
 G_PLAIN = {'encoder': (('conv1', 64), ('conv2', 128), ('conv3', 256), ('conv4', 512)),

@@ -626,10 +626,21 @@ class Session:
         if pending:
             join()
 
+    def _dp_eager(self):
+        """A data-parallel process with stream-ordered collectives captures NO HIP graph at all, also for its programs
+        without collectives (evaluation rollouts): the process group's watchdog thread polls events of outstanding
+        all-reduces, and an event query that lands inside another thread's stream capture aborts the process (seen
+        intermittently with host-side collectives between graph segments).  Eager launch lists run as fast here."""
+        dp = self.graph.collections.get('data_parallel')
+        if dp is None or not dp.active or getattr(dp, 'collectives', 'stream') != 'stream':
+            return False
+        import os
+        return os.environ.get('ACG_CAPTURE_COLLECTIVES') != '1'
+
     def _execute(self, prog):
         rt = self.rt
         prog.runs += 1
-        if not self.use_hip_graphs or prog.runs == 1 or prog.eager:
+        if not self.use_hip_graphs or prog.runs == 1 or prog.eager or self._dp_eager():
             # eager launch list (first run of a program is always eager: it also warms every kernel)
             for kind, seg in prog.segments:
                 if kind == 'host':

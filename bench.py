@@ -54,7 +54,7 @@ def parse():
     ap.add_argument('--no-pair', action='store_true', help='experiment: a layer\'s dgrad and wgrad as two launches instead of one')
     ap.add_argument('--overlap-wgrad', action='store_true', help='experiment: weight gradients on a second HIP stream')
     ap.add_argument('--dp-collectives', default='stream', choices=['stream', 'side'], help='gradient all-reduces in stream order on the compute stream (eager launches) or on a side stream between HIP-graph segments')
-    ap.add_argument('--buckets', type=int, default=3, help='gradient all-reduce buckets per optimizer (data parallel)')
+    ap.add_argument('--buckets', type=int, default=0, help='gradient all-reduce buckets per optimizer (data parallel); 0 = 1 for stream-ordered collectives, 3 for side-stream ones')
     ap.add_argument('--exact-global-batch', action='store_true', help='data parallel that reproduces one device at the global batch: SyncBN + GDL scaling + global state-loss norm')
     ap.add_argument('--sync-bn', action='store_true', help='data parallel with BatchNorm statistics of the global batch (one small all-reduce per BatchNorm layer and direction)')
     ap.add_argument('--force-dp', action='store_true', help='run the data-parallel machinery (RCCL all-reduce buckets, graph segments) even on one rank')
@@ -173,7 +173,7 @@ def main():
     # ---- eval rollout: Trainer.test_sequence, T-1 recursive G-only steps through the
     # reference's numpy-in / numpy-out API (train.py:157-176), after the timed region ---------------------------
     rollout = None
-    if rank == 0 and dna:
+    if rank == 0 and dna and world == 1:      # a one-GPU side metric; multi-GPU runs go straight to the result line
         r_img = rng.uniform(-1, 1, (B, args.seq_len, S, S, 3)).astype(np.float32)
         r_act = rng.standard_normal((B, args.seq_len, 10)).astype(np.float32)
         for _ in range(3):

@@ -96,11 +96,10 @@ def test_two_rank_allreduce_matches_mean_gradient_update(collectives):
     # replicas stay bit-identical through the following G step
     assert np.array_equal(dp[0]['g_param1'], dp[1]['g_param1'])
     assert np.array_equal(dp[0]['g_grad'], dp[1]['g_grad'])
-    assert int(dp[0]['n_allreduce']) >= 4                                            # bucketed, several per optimizer
-    if collectives == 'side':
-        assert int(dp[0]['n_host_segments']) >= 2 and int(dp[0]['eager']) == 0
-    else:
-        assert int(dp[0]['n_host_segments']) == 0 and int(dp[0]['eager']) == 1
+    if collectives == 'side':          # bucketed, several per optimizer, host ops between program segments
+        assert int(dp[0]['n_allreduce']) >= 4 and int(dp[0]['n_host_segments']) >= 2 and int(dp[0]['eager']) == 0
+    else:                              # one message per optimizer, in stream order, eager program
+        assert 2 <= int(dp[0]['n_allreduce']) <= 3 and int(dp[0]['n_host_segments']) == 0 and int(dp[0]['eager']) == 1     # D, G (and G pre-training)
 
 
 def _single(_, rank, outdir):

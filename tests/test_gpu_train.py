@@ -198,4 +198,4 @@ def test_data_parallel_machinery_on_one_rank():
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533')
     r = subprocess.run([sys.executable, os.path.join(here, 'dp_one_rank.py')], env=env, capture_output=True, text=True,
                        timeout=600)
-    assert 'DP_ONE_RANK_OK' in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    assert 'DP_ONE_RANK_OK' in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[:3000], r.stderr[-2000:])

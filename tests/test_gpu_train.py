@@ -66,6 +66,50 @@ def test_batch32_step_is_finite_and_learns():
     assert np.isfinite(frames).all()
 
 
+@pytest.mark.timeout(900)
+def test_config2_full_size_matches_oracle_live():
+    """BASELINE config 2 at its FULL size (batch 32, 64x64x3, DNA k=5, bce, Adam, fp32 - the bench workload): the
+    evaluation pass, one D step and one G step against the fp64 oracle run live on the host, 1e-3 - the predicted
+    frame and state, the three losses and the per-variable gradient norms of both steps (every conv / BatchNorm /
+    DNA kernel at the shapes and launch geometries the benchmark times, paired launches and deferred reductions
+    included)."""
+    import torch
+    from oracle import models as OM
+    from oracle.trainer import OracleTrainer
+    from action_conditioned_gans_amd import optim, train as T
+    B, S, K = 32, 64, 5
+    params = OM.init_params(True, batch=B, img=S, ksize=K, seed=9, dtype=torch.float32)
+    G.reset_default_graph()
+    optim.set_data_parallel(1)
+    sess = gpu_session()
+    tr = T.Trainer(sess, True, 'bce', 'adam', True, batch_size=B, img_size=S, ksize=K)
+    sess.run(G.global_variables_initializer())
+    g = G.get_default_graph()
+    for n, v in g.variables.items():
+        sess.set_value(v, params[n])
+    rng = np.random.default_rng(21)
+    x = rng.uniform(-1, 1, (B, S, S, 3)).astype(np.float32)
+    y = np.clip(np.roll(x, 2, axis=2) + 0.05 * rng.standard_normal(x.shape).astype(np.float32), -1, 1)
+    a = rng.standard_normal((B, 10)).astype(np.float32)
+    s = rng.standard_normal((B, 5)).astype(np.float32)
+    td = lambda t: torch.from_numpy(t).double()     # noqa: E731
+    torch.set_num_threads(16)
+    ot = OracleTrainer({k: v.double() for k, v in params.items()}, True, 'bce', 'adam', True, K)
+    frame, state, _ = tr.test(x, y, a)
+    oframe, ostate, _ = ot.test(td(x), td(y), td(a))
+    assert TC.rel(frame, oframe.numpy()) <= 1e-3 and TC.rel(state, ostate.numpy()) <= 1e-3
+    dsumm = tr.train_d(x, y, a, summarize=True)
+    od = ot.train_d(td(x), td(y), td(a), return_all=True)
+    assert abs(dsumm['discriminator_loss'] - float(od['d_loss'])) <= 1e-3 * max(abs(float(od['d_loss'])), 1.0)
+    TC.check_norms(TC.flat_grad_norms(sess, tr.d_opt_op), {'dgrad_norm/' + k: v.norm() for k, v in ot.last_grads.items()},
+                   'dgrad_norm/', 1e-3, 'D grad (batch 32)')
+    res = sess.run([tr.g_opt_op, tr.g_loss], tr._feed(x, y, a, s))
+    og = ot.train_g(td(x), td(y), td(a), td(s), return_all=True)
+    assert abs(res[1][0] - float(og['g_loss'])) <= 1e-3 * abs(float(og['g_loss']))
+    TC.check_norms(TC.flat_grad_norms(sess, tr.g_opt_op), {'ggrad_norm/' + k: v.norm() for k, v in ot.last_grads.items()},
+                   'ggrad_norm/', 1e-3, 'G grad (batch 32)')
+
+
 def test_config5_shapes_128x128_k11_match_oracle():
     """BASELINE config 5 geometry (128x128, 11x11 DNA kernel; fp32 here): action tile H/16 = 8, D logits 4x4,
     state head 8x8 VALID (64 taps).  Checked live against the fp64 oracle at batch 2."""

@@ -67,9 +67,10 @@ def test_batch32_step_is_finite_and_learns():
 
 
 @pytest.mark.timeout(900)
-def test_config2_full_size_matches_oracle_live():
-    """BASELINE config 2 at its FULL size (batch 32, 64x64x3, DNA k=5, bce, Adam, fp32 - the bench workload): the
-    evaluation pass, one D step and one G step against the fp64 oracle run live on the host, 1e-3 - the predicted
+@pytest.mark.parametrize('loss,opt', [('bce', 'adam'), ('wass', 'rmsprop')], ids=['config2', 'config4'])
+def test_config2_full_size_matches_oracle_live(loss, opt):
+    """BASELINE config 2 at its FULL size (batch 32, 64x64x3, DNA k=5, bce, Adam, fp32 - the bench workload) and config
+    4's losses / optimizer (Wasserstein + RMSProp + clip; there also the weights after the two updates): the evaluation pass, one D step and one G step against the fp64 oracle run live on the host, 1e-3 - the predicted
     frame and state, the three losses and the per-variable gradient norms of both steps (every conv / BatchNorm /
     DNA kernel at the shapes and launch geometries the benchmark times, paired launches and deferred reductions
     included)."""
@@ -82,7 +83,7 @@ def test_config2_full_size_matches_oracle_live():
     G.reset_default_graph()
     optim.set_data_parallel(1)
     sess = gpu_session()
-    tr = T.Trainer(sess, True, 'bce', 'adam', True, batch_size=B, img_size=S, ksize=K)
+    tr = T.Trainer(sess, True, loss, opt, True, batch_size=B, img_size=S, ksize=K)
     sess.run(G.global_variables_initializer())
     g = G.get_default_graph()
     for n, v in g.variables.items():
@@ -94,7 +95,7 @@ def test_config2_full_size_matches_oracle_live():
     s = rng.standard_normal((B, 5)).astype(np.float32)
     td = lambda t: torch.from_numpy(t).double()     # noqa: E731
     torch.set_num_threads(16)
-    ot = OracleTrainer({k: v.double() for k, v in params.items()}, True, 'bce', 'adam', True, K)
+    ot = OracleTrainer({k: v.double() for k, v in params.items()}, True, loss, opt, True, K)
     frame, state, _ = tr.test(x, y, a)
     oframe, ostate, _ = ot.test(td(x), td(y), td(a))
     assert TC.rel(frame, oframe.numpy()) <= 1e-3 and TC.rel(state, ostate.numpy()) <= 1e-3
@@ -108,6 +109,10 @@ def test_config2_full_size_matches_oracle_live():
     assert abs(res[1][0] - float(og['g_loss'])) <= 1e-3 * abs(float(og['g_loss']))
     TC.check_norms(TC.flat_grad_norms(sess, tr.g_opt_op), {'ggrad_norm/' + k: v.norm() for k, v in ot.last_grads.items()},
                    'ggrad_norm/', 1e-3, 'G grad (batch 32)')
+    if opt == 'rmsprop':                                   # weights after 1 D (+ clip) + 1 G update
+        for n, v in g.variables.items():
+            got, want = sess.get_value(v).double(), ot.p[n]
+            assert (got - want).abs().max().item() <= 1e-3 * max(want.abs().max().item(), 1e-3) + 2e-6, n
 
 
 def test_config5_shapes_128x128_k11_match_oracle():

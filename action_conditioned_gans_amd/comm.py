@@ -1,0 +1,154 @@
+"""Gradient all-reduce transport: this process's own RCCL communicator (GPU) or a gloo process group (CPU tests).
+
+The data-parallel step needs exactly one collective - a sum all-reduce of contiguous float32 ranges of the flat gradient
+buffers - plus a few tiny ones in the optional exact-global-batch mode.  On the GPU they are issued as
+plain ``ncclAllReduce`` calls on a ``hipStream_t`` of the caller's choice through ctypes on the librccl.so that PyTorch
+ships (the one HIP runtime of the process): stream-ordered, capturable into the step's HIP graph, no helper threads,
+no events, and an ordinary ``ncclCommDestroy`` at the end.  ``torch.distributed`` is used for the *bootstrap* only
+(the 128-byte unique id travels through a gloo group or a TCPStore) - never for device traffic, so no
+ProcessGroupNCCL (and no watchdog thread polling events beside a stream capture) exists in the process.
+"""
+import ctypes
+import os
+
+import torch
+
+NCCL_UNIQUE_ID_BYTES = 128
+NCCL_SUM, NCCL_MAX = 0, 2
+NCCL_INT32, NCCL_FLOAT32, NCCL_FLOAT64, NCCL_BFLOAT16 = 2, 7, 8, 9
+_DTYPES = {torch.float32: NCCL_FLOAT32, torch.float64: NCCL_FLOAT64, torch.int32: NCCL_INT32, torch.bfloat16: NCCL_BFLOAT16}
+
+
+class CommError(RuntimeError):
+    pass
+
+
+class _UniqueId(ctypes.Structure):
+    _fields_ = [('internal', ctypes.c_char * NCCL_UNIQUE_ID_BYTES)]
+
+
+_RCCL = None
+
+
+def _rccl():
+    """librccl.so next to torch's libamdhip64.so: the process keeps ONE HIP runtime (see _lib.py on import order)."""
+    global _RCCL
+    if _RCCL is None:
+        path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+        if not os.path.exists(path):
+            raise CommError('librccl.so not found next to torch (%s): no multi-GPU transport' % path)
+        lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        P = ctypes.c_void_p
+        lib.ncclGetUniqueId.argtypes, lib.ncclGetUniqueId.restype = [ctypes.POINTER(_UniqueId)], ctypes.c_int
+        lib.ncclCommInitRank.argtypes = [ctypes.POINTER(P), ctypes.c_int, _UniqueId, ctypes.c_int]
+        lib.ncclCommInitRank.restype = ctypes.c_int
+        lib.ncclAllReduce.argtypes = [P, P, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, P, P]
+        lib.ncclAllReduce.restype = ctypes.c_int
+        lib.ncclCommDestroy.argtypes, lib.ncclCommDestroy.restype = [P], ctypes.c_int
+        lib.ncclGetErrorString.argtypes, lib.ncclGetErrorString.restype = [ctypes.c_int], ctypes.c_char_p
+        lib.ncclGetVersion.argtypes, lib.ncclGetVersion.restype = [ctypes.POINTER(ctypes.c_int)], ctypes.c_int
+        _RCCL = lib
+    return _RCCL
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise CommError('%s failed: %s (ncclResult %d)' % (what, _rccl().ncclGetErrorString(rc).decode(), rc))
+
+
+def _share_unique_id(uid_bytes, world_size, rank, process_group):
+    """Rank 0's unique id to every rank, over CPU only: an initialised non-NCCL process group, else a TCPStore at
+    MASTER_ADDR:MASTER_PORT (under torch.distributed.run the agent already serves one there)."""
+    import torch.distributed as dist
+    if process_group is not None or (dist.is_available() and dist.is_initialized()):
+        if dist.get_backend(process_group) == 'nccl':
+            raise CommError('bootstrap needs a CPU process group (gloo): ProcessGroupNCCL is not used by this package')
+        box = [uid_bytes if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=process_group)
+        return box[0]
+    addr, port = os.environ.get('MASTER_ADDR'), os.environ.get('MASTER_PORT')
+    if not addr or not port:
+        raise CommError('multi-rank communicator needs a gloo process group or MASTER_ADDR / MASTER_PORT')
+    agent_store = os.environ.get('TORCHELASTIC_USE_AGENT_STORE', '').lower() == 'true'
+    store = dist.TCPStore(addr, int(port), world_size, is_master=(rank == 0 and not agent_store))
+    key = 'acg/rccl_unique_id/%s' % os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')
+    if rank == 0:
+        store.set(key, uid_bytes)
+        return uid_bytes
+    return bytes(store.get(key))
+
+
+class Communicator:
+    """``all_reduce(tensor, op, stream)``: in place, asynchronous, ordered on ``stream`` (None = the current one)."""
+    world_size, rank = 1, 0
+    capturable = False
+
+    def all_reduce(self, tensor, op='sum', stream=None):
+        raise NotImplementedError
+
+    def destroy(self):
+        pass
+
+
+class RcclCommunicator(Communicator):
+    capturable = True      # ncclAllReduce on a capturing stream becomes graph nodes (validated: tests/dp_one_rank.py)
+
+    def __init__(self, device, world_size=1, rank=0, process_group=None):
+        device = torch.device(device)
+        if device.type != 'cuda' or not torch.cuda.is_available():
+            raise CommError('RcclCommunicator needs a GPU device, got %s' % device)
+        self.device, self.world_size, self.rank = device, int(world_size), int(rank)
+        lib = _rccl()
+        uid = _UniqueId()
+        if self.rank == 0:
+            _check(lib.ncclGetUniqueId(ctypes.byref(uid)), 'ncclGetUniqueId')
+        if self.world_size > 1:
+            raw = _share_unique_id(bytes(uid.internal) if self.rank == 0 else None, self.world_size, self.rank, process_group)
+            ctypes.memmove(ctypes.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)
+        self._comm = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _check(lib.ncclCommInitRank(ctypes.byref(self._comm), self.world_size, uid, self.rank), 'ncclCommInitRank')
+        self._lib = lib
+        self.calls = 0
+
+    def all_reduce_ptr(self, ptr, count, nccl_dtype, nccl_op, stream_ptr):
+        """The raw form the launch lists use: everything precomputed, one C call."""
+        rc = self._lib.ncclAllReduce(ptr, ptr, count, nccl_dtype, nccl_op, self._comm, stream_ptr)
+        if rc != 0:
+            _check(rc, 'ncclAllReduce')
+        self.calls += 1
+
+    def all_reduce(self, tensor, op='sum', stream=None):
+        if not (tensor.is_cuda and tensor.is_contiguous()):
+            raise CommError('all_reduce: contiguous GPU tensor expected')
+        sp = stream if stream is not None else ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self.all_reduce_ptr(ctypes.c_void_p(tensor.data_ptr()), tensor.numel(), _DTYPES[tensor.dtype],
+                            NCCL_MAX if op == 'max' else NCCL_SUM, sp)
+
+    def destroy(self):
+        if self._comm is not None and self._comm.value:
+            torch.cuda.synchronize(self.device)        # nothing of ours may still be queued on the communicator
+            _check(self._lib.ncclCommDestroy(self._comm), 'ncclCommDestroy')
+            self._comm = None
+
+
+class ProcessGroupCommunicator(Communicator):
+    """CPU stand-in (world_size-2 gloo tests): the same interface over torch.distributed, synchronous."""
+
+    def __init__(self, process_group=None, world_size=None, rank=None):
+        import torch.distributed as dist
+        self._dist, self.group = dist, process_group
+        self.world_size = world_size if world_size is not None else dist.get_world_size(process_group)
+        self.rank = rank if rank is not None else dist.get_rank(process_group)
+
+    def all_reduce(self, tensor, op='sum', stream=None):
+        d = self._dist
+        d.all_reduce(tensor, op=d.ReduceOp.MAX if op == 'max' else d.ReduceOp.SUM, group=self.group)
+
+
+def create(device, world_size=1, rank=0, process_group=None):
+    """The transport for ``device``: RCCL on a GPU, the given (gloo) process group on the CPU."""
+    device = torch.device(device)
+    if device.type == 'cuda':
+        return RcclCommunicator(device, world_size, rank, process_group)
+    return ProcessGroupCommunicator(process_group, world_size, rank)

@@ -100,8 +100,8 @@ class Variable(Tensor):
 
 class Op:
     """One node of the static program.  ``bind(rt)`` returns ``fn(stream_ptr)`` that enqueues it."""
-    host = False        # True: cannot be captured into a HIP graph (collectives)
-    side_stream = False  # True: may run on the session's second stream, overlapping the main chain
+    host = False        # True: runs between HIP-graph segments (torch kernels of the exact-global-batch mode)
+    side_stream = False  # True: runs on the session's second stream, overlapping the main chain (gradient all-reduce)
     run_last = False    # True: ordered after everything else in a program (weight clip, defect D6)
 
     def __init__(self, graph, name, inputs, outputs, control_inputs=()):
@@ -296,14 +296,23 @@ class _Program:
 class Runtime:
     """What an Op needs to bind itself: the kernel library, the device, buffers, process group."""
 
-    def __init__(self, lib, device, world_size=1, rank=0, process_group=None, conv_dtype=0):
+    def __init__(self, lib, device, world_size=1, rank=0, process_group=None, conv_dtype=0, comm=None):
         self.lib, self.device = lib, torch.device(device)
         self.conv_dtype = conv_dtype          # ACG_F32 / ACG_BF16 for the conv contractions
         self.world_size, self.rank, self.process_group = world_size, rank, process_group
         self.is_cuda = self.device.type == 'cuda'
-        self.comm_stream = torch.cuda.Stream(self.device) if self.is_cuda else None
         self.side_stream = torch.cuda.Stream(self.device) if self.is_cuda else None
+        self._comm = comm
         self._scratch = {}
+
+    @property
+    def comm(self):
+        """The gradient transport (comm.py), created on first use: this process's own RCCL communicator on a GPU, the
+        given gloo process group on the CPU."""
+        if self._comm is None:
+            from . import comm as C
+            self._comm = C.create(self.device, self.world_size, self.rank, self.process_group)
+        return self._comm
 
     def workspace(self, nbytes):
         """A private zero-initialised scratch buffer (never shared: ops may overlap across streams).  It lives as long
@@ -334,7 +343,7 @@ class Session:
     """``tf.Session`` stand-in bound to one GPU (one process per GPU)."""
 
     def __init__(self, device='cuda:0', graph=None, use_hip_graphs=True, lib=None,
-                 world_size=1, rank=0, process_group=None, overlap_wgrad=False, dtype='f32', pair_bwd=True):
+                 world_size=1, rank=0, process_group=None, dtype='f32', pair_bwd=True, comm=None):
         self.graph = graph or get_default_graph()
         dev = torch.device(device)
         if lib is None:
@@ -345,13 +354,12 @@ class Session:
                 raise RuntimeError('no GPU visible: the HIP path cannot run and there is no CPU fallback')
         if dtype not in ('f32', 'bf16'):
             raise ValueError("dtype must be 'f32' or 'bf16' (bf16 matrix-core operands, fp32 storage and accumulation)")
-        self.rt = Runtime(lib, dev, world_size, rank, process_group, _lib.ACG_BF16 if dtype == 'bf16' else _lib.ACG_F32)
+        self.rt = Runtime(lib, dev, world_size, rank, process_group, _lib.ACG_BF16 if dtype == 'bf16' else _lib.ACG_F32, comm)
         if dev.type == 'cuda':
             torch.cuda.set_device(dev)
         self.use_hip_graphs = use_hip_graphs and dev.type == 'cuda'
-        self.overlap_wgrad = overlap_wgrad and dev.type == 'cuda'
         # a layer's input gradient and weight gradient in ONE launch (acg_conv2d_bwd_pair) when they are neighbours in a program
-        self.pair_bwd = bool(pair_bwd) and not self.overlap_wgrad
+        self.pair_bwd = bool(pair_bwd)
         self._programs = {}
         self._initialized = False
 
@@ -359,7 +367,14 @@ class Session:
         return self
 
     def __exit__(self, *a):
+        self.close()
         return False
+
+    def close(self):
+        """Tear the gradient transport down (ncclCommDestroy); the session must not run afterwards."""
+        if self.rt._comm is not None:
+            self.rt._comm.destroy()
+            self.rt._comm = None
 
     # ---- buffers
     def _materialize(self, t):
@@ -471,7 +486,7 @@ class Session:
         for ph in feeds:
             self._materialize(ph)
         prog = _Program(segments, fetch_tensors, list(feeds))
-        prog.eager = any(getattr(op, 'no_graph', False) for op in ops)     # stream-ordered collectives: no HIP graph
+        prog.eager = any(getattr(op, 'no_graph', False) for op in ops)     # an op that cannot be captured: eager launch list
         return prog
 
     @staticmethod
@@ -591,13 +606,12 @@ class Session:
         return next(it)
 
     def _launch_segment(self, seg):
-        """Enqueue one device segment.  With ``overlap_wgrad`` (off by default) ops flagged ``side_stream``
-        (weight gradients: nothing on the dgrad chain consumes them) go to a second HIP stream, ordered behind
-        their producers by an event and joined before the first op that depends on them - a fork/join in the
-        captured graph.  Measured on MI355X at config 2 it LOSES (254 vs 274 steps/s: every conv launch already
-        fills the chip, so the fork only adds event nodes and contention), hence the default."""
+        """Enqueue one device segment.  Ops flagged ``side_stream`` (the gradient all-reduces of
+        ``collectives='side'``) go to the session's second HIP stream: ordered behind everything enqueued so far by
+        one edge, and joined back into the main stream in front of the first op that depends on them (the optimizer
+        update) - a fork/join that is captured into the program's HIP graph like any other dependency."""
         rt = self.rt
-        if not (rt.is_cuda and self.overlap_wgrad):
+        if not (rt.is_cuda and any(op.side_stream for op, _ in seg)):
             sp = rt.stream_ptr()
             for _, fn in seg:
                 fn(sp)
@@ -626,21 +640,10 @@ class Session:
         if pending:
             join()
 
-    def _dp_eager(self):
-        """A data-parallel process with stream-ordered collectives captures NO HIP graph at all, also for its programs
-        without collectives (evaluation rollouts): the process group's watchdog thread polls events of outstanding
-        all-reduces, and an event query that lands inside another thread's stream capture aborts the process (seen
-        intermittently with host-side collectives between graph segments).  Eager launch lists run as fast here."""
-        dp = self.graph.collections.get('data_parallel')
-        if dp is None or not dp.active or getattr(dp, 'collectives', 'stream') != 'stream':
-            return False
-        import os
-        return os.environ.get('ACG_CAPTURE_COLLECTIVES') != '1'
-
     def _execute(self, prog):
         rt = self.rt
         prog.runs += 1
-        if not self.use_hip_graphs or prog.runs == 1 or prog.eager or self._dp_eager():
+        if not self.use_hip_graphs or prog.runs == 1 or prog.eager:
             # eager launch list (first run of a program is always eager: it also warms every kernel)
             for kind, seg in prog.segments:
                 if kind == 'host':
@@ -656,7 +659,9 @@ class Session:
                     prog.graphs.append(None)
                     continue
                 gr = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gr):
+                # thread_local: HIP calls of OTHER threads (none of ours; a host library's helper thread at worst) neither
+                # see nor invalidate this thread's capture
+                with torch.cuda.graph(gr, capture_error_mode='thread_local'):
                     self._launch_segment(seg)     # current stream = the capture stream
                 prog.graphs.append(gr)
         for (kind, seg), gr in zip(prog.segments, prog.graphs):

@@ -222,7 +222,6 @@ class ConvDgradOp(_ConvBase):
 
 class ConvWgradOp(_ConvBase):
     which = CONV_WGRAD
-    side_stream = True      # only the optimizer step consumes it: overlaps the dgrad chain (graph.py)
 
     def __init__(self, x, dy, dst, accumulate, desc, transposed, name):
         self.desc, self.transposed, self.accumulate = desc, transposed, float(accumulate)
@@ -364,13 +363,12 @@ class BnMomentsAllReduceOp(G.Op):
         super().__init__(G.get_default_graph(), name, [moments], [_new(moments.shape, name + ':0')])
 
     def bind(self, rt):
-        import torch.distributed as dist
         src, dst, g, c = self.inputs[0], self.outputs[0], self.groups, self.c
 
         def run():
             m = src.buf.view(g, 2, c)
             t = torch.stack([m[:, 0], m[:, 1] + m[:, 0] * m[:, 0]], dim=1).contiguous()
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=rt.process_group)
+            rt.comm.all_reduce(t)
             t /= rt.world_size
             out = dst.buf.view(g, 2, c)
             out[:, 0] = t[:, 0]
@@ -433,13 +431,12 @@ class BnSumsAllReduceOp(G.Op):
         super().__init__(G.get_default_graph(), name, [sums], [_new(sums.shape, name + ':global'), _new(sums.shape, name + ':local')])
 
     def bind(self, rt):
-        import torch.distributed as dist
         src, glob, loc = self.inputs[0], self.outputs[0], self.outputs[1]
 
         def run():
             loc.buf.copy_(src.buf)
             glob.buf.copy_(src.buf)
-            dist.all_reduce(glob.buf, op=dist.ReduceOp.SUM, group=rt.process_group)
+            rt.comm.all_reduce(glob.buf)
         return run
 
 
@@ -1087,12 +1084,11 @@ class ScalarAllReduceOp(G.Op):
         super().__init__(G.get_default_graph(), name, [x], [_new(x.shape, name + ':0')])
 
     def bind(self, rt):
-        import torch.distributed as dist
         src, dst = self.inputs[0], self.outputs[0]
 
         def run():
             dst.buf.copy_(src.buf)
-            dist.all_reduce(dst.buf, op=dist.ReduceOp.SUM, group=rt.process_group)
+            rt.comm.all_reduce(dst.buf)
         return run
 
 

@@ -7,13 +7,13 @@ shape (train.py:91-102) and TensorFlow-1.0's update formulas.  ``mi
    with the same layout (graph.py), so wgrad kernels write gradients in place;
 2. builds the backward ops (graph.build_gradients) - only along paths that reach ``var_list``;
 3. with world_size > 1, cuts the flat gradient buffer into contiguous buckets in backward-completion
-   order and inserts one RCCL all-reduce per bucket right after the op that completes it - in stream
-   order on the compute stream (default) or on a side HIP stream overlapping the rest of backward
-   (``collectives='side'``; see DataParallel); the optimizer step runs behind all of them;
+   order and inserts one RCCL all-reduce per bucket right after the op that completes it - on the
+   compute stream in program order, or on a side HIP stream overlapping the rest of backward
+   (``collectives='side'``; see DataParallel) - captured into the step's HIP graph either way; the
+   optimizer step runs behind all of them;
 4. appends ONE fused update launch over the flat buffers (+ the weight clip when it is fetched with it).
 """
 import torch
-import torch.distributed as dist
 
 from . import graph as G
 from . import ops as O
@@ -28,24 +28,21 @@ def _f32(v):
 
 
 class DataParallel:
-    """Per-graph data-parallel configuration (one process per GPU; RCCL via torch.distributed)."""
+    """Per-graph data-parallel configuration (one process per GPU; this process's own RCCL communicator, comm.py)."""
 
     def __init__(self, world_size=1, n_buckets=None, force=False, sync_bn=False, exact_global_batch=False, collectives='stream'):
         self.world_size, self.force = int(world_size), bool(force)
-        # 'stream': each bucket's all-reduce is an ordinary call in stream order on the compute stream and the step's
-        #           programs are launched eagerly (an eager launch list runs as fast as a replayed HIP graph here, and the
-        #           host-side collective no longer cuts a graph into segments: 372 vs 337 steps/s on a one-rank
-        #           communicator, profiles/r1/w_stream_edges.txt); with ACG_CAPTURE_COLLECTIVES=1 the all-reduces are
-        #           captured INTO the step's HIP graph instead (375; validated on one rank only, hence opt-in);
-        # 'side':   the all-reduce runs asynchronously on a communication stream, overlapping the rest of backward, as a
-        #           host op between graph segments (each cross-stream edge and each segment boundary costs ~18-24 us).
+        # Every bucket's all-reduce is a plain ncclAllReduce on a HIP stream, captured into the step's HIP graph:
+        # 'stream': on the compute stream, in program order right behind the op that completes the bucket;
+        # 'side':   on the session's second stream, behind one fork edge, overlapping the rest of backward; one join
+        #           edge in front of the optimizer update (north_star: "overlapped with backward on a side HIP stream").
         if collectives not in ('stream', 'side'):
             raise ValueError("collectives must be 'stream' or 'side'")
         self.collectives = collectives
-        # buckets per optimizer: stream-ordered all-reduces hide nothing, so ONE large message per optimizer is best (374.6
-        # vs 369.5 steps/s with three on a one-rank communicator); the side-stream form overlaps the early buckets with
-        # the rest of backward and defaults to three
-        self.n_buckets = int(n_buckets) if n_buckets else (1 if collectives == 'stream' else 3)
+        # buckets per optimizer: an in-order all-reduce hides nothing, so ONE large message per optimizer is best there;
+        # the side-stream form sends the layers that finish first (the last-created, for D 69 % of the bytes) while the
+        # rest of backward still runs, in two messages
+        self.n_buckets = int(n_buckets) if n_buckets else (1 if collectives == 'stream' else 2)
         # exact_global_batch: the run reproduces ONE device at the global batch - BatchNorm over the global batch,
         # the GDL sum scaled by the world size, the state-loss norm taken over all ranks (SURVEY 8(e) caveats 1-3)
         self.exact_global_batch = bool(exact_global_batch)
@@ -58,7 +55,7 @@ class DataParallel:
 
 def set_data_parallel(world_size, n_buckets=None, graph=None, force=False, sync_bn=False, exact_global_batch=False, collectives='stream'):
     """``force`` inserts the bucketed all-reduce even at world_size 1 (a one-rank communicator): lets a single GPU
-    exercise the collective / side-stream / graph-segment machinery the multi-GPU runs depend on."""
+    exercise the collective / side-stream / graph-capture machinery the multi-GPU runs depend on."""
     (graph or G.get_default_graph()).collections['data_parallel'] = DataParallel(world_size, n_buckets, force, sync_bn, exact_global_batch, collectives)
 
 
@@ -66,65 +63,26 @@ def _dp(graph):
     return graph.collections.get('data_parallel') or DataParallel(1)
 
 
-def _capture_collectives():
-    """ACG_CAPTURE_COLLECTIVES=1 (opt-in): with stream-ordered collectives the programs stay HIP graphs and the
-    all-reduces are captured INTO them.  RCCL supports capture on this stack (tools/micro/rccl_capture_probe.py);
-    validated here on one rank only, hence opt-in until a multi-GPU run has measured it."""
-    import os
-    return os.environ.get('ACG_CAPTURE_COLLECTIVES') == '1'
-
-
 class AllReduceOp(G.Op):
-    """Sum-all-reduce of one contiguous gradient bucket: in stream order on the compute stream (collectives='stream')
-    or asynchronously on the communication stream (collectives='side')."""
-    host = True
+    """Sum-all-reduce of one contiguous gradient bucket, in place: ``ncclAllReduce`` on the stream the launch list
+    hands it - the compute stream (collectives='stream') or the session's side stream (collectives='side',
+    ``side_stream`` makes graph._launch_segment fork and join around it).  A device op like any kernel launch."""
 
-    def __init__(self, flat_grad, start, end, after, name, stream_ordered=True):
+    def __init__(self, flat_grad, start, end, after, name, side):
         super().__init__(flat_grad.graph, name, [], [], control_inputs=after)
         self.flat_grad, self.start, self.end = flat_grad, start, end
         self.index = max(o.index for o in after) + 0.5     # right behind the op that completes the bucket
-        self.work = None
-        self.host = not stream_ordered
-        self.no_graph = stream_ordered and not _capture_collectives()   # its programs are launched eagerly (graph._execute)
+        self.side_stream = bool(side)
 
     def bind(self, rt):
+        comm = rt.comm
         view = self.flat_grad.buf[self.start:self.end]
-        op = self
-        if not self.host:          # in stream order on whatever stream the segment is being enqueued on
-            return lambda s: dist.all_reduce(view, op=dist.ReduceOp.SUM, group=rt.process_group)
-
-        def launch():
-            if rt.is_cuda:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(rt.device))
-                rt.comm_stream.wait_event(ev)
-                with torch.cuda.stream(rt.comm_stream):
-                    op.work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=rt.process_group, async_op=True)
-            else:
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=rt.process_group)
-        return launch
-
-
-class AllReduceWaitOp(G.Op):
-    """collectives='side': makes the compute stream wait for every outstanding bucket (no host synchronisation)."""
-    host = True
-
-    def __init__(self, graph, reduces, name):
-        super().__init__(graph, name, [], [], control_inputs=reduces)
-        self.reduces = reduces
-        self.host = any(r.host for r in reduces)
-
-    def bind(self, rt):
-        reduces = self.reduces
-        if not self.host:
-            return None            # stream order already serialises the all-reduces before the update
-
-        def wait():
-            for r in reduces:
-                if r.work is not None:
-                    r.work.wait()
-                    r.work = None
-        return wait
+        self.no_graph = rt.is_cuda and not comm.capturable
+        if hasattr(comm, 'all_reduce_ptr'):
+            from . import comm as C
+            ptr, n, call = _p(view), view.numel(), comm.all_reduce_ptr
+            return lambda s: call(ptr, n, C.NCCL_FLOAT32, C.NCCL_SUM, s)
+        return lambda s: comm.all_reduce(view)
 
 
 class StepOp(G.Op):
@@ -198,8 +156,7 @@ class Optimizer:
         writers = [op for ops_ in ctx.writers.values() for op in ops_]
         deps = list(dict.fromkeys(writers))
         if dp.active:
-            reduces = self._insert_allreduce(var_list, ctx, flat_grad, offsets, buckets, dp.collectives == 'stream')
-            deps.append(AllReduceWaitOp(g, reduces, self.name + '/allreduce_wait'))
+            deps += self._insert_allreduce(var_list, ctx, flat_grad, offsets, buckets, dp.collectives == 'side')
         slots = self._make_slots(g, total)
         return StepOp(self, scope, [v.name for v in var_list], flat_param, flat_grad, slots, deps, 1.0 / dp.world_size)
 
@@ -233,14 +190,14 @@ class Optimizer:
                 if ctx.writers.get(v.name) and ctx.writers[v.name][0] in group:
                     ctx.writers[v.name] = [red]
 
-    def _insert_allreduce(self, var_list, ctx, flat_grad, offsets, buckets, stream_ordered):
+    def _insert_allreduce(self, var_list, ctx, flat_grad, offsets, buckets, side):
         order = sorted(var_list, key=lambda v: offsets[v.name])
         reduces = []
         for k, (lo, hi_) in enumerate(buckets):
             after = list(dict.fromkeys(op for v in order if lo <= offsets[v.name] < hi_ for op in ctx.writers.get(v.name, [])))
             if not after:
                 continue
-            reduces.append(AllReduceOp(flat_grad, lo, hi_, after, '%s/allreduce_%d' % (self.name, k), stream_ordered))
+            reduces.append(AllReduceOp(flat_grad, lo, hi_, after, '%s/allreduce_%d' % (self.name, k), side))
         return reduces
 
 

@@ -296,7 +296,9 @@ def main(argv=None):
     world_size, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world_size > 1:
-        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        # control plane only (bootstrap of the RCCL communicator, comm.py): gradients never go through torch.distributed
+        torch.cuda.set_device(local_rank)
+        torch.distributed.init_process_group('gloo')
     train(args.input_path, os.path.join(args.output_path, 'train_output'), os.path.join(args.output_path, 'test_output'),
           log_dir, model_dir, args.adv, args.loss, args.opt, args.dna, batch_size=args.batch_size, img_size=args.img_size,
           seq_len=args.seq_len, ksize=args.ksize, train_iter=args.train_iter, pretrain_iter=args.pretrain_iter,

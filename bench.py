@@ -52,9 +52,9 @@ def parse():
     ap.add_argument('--profile-repeats', type=int, default=3)
     ap.add_argument('--cpu-steps', type=int, default=20)
     ap.add_argument('--no-pair', action='store_true', help='experiment: a layer\'s dgrad and wgrad as two launches instead of one')
-    ap.add_argument('--overlap-wgrad', action='store_true', help='experiment: weight gradients on a second HIP stream')
-    ap.add_argument('--dp-collectives', default='stream', choices=['stream', 'side'], help='gradient all-reduces in stream order on the compute stream (eager launches) or on a side stream between HIP-graph segments')
-    ap.add_argument('--buckets', type=int, default=0, help='gradient all-reduce buckets per optimizer (data parallel); 0 = 1 for stream-ordered collectives, 3 for side-stream ones')
+    ap.add_argument('--dp-collectives', default=None, choices=['stream', 'side'], help='gradient all-reduces (ncclAllReduce captured into the step\'s HIP graph) on the compute stream in program order, or on a side HIP stream overlapping the rest of backward; default: side with more than one rank')
+    ap.add_argument('--buckets', type=int, default=0, help='gradient all-reduce buckets per optimizer (data parallel); 0 = 1 for in-order collectives, 2 for side-stream ones')
+    ap.add_argument('--min-seconds', type=float, default=1.0, help='the timed K-step block is repeated until this much time has been measured; the median block is reported')
     ap.add_argument('--exact-global-batch', action='store_true', help='data parallel that reproduces one device at the global batch: SyncBN + GDL scaling + global state-loss norm')
     ap.add_argument('--sync-bn', action='store_true', help='data parallel with BatchNorm statistics of the global batch (one small all-reduce per BatchNorm layer and direction)')
     ap.add_argument('--force-dp', action='store_true', help='run the data-parallel machinery (RCCL all-reduce buckets, graph segments) even on one rank')
@@ -108,16 +108,13 @@ def main():
             raise SystemExit('--gpus %d needs torch.distributed.run with --nproc-per-node %d' % (args.gpus, args.gpus))
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
-    pg = None
-    if world > 1 or args.force_dp:
+    if world > 1:
+        # control plane only (rendezvous, barriers, the max over ranks): a CPU gloo group.  Gradients travel over this
+        # process's own RCCL communicator (action_conditioned_gans_amd/comm.py), bootstrapped through this group.
         import torch.distributed as dist
-        if args.force_dp and 'MASTER_ADDR' not in os.environ:
-            import socket
-            with socket.socket() as sk:          # a free port: back-to-back runs must not meet the previous run's socket
-                sk.bind(('127.0.0.1', 0))
-                port = sk.getsockname()[1]
-            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')
-        dist.init_process_group('nccl', device_id=device)
+        dist.init_process_group('gloo')
+    if args.dp_collectives is None:
+        args.dp_collectives = 'side' if world > 1 else 'stream'
 
     from action_conditioned_gans_amd import graph as G, ops as O, optim, train as T
 
@@ -126,7 +123,7 @@ def main():
     G.reset_default_graph()
     optim.set_data_parallel(world, n_buckets=args.buckets, force=args.force_dp, sync_bn=args.sync_bn, exact_global_batch=args.exact_global_batch,
                             collectives=args.dp_collectives)
-    sess = G.Session(device=device, overlap_wgrad=args.overlap_wgrad, pair_bwd=not args.no_pair, use_hip_graphs=not args.no_graphs, world_size=world, rank=rank, process_group=pg, dtype=args.dtype)
+    sess = G.Session(device=device, pair_bwd=not args.no_pair, use_hip_graphs=not args.no_graphs, world_size=world, rank=rank, dtype=args.dtype)
     tr = T.Trainer(sess, adv, args.loss, args.opt, dna, batch_size=B, img_size=S, ksize=args.ksize, seed=0)
     sess.run(G.global_variables_initializer())
 
@@ -158,16 +155,30 @@ def main():
         step(i)
     for i in range(args.warmup):
         step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        frames = step(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    def timed_block():
+        """EXACTLY args.steps steps between two barrier + synchronize brackets; the max over ranks."""
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = step(i)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
+    # a K-step block can be a few tens of milliseconds: repeat it until --min-seconds have been measured (every rank
+    # derives the same count from the max-reduced first block) and report the median block
+    first, frames = timed_block()
+    blocks = [first]
+    repeats = int(min(max(np.ceil(args.min_seconds / max(first, 1e-6)), 1), 200))
+    for _ in range(repeats - 1):
+        dt, frames = timed_block()
+        blocks.append(dt)
+    elapsed = float(np.median(blocks))
     assert torch.isfinite(frames).all(), 'generated frames are not finite'
 
     # ---- eval rollout (SURVEY 8(f) rank 1): Trainer.test_sequence, T-1 recursive G-only steps through the
@@ -246,7 +257,7 @@ def main():
                         'algorithmic_mb_per_step': round(dna_bytes / 1e6, 2), 'ms_per_step_in_kernel': round(dna_ms, 4)}
 
     if rank != 0:
-        _leave_distributed()
+        _leave_distributed(sess)
         return
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
@@ -263,30 +274,25 @@ def main():
                                   B, S, S, args.seq_len, '--adv ' if adv else '', args.loss, '--dna ' if dna else 'plain-G ',
                                   args.ksize, args.opt, 'fp32' if args.dtype == 'f32' else 'bf16-MFMA/fp32-accumulate'),
                    'global_batch': B * world, 'n_critic': n_critic, 'parallelism': 'dp%d' % world,
-                   'hip_graphs': (not args.no_graphs) and not ((world > 1 or args.force_dp) and args.dp_collectives == 'stream' and os.environ.get('ACG_CAPTURE_COLLECTIVES') != '1'),
+                   'hip_graphs': not args.no_graphs, 'timed_blocks': len(blocks), 'timed_seconds': round(float(np.sum(blocks)), 3),
+                   'block_ms_per_step_min_max': [round(min(blocks) / args.steps * 1e3, 4), round(max(blocks) / args.steps * 1e3, 4)],
                    'dp_collectives': args.dp_collectives if (world > 1 or args.force_dp) else None, 'sequences_per_s': round(world * B * args.steps / elapsed, 1)},
         'roofline': roof, 'roofline_dna': roof_dna, 'cpu_baseline': cpu, 'eval_rollout': rollout,
         'op_ms_per_step': {k: round(v, 4) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])},
     }
     print(json.dumps(line), flush=True)
-    if world > 1 or args.force_dp:
-        _leave_distributed()
+    _leave_distributed(sess)
 
 
-def _leave_distributed():
-    """All ranks meet once more, then leave WITHOUT communicator teardown: the result line is already out, and an RCCL
-    destroy that aborts (seen once on the GPU box inside a long-lived process) must not turn a finished run into a
-    failed one."""
+def _leave_distributed(sess):
+    """Ordinary teardown: ncclCommDestroy of this process's communicator, then the gloo control group, then a normal
+    interpreter exit."""
     import torch.distributed as dist
+    torch.cuda.synchronize()
+    sess.close()
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
-        torch.cuda.synchronize()
-        sys.stdout.flush()
-        sys.stderr.flush()
-        if os.environ.get('ACG_BENCH_DESTROY_PG') == '1':      # profilers need a normal interpreter exit
-            dist.destroy_process_group()
-            return
-        os._exit(0)
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

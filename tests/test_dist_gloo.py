@@ -72,8 +72,8 @@ def _free_port():
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize('collectives', ['stream', 'side'])
 def test_two_rank_allreduce_matches_mean_gradient_update(collectives):
-    """Both ways of issuing the bucketed all-reduce: in stream order (default; the step is then launched eagerly) and
-    asynchronously as a host op between program segments."""
+    """Both ways of issuing the bucketed all-reduce: one message per optimizer in program order, and two buckets flagged
+    for the side stream (on the CPU stand-in both run in program order; the GPU forks / joins around them)."""
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(2, _free_port(), d, collectives), nprocs=2, join=True)
         for r in (0, 1):                      # independent single-process references on each shard
@@ -96,10 +96,12 @@ def test_two_rank_allreduce_matches_mean_gradient_update(collectives):
     # replicas stay bit-identical through the following G step
     assert np.array_equal(dp[0]['g_param1'], dp[1]['g_param1'])
     assert np.array_equal(dp[0]['g_grad'], dp[1]['g_grad'])
-    if collectives == 'side':          # bucketed, several per optimizer, host ops between program segments
-        assert int(dp[0]['n_allreduce']) >= 4 and int(dp[0]['n_host_segments']) >= 2 and int(dp[0]['eager']) == 0
-    else:                              # one message per optimizer, in stream order, eager program
-        assert 2 <= int(dp[0]['n_allreduce']) <= 3 and int(dp[0]['n_host_segments']) == 0 and int(dp[0]['eager']) == 1     # D, G (and G pre-training)
+    # the all-reduces are device ops of the launch list (no host segments), in both modes
+    assert int(dp[0]['n_host_segments']) == 0 and int(dp[0]['eager']) == 0
+    if collectives == 'side':          # two buckets per optimizer
+        assert int(dp[0]['n_allreduce']) >= 4
+    else:                              # one message per optimizer: D, G (and G pre-training)
+        assert 2 <= int(dp[0]['n_allreduce']) <= 3
 
 
 def _single(_, rank, outdir):

@@ -23,12 +23,11 @@ def test_trainer_matches_golden(name):
 
 @pytest.mark.parametrize('name', ['c2_dna_bce_adam', 'c4_dna_wass_rmsprop'])
 def test_hip_graph_replay_equals_eager(name):
-    """Run 1 is eager, run 2 captures, run 3+ replays (with the weight-gradient kernels forked onto a second
-    stream): the weights must match an all-eager, single-stream session bit for bit."""
+    """Run 1 is eager, run 2 captures, run 3+ replays: the weights must match an all-eager session bit for bit."""
     x, y, a, s = TC.MG.inputs(2)
     finals = []
     for use_graphs in (False, True):
-        sess, tr = TC.build_trainer(gpu_session, name, use_hip_graphs=use_graphs, overlap_wgrad=False)
+        sess, tr = TC.build_trainer(gpu_session, name, use_hip_graphs=use_graphs)
         for _ in range(4):
             tr.train_d(x, y, a)
             frames = tr.train_g(x, y, a, s)
@@ -234,32 +233,15 @@ def test_bf16_mode_tracks_fp32():
             assert cos >= 0.95, (n, cos)
 
 
-def _dp_child(which, port):
+def test_data_parallel_machinery_on_one_rank():
+    """The multi-GPU path cannot be launched from here, so drive everything but the peers on ONE rank: this process's
+    own RCCL communicator of size 1 (comm.py), the per-bucket ncclAllReduce captured into the step's HIP graphs - on the
+    compute stream and on the side stream (fork / join edges) - the 1/world scale in the optimizer, and the
+    exact-global-batch mode (SyncBN, global state-loss norm).  Weights must equal the plain single-GPU run bit for bit.
+    Runs in a child process (tests/dp_one_rank.py) that ends with ncclCommDestroy and a normal exit: any abort fails."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    return subprocess.run([sys.executable, os.path.join(here, 'dp_one_rank.py'), which], env=env, capture_output=True, text=True,
-                          timeout=600)
-
-
-def test_data_parallel_machinery_on_one_rank():
-    """The multi-GPU path cannot be launched from here, so drive everything but the peers on ONE rank: an RCCL
-    communicator of size 1, the per-optimizer all-reduce in stream order behind the deferred weight-gradient reduction,
-    eager launches, the 1/world scale in the optimizer - and the exact-global-batch mode (SyncBN, global state-loss
-    norm).  The result must equal the plain single-GPU run bit for bit.  Runs in a child process
-    (tests/dp_one_rank.py): it reports and leaves without tearing the communicator down."""
-    r = _dp_child('default', 29533)
-    assert 'DP_ONE_RANK_OK' in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[:3000], r.stderr[-2000:])
-
-
-def test_data_parallel_experimental_modes_on_one_rank():
-    """The non-default modes: side-stream all-reduce as a host op between HIP-graph segments, and all-reduces captured
-    INTO the HIP graph (ACG_CAPTURE_COLLECTIVES=1).  Same bit-identity bar.  A process that captures graphs while
-    all-reduce work is outstanding was seen to abort (SIGABRT from a background thread, ~1 run in 6):
-    that known runtime hazard - the reason these modes are not the default - is reported as a skip, anything else fails."""
-    r = _dp_child('experimental', 29534)
-    if r.returncode == -6 and 'DP_ONE_RANK_OK' not in r.stdout and 'AssertionError' not in r.stderr:
-        pytest.skip('child aborted inside the runtime (graph capture beside outstanding collectives): ' + r.stderr[:300])
-    assert 'DP_ONE_RANK_OK' in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[:3000], r.stderr[-2000:])
+    r = subprocess.run([sys.executable, os.path.join(here, 'dp_one_rank.py')], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'DP_ONE_RANK_OK' in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[:3000], r.stderr[-2000:])

@@ -93,15 +93,16 @@ def test_weight_gradient_reductions_share_one_launch():
     r = [op for op in prog_ops if isinstance(op, O.WgradReduceOp)][0]
     assert len(r._keep) == 1 and r._keep[0][1] == len(wg)       # the oracle splits every layer at batch 2: all deferred
     # data parallel: one reduction per bucket, the bucket's all-reduce right behind it
-    sess, tr = TC.build_trainer(cpu_session, 'c2_dna_bce_adam', world_size=2, collectives='side')     # three buckets per optimizer
+    sess, tr = TC.build_trainer(cpu_session, 'c2_dna_bce_adam', world_size=2, collectives='side')     # two buckets per optimizer
     ops_ = TC.program_op_names(sess, [tr.g_opt_op, tr.g_next_frame], tr._feed(x, y, a, s))
     red = [o for o in ops_ if o[1] == 'WgradReduceOp']
     ar = [o for o in ops_ if o[1] == 'AllReduceOp']
-    assert 2 <= len(red) <= len(ar) == 3
+    assert len(red) == len(ar) == 2
+    assert all(op.side_stream for op in G.get_default_graph().ops if isinstance(op, optim.AllReduceOp))
     for k, r_ in enumerate(red):
         later = [o for o in ar if o[0] > r_[0]]
         assert later and min(o[0] for o in later) - r_[0] == 0.5, (k, r_, ar)
-    # stream-ordered collectives (the default): ONE bucket per optimizer, its all-reduce behind the single reduction
+    # in-order collectives on the compute stream: ONE bucket per optimizer, its all-reduce behind the single reduction
     sess, tr = TC.build_trainer(cpu_session, 'c2_dna_bce_adam', world_size=2)
     ops_ = TC.program_op_names(sess, [tr.g_opt_op, tr.g_next_frame], tr._feed(x, y, a, s))
     red = [o for o in ops_ if o[1] == 'WgradReduceOp']

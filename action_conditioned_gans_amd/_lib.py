@@ -39,10 +39,16 @@ class ReduceList(ctypes.Structure):
                 ('accumulate', c_float * 32)]
 
 
+class PrepList(ctypes.Structure):
+    """struct acg_prep_list (ACG_PREP_MAX = 32 filters)."""
+    _fields_ = [('src', c_void_p * 32), ('rm', c_void_p * 32), ('tr', c_void_p * 32), ('taps', c_int32 * 32), ('a', c_int32 * 32),
+                ('b', c_int32 * 32)]
+
+
 class CopyList(ctypes.Structure):
     """struct acg_copy_list (ACG_COPY_MAX = 8 segments)."""
     _fields_ = [('src', c_void_p * 8), ('dst', c_void_p * 8), ('rows', c_int64 * 8), ('cols', c_int32 * 8),
-                ('dst_pitch', c_int32 * 8)]
+                ('dst_pitch', c_int32 * 8), ('dst_dtype', c_int32 * 8)]
 
 
 _P = c_void_p
@@ -67,6 +73,7 @@ SIGNATURES = {
     'acg_conv2d_bwd_pair': (c_int32, [_P, _P, _P, _P, _P, c_float, _D, c_int32, _P, c_size_t, _P, c_size_t, c_int32, _P]),
     'acg_deconv2d_bwd_pair': (c_int32, [_P, _P, _P, _P, _P, c_float, _D, c_int32, _P, c_size_t, _P, c_size_t, c_int32, _P]),
     'acg_splitk_reduce_many': (c_int32, [ctypes.POINTER(ReduceList), c_int32, _P]),
+    'acg_weights_prepare_bf16': (c_int32, [ctypes.POINTER(PrepList), c_int32, _P]),
     'acg_deconv2d_fwd': (c_int32, _conv),
     'acg_deconv2d_dgrad': (c_int32, _conv),
     'acg_deconv2d_wgrad': (c_int32, _wgrad),
@@ -76,16 +83,17 @@ SIGNATURES = {
     'acg_bn_bwd_sums': (c_int32, [_P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_float, c_int32, _P, c_size_t, _P]),
     'acg_bn_act_bwd_sums': (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, c_float, c_int64, c_int32, c_int32, c_int32,
                                       c_float, c_int32, _P]),
-    'acg_bn_act_fwd': (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_float, c_int32, c_float,
+    'acg_bn_act_fwd': (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, c_float,
                                  c_int32, _P, c_size_t, _P]),
-    'acg_bn_act_bwd': (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int64, c_int32, c_int32, c_int32,
+    'acg_bn_act_bwd': (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
                                  c_float, c_int32, _P, c_size_t, _P]),
     'acg_bias_workspace_bytes': (c_size_t, [c_int64, c_int32]),
-    'acg_bias_act_fwd': (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_float, c_int32, _P]),
-    'acg_bias_act_bwd': (c_int32, [_P, _P, _P, _P, c_float, c_int64, c_int32, c_int32, c_float, c_int32,
+    'acg_bias_act_fwd': (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, _P]),
+    'acg_bias_act_bwd': (c_int32, [_P, _P, _P, _P, c_float, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_int32,
                                    _P, c_size_t, _P]),
-    'acg_dna_fwd': (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
-    'acg_dna_bwd': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
+    'acg_dna_workspace_bytes': (c_size_t, [c_int32] * 4),
+    'acg_dna_fwd': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
+    'acg_dna_bwd': (c_int32, [_P, _P, _P, _P, _P, _P, c_float, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_size_t, _P]),
     'acg_cdna_workspace_bytes': (c_size_t, [c_int32] * 6),
     'acg_cdna_fwd': (c_int32, [_P, _P, _P, _P] + [c_int32] * 6 + [c_float, c_int32, _P]),
     'acg_cdna_bwd': (c_int32, [_P, _P, _P, _P, _P, _P] + [c_int32] * 6 + [c_float, c_int32, _P, c_size_t, _P]),
@@ -118,6 +126,21 @@ SIGNATURES = {
 
 COPY_MAX = 8
 REDUCE_MAX = 32
+PREP_MAX = 32
+
+
+def dtype2(first, second):
+    """ACG_DTYPE2: two storage types in one dtype argument (the plain code when they agree)."""
+    return first if first == second else first | (second << 4) | 0x100
+
+
+def code(torch_dtype):
+    """ACG_F32 / ACG_BF16 of a torch dtype."""
+    if torch_dtype == torch.float32:
+        return ACG_F32
+    if torch_dtype == torch.bfloat16:
+        return ACG_BF16
+    raise TypeError('no storage code for %s' % torch_dtype)
 VALUE_RETURNING = ('acg_version', 'acg_conv2d_splits')     # int32 results that are not status codes
 
 

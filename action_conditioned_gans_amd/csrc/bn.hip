@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -79,16 +80,8 @@ __device__ __forceinline__ VMap<V> vmap(int C) {
   m.nchunk = (m.Cv + m.Cb - 1) / m.Cb;
   return m;
 }
-template <int V>
-__device__ __forceinline__ void ldv(const float* p, float (&v)[V]) {
-  if constexpr (V == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-  else v[0] = *p;
-}
-template <int V>
-__device__ __forceinline__ void stv(float* p, const float (&v)[V]) {
-  if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-  else *p = v[0];
-}
+using acg::ldv;
+using acg::stv;
 
 // Reduce 2*V per-thread values over the rsub dimension through LDS (sh: 2*V*256 floats); valid where rsub == 0.
 template <int V>
@@ -109,13 +102,13 @@ __device__ __forceinline__ void reduce_rsub_v(const VMap<V>& m, float (&a)[V], f
 
 // partial layout: part[((g * nblk + b) * 2 + which) * C + c]
 // ---- BN forward ---------------------------------------------------------------------------------------
-template <int V>
-__global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ x, float* __restrict__ part,
-                                                        long long R, int C, int nblk) {
+template <int V, typename TX>
+__global__ __launch_bounds__(256) void bn_stats_partial(const TX* __restrict__ x, float* __restrict__ part,
+                                                        long long R, int C, int nblk, int XP) {
   __shared__ float sh[2 * V * 256];
   const VMap<V> m = vmap<V>(C);
   const int g = blockIdx.y, b = blockIdx.x;
-  const float* xg = x + (long long)g * R * C;
+  const TX* xg = x + (long long)g * R * XP;
   const long long rpb = (R + nblk - 1) / nblk;
   const long long r0 = (long long)b * rpb, r1 = min(R, r0 + rpb);
   for (int ch = 0; ch < m.nchunk; ++ch) {
@@ -130,7 +123,7 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
       for (long long r = r0 + m.rsub; r < r1; r += kU * m.RPP) {
         float v[kU][V];
 #pragma unroll
-        for (int u = 0; u < kU; ++u) ldv<V>(xg + min(r + u * m.RPP, r1 - 1) * C + c, v[u]);
+        for (int u = 0; u < kU; ++u) ldv<V>(xg + min(r + u * m.RPP, r1 - 1) * XP + c, v[u]);
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
           const float w = r + u * m.RPP < r1 ? 1.f : 0.f;
@@ -186,11 +179,11 @@ __device__ __forceinline__ void sum_partials(const float* __restrict__ part, int
   }
 }
 
-template <int V>
-__global__ __launch_bounds__(256) void bn_apply_fwd(const float* __restrict__ x, const float* __restrict__ beta,
-                                                    const float* __restrict__ part, float* __restrict__ y,
+template <int V, typename TX, typename TY>
+__global__ __launch_bounds__(256) void bn_apply_fwd(const TX* __restrict__ x, const float* __restrict__ beta,
+                                                    const float* __restrict__ part, TY* __restrict__ y,
                                                     float* __restrict__ save_mean, float* __restrict__ save_rstd,
-                                                    long long R, int C, int nblk, float eps, int act, float leak) {
+                                                    long long R, int C, int nblk, float eps, int act, float leak, int XP, int YP) {
   __shared__ float sh[4 * 8 * 2 * V];
   const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3, g = blockIdx.z;
   const int c = (blockIdx.y * 8 + cq) * V;
@@ -198,8 +191,8 @@ __global__ __launch_bounds__(256) void bn_apply_fwd(const float* __restrict__ x,
   float s1[V], s2[V];
   sum_partials<V>(part, g, nblk, C, c, cvalid, rl, s1, s2, sh);
   if (!cvalid) return;
-  const float* xg = x + (long long)g * R * C;
-  float* yg = y + (long long)g * R * C;
+  const TX* xg = x + (long long)g * R * XP;
+  TY* yg = y + (long long)g * R * YP;
   float pv[V], mean[V], rstd[V], bt[V];
   ldv<V>(xg + c, pv);
   ldv<V>(beta + c, bt);
@@ -217,29 +210,29 @@ __global__ __launch_bounds__(256) void bn_apply_fwd(const float* __restrict__ x,
   for (long long r = (long long)blockIdx.x * 32 + rl; r < R; r += kU * rstep) {
     float v[kU][V];
 #pragma unroll
-    for (int u = 0; u < kU; ++u) ldv<V>(xg + min(r + u * rstep, R - 1) * C + c, v[u]);
+    for (int u = 0; u < kU; ++u) ldv<V>(xg + min(r + u * rstep, R - 1) * XP + c, v[u]);
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       if (r + u * rstep < R) {
 #pragma unroll
         for (int j = 0; j < V; ++j) v[u][j] = acg::act_apply(act, (v[u][j] - mean[j]) * rstd[j] + bt[j], leak);
-        stv<V>(yg + (r + u * rstep) * C + c, v[u]);
+        stv<V>(yg + (r + u * rstep) * YP + c, v[u]);
       }
     }
   }
 }
 
 // ---- BN backward ----------------------------------------------------------------------------------------
-template <int V>
-__global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ x, const float* __restrict__ dy,
+template <int V, typename TX, typename TY>
+__global__ __launch_bounds__(256) void bn_bwd_partial(const TX* __restrict__ x, const TY* __restrict__ dy,
                                                       const float* __restrict__ beta, const float* __restrict__ save_mean,
                                                       const float* __restrict__ save_rstd, float* __restrict__ part,
-                                                      long long R, int C, int nblk, int act, float leak) {
+                                                      long long R, int C, int nblk, int act, float leak, int XP, int YP) {
   __shared__ float sh[2 * V * 256];
   const VMap<V> m = vmap<V>(C);
   const int g = blockIdx.y, b = blockIdx.x;
-  const float* xg = x + (long long)g * R * C;
-  const float* dyg = dy + (long long)g * R * C;
+  const TX* xg = x + (long long)g * R * XP;
+  const TY* dyg = dy + (long long)g * R * YP;
   const long long rpb = (R + nblk - 1) / nblk;
   const long long r0 = (long long)b * rpb, r1 = min(R, r0 + rpb);
   for (int ch = 0; ch < m.nchunk; ++ch) {
@@ -255,7 +248,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
           const long long rr = min(r + u * m.RPP, r1 - 1);
-          ldv<V>(xg + rr * C + c, xv[u]); ldv<V>(dyg + rr * C + c, dv[u]);
+          ldv<V>(xg + rr * XP + c, xv[u]); ldv<V>(dyg + rr * YP + c, dv[u]);
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
@@ -278,12 +271,12 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
   }
 }
 
-template <int V>
-__global__ __launch_bounds__(256) void bn_apply_bwd(const float* __restrict__ x, const float* __restrict__ dy,
+template <int V, typename TX, typename TY>
+__global__ __launch_bounds__(256) void bn_apply_bwd(const TX* __restrict__ x, const TY* __restrict__ dy,
                                                     const float* __restrict__ beta, const float* __restrict__ save_mean,
                                                     const float* __restrict__ save_rstd, const float* __restrict__ part,
-                                                    float* __restrict__ dx, float* __restrict__ dbeta, float dbeta_acc,
-                                                    long long R, int C, int groups, int nblk, int act, float leak) {
+                                                    TX* __restrict__ dx, float* __restrict__ dbeta, float dbeta_acc,
+                                                    long long R, int C, int groups, int nblk, int act, float leak, int XP, int YP) {
   __shared__ float sh[4 * 8 * 2 * V];
   const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3, g = blockIdx.z;
   const int c = (blockIdx.y * 8 + cq) * V;
@@ -317,9 +310,9 @@ __global__ __launch_bounds__(256) void bn_apply_bwd(const float* __restrict__ x,
     sum_partials<V>(part, g, nblk, C, c, cvalid, rl, s1, s2, sh);
   }
   if (!cvalid) return;
-  const float* xg = x + (long long)g * R * C;
-  const float* dyg = dy + (long long)g * R * C;
-  float* dxg = dx + (long long)g * R * C;
+  const TX* xg = x + (long long)g * R * XP;
+  const TY* dyg = dy + (long long)g * R * YP;
+  TX* dxg = dx + (long long)g * R * XP;
   float mean[V], rstd[V], bt[V], m1[V], m2[V];
   ldv<V>(save_mean + g * C + c, mean); ldv<V>(save_rstd + g * C + c, rstd); ldv<V>(beta + c, bt);
   const float invR = 1.f / (float)R;
@@ -331,7 +324,7 @@ __global__ __launch_bounds__(256) void bn_apply_bwd(const float* __restrict__ x,
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const long long rr = min(r + u * rstep, R - 1);
-      ldv<V>(xg + rr * C + c, xv[u]); ldv<V>(dyg + rr * C + c, dv[u]);
+      ldv<V>(xg + rr * XP + c, xv[u]); ldv<V>(dyg + rr * YP + c, dv[u]);
     }
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
@@ -342,7 +335,7 @@ __global__ __launch_bounds__(256) void bn_apply_bwd(const float* __restrict__ x,
           const float dp = dv[u][j] * acg::act_deriv_pre(act, xh + bt[j], leak);
           dv[u][j] = rstd[j] * (dp - m1[j] - xh * m2[j]);
         }
-        stv<V>(dxg + (r + u * rstep) * C + c, dv[u]);
+        stv<V>(dxg + (r + u * rstep) * XP + c, dv[u]);
       }
     }
   }
@@ -372,17 +365,17 @@ __device__ __forceinline__ void block_sum(float (&v)[N], float* sh /* 4 * N floa
   for (int j = 0; j < N; ++j) v[j] = sh[j] + sh[N + j] + sh[2 * N + j] + sh[3 * N + j];
 }
 
-template <int V, int NR>
-__global__ __launch_bounds__(256) void bn_resident_fwd(const float* __restrict__ x, const float* __restrict__ beta,
-                                                       float* __restrict__ y, float* __restrict__ save_mean,
-                                                       float* __restrict__ save_rstd, int R, int C, float eps, int act, float leak) {
+template <int V, int NR, typename TX, typename TY>
+__global__ __launch_bounds__(256) void bn_resident_fwd(const TX* __restrict__ x, const float* __restrict__ beta,
+                                                       TY* __restrict__ y, float* __restrict__ save_mean,
+                                                       float* __restrict__ save_rstd, int R, int C, float eps, int act, float leak, int XP, int YP) {
   __shared__ float sh[4 * 2 * V];
   const int c = blockIdx.x * V, g = blockIdx.y;
-  const float* xg = x + (long long)g * R * C + c;
-  float* yg = y + (long long)g * R * C + c;
+  const TX* xg = x + (long long)g * R * XP + c;
+  TY* yg = y + (long long)g * R * YP + c;
   float v[NR][V], pv[V], bt[V];
 #pragma unroll
-  for (int u = 0; u < NR; ++u) ldv<V>(xg + min((int)threadIdx.x + u * 256, R - 1) * C, v[u]);
+  for (int u = 0; u < NR; ++u) ldv<V>(xg + min((int)threadIdx.x + u * 256, R - 1) * XP, v[u]);
   ldv<V>(xg, pv);      // shift by the group's first row, as in bn_stats_partial
   ldv<V>(beta + c, bt);
   float s[2 * V];
@@ -411,18 +404,18 @@ __global__ __launch_bounds__(256) void bn_resident_fwd(const float* __restrict__
     if (r < R) {
 #pragma unroll
       for (int j = 0; j < V; ++j) v[u][j] = acg::act_apply(act, (v[u][j] - mean[j]) * rstd[j] + bt[j], leak);
-      stv<V>(yg + r * C, v[u]);
+      stv<V>(yg + r * YP, v[u]);
     }
   }
 }
 
 // One block per V channels walks the groups in turn (dbeta is the sum over groups of its first reduction).
-template <int V, int NR>
-__global__ __launch_bounds__(256) void bn_resident_bwd(const float* __restrict__ x, const float* __restrict__ dy,
+template <int V, int NR, typename TX, typename TY>
+__global__ __launch_bounds__(256) void bn_resident_bwd(const TX* __restrict__ x, const TY* __restrict__ dy,
                                                        const float* __restrict__ beta, const float* __restrict__ save_mean,
-                                                       const float* __restrict__ save_rstd, float* __restrict__ dx,
+                                                       const float* __restrict__ save_rstd, TX* __restrict__ dx,
                                                        float* __restrict__ dbeta, float dbeta_acc, int R, int C, int groups,
-                                                       int act, float leak) {
+                                                       int act, float leak, int XP, int YP) {
   __shared__ float sh[4 * 2 * V];
   const int c = blockIdx.x * V;
   float bt[V], tot[V];
@@ -430,12 +423,12 @@ __global__ __launch_bounds__(256) void bn_resident_bwd(const float* __restrict__
 #pragma unroll
   for (int j = 0; j < V; ++j) tot[j] = 0.f;
   for (int g = 0; g < groups; ++g) {
-    const long long base = (long long)g * R * C + c;
+    const long long base = (long long)g * R * XP + c, ybase = (long long)g * R * YP + c;
     float xv[NR][V], dv[NR][V], mean[V], rstd[V];
 #pragma unroll
     for (int u = 0; u < NR; ++u) {
-      const int rr = min((int)threadIdx.x + u * 256, R - 1) * C;
-      ldv<V>(x + base + rr, xv[u]); ldv<V>(dy + base + rr, dv[u]);
+      const int rq = min((int)threadIdx.x + u * 256, R - 1);
+      ldv<V>(x + base + rq * XP, xv[u]); ldv<V>(dy + ybase + rq * YP, dv[u]);
     }
     ldv<V>(save_mean + g * C + c, mean); ldv<V>(save_rstd + g * C + c, rstd);
     float s[2 * V];
@@ -462,7 +455,7 @@ __global__ __launch_bounds__(256) void bn_resident_bwd(const float* __restrict__
       if (r < R) {
 #pragma unroll
         for (int j = 0; j < V; ++j) dv[u][j] = rstd[j] * (dv[u][j] - s[j] * invR - xv[u][j] * (s[V + j] * invR));
-        stv<V>(dx + base + r * C, dv[u]);
+        stv<V>(dx + base + r * XP, dv[u]);
       }
     }
   }
@@ -493,8 +486,10 @@ int resident_nr(long long R, int max_nr) {
 }
 
 // ---- bias + activation --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bias_act_fwd_k(const float* __restrict__ x, const float* __restrict__ bias,
-                                                      float* __restrict__ y, long long R, int C, int act, float leak) {
+// x rows are xp elements apart, y rows yp (>= C; pad channels are neither read nor written)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void bias_act_fwd_k(const TI* __restrict__ x, const float* __restrict__ bias,
+                                                      TO* __restrict__ y, long long R, int C, int xp, int yp, int act, float leak) {
   const ColMap m = col_map(C);
   if (!m.active) return;
   for (int ch = 0; ch < m.nchunk; ++ch) {
@@ -502,14 +497,15 @@ __global__ __launch_bounds__(256) void bias_act_fwd_k(const float* __restrict__ 
     if (c >= C) continue;
     const float bt = bias ? bias[c] : 0.f;
     for (long long r = (long long)blockIdx.x * m.RPP + m.rsub; r < R; r += (long long)gridDim.x * m.RPP)
-      y[r * C + c] = acg::act_apply(act, x[r * C + c] + bt, leak);
+      acg::stf(y + r * yp + c, acg::act_apply(act, acg::ldf(x + r * xp + c) + bt, leak));
   }
 }
 
 // dx = dy * act'(y) and per-block column sums of it -> part[nblk][C]
-__global__ __launch_bounds__(256) void bias_act_bwd_partial(const float* __restrict__ y, const float* __restrict__ dy,
-                                                            float* __restrict__ dx, float* __restrict__ part,
-                                                            long long R, int C, int nblk, int act, float leak) {
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void bias_act_bwd_partial(const TO* __restrict__ y, const TO* __restrict__ dy,
+                                                            TI* __restrict__ dx, float* __restrict__ part,
+                                                            long long R, int C, int xp, int yp, int nblk, int act, float leak) {
   __shared__ float sh[512];
   const ColMap m = col_map(C);
   const int b = blockIdx.x;
@@ -525,14 +521,14 @@ __global__ __launch_bounds__(256) void bias_act_bwd_partial(const float* __restr
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const long long rr = min(r + u * m.RPP, r1 - 1);
-          g[u] = dy[rr * C + c];
-          yv[u] = act != ACG_ACT_NONE ? y[rr * C + c] : 0.f;
+          g[u] = acg::ldf(dy + rr * yp + c);
+          yv[u] = act != ACG_ACT_NONE ? acg::ldf(y + rr * yp + c) : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if (r + u * m.RPP < r1) {
             const float gq = g[u] * acg::act_deriv_out(act, yv[u], leak);
-            if (dx) dx[(r + u * m.RPP) * C + c] = gq;
+            if (dx) acg::stf(dx + (r + u * m.RPP) * xp + c, gq);
             s1 += gq;
           }
         }
@@ -684,34 +680,20 @@ bool vec4_ok(int C, const void* a, const void* b, const void* c) {
   return C % 4 == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
 }
 
-}  // namespace
-
-extern "C" {
-
-size_t acg_bn_workspace_bytes(int64_t rows, int32_t channels, int32_t groups) {
-  (void)rows;
-  if (channels <= 0 || groups <= 0) return 0;
-  return (size_t)groups * ((size_t)kMaxPartialBlocks * 2 + 2) * (size_t)channels * sizeof(float);
-}
-
-int32_t acg_bn_act_fwd(const void* x, const float* beta, void* y, float* save_mean, float* save_rstd, int64_t rows,
-                       int32_t C, int32_t groups, float eps, int32_t act, float leak, int32_t dtype, void* ws,
-                       size_t wsb, acg_stream_t stream) {
-  ACG_REQUIRE_F32(dtype);
-  if (int rc = check_bn("bn_act_fwd", rows, C, groups)) return rc;
-  ACG_REQUIRE(x && beta && y && save_mean && save_rstd, ACG_ERR_INVALID_ARG, "bn_act_fwd: null pointer");
-  ACG_REQUIRE(act == ACG_ACT_NONE || act == ACG_ACT_RELU || act == ACG_ACT_LRELU, ACG_ERR_UNSUPPORTED, "bn_act_fwd: activation %d", act);
-  ACG_REQUIRE(ws && wsb >= acg_bn_workspace_bytes(rows, C, groups), ACG_ERR_WORKSPACE, "bn_act_fwd: workspace too small");
-  const long long R = rows / groups;
-  hipStream_t st = acg::to_stream(stream);
-  const float* xf = (const float*)x;
-  float* part = (float*)ws;
-  const bool v4 = vec4_ok(C, x, y, beta) && vec4_ok(C, save_mean, save_rstd, ws);
+// One BatchNorm direction for one pair of storage types.  The mixed pair (bf16 x, float32 y: the loss-facing last
+// layer of a bf16 network) exists for the scalar (V = 1) variants only.
+template <typename TX, typename TY>
+int bn_fwd_typed(const void* x, const float* beta, void* y, float* save_mean, float* save_rstd, long long R, int C, int groups,
+                 float eps, int act, float leak, float* part, bool v4, int XP, int YP, hipStream_t st) {
+  constexpr bool same = std::is_same<TX, TY>::value;
+  const TX* xf = (const TX*)x;
+  TY* yf = (TY*)y;
+  if (!same) v4 = false;
   const int V = v4 ? 4 : 1;
   if (const int nr = resident_nr(R, 32)) {
     const dim3 rg(C / V, groups);
-#define ACG_BN_RES_FWD(VV, NN) ACG_LAUNCH((bn_resident_fwd<VV, NN>), rg, dim3(256), 0, st, xf, beta, (float*)y, save_mean, save_rstd, (int)R, C, eps, act, leak)
-#define ACG_BN_RES_FWD_V(NN) do { if (v4) ACG_BN_RES_FWD(4, NN); else ACG_BN_RES_FWD(1, NN); } while (0)
+#define ACG_BN_RES_FWD(VV, NN) ACG_LAUNCH((bn_resident_fwd<VV, NN, TX, TY>), rg, dim3(256), 0, st, xf, beta, yf, save_mean, save_rstd, (int)R, C, eps, act, leak, XP, YP)
+#define ACG_BN_RES_FWD_V(NN) do { if constexpr (same) { if (v4) ACG_BN_RES_FWD(4, NN); else ACG_BN_RES_FWD(1, NN); } else ACG_BN_RES_FWD(1, NN); } while (0)
     switch (nr) {
       case 1: ACG_BN_RES_FWD_V(1); break;
       case 2: ACG_BN_RES_FWD_V(2); break;
@@ -726,34 +708,33 @@ int32_t acg_bn_act_fwd(const void* x, const float* beta, void* y, float* save_me
   }
   static const int stats_iters = env_int("ACG_BN_STATS_ITERS", 8);  // tuning hook
   const int nblk = vpartial_blocks(R, C, V, stats_iters);
-  if (v4) ACG_LAUNCH(bn_stats_partial<4>, dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk);
-  else ACG_LAUNCH(bn_stats_partial<1>, dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk);
+  if (same && v4) ACG_LAUNCH((bn_stats_partial<4, TX>), dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk, XP);
+  else ACG_LAUNCH((bn_stats_partial<1, TX>), dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk, XP);
   if (int rc = acg::check_launch("bn_stats_partial")) return rc;
   const dim3 ag(tile_row_blocks(R, C, V), (C + 8 * V - 1) / (8 * V), groups);
-  if (v4) ACG_LAUNCH(bn_apply_fwd<4>, ag, dim3(256), 0, st, xf, beta, (const float*)part, (float*)y, save_mean, save_rstd, R, C, nblk, eps, act, leak);
-  else ACG_LAUNCH(bn_apply_fwd<1>, ag, dim3(256), 0, st, xf, beta, (const float*)part, (float*)y, save_mean, save_rstd, R, C, nblk, eps, act, leak);
+  if constexpr (same) {
+    if (v4) ACG_LAUNCH((bn_apply_fwd<4, TX, TY>), ag, dim3(256), 0, st, xf, beta, (const float*)part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP);
+    else ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, xf, beta, (const float*)part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP);
+  } else {
+    ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, xf, beta, (const float*)part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP);
+  }
   return acg::check_launch("bn_apply_fwd");
 }
 
-int32_t acg_bn_act_bwd(const void* x, const void* dy, const float* beta, const float* save_mean, const float* save_rstd,
-                       void* dx, float* dbeta, float dbeta_acc, int64_t rows, int32_t C, int32_t groups, int32_t act,
-                       float leak, int32_t dtype, void* ws, size_t wsb, acg_stream_t stream) {
-  ACG_REQUIRE_F32(dtype);
-  if (int rc = check_bn("bn_act_bwd", rows, C, groups)) return rc;
-  ACG_REQUIRE(x && dy && beta && save_mean && save_rstd && dx && dbeta, ACG_ERR_INVALID_ARG, "bn_act_bwd: null pointer");
-  ACG_REQUIRE(act == ACG_ACT_NONE || act == ACG_ACT_RELU || act == ACG_ACT_LRELU, ACG_ERR_UNSUPPORTED, "bn_act_bwd: activation %d", act);
-  ACG_REQUIRE(ws && wsb >= acg_bn_workspace_bytes(rows, C, groups), ACG_ERR_WORKSPACE, "bn_act_bwd: workspace too small");
-  const long long R = rows / groups;
-  hipStream_t st = acg::to_stream(stream);
-  const float* xf = (const float*)x;
-  const float* dyf = (const float*)dy;
-  float* part = (float*)ws;
-  const bool v4 = vec4_ok(C, x, dy, dx) && vec4_ok(C, save_mean, save_rstd, ws) && vec4_ok(C, beta, dbeta, ws);
+template <typename TX, typename TY>
+int bn_bwd_typed(const void* x, const void* dy, const float* beta, const float* save_mean, const float* save_rstd, void* dx,
+                 float* dbeta, float dbeta_acc, long long R, int C, int groups, int act, float leak, float* part, bool v4, int XP, int YP,
+                 hipStream_t st) {
+  constexpr bool same = std::is_same<TX, TY>::value;
+  const TX* xf = (const TX*)x;
+  const TY* dyf = (const TY*)dy;
+  TX* dxf = (TX*)dx;
+  if (!same) v4 = false;
   const int V = v4 ? 4 : 1;
   if (const int nr = resident_nr(R * groups, 16) ? resident_nr(R, 16) : 0) {
     const dim3 rg(C / V);
-#define ACG_BN_RES_BWD(VV, NN) ACG_LAUNCH((bn_resident_bwd<VV, NN>), rg, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (float*)dx, dbeta, dbeta_acc, (int)R, C, groups, act, leak)
-#define ACG_BN_RES_BWD_V(NN) do { if (v4) ACG_BN_RES_BWD(4, NN); else ACG_BN_RES_BWD(1, NN); } while (0)
+#define ACG_BN_RES_BWD(VV, NN) ACG_LAUNCH((bn_resident_bwd<VV, NN, TX, TY>), rg, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, (int)R, C, groups, act, leak, XP, YP)
+#define ACG_BN_RES_BWD_V(NN) do { if constexpr (same) { if (v4) ACG_BN_RES_BWD(4, NN); else ACG_BN_RES_BWD(1, NN); } else ACG_BN_RES_BWD(1, NN); } while (0)
     switch (nr) {
       case 1: ACG_BN_RES_BWD_V(1); break;
       case 2: ACG_BN_RES_BWD_V(2); break;
@@ -767,13 +748,57 @@ int32_t acg_bn_act_bwd(const void* x, const void* dy, const float* beta, const f
   }
   static const int bwd_iters = env_int("ACG_BN_BWD_ITERS", 4);      // tuning hook
   const int nblk = vpartial_blocks(R, C, V, bwd_iters);
-  if (v4) ACG_LAUNCH(bn_bwd_partial<4>, dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak);
-  else ACG_LAUNCH(bn_bwd_partial<1>, dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak);
-  if (int rc = acg::check_launch("bn_bwd_partial")) return rc;
   const dim3 ag(tile_row_blocks(R, C, V), (C + 8 * V - 1) / (8 * V), groups);
-  if (v4) ACG_LAUNCH(bn_apply_bwd<4>, ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)part, (float*)dx, dbeta, dbeta_acc, R, C, groups, nblk, act, leak);
-  else ACG_LAUNCH(bn_apply_bwd<1>, ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)part, (float*)dx, dbeta, dbeta_acc, R, C, groups, nblk, act, leak);
+  if constexpr (same) {
+    if (v4) ACG_LAUNCH((bn_bwd_partial<4, TX, TY>), dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak, XP, YP);
+    else ACG_LAUNCH((bn_bwd_partial<1, TX, TY>), dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak, XP, YP);
+    if (int rc = acg::check_launch("bn_bwd_partial")) return rc;
+    if (v4) ACG_LAUNCH((bn_apply_bwd<4, TX, TY>), ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)part, dxf, dbeta, dbeta_acc, R, C, groups, nblk, act, leak, XP, YP);
+    else ACG_LAUNCH((bn_apply_bwd<1, TX, TY>), ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)part, dxf, dbeta, dbeta_acc, R, C, groups, nblk, act, leak, XP, YP);
+  } else {
+    ACG_LAUNCH((bn_bwd_partial<1, TX, TY>), dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak, XP, YP);
+    if (int rc = acg::check_launch("bn_bwd_partial")) return rc;
+    ACG_LAUNCH((bn_apply_bwd<1, TX, TY>), ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)part, dxf, dbeta, dbeta_acc, R, C, groups, nblk, act, leak, XP, YP);
+  }
   return acg::check_launch("bn_apply_bwd");
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t acg_bn_workspace_bytes(int64_t rows, int32_t channels, int32_t groups) {
+  (void)rows;
+  if (channels <= 0 || groups <= 0) return 0;
+  return (size_t)groups * ((size_t)kMaxPartialBlocks * 2 + 2) * (size_t)channels * sizeof(float);
+}
+
+int32_t acg_bn_act_fwd(const void* x, const float* beta, void* y, float* save_mean, float* save_rstd, int64_t rows,
+                       int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t groups, float eps, int32_t act, float leak, int32_t dtype,
+                       void* ws, size_t wsb, acg_stream_t stream) {
+  const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
+  ACG_REQUIRE(XP >= C && YP >= C, ACG_ERR_INVALID_ARG, "bn_act_fwd: pitch smaller than the row");
+  if (int rc = check_bn("bn_act_fwd", rows, C, groups)) return rc;
+  ACG_REQUIRE(x && beta && y && save_mean && save_rstd, ACG_ERR_INVALID_ARG, "bn_act_fwd: null pointer");
+  ACG_REQUIRE(act == ACG_ACT_NONE || act == ACG_ACT_RELU || act == ACG_ACT_LRELU, ACG_ERR_UNSUPPORTED, "bn_act_fwd: activation %d", act);
+  ACG_REQUIRE(ws && wsb >= acg_bn_workspace_bytes(rows, C, groups), ACG_ERR_WORKSPACE, "bn_act_fwd: workspace too small");
+  const long long R = rows / groups;
+  const bool v4 = vec4_ok(C, x, y, beta) && vec4_ok(C, save_mean, save_rstd, ws) && XP % 4 == 0 && YP % 4 == 0;
+  ACG_WITH_TYPES(dtype, "bn_act_fwd", return (bn_fwd_typed<TA, TB>(x, beta, y, save_mean, save_rstd, R, C, groups, eps, act, leak, (float*)ws, v4, XP, YP, acg::to_stream(stream))));
+}
+
+int32_t acg_bn_act_bwd(const void* x, const void* dy, const float* beta, const float* save_mean, const float* save_rstd,
+                       void* dx, float* dbeta, float dbeta_acc, int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch,
+                       int32_t groups, int32_t act, float leak, int32_t dtype, void* ws, size_t wsb, acg_stream_t stream) {
+  const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
+  ACG_REQUIRE(XP >= C && YP >= C, ACG_ERR_INVALID_ARG, "bn_act_bwd: pitch smaller than the row");
+  if (int rc = check_bn("bn_act_bwd", rows, C, groups)) return rc;
+  ACG_REQUIRE(x && dy && beta && save_mean && save_rstd && dx && dbeta, ACG_ERR_INVALID_ARG, "bn_act_bwd: null pointer");
+  ACG_REQUIRE(act == ACG_ACT_NONE || act == ACG_ACT_RELU || act == ACG_ACT_LRELU, ACG_ERR_UNSUPPORTED, "bn_act_bwd: activation %d", act);
+  ACG_REQUIRE(ws && wsb >= acg_bn_workspace_bytes(rows, C, groups), ACG_ERR_WORKSPACE, "bn_act_bwd: workspace too small");
+  const long long R = rows / groups;
+  const bool v4 = vec4_ok(C, x, dy, dx) && vec4_ok(C, save_mean, save_rstd, ws) && vec4_ok(C, beta, dbeta, ws) && XP % 4 == 0 && YP % 4 == 0;
+  ACG_WITH_TYPES(dtype, "bn_act_bwd", return (bn_bwd_typed<TA, TB>(x, dy, beta, save_mean, save_rstd, dx, dbeta, dbeta_acc, R, C, groups, act, leak, (float*)ws, v4, XP, YP, acg::to_stream(stream))));
 }
 
 int32_t acg_bn_moments(const void* x, float* moments, int64_t rows, int32_t C, int32_t groups, int32_t dtype, void* ws,
@@ -786,8 +811,8 @@ int32_t acg_bn_moments(const void* x, float* moments, int64_t rows, int32_t C, i
   hipStream_t st = acg::to_stream(stream);
   const bool v4 = vec4_ok(C, x, x, ws);
   const int V = v4 ? 4 : 1, nblk = vpartial_blocks(R, C, V, 8);
-  if (v4) ACG_LAUNCH(bn_stats_partial<4>, dim3(nblk, groups), dim3(256), 0, st, (const float*)x, (float*)ws, R, C, nblk);
-  else ACG_LAUNCH(bn_stats_partial<1>, dim3(nblk, groups), dim3(256), 0, st, (const float*)x, (float*)ws, R, C, nblk);
+  if (v4) ACG_LAUNCH((bn_stats_partial<4, float>), dim3(nblk, groups), dim3(256), 0, st, (const float*)x, (float*)ws, R, C, nblk, C);
+  else ACG_LAUNCH((bn_stats_partial<1, float>), dim3(nblk, groups), dim3(256), 0, st, (const float*)x, (float*)ws, R, C, nblk, C);
   if (int rc = acg::check_launch("bn_stats_partial")) return rc;
   ACG_LAUNCH(bn_moments_finalize, dim3((groups * C + 255) / 256), dim3(256), 0, st, (const float*)ws, (const float*)x, moments, R, C, groups, nblk);
   return acg::check_launch("bn_moments_finalize");
@@ -817,8 +842,8 @@ int32_t acg_bn_bwd_sums(const void* x, const void* dy, const float* beta, const 
   hipStream_t st = acg::to_stream(stream);
   const bool v4 = vec4_ok(C, x, dy, ws) && vec4_ok(C, save_mean, save_rstd, beta);
   const int V = v4 ? 4 : 1, nblk = vpartial_blocks(R, C, V, 4);
-  if (v4) ACG_LAUNCH(bn_bwd_partial<4>, dim3(nblk, groups), dim3(256), 0, st, (const float*)x, (const float*)dy, beta, save_mean, save_rstd, (float*)ws, R, C, nblk, act, leak);
-  else ACG_LAUNCH(bn_bwd_partial<1>, dim3(nblk, groups), dim3(256), 0, st, (const float*)x, (const float*)dy, beta, save_mean, save_rstd, (float*)ws, R, C, nblk, act, leak);
+  if (v4) ACG_LAUNCH((bn_bwd_partial<4, float, float>), dim3(nblk, groups), dim3(256), 0, st, (const float*)x, (const float*)dy, beta, save_mean, save_rstd, (float*)ws, R, C, nblk, act, leak, C, C);
+  else ACG_LAUNCH((bn_bwd_partial<1, float, float>), dim3(nblk, groups), dim3(256), 0, st, (const float*)x, (const float*)dy, beta, save_mean, save_rstd, (float*)ws, R, C, nblk, act, leak, C, C);
   if (int rc = acg::check_launch("bn_bwd_partial")) return rc;
   ACG_LAUNCH(bn_sums_finalize, dim3((groups * C + 255) / 256), dim3(256), 0, st, (const float*)ws, sums, C, groups, nblk);
   return acg::check_launch("bn_sums_finalize");
@@ -846,20 +871,24 @@ size_t acg_bias_workspace_bytes(int64_t rows, int32_t channels) {
   return channels > 0 ? (size_t)kMaxPartialBlocks * (size_t)channels * sizeof(float) : 0;
 }
 
-int32_t acg_bias_act_fwd(const void* x, const float* bias, void* y, int64_t rows, int32_t C, int32_t act, float leak,
-                         int32_t dtype, acg_stream_t stream) {
-  ACG_REQUIRE_F32(dtype);
+int32_t acg_bias_act_fwd(const void* x, const float* bias, void* y, int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch,
+                         int32_t act, float leak, int32_t dtype, acg_stream_t stream) {
   ACG_REQUIRE(rows > 0 && C > 0, ACG_ERR_INVALID_ARG, "bias_act_fwd: non-positive size");
   ACG_REQUIRE(x && y, ACG_ERR_INVALID_ARG, "bias_act_fwd: null pointer");
   ACG_REQUIRE(act >= ACG_ACT_NONE && act <= ACG_ACT_TANH, ACG_ERR_INVALID_ARG, "bias_act_fwd: activation %d", act);
-  ACG_LAUNCH(bias_act_fwd_k, dim3(apply_blocks(rows, C)), dim3(256), 0, acg::to_stream(stream), (const float*)x,
-                     bias, (float*)y, (long long)rows, C, act, leak);
+  const int xp = x_pitch > 0 ? x_pitch : C, yp = y_pitch > 0 ? y_pitch : C;
+  ACG_REQUIRE(xp >= C && yp >= C, ACG_ERR_INVALID_ARG, "bias_act_fwd: pitch smaller than the row");
+  ACG_WITH_TYPES(dtype, "bias_act_fwd",
+                 ACG_LAUNCH((bias_act_fwd_k<TA, TB>), dim3(apply_blocks(rows, C)), dim3(256), 0, acg::to_stream(stream), (const TA*)x, bias,
+                            (TB*)y, (long long)rows, C, xp, yp, act, leak));
   return acg::check_launch("bias_act_fwd");
 }
 
 int32_t acg_bias_act_bwd(const void* y, const void* dy, void* dx, float* dbias, float dbias_acc, int64_t rows, int32_t C,
-                         int32_t act, float leak, int32_t dtype, void* ws, size_t wsb, acg_stream_t stream) {
-  ACG_REQUIRE_F32(dtype);
+                         int32_t x_pitch, int32_t y_pitch, int32_t act, float leak, int32_t dtype, void* ws, size_t wsb,
+                         acg_stream_t stream) {
+  const int xp = x_pitch > 0 ? x_pitch : C, yp = y_pitch > 0 ? y_pitch : C;
+  ACG_REQUIRE(xp >= C && yp >= C, ACG_ERR_INVALID_ARG, "bias_act_bwd: pitch smaller than the row");
   ACG_REQUIRE(rows > 0 && C > 0, ACG_ERR_INVALID_ARG, "bias_act_bwd: non-positive size");
   ACG_REQUIRE(y && dy && (dbias || dx), ACG_ERR_INVALID_ARG, "bias_act_bwd: null pointer");
   ACG_REQUIRE(act >= ACG_ACT_NONE && act <= ACG_ACT_TANH, ACG_ERR_INVALID_ARG, "bias_act_bwd: activation %d", act);
@@ -867,8 +896,9 @@ int32_t acg_bias_act_bwd(const void* y, const void* dy, void* dx, float* dbias, 
   ACG_REQUIRE(!dbias || (ws && wsb >= acg_bias_workspace_bytes(rows, C)), ACG_ERR_WORKSPACE, "bias_act_bwd: workspace too small");
   const int nblk = partial_blocks(rows, C);
   hipStream_t st = acg::to_stream(stream);
-  ACG_LAUNCH(bias_act_bwd_partial, dim3(nblk), dim3(256), 0, st, (const float*)y, (const float*)dy, (float*)dx,
-                     dbias ? (float*)ws : (float*)nullptr, (long long)rows, C, nblk, act, leak);
+  ACG_WITH_TYPES(dtype, "bias_act_bwd",
+                 ACG_LAUNCH((bias_act_bwd_partial<TA, TB>), dim3(nblk), dim3(256), 0, st, (const TB*)y, (const TB*)dy, (TA*)dx,
+                            dbias ? (float*)ws : (float*)nullptr, (long long)rows, C, xp, yp, nblk, act, leak));
   if (int rc = acg::check_launch("bias_act_bwd_partial")) return rc;
   if (!dbias) return ACG_OK;
   ACG_LAUNCH(colsum_finalize, dim3((C + 31) / 32), dim3(256), 0, st, (const float*)ws, dbias, dbias_acc, C, nblk);

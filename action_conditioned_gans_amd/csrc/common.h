@@ -81,6 +81,37 @@ __device__ __forceinline__ float act_deriv_out(int act, float y, float leak) {
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ---- storage types ---------------------------------------------------------------------------------
+// A `dtype` argument names the storage type of a call's activation-class tensors: ACG_F32 / ACG_BF16 for all of
+// them, or ACG_DTYPE2(first, second) where two differ (include/acgan_hip.h).
+static inline bool dt_valid(int dt) {
+  if (dt == ACG_F32 || dt == ACG_BF16) return true;
+  return (dt & ~0xFF) == 0x100 && (dt & 0xF) <= ACG_BF16 && ((dt >> 4) & 0xF) <= ACG_BF16;
+}
+static inline int dt_first(int dt) { return (dt & 0x100) ? (dt & 0xF) : dt; }
+static inline int dt_second(int dt) { return (dt & 0x100) ? ((dt >> 4) & 0xF) : dt; }
+static inline int dt_size(int t) { return t == ACG_BF16 ? 2 : 4; }
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__device__ __forceinline__ float ldf(const T* p) { return (float)*p; }
+template <typename T>
+__device__ __forceinline__ void stf(T* p, float v) { *p = (T)v; }
+// V consecutive elements (V = 4: one 16-byte / 8-byte access, p aligned to it; V = 1: scalar)
+template <int V, typename T>
+__device__ __forceinline__ void ldv(const T* p, float (&v)[V]) {
+  if constexpr (V == 4 && sizeof(T) == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+  else if constexpr (V == 4) { const bf16x4 t = *reinterpret_cast<const bf16x4*>(p); v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3]; }
+  else v[0] = (float)*p;
+}
+template <int V, typename T>
+__device__ __forceinline__ void stv(T* p, const float (&v)[V]) {
+  if constexpr (V == 4 && sizeof(T) == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  else if constexpr (V == 4) *reinterpret_cast<bf16x4*>(p) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  else *p = (T)v[0];
+}
+
 }  // namespace acg
 
 #define ACG_REQUIRE(cond, code, ...) \
@@ -88,3 +119,24 @@ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
     if (!(cond)) return acg::fail(code, __VA_ARGS__); \
   } while (0)
 #define ACG_REQUIRE_F32(dtype) ACG_REQUIRE((dtype) == ACG_F32, ACG_ERR_UNSUPPORTED, "%s: only ACG_F32 is implemented for this entry point", __func__)
+
+// Run BODY with TA / TB bound to the storage types named by a dtype argument: (f32, f32), (bf16, bf16) or the mixed
+// pair (bf16, f32) - a bf16 network whose loss-facing tensor stays float32.
+#define ACG_WITH_TYPES(dt, who, BODY)                                                                         \
+  do {                                                                                                        \
+    const int acg_t1 = acg::dt_valid(dt) ? acg::dt_first(dt) : -1, acg_t2 = acg::dt_valid(dt) ? acg::dt_second(dt) : -1; \
+    if (acg_t1 == ACG_F32 && acg_t2 == ACG_F32) { using TA = float; using TB = float; BODY; }                  \
+    else if (acg_t1 == ACG_BF16 && acg_t2 == ACG_BF16) { using TA = __bf16; using TB = __bf16; BODY; }         \
+    else if (acg_t1 == ACG_BF16 && acg_t2 == ACG_F32) { using TA = __bf16; using TB = float; BODY; }           \
+    else return acg::fail(ACG_ERR_UNSUPPORTED, "%s: dtype %d (storage types must be f32, bf16 or bf16 -> f32)", who, (int)(dt)); \
+  } while (0)
+// the same with the fourth pair (f32 -> bf16): float32 sources written into a bf16 network's tensors
+#define ACG_WITH_TYPES_ANY(dt, who, BODY)                                                                     \
+  do {                                                                                                        \
+    const int acg_t1 = acg::dt_valid(dt) ? acg::dt_first(dt) : -1, acg_t2 = acg::dt_valid(dt) ? acg::dt_second(dt) : -1; \
+    if (acg_t1 == ACG_F32 && acg_t2 == ACG_F32) { using TA = float; using TB = float; BODY; }                  \
+    else if (acg_t1 == ACG_BF16 && acg_t2 == ACG_BF16) { using TA = __bf16; using TB = __bf16; BODY; }         \
+    else if (acg_t1 == ACG_BF16 && acg_t2 == ACG_F32) { using TA = __bf16; using TB = float; BODY; }           \
+    else if (acg_t1 == ACG_F32 && acg_t2 == ACG_BF16) { using TA = float; using TB = __bf16; BODY; }           \
+    else return acg::fail(ACG_ERR_UNSUPPORTED, "%s: dtype %d", who, (int)(dt));                                \
+  } while (0)

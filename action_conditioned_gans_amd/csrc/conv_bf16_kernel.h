@@ -1,0 +1,429 @@
+// Kernel template of the bf16 implicit-GEMM convolution (bf16 tensors in HBM, v_mfma_f32_32x32x16_bf16, fp32 accumulate).
+// Same contractions, descriptors and pipeline as conv_f32_kernel.h; what bf16 storage changes:
+//  * a 16-byte unit is an OCT of 8 channels, a K-step is 64 k (8 octs): one buffer_load_dwordx4 per oct, written to LDS
+//    as it arrived - no conversion, no per-element work;
+//  * every channel count is padded to a multiple of 8 IN MEMORY (activations at pitch round8(C), zero pad channels;
+//    filters in the two prepared bf16 layouts of acg_weights_prepare_bf16), so there is no ragged path;
+//  * FWD and DGRAD take BOTH operands k-fast (the filter copy [tap][n][c8] for FWD, [tap][c][o8] for DGRAD), in the
+//    conflict-free [slot][P(col)^slot] LDS image of the fp32 kernel;
+//  * WGRAD contracts over pixels, the slow axis of both of its operands: the tiles go to LDS as they lie in memory,
+//    [pixel][channel] in 8-row x 32-column subtiles, and the MFMA fragments are read with ds_read_b64_tr_b16 (hardware
+//    transpose, two reads per fragment) - no register transpose.
+// Tiles: 64x64 and 128x128 per 256-thread block (wave tile 32x32 / 64x64).
+#pragma once
+#include "conv_f32_kernel.h"
+
+namespace acgconv {
+
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef short s8v __attribute__((ext_vector_type(8)));
+
+constexpr int BKH = 64;   // k per K-step: 8 octs
+
+template <int MODE, int BM, int BN>
+constexpr int conv16_lds_bytes() {
+  return 2 * 8 * (BM + BN) * 16 + ((MODE == MODE_WGRAD) ? 2 * 256 : BM) * (int)sizeof(RowInfo) + 2 * kMaxTaps * (int)sizeof(int);
+}
+
+__device__ __forceinline__ f4 guarded_oct(__amdgpu_buffer_rsrc_t rs, int elem_off, bool ok) {
+  const unsigned off = ok ? (unsigned)elem_off * 2u : kOob;
+  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+}
+
+// byte offset of 16-byte chunk `ch` of row `row` in a [rows][W16 chunks] bf16 tile stored as 8-row x 32-column
+// subtiles (cdna guide T10, image (a)): row reads and transposed reads are both conflict-free
+template <int W16>
+__device__ __forceinline__ int tr_off(int row, int ch) {
+  return (W16 / 4) * 512 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
+}
+
+template <int MODE, int BM, int BN>
+__device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, const int by, const int bz, const int gx, char* smem) {
+  constexpr int WM = 2, WN = 2;
+  constexpr int TA = BM / (32 * WM), TB = BN / (32 * WN);
+  constexpr int QA = BM / 32, QB = BN / 32;          // octs per thread per K-step and operand
+  constexpr int NROW = (MODE == MODE_WGRAD) ? 2 * 256 : BM;
+  constexpr int NST = 3;
+  constexpr int ASZ = 8 * BM, BSZ = 8 * BN;          // 16-byte cells per K-step
+  f4* const As_all = reinterpret_cast<f4*>(smem);
+  f4* const Bs_all = As_all + 2 * ASZ;
+  RowInfo* const rows = reinterpret_cast<RowInfo*>(Bs_all + 2 * BSZ);
+  int* const tapA = reinterpret_cast<int*>(rows + NROW);
+  int* const tapB = tapA + kMaxTaps;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gsrc), 0, p.g_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dense), 0, p.d_bytes, 0x00020000);
+
+  // ---- geometry (wave-uniform); Cp = channels of the gathered tensor = its pitch in memory (multiple of 8) ------
+  const int Cin8 = (p.C + 7) & ~7, K8 = (p.K + 7) & ~7;
+  int M, N, Kdim, Cp, ntaps;
+  int ph = 0, pw = 0, i0 = 0, j0 = 0, nti = 1, ntj = 1, dp0 = 0, dq0 = 0, Hc = 0, Wc = 0;
+  if constexpr (MODE == MODE_FWD) {
+    Cp = Cin8; ntaps = p.KH * p.KW;
+    M = p.batch * p.OH * p.OW; N = p.K; Kdim = ntaps * Cp;
+  } else if constexpr (MODE == MODE_DGRAD) {
+    const int cls = by;
+    ph = cls / p.sw; pw = cls - ph * p.sw;
+    Hc = ph < p.H ? (p.H - ph + p.sh - 1) / p.sh : 0;
+    Wc = pw < p.W ? (p.W - pw + p.sw - 1) / p.sw : 0;
+    Cp = K8;
+    M = p.batch * Hc * Wc; N = p.C;
+    i0 = (ph + p.pt) % p.sh; j0 = (pw + p.pl) % p.sw;
+    nti = i0 < p.KH ? (p.KH - i0 + p.sh - 1) / p.sh : 0;
+    ntj = j0 < p.KW ? (p.KW - j0 + p.sw - 1) / p.sw : 0;
+    dp0 = (ph + p.pt - i0) / p.sh; dq0 = (pw + p.pl - j0) / p.sw;
+    ntaps = nti * ntj; Kdim = ntaps * Cp;
+  } else {
+    Cp = Cin8; ntaps = p.KH * p.KW;
+    M = ntaps * Cp; N = p.K; Kdim = p.batch * p.OH * p.OW;
+  }
+  const int tiles_n = (N + BN - 1) / BN;
+  int bid = bx;
+  {
+    const int nwg = gx, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  if (m0 >= M) return;
+
+  const int nk = (Kdim + BKH - 1) / BKH;
+  const int per = (nk + p.splits - 1) / p.splits;
+  const int ks_begin = bz * per;
+  const int ks_end = min(nk, ks_begin + per);
+
+  // ---- tap tables (element offsets) ------------------------------------------------------------
+  if (tid < kMaxTaps && tid < ntaps) {
+    const int t = tid;
+    if constexpr (MODE == MODE_DGRAD) {
+      const int ti = t / ntj, tj = t - ti * ntj;
+      tapA[t] = -(ti * p.OW + tj) * K8;
+      tapB[t] = ((i0 + p.sh * ti) * p.KW + (j0 + p.sw * tj)) * p.C * K8;      // filter copy [tap][c][o8]
+    } else {
+      const int i = t / p.KW, j = t - i * p.KW;
+      tapA[t] = (i * p.W + j) * Cin8;
+      tapB[t] = t * p.K * Cin8;                                               // filter copy [tap][o][c8] (FWD)
+    }
+  }
+
+  auto fill_row_fwd = [&](int r, int limit) -> RowInfo {
+    RowInfo ri; ri.base = 0; ri.mask_lo = 0; ri.mask_hi = 0; ri.out_off = 0;
+    if (r < limit) {
+      const int t2 = div_fast(r, p.mg_ow, p.sh_ow), q = r - t2 * p.OW;
+      const int b = div_fast(t2, p.mg_oh, p.sh_oh), pp = t2 - b * p.OH;
+      const int y0 = pp * p.sh - p.pt, x0 = q * p.sw - p.pl;
+      ri.base = ((b * p.H + y0) * p.W + x0) * Cin8;
+      const unsigned long long m = tap_mask(max(0, -y0), min(p.KH, p.H - y0), max(0, -x0), min(p.KW, p.W - x0), p.KW);
+      ri.mask_lo = (unsigned)m; ri.mask_hi = (unsigned)(m >> 32);
+    }
+    return ri;
+  };
+  if constexpr (MODE == MODE_FWD) {
+    for (int r = tid; r < BM; r += 256) rows[r] = fill_row_fwd(m0 + r, M);
+  } else if constexpr (MODE == MODE_DGRAD) {
+    for (int r = tid; r < BM; r += 256) {
+      RowInfo ri; ri.base = 0; ri.mask_lo = 0; ri.mask_hi = 0; ri.out_off = 0;
+      const int m = m0 + r;
+      if (m < M) {
+        const int w2 = m % Wc; const int t2 = m / Wc; const int h2 = t2 % Hc; const int b = t2 / Hc;
+        const int y0 = h2 + dp0, x0 = w2 + dq0;
+        ri.base = ((b * p.OH + y0) * p.OW + x0) * K8;
+        ri.out_off = ((b * p.H + h2 * p.sh + ph) * p.W + (w2 * p.sw + pw)) * Cin8;
+        const unsigned long long mk = tap_mask(max(0, y0 - p.OH + 1), min(nti, y0 + 1), max(0, x0 - p.OW + 1), min(ntj, x0 + 1), ntj);
+        ri.mask_lo = (unsigned)mk; ri.mask_hi = (unsigned)(mk >> 32);
+      }
+      rows[r] = ri;
+    }
+  }
+  __syncthreads();
+
+  // ---- loaders -------------------------------------------------------------------------------------
+  f4 ra[NST][QA], rb[NST][QB];
+  auto tap_of = [&](int kp, int& t, int& c) { t = div_fast(kp, p.mg_cp, p.sh_cp); c = kp - t * Cp; };
+
+  // k-fast operands (FWD / DGRAD): thread -> (row group rg = tid>>3, oct slot kq = tid&7); rows rg + 32u
+  RowInfo myrow[MODE == MODE_WGRAD ? 1 : QA];
+  int nK[MODE == MODE_WGRAD ? 1 : QB];
+  bool nOk[MODE == MODE_WGRAD ? 1 : QB];
+  if constexpr (MODE != MODE_WGRAD) {
+#pragma unroll
+    for (int u = 0; u < QA; ++u) myrow[u] = rows[(tid >> 3) + 32 * u];
+#pragma unroll
+    for (int u = 0; u < QB; ++u) { const int n = n0 + (tid >> 3) + 32 * u; nK[u] = n * Cp; nOk[u] = n < N; }
+  }
+  const int step_t = BKH / Cp, step_c = BKH - step_t * Cp;
+  int run_kt = 0, run_kc = 0;
+  if constexpr (MODE != MODE_WGRAD) tap_of(ks_begin * BKH + 8 * (tid & 7), run_kt, run_kc);
+
+  // pixel-major operands (WGRAD): thread -> (pixel row kr0 + e * RPA, oct ja of the tile row)
+  constexpr int OA = BM / 8, OB = BN / 8, RPA = 256 / OA, RPB = 256 / OB;   // octs per tile row; rows per pass
+  const int ja = tid % OA, kra = tid / OA, jb = tid % OB, krb = tid / OB;
+  int wg_t = 0, wg_off = 0;
+  bool wg_ok = false;
+  if constexpr (MODE == MODE_WGRAD) {
+    const int mp = m0 + 8 * ja;
+    if (mp < M) {
+      wg_t = mp / Cp;
+      wg_off = tapA[wg_t] + (mp - wg_t * Cp);
+      wg_ok = true;
+    }
+  }
+  const int nB = n0 + 8 * jb;
+  int run_boff = 0;
+  if constexpr (MODE == MODE_WGRAD) run_boff = (ks_begin * BKH + krb) * K8 + nB;
+
+  struct Prep {
+    int t, aoff, tb, brow, boff;
+    bool kv;
+    RowInfo wri[MODE == MODE_WGRAD ? QA : 1];
+  };
+  auto load_prep = [&](int ks, bool live) {
+    Prep q{};
+    if constexpr (MODE == MODE_WGRAD) {
+#pragma unroll
+      for (int e = 0; e < QA; ++e) q.wri[e] = rows[((ks - ks_begin) & 7) * BKH + kra + e * RPA];
+      q.boff = run_boff; q.brow = ks * BKH + krb;
+      run_boff += BKH * K8;
+    } else {
+      q.kv = live && run_kt < ntaps;
+      q.t = q.kv ? run_kt : 0;
+      q.aoff = tapA[q.t] + run_kc;
+      q.tb = tapB[q.t] + run_kc;
+      run_kt += step_t; run_kc += step_c;
+      const bool wrap = run_kc >= Cp;
+      run_kc -= wrap ? Cp : 0; run_kt += wrap ? 1 : 0;
+    }
+    return q;
+  };
+  constexpr int NLD = QA + QB;
+  auto load_piece = [&](auto stage, bool live, const Prep& q, auto pc) {
+    constexpr int ST = decltype(stage)::value;
+    constexpr int I = decltype(pc)::value;
+    if constexpr (I < QA) {
+      if constexpr (MODE == MODE_WGRAD) {
+        const RowInfo ri = q.wri[I];
+        ra[ST][I] = guarded_oct(rs_g, ri.base + wg_off, live && wg_ok && tap_ok(ri, wg_t));
+      } else {
+        const RowInfo ri = myrow[I];
+        ra[ST][I] = guarded_oct(rs_g, ri.base + q.aoff, q.kv && tap_ok(ri, q.t));
+      }
+    } else {
+      constexpr int U = I - QA;
+      if constexpr (MODE == MODE_WGRAD) {
+        rb[ST][U] = guarded_oct(rs_d, q.boff + U * RPB * K8, live && q.brow + U * RPB < Kdim && nB < N);
+      } else {
+        rb[ST][U] = guarded_oct(rs_d, q.tb + nK[U], q.kv && nOk[U]);
+      }
+    }
+  };
+  auto load_tiles = [&](auto stage, int ks, bool live) {
+    const Prep q = load_prep(ks, live);
+    static_for<0, NLD>([&](auto pc) { load_piece(stage, live, q, pc); });
+  };
+
+  auto pcol = [](int col, int kq) {
+    const int j = (col >> 2) & 7, e = col & 3;
+    return ((col & ~31) | (e << 3) | (j ^ ((e >> 1) << 2))) ^ kq;
+  };
+  auto store_tiles = [&](auto stage, int buf) {
+    constexpr int ST = decltype(stage)::value;
+    f4* const As = As_all + buf * ASZ;
+    f4* const Bs = Bs_all + buf * BSZ;
+    if constexpr (MODE == MODE_WGRAD) {
+      char* const Ab = reinterpret_cast<char*>(As);
+      char* const Bb = reinterpret_cast<char*>(Bs);
+#pragma unroll
+      for (int e = 0; e < QA; ++e) *reinterpret_cast<f4*>(Ab + tr_off<OA>(kra + e * RPA, ja)) = ra[ST][e];
+#pragma unroll
+      for (int e = 0; e < QB; ++e) *reinterpret_cast<f4*>(Bb + tr_off<OB>(krb + e * RPB, jb)) = rb[ST][e];
+    } else {
+      const int kq = tid & 7, rg = tid >> 3;
+#pragma unroll
+      for (int u = 0; u < QA; ++u) As[kq * BM + pcol(rg + 32 * u, kq)] = ra[ST][u];
+#pragma unroll
+      for (int u = 0; u < QB; ++u) Bs[kq * BN + pcol(rg + 32 * u, kq)] = rb[ST][u];
+    }
+  };
+
+  // ---- main loop ------------------------------------------------------------------------------------
+  f32x16 acc[TA][TB];
+#pragma unroll
+  for (int a = 0; a < TA; ++a)
+#pragma unroll
+    for (int b = 0; b < TB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int wr = wave / WN, wc = wave - wr * WN;
+  const int wm0 = wr * (BM / WM), wn0 = wc * (BN / WN);
+  const int lrow = lane & 31, lk = lane >> 5;
+
+  // transposed-read addressing (WGRAD): lane 4q+p of a 16-lane group gives row q, columns 4p..4p+3 of a 4 x 16 block
+  int tra[MODE == MODE_WGRAD ? TA : 1][2], trb[MODE == MODE_WGRAD ? TB : 1][2];
+  if constexpr (MODE == MODE_WGRAD) {
+    const int g1 = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int x = (2 * lk + s) & 3, rowpart = (OA / 4) * 512 * lk + 64 * (q + 4 * s);
+#pragma unroll
+      for (int a = 0; a < TA; ++a) {
+        const int col = wm0 + 32 * a + 16 * g1 + 4 * pp, ch = col >> 3;
+        tra[a][s] = rowpart + 512 * (ch >> 2) + 16 * ((ch & 3) ^ x) + 8 * ((col >> 2) & 1);
+      }
+      const int rowpartb = (OB / 4) * 512 * lk + 64 * (q + 4 * s);
+#pragma unroll
+      for (int b = 0; b < TB; ++b) {
+        const int col = wn0 + 32 * b + 16 * g1 + 4 * pp, ch = col >> 3;
+        trb[b][s] = rowpartb + 512 * (ch >> 2) + 16 * ((ch & 3) ^ x) + 8 * ((col >> 2) & 1);
+      }
+    }
+  }
+
+  // MFMA work of a K-step: 4 k-slices of 16; slice t takes oct 2t + (lane>>5) of both tiles
+  constexpr int NT = 4, GM = TA * TB, NM = NT * GM;
+  f4 av[2][TA], bv[2][TB];
+  auto frag_read = [&](int buf, auto tc) {
+    constexpr int T = decltype(tc)::value;
+    if constexpr (MODE == MODE_WGRAD) {
+      typedef s4v __attribute__((address_space(3))) * lds_s4;
+      char* const Ab = reinterpret_cast<char*>(As_all + buf * ASZ) + T * 2 * (OA / 4) * 512;
+      char* const Bb = reinterpret_cast<char*>(Bs_all + buf * BSZ) + T * 2 * (OB / 4) * 512;
+#pragma unroll
+      for (int a = 0; a < TA; ++a) {
+        const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(Ab + tra[a][0]));
+        const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(Ab + tra[a][1]));
+        av[T & 1][a] = __builtin_bit_cast(f4, s8v{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+      }
+#pragma unroll
+      for (int b = 0; b < TB; ++b) {
+        const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(Bb + trb[b][0]));
+        const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(Bb + trb[b][1]));
+        bv[T & 1][b] = __builtin_bit_cast(f4, s8v{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+      }
+    } else {
+      const f4* const As = As_all + buf * ASZ;
+      const f4* const Bs = Bs_all + buf * BSZ;
+      const int kq = 2 * T + lk;
+#pragma unroll
+      for (int a = 0; a < TA; ++a) av[T & 1][a] = As[kq * BM + pcol(wm0 + 32 * a + lrow, kq)];
+#pragma unroll
+      for (int b = 0; b < TB; ++b) bv[T & 1][b] = Bs[kq * BN + pcol(wn0 + 32 * b + lrow, kq)];
+    }
+  };
+  auto mfma = [&](auto ic) {
+    constexpr int I = decltype(ic)::value;
+    constexpr int T = I / GM, AB = I % GM, A = AB / TB, B = AB % TB;
+    acc[A][B] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, av[T & 1][A]), __builtin_bit_cast(bf8, bv[T & 1][B]), acc[A][B], 0, 0, 0);
+  };
+
+  // WGRAD row infos: 4 K-steps (256 pixel rows, one per thread) per chunk, two chunks resident
+  auto wgrad_rows = [&](int chunk) {
+    if constexpr (MODE == MODE_WGRAD) rows[(chunk & 1) * 256 + tid] = fill_row_fwd((ks_begin + 4 * chunk) * BKH + tid, Kdim);
+  };
+
+  if (ks_begin < ks_end) {
+    if constexpr (MODE == MODE_WGRAD) { wgrad_rows(0); __syncthreads(); }
+    static_for<0, NST>([&](auto jc) {
+      constexpr int J = decltype(jc)::value;
+      load_tiles(jc, ks_begin + J, ks_begin + J < ks_end);
+    });
+    store_tiles(std::integral_constant<int, 0>{}, 0);
+    __syncthreads();
+  }
+  auto iterate = [&](auto jc, int ks, int buf) {
+    constexpr int J = decltype(jc)::value;
+    using SN = std::integral_constant<int, (J + 1) % NST>;
+    const bool live = ks + NST < ks_end;
+    frag_read(buf, std::integral_constant<int, 0>{});
+    const Prep q = load_prep(ks + NST, live);
+    store_tiles(SN{}, buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, NM>([&](auto ic) {
+      constexpr int I = decltype(ic)::value;
+      mfma(ic);
+      if constexpr (I % GM == 0 && I / GM + 1 < NT) frag_read(buf, std::integral_constant<int, I / GM + 1>{});
+      static_for<0, NLD>([&](auto pc) {
+        constexpr int P = decltype(pc)::value;
+        if constexpr ((P * NM) / NLD == I) load_piece(jc, live, q, pc);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if constexpr (MODE == MODE_WGRAD) {
+      const int rel = ks - ks_begin + NST + 1;
+      if ((rel & 3) == 0 && ks + NST + 1 < ks_end) wgrad_rows(rel >> 2);
+    }
+    __syncthreads();
+  };
+  if (ks_begin < ks_end) {
+    constexpr int UNR = 2 * NST;
+    int ks = ks_begin;
+    while (run_unrolled<0, UNR>([&](auto ic) {
+      constexpr int I = decltype(ic)::value;
+      iterate(std::integral_constant<int, I % NST>{}, ks, I & 1);
+      return ++ks < ks_end;
+    })) {
+    }
+  }
+
+  // ---- epilogue --------------------------------------------------------------------------------------
+  // splits == 1: FWD / DGRAD write the bf16 activation (pitch round8), WGRAD the fp32 gradient; splits > 1: fp32 slabs
+  // of out_numel elements laid out like the final tensor, summed (and rounded to bf16) by splitk_reduce.
+  const bool to_bf16 = MODE != MODE_WGRAD && p.splits == 1;
+  float* const outf = p.out + (p.splits > 1 ? (long long)bz * p.out_numel : 0ll);
+  __bf16* const outh = reinterpret_cast<__bf16*>(p.out);
+#pragma unroll
+  for (int a = 0; a < TA; ++a)
+#pragma unroll
+    for (int b = 0; b < TB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int n = n0 + wn0 + 32 * b + lrow;
+        const int m = m0 + row;
+        if (m < M && n < N) {
+          long long idx;
+          bool ok = true;
+          if constexpr (MODE == MODE_DGRAD) {
+            idx = (long long)rows[row].out_off + n;
+          } else if constexpr (MODE == MODE_WGRAD) {
+            const int t = m / Cp, c = m - t * Cp;
+            ok = c < p.C;
+            idx = ((long long)t * p.C + c) * N + n;
+          } else {
+            idx = (long long)m * K8 + n;
+          }
+          if (ok) {
+            float v = acc[a][b][r];
+            if constexpr (MODE == MODE_WGRAD) {
+              if (p.splits == 1 && p.accumulate != 0.f) v += p.accumulate * outf[idx];
+              outf[idx] = v;
+            } else {
+              if (to_bf16) outh[idx] = (__bf16)v;
+              else outf[idx] = v;
+            }
+          }
+        }
+      }
+}
+
+template <int MODE, int BM, int BN>
+__global__ __launch_bounds__(256) void conv_mfma_bf16(const ConvArgs p) {
+  __shared__ __align__(16) char smem[conv16_lds_bytes<MODE, BM, BN>()];
+  conv16_body<MODE, BM, BN>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
+}
+
+template <int MODE>
+int launch_mode16(const Plan& pl, const ConvArgs& a, hipStream_t st);
+
+#define ACG_DEFINE_CONV16_LAUNCH(MODE)                                                                        \
+  template <>                                                                                                 \
+  int launch_mode16<MODE>(const Plan& pl, const ConvArgs& a, hipStream_t st) {                                \
+    const dim3 grid((unsigned)(acg::ceil_div(pl.M, pl.bm) * acg::ceil_div(pl.N, pl.bn)), (unsigned)pl.classes, \
+                    (unsigned)pl.splits);                                                                     \
+    if (pl.bm == 128) ACG_LAUNCH((conv_mfma_bf16<MODE, 128, 128>), grid, dim3(256), 0, st, a);                \
+    else ACG_LAUNCH((conv_mfma_bf16<MODE, 64, 64>), grid, dim3(256), 0, st, a);                               \
+    return acg::check_launch("conv_mfma_bf16");                                                               \
+  }
+
+}  // namespace acgconv

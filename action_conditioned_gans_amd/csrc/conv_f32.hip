@@ -26,7 +26,7 @@
 // slabs that a second kernel sums in fixed order (deterministic; no float atomics).
 #include <stdlib.h>
 
-#include "conv_f32_kernel.h"
+#include "conv_bf16_kernel.h"
 
 using namespace acgconv;
 
@@ -57,6 +57,50 @@ __device__ __forceinline__ void reduce_slabs(const float* __restrict__ slabs, fl
 __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ slabs, float* __restrict__ out,
                                                      long long numel, int splits, float accumulate) {
   reduce_slabs(slabs, out, numel, splits, accumulate, blockIdx.x, gridDim.x);
+}
+
+// bf16 activations (FWD / DGRAD of the bf16 path): out[i] = bf16(sum_z slabs[z][i]); numel is a multiple of 8 (pitch round8)
+__global__ __launch_bounds__(256) void splitk_reduce_bf16(const float* __restrict__ slabs, __bf16* __restrict__ out,
+                                                          long long numel, int splits) {
+  const long long n4 = numel / 4, stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    f4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int z = 0; z < splits; ++z) s += reinterpret_cast<const f4*>(slabs + (long long)z * numel)[i];
+    reinterpret_cast<bf4*>(out)[i] = bf4{(__bf16)s[0], (__bf16)s[1], (__bf16)s[2], (__bf16)s[3]};
+  }
+}
+
+// fp32 master weights [taps][A][B] -> the two bf16 operand layouts of the bf16 conv kernels, zero padded to multiples
+// of 8: rm [taps][A][B8] (k-fast along B) and tr [taps][B][A8] (k-fast along A).  All filters of a scope in ONE launch.
+struct PrepList {
+  const float* src[ACG_PREP_MAX];
+  __bf16* rm[ACG_PREP_MAX];
+  __bf16* tr[ACG_PREP_MAX];
+  int taps[ACG_PREP_MAX], A[ACG_PREP_MAX], B[ACG_PREP_MAX];
+  int first_block[ACG_PREP_MAX + 1];
+};
+__global__ __launch_bounds__(256) void weights_prepare_bf16(const PrepList l, int count) {
+  int e = 0;
+  while (e + 1 < count && (int)blockIdx.x >= l.first_block[e + 1]) ++e;
+  const int A = l.A[e], B = l.B[e], A8 = (A + 7) & ~7, B8 = (B + 7) & ~7, taps = l.taps[e];
+  const float* __restrict__ src = l.src[e];
+  const long long nrm = (long long)taps * A * B8, ntr = (long long)taps * B * A8;
+  const long long stride = (long long)(l.first_block[e + 1] - l.first_block[e]) * 256;
+  for (long long i = (long long)((int)blockIdx.x - l.first_block[e]) * 256 + threadIdx.x; i < nrm + ntr; i += stride) {
+    if (i < nrm) {
+      const int b = (int)(i % B8);
+      const long long ta = i / B8;
+      l.rm[e][i] = b < B ? (__bf16)src[ta * B + b] : (__bf16)0.f;
+    } else {
+      const long long j = i - nrm;
+      const int a = (int)(j % A8);
+      const long long tb = j / A8;
+      const int b = (int)(tb % B);
+      const long long t = tb / B;
+      l.tr[e][j] = a < A ? (__bf16)src[(t * A + a) * B + b] : (__bf16)0.f;
+    }
+  }
 }
 
 // The slab reductions of several weight gradients in ONE launch (acg_splitk_reduce_many): a launch costs ~4-5 us in
@@ -112,16 +156,17 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
   Plan pl{};
   pl.bf16 = bf16;
   long long K;
-  const long long cin_p = (d.in_c + 3) & ~3, cout_p = (d.out_c + 3) & ~3;
+  const int pad = bf16 ? 7 : 3;       // channels per tap are padded to the 16-byte unit: 4 floats / 8 bf16
+  const long long cin_p = (d.in_c + pad) & ~pad, cout_p = (d.out_c + pad) & ~pad;
   if (which == ACG_CONV_FWD) {
     pl.M = (long long)d.batch * d.out_h * d.out_w; pl.N = d.out_c; K = (long long)d.kh * d.kw * cin_p; pl.classes = 1;
-    pl.out_numel = pl.M * (d.out_pitch > 0 ? d.out_pitch : d.out_c);
+    pl.out_numel = pl.M * (bf16 ? cout_p : (d.out_pitch > 0 ? d.out_pitch : d.out_c));
   } else if (which == ACG_CONV_DGRAD) {
     const int hc = (d.in_h + d.stride_h - 1) / d.stride_h, wc = (d.in_w + d.stride_w - 1) / d.stride_w;
     pl.M = (long long)d.batch * hc * wc; pl.N = d.in_c;
     K = (long long)((d.kh + d.stride_h - 1) / d.stride_h) * ((d.kw + d.stride_w - 1) / d.stride_w) * cout_p;
     pl.classes = d.stride_h * d.stride_w;
-    pl.out_numel = (long long)d.batch * d.in_h * d.in_w * (d.in_pitch > 0 ? d.in_pitch : d.in_c);
+    pl.out_numel = (long long)d.batch * d.in_h * d.in_w * (bf16 ? cin_p : (d.in_pitch > 0 ? d.in_pitch : d.in_c));
   } else {
     pl.M = (long long)d.kh * d.kw * cin_p; pl.N = d.out_c; K = (long long)d.batch * d.out_h * d.out_w; pl.classes = 1;
     pl.out_numel = (long long)d.kh * d.kw * d.in_c * d.out_c;
@@ -132,7 +177,8 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
   pl.ragged = (cs & 3) != 0;
   // dense operand rows: the filter [.., N] (FWD) or dY at its channel pitch (WGRAD)
   pl.nvec = ((which == ACG_CONV_WGRAD ? ky : (int)pl.N) & 3) == 0;
-  pl.nk = (int)((K + BK - 1) / BK);
+  const int bk = bf16 ? BKH : BK;
+  pl.nk = (int)((K + bk - 1) / bk);
   if (pl.nk < 1) pl.nk = 1;
   auto tiles_for = [&](int bm, int bn) { return acg::ceil_div(pl.M, bm) * acg::ceil_div(pl.N, bn) * pl.classes; };
   // Planner (evidence: profiles/r1 tuning sweeps, tools/fit_planner.py).  Split K until ~1 block per CU for
@@ -141,6 +187,15 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
   pl.cfg = pl.N <= 32 ? 2 : 3;
   if (g_force_cfg >= 0 && g_force_cfg < 4) pl.cfg = g_force_cfg <= 2 ? 2 : 3;
   pl.bm = pl.cfg == 2 ? 128 : 64; pl.bn = pl.cfg == 2 ? 32 : 64;
+  if (bf16) {
+    // bf16: 128x128 tiles once they fill the chip (a K-step then carries 16 MFMAs per wave for the same 8 loads per
+    // thread as two 64x64 blocks carry 8), 64x64 tiles + split-K below that
+    static const int big_min = env_int("ACG_PLAN16_BIG_TILES", 256);
+    const bool big = pl.N > 64 && tiles_for(128, 128) >= big_min;
+    pl.cfg = big ? 1 : 3; pl.bm = pl.bn = big ? 128 : 64;
+    if (g_force_cfg == 1 || g_force_cfg == 3) { pl.cfg = g_force_cfg; pl.bm = pl.bn = g_force_cfg == 1 ? 128 : 64; }
+    pl.ragged = false; pl.nvec = true;
+  }
   pl.tiles = tiles_for(pl.bm, pl.bn);
   // tuning hooks (whole-step sweeps): ACG_PLAN_TARGET_FD / _W / ACG_PLAN_MIN_STEPS override the constants below
   static const int t_fd = env_int("ACG_PLAN_TARGET_FD", 0), t_w = env_int("ACG_PLAN_TARGET_W", 512), min_steps = env_int("ACG_PLAN_MIN_STEPS", 4);
@@ -186,7 +241,16 @@ int prepare(Job& j, int which, const float* gsrc, const float* dense, float* out
   ConvArgs a{};
   a.gsrc = gsrc; a.dense = dense; a.out = pl.splits > 1 ? (float*)ws : out; a.out_numel = pl.out_numel;
   a.accumulate = accumulate;
-  {
+  const bool h = dtype == ACG_BF16;
+  const int cin8 = (d->in_c + 7) & ~7, cout8 = (d->out_c + 7) & ~7;
+  if (h) {   // bf16 tensors: activations at pitch round8(C); `dense` is a prepared filter copy (acg_weights_prepare_bf16)
+    ACG_REQUIRE((d->in_pitch == 0 || d->in_pitch == cin8) && (d->out_pitch == 0 || d->out_pitch == cout8), ACG_ERR_INVALID_ARG,
+                "%s: bf16 tensors are stored at the channel pitch round8(C)", who);
+    const long long nx = (long long)d->batch * d->in_h * d->in_w * cin8, ny = (long long)d->batch * d->out_h * d->out_w * cout8;
+    const long long nw = (long long)d->kh * d->kw * (which == ACG_CONV_FWD ? (long long)d->out_c * cin8 : (long long)d->in_c * cout8);
+    a.g_bytes = (unsigned)((which == ACG_CONV_DGRAD ? ny : nx) * 2);
+    a.d_bytes = (unsigned)((which == ACG_CONV_WGRAD ? ny : nw) * 2);
+  } else {
     const long long nx = (long long)d->batch * d->in_h * d->in_w * (d->in_pitch > 0 ? d->in_pitch : d->in_c), ny = (long long)d->batch * d->out_h * d->out_w * (d->out_pitch > 0 ? d->out_pitch : d->out_c);
     const long long nw = (long long)d->kh * d->kw * d->in_c * d->out_c;
     const long long ng = which == ACG_CONV_DGRAD ? ny : nx;                       // gathered tensor
@@ -199,18 +263,27 @@ int prepare(Job& j, int which, const float* gsrc, const float* dense, float* out
   a.KH = d->kh; a.KW = d->kw; a.sh = d->stride_h; a.sw = d->stride_w; a.pt = d->pad_top; a.pl = d->pad_left;
   a.splits = pl.splits;
   { const FastDiv fw = fast_div(d->out_w), fh = fast_div(d->out_h); a.mg_ow = fw.magic; a.sh_ow = fw.shift; a.mg_oh = fh.magic; a.sh_oh = fh.shift;
-    const FastDiv fc = fast_div(((which == ACG_CONV_DGRAD ? d->out_c : d->in_c) + 3) & ~3); a.mg_cp = fc.magic; a.sh_cp = fc.shift; }
+    const FastDiv fc = fast_div(which == ACG_CONV_DGRAD ? (h ? cout8 : (d->out_c + 3) & ~3) : (h ? cin8 : (d->in_c + 3) & ~3)); a.mg_cp = fc.magic; a.sh_cp = fc.shift; }
   j.which = which; j.pl = pl; j.a = a; j.ws = ws; j.out = out; j.accumulate = accumulate; j.slabs_only = slabs_only;
   return ACG_OK;
 }
 
 int launch(const Job& j, hipStream_t st) {
+  if (j.pl.bf16) {
+    if (j.which == ACG_CONV_FWD) return launch_mode16<MODE_FWD>(j.pl, j.a, st);
+    if (j.which == ACG_CONV_DGRAD) return launch_mode16<MODE_DGRAD>(j.pl, j.a, st);
+    return launch_mode16<MODE_WGRAD>(j.pl, j.a, st);
+  }
   if (j.which == ACG_CONV_FWD) return launch_mode<MODE_FWD>(j.pl, j.a, st);
   if (j.which == ACG_CONV_DGRAD) return launch_mode<MODE_DGRAD>(j.pl, j.a, st);
   return launch_mode<MODE_WGRAD>(j.pl, j.a, st);
 }
 
 int reduce(const Job& j, hipStream_t st) {
+  if (j.pl.splits > 1 && !j.slabs_only && j.pl.bf16 && j.which != ACG_CONV_WGRAD) {
+    ACG_LAUNCH(splitk_reduce_bf16, dim3(reduce_blocks(j.pl.out_numel)), dim3(256), 0, st, (const float*)j.ws, (__bf16*)j.out, j.pl.out_numel, j.pl.splits);
+    return acg::check_launch("splitk_reduce_bf16");
+  }
   if (j.pl.splits > 1 && !j.slabs_only) {
     ACG_LAUNCH(splitk_reduce, dim3(reduce_blocks(j.pl.out_numel)), dim3(256), 0, st, (const float*)j.ws, j.out, j.pl.out_numel, j.pl.splits,
                j.which == ACG_CONV_WGRAD ? j.accumulate : 0.f);
@@ -327,6 +400,24 @@ int32_t acg_splitk_reduce_many(const acg_reduce_list* list, int32_t count, acg_s
   l.first_block[count] = blocks;
   ACG_LAUNCH(splitk_reduce_many, dim3(blocks), dim3(256), 0, acg::to_stream(stream), l, (int)count);
   return acg::check_launch("splitk_reduce_many");
+}
+
+int32_t acg_weights_prepare_bf16(const acg_prep_list* list, int32_t count, acg_stream_t stream) {
+  ACG_REQUIRE(list && count >= 1 && count <= ACG_PREP_MAX, ACG_ERR_INVALID_ARG, "weights_prepare_bf16: 1..%d entries", ACG_PREP_MAX);
+  PrepList l{};
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    ACG_REQUIRE(list->src[i] && list->rm[i] && list->tr[i] && list->taps[i] > 0 && list->a[i] > 0 && list->b[i] > 0, ACG_ERR_INVALID_ARG,
+                "weights_prepare_bf16: bad entry %d", i);
+    l.src[i] = (const float*)list->src[i]; l.rm[i] = (__bf16*)list->rm[i]; l.tr[i] = (__bf16*)list->tr[i];
+    l.taps[i] = list->taps[i]; l.A[i] = list->a[i]; l.B[i] = list->b[i];
+    const long long n = (long long)l.taps[i] * ((long long)l.A[i] * ((l.B[i] + 7) & ~7) + (long long)l.B[i] * ((l.A[i] + 7) & ~7));
+    l.first_block[i] = blocks;
+    blocks += (int)std::max<long long>(1, std::min<long long>(acg::ceil_div(n, 256 * 4), 1024));
+  }
+  l.first_block[count] = blocks;
+  ACG_LAUNCH(weights_prepare_bf16, dim3(blocks), dim3(256), 0, acg::to_stream(stream), l, (int)count);
+  return acg::check_launch("weights_prepare_bf16");
 }
 
 int32_t acg_conv2d_fwd(const void* x, const void* w, void* y, const acg_conv_desc* d, int32_t dtype, void* ws,

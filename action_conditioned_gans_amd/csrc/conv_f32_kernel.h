@@ -121,9 +121,7 @@ __device__ __forceinline__ float guarded_scalar(__amdgpu_buffer_rsrc_t rs, int e
 
 // RAGGED: gathered channel count not a multiple of 4; NVEC: dense operand rows are float4-loadable (N % 4 == 0).
 // Both are compile-time so that the slow variants never share registers (and waits) with the fast one.
-// BF16: operands are rounded to bf16 (RNE) as they are staged into LDS and contracted by v_mfma_f32_32x32x16_bf16
-// (fp32 accumulate); tensors stay fp32 in memory.  LDS then holds 8-k "octs": quad kq lands in half (kq&1) of
-// oct kq>>1, and lane half h feeds oct 2t+h of both tiles to MFMA t (2 MFMAs per 32-deep K-step instead of 16).
+// (bf16 tensors take their own kernel: conv_bf16_kernel.h.)
 //
 // Pipeline (one barrier per K-step): LDS holds TWO K-steps of both tiles.  In iteration ks a wave (1) drains the
 // register stage of step ks+1 into the other LDS buffer, (2) runs the MFMAs of step ks out of the current buffer and
@@ -142,13 +140,13 @@ __device__ __forceinline__ float guarded_scalar(__amdgpu_buffer_rsrc_t rs, int e
 // The block program.  (bx, by, bz) / gx stand in for blockIdx / gridDim.x so that conv_pair_f32 below can run the blocks
 // of two contractions out of one 1-D grid.
 // LDS of one block program: two K-steps of both tiles, the row infos, the tap tables.
-template <int MODE, int BM, int BN, bool BF16>
+template <int MODE, int BM, int BN>
 constexpr int conv_lds_bytes() {
-  return 2 * (BF16 ? 4 : 8) * (BM + BN) * (int)sizeof(f4) + ((MODE == MODE_WGRAD) ? 2 * 256 : BM) * (int)sizeof(RowInfo) +
+  return 2 * 8 * (BM + BN) * (int)sizeof(f4) + ((MODE == MODE_WGRAD) ? 2 * 256 : BM) * (int)sizeof(RowInfo) +
          2 * kMaxTaps * (int)sizeof(int);
 }
 
-template <int MODE, int BM, int BN, int WM, int WN, bool RAGGED, bool NVEC, bool BF16>
+template <int MODE, int BM, int BN, int WM, int WN, bool RAGGED, bool NVEC>
 __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const int by, const int bz, const int gx, char* smem) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int TA = BM / (32 * WM), TB = BN / (32 * WN);
@@ -159,9 +157,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
 #endif
   constexpr int NST = ACG_NST;           // register stages: global loads run NST K-steps ahead of their MFMAs
 
-  constexpr int KSLOTS = BF16 ? 4 : 8;   // 16-byte k-slots per tile column: 8 quads (fp32) or 4 octs (bf16)
+  constexpr int KSLOTS = 8;              // 16-byte k-slots (quads) per tile column
   constexpr int ASZ = KSLOTS * BM, BSZ = KSLOTS * BN;
-  static_assert(conv_lds_bytes<MODE, BM, BN, BF16>() == (2 * ASZ + 2 * BSZ) * (int)sizeof(f4) + NROW * (int)sizeof(RowInfo) + 2 * kMaxTaps * (int)sizeof(int), "LDS layout");
+  static_assert(conv_lds_bytes<MODE, BM, BN>() == (2 * ASZ + 2 * BSZ) * (int)sizeof(f4) + NROW * (int)sizeof(RowInfo) + 2 * kMaxTaps * (int)sizeof(int), "LDS layout");
   f4* const As_all = reinterpret_cast<f4*>(smem);                         // [2 * ASZ]
   f4* const Bs_all = As_all + 2 * ASZ;                                    // [2 * BSZ]
   RowInfo* const rows = reinterpret_cast<RowInfo*>(Bs_all + 2 * BSZ);     // [NROW]
@@ -418,32 +416,16 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
     return ((col & ~31) | (e << 3) | (j ^ ((e >> 1) << 2))) ^ kq;
   };
 
-  // write quad `kq` of tile column `col`: a 16-byte slot (fp32) or one half of the column's oct (bf16)
-  auto put = [&](f4* tile, int width, int kq, int col, const f4& q) {
-    if constexpr (BF16) {
-      const int oct = kq >> 1;
-      char* dst = reinterpret_cast<char*>(tile + oct * width + pcol(col, oct)) + (kq & 1) * 8;
-      *reinterpret_cast<bf4*>(dst) = bf4{(__bf16)q[0], (__bf16)q[1], (__bf16)q[2], (__bf16)q[3]};
-    } else {
-      tile[kq * width + pcol(col, kq)] = q;
-    }
-  };
+  // write quad `kq` of tile column `col`
+  auto put = [&](f4* tile, int width, int kq, int col, const f4& q) { tile[kq * width + pcol(col, kq)] = q; };
 
   // write k-rows sub..sub+L-1 of quad `kq` of tile column `col` (L = 4, 2, 1: a whole, half or quarter quad)
   auto put_part = [&](f4* tile, int width, int kq, int sub, int col, auto lc, const float* v) {
     constexpr int L = decltype(lc)::value;
-    if constexpr (BF16) {
-      const int oct = kq >> 1;
-      char* dst = reinterpret_cast<char*>(tile + oct * width + pcol(col, oct)) + (kq & 1) * 8 + sub * 2;
-      if constexpr (L == 4) *reinterpret_cast<bf4*>(dst) = bf4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-      else if constexpr (L == 2) *reinterpret_cast<bf2*>(dst) = bf2{(__bf16)v[0], (__bf16)v[1]};
-      else *reinterpret_cast<__bf16*>(dst) = (__bf16)v[0];
-    } else {
-      char* dst = reinterpret_cast<char*>(tile + kq * width + pcol(col, kq)) + sub * 4;
-      if constexpr (L == 4) *reinterpret_cast<f4*>(dst) = f4{v[0], v[1], v[2], v[3]};
-      else if constexpr (L == 2) *reinterpret_cast<f2*>(dst) = f2{v[0], v[1]};
-      else *reinterpret_cast<float*>(dst) = v[0];
-    }
+    char* dst = reinterpret_cast<char*>(tile + kq * width + pcol(col, kq)) + sub * 4;
+    if constexpr (L == 4) *reinterpret_cast<f4*>(dst) = f4{v[0], v[1], v[2], v[3]};
+    else if constexpr (L == 2) *reinterpret_cast<f2*>(dst) = f2{v[0], v[1]};
+    else *reinterpret_cast<float*>(dst) = v[0];
   };
 
   auto store_tiles = [&](auto stage, int buf) {
@@ -510,10 +492,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
   const int lrow = lane & 31, lk = lane >> 5;
 
   // MFMA work of one K-step as NM single instructions in NT groups (a group = one k-slot per lane half): group t
-  // reads quad (fp32) / oct (bf16) 2t+h of BOTH tiles for lane half h - the MFMA contracts slot (lane>>5) of A with
-  // the same slot of B, so the k order inside a K-step is free - and feeds it to GM MFMAs.
-  constexpr int NT = BF16 ? 2 : 4, GM = (BF16 ? 1 : 4) * TA * TB, NM = NT * GM;
-  f4 av[2][TA], bv[2][TB];        // operand fragments of group t live in av[t & 1] (bf16: 8 values in the 16 bytes)
+  // reads quad 2t+h of BOTH tiles for lane half h - the MFMA contracts slot (lane>>5) of A with the same slot of B,
+  // so the k order inside a K-step is free - and feeds it to GM MFMAs.
+  constexpr int NT = 4, GM = 4 * TA * TB, NM = NT * GM;
+  f4 av[2][TA], bv[2][TB];        // operand fragments of group t live in av[t & 1]
   auto frag_read = [&](int buf, auto tc) {
     constexpr int T = decltype(tc)::value;
     const f4* const As = As_all + buf * ASZ;
@@ -527,12 +509,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
   auto mfma = [&](auto ic) {
     constexpr int I = decltype(ic)::value;
     constexpr int T = I / GM, R = I % GM, AB = R % (TA * TB), A = AB / TB, B = AB % TB;
-    if constexpr (BF16) {
-      accs[T % NSET][A][B] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, av[T & 1][A]), __builtin_bit_cast(bf8, bv[T & 1][B]), accs[T % NSET][A][B], 0, 0, 0);
-    } else {
-      constexpr int E = R / (TA * TB);
-      accs[E % NSET][A][B] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[T & 1][A][E], bv[T & 1][B][E], accs[E % NSET][A][B], 0, 0, 0);
-    }
+    constexpr int E = R / (TA * TB);
+    accs[E % NSET][A][B] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[T & 1][A][E], bv[T & 1][B][E], accs[E % NSET][A][B], 0, 0, 0);
   };
 
   // WGRAD gathers along the reduction: the row infos change every K-step.  They are derived 8 K-steps (256 rows,
@@ -640,10 +618,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
       }
 }
 
-template <int MODE, int BM, int BN, int WM, int WN, bool RAGGED, bool NVEC, bool BF16>
+template <int MODE, int BM, int BN, int WM, int WN, bool RAGGED, bool NVEC>
 __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
-  __shared__ __align__(16) char smem[conv_lds_bytes<MODE, BM, BN, BF16>()];
-  conv_body<MODE, BM, BN, WM, WN, RAGGED, NVEC, BF16>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
+  __shared__ __align__(16) char smem[conv_lds_bytes<MODE, BM, BN>()];
+  conv_body<MODE, BM, BN, WM, WN, RAGGED, NVEC>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
 }
 
 
@@ -658,15 +636,15 @@ struct PairGeom { int nA, gxA, gyA, gxB; };
 
 template <int MODE_A, int BMA, int BNA, int WMA, int WNA, int BMB, int BNB, int WMB, int WNB, bool RAGGED>
 __global__ __launch_bounds__(256) void conv_pair_f32(const ConvArgs a, const ConvArgs b, const PairGeom g) {
-  constexpr int LA = conv_lds_bytes<MODE_A, BMA, BNA, false>(), LB = conv_lds_bytes<MODE_WGRAD, BMB, BNB, false>();
+  constexpr int LA = conv_lds_bytes<MODE_A, BMA, BNA>(), LB = conv_lds_bytes<MODE_WGRAD, BMB, BNB>();
   __shared__ __align__(16) char smem[LA > LB ? LA : LB];      // one block runs one of the two programs
   const int L = (int)blockIdx.x;
   if (L < g.nA) {
     const int t = L / g.gxA;
-    conv_body<MODE_A, BMA, BNA, WMA, WNA, RAGGED, true, false>(a, L - t * g.gxA, t % g.gyA, t / g.gyA, g.gxA, smem);
+    conv_body<MODE_A, BMA, BNA, WMA, WNA, RAGGED, true>(a, L - t * g.gxA, t % g.gyA, t / g.gyA, g.gxA, smem);
   } else {
     const int l = L - g.nA, bz = l / g.gxB;
-    conv_body<MODE_WGRAD, BMB, BNB, WMB, WNB, RAGGED, true, false>(b, l - bz * g.gxB, 0, bz, g.gxB, smem);
+    conv_body<MODE_WGRAD, BMB, BNB, WMB, WNB, RAGGED, true>(b, l - bz * g.gxB, 0, bz, g.gxB, smem);
   }
 }
 
@@ -687,30 +665,29 @@ int launch_mode(const Plan& pl, const ConvArgs& a, hipStream_t st);
 bool pair_supported(int modeA, const Plan& pa, const Plan& pb);
 int launch_pair(int modeA, const Plan& pa, const ConvArgs& a, const Plan& pb, const ConvArgs& b, hipStream_t st);
 
-template <int MODE, bool RAGGED, bool NVEC, bool BF16>
+template <int MODE, bool RAGGED, bool NVEC>
 static inline void launch_cfg(const Plan& pl, const ConvArgs& a, hipStream_t st) {
   const dim3 grid((unsigned)(acg::ceil_div(pl.M, pl.bm) * acg::ceil_div(pl.N, pl.bn)), (unsigned)pl.classes, (unsigned)pl.splits);
   // two tile shapes: 128x32 for narrow N, 64x64 otherwise.  128x128 / 128x64 variants existed through v4; with the
   // one-barrier pipeline they lost every layer of the tuning sweep (profiles/r1) and were dropped.
-  if (pl.cfg == 2) ACG_LAUNCH((conv_mfma_f32<MODE, 128, 32, 4, 1, RAGGED, NVEC, BF16>), grid, dim3(256), 0, st, a);
-  else ACG_LAUNCH((conv_mfma_f32<MODE, 64, 64, 2, 2, RAGGED, NVEC, BF16>), grid, dim3(256), 0, st, a);
+  if (pl.cfg == 2) ACG_LAUNCH((conv_mfma_f32<MODE, 128, 32, 4, 1, RAGGED, NVEC>), grid, dim3(256), 0, st, a);
+  else ACG_LAUNCH((conv_mfma_f32<MODE, 64, 64, 2, 2, RAGGED, NVEC>), grid, dim3(256), 0, st, a);
 }
-template <int MODE, bool BF16>
+template <int MODE>
 static inline void launch_variant(const Plan& pl, const ConvArgs& a, hipStream_t st) {
   if (pl.ragged) {
-    if (pl.nvec) launch_cfg<MODE, true, true, BF16>(pl, a, st);
-    else launch_cfg<MODE, true, false, BF16>(pl, a, st);
+    if (pl.nvec) launch_cfg<MODE, true, true>(pl, a, st);
+    else launch_cfg<MODE, true, false>(pl, a, st);
   } else {
-    if (pl.nvec) launch_cfg<MODE, false, true, BF16>(pl, a, st);
-    else launch_cfg<MODE, false, false, BF16>(pl, a, st);
+    if (pl.nvec) launch_cfg<MODE, false, true>(pl, a, st);
+    else launch_cfg<MODE, false, false>(pl, a, st);
   }
 }
 
 #define ACG_DEFINE_CONV_LAUNCH(MODE)                                                    \
   template <>                                                                           \
   int launch_mode<MODE>(const Plan& pl, const ConvArgs& a, hipStream_t st) {            \
-    if (pl.bf16) launch_variant<MODE, true>(pl, a, st);                                 \
-    else launch_variant<MODE, false>(pl, a, st);                                        \
+    launch_variant<MODE>(pl, a, st);                                                    \
     return acg::check_launch("conv_mfma_f32");                                          \
   }
 

@@ -40,8 +40,9 @@ int grid_for(long long n) {
 
 // y[r, 0:ca] = a[r, :]; y[r, ca:ca+cb] = b[r / rows_per_b, :]  (rows_per_b = 1: plain concat; = hw: tiled actions);
 // y rows are `pitch` floats apart, pad channels are not written
-__global__ __launch_bounds__(256) void concat_k(const float* __restrict__ a, const float* __restrict__ b,
-                                                float* __restrict__ y, long long rows, int ca, int cb, int rows_per_b,
+template <typename TI, typename TS, typename TO>
+__global__ __launch_bounds__(256) void concat_k(const TI* __restrict__ a, const TS* __restrict__ b,
+                                                TO* __restrict__ y, long long rows, int ca, int cb, int rows_per_b,
                                                 int pitch) {
   const int cy = ca + cb;
   const long long n = rows * cy, stride = (long long)gridDim.x * 256;
@@ -49,66 +50,76 @@ __global__ __launch_bounds__(256) void concat_k(const float* __restrict__ a, con
     const unsigned n32 = (unsigned)n, st32 = (unsigned)stride, ucy = (unsigned)cy, urpb = (unsigned)rows_per_b;
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n32; i += st32) {
       const unsigned r = i / ucy, c = i - r * ucy;
-      y[(size_t)r * pitch + c] = c < (unsigned)ca ? a[(size_t)r * ca + c] : b[(size_t)(r / urpb) * cb + (c - ca)];
+      acg::stf(y + (size_t)r * pitch + c, c < (unsigned)ca ? acg::ldf(a + (size_t)r * ca + c) : acg::ldf(b + (size_t)(r / urpb) * cb + (c - ca)));
     }
     return;
   }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     const long long r = i / cy;
     const int c = (int)(i - r * cy);
-    y[r * pitch + c] = c < ca ? a[r * ca + c] : b[(r / rows_per_b) * cb + (c - ca)];
+    acg::stf(y + r * pitch + c, c < ca ? acg::ldf(a + r * ca + c) : acg::ldf(b + (r / rows_per_b) * cb + (c - ca)));
   }
 }
 
-__global__ __launch_bounds__(256) void slice_k(const float* __restrict__ src, float* __restrict__ dst, float acc,
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void slice_k(const TI* __restrict__ src, TO* __restrict__ dst, float acc,
                                                long long rows, int c_src, int c_off, int c_dst) {
   const long long n = rows * c_dst, stride = (long long)gridDim.x * 256;
   if (n < (1ll << 31) && rows * c_src < (1ll << 31)) {
     const unsigned n32 = (unsigned)n, st32 = (unsigned)stride, ud = (unsigned)c_dst;
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n32; i += st32) {
       const unsigned r = i / ud, c = i - r * ud;
-      const float v = src[r * (unsigned)c_src + c_off + c];
-      dst[i] = acc != 0.f ? acc * dst[i] + v : v;
+      const float v = acg::ldf(src + r * (unsigned)c_src + c_off + c);
+      acg::stf(dst + i, acc != 0.f ? acc * acg::ldf(dst + i) + v : v);
     }
     return;
   }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     const long long r = i / c_dst;
     const int c = (int)(i - r * c_dst);
-    const float v = src[r * c_src + c_off + c];
-    dst[i] = acc != 0.f ? acc * dst[i] + v : v;
+    const float v = acg::ldf(src + r * c_src + c_off + c);
+    acg::stf(dst + i, acc != 0.f ? acc * acg::ldf(dst + i) + v : v);
   }
 }
 
-__global__ __launch_bounds__(256) void add_k(const float* __restrict__ a, const float* __restrict__ b,
-                                             float* __restrict__ y, long long n) {
+template <typename T>
+__global__ __launch_bounds__(256) void add_k(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long long n) {
   const long long stride = (long long)gridDim.x * 256;
-  const long long n4 = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 ? n / 4 : 0;
-  const float4* a4 = reinterpret_cast<const float4*>(a);
-  const float4* b4 = reinterpret_cast<const float4*>(b);
-  float4* y4 = reinterpret_cast<float4*>(y);
+  const unsigned al = 4 * sizeof(T) - 1;
+  const long long n4 = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(y)) & al) == 0 ? n / 4 : 0;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-    const float4 u = a4[i], v = b4[i];
-    y4[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+    float u[4], v[4];
+    acg::ldv<4>(a + 4 * i, u); acg::ldv<4>(b + 4 * i, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) u[e] += v[e];
+    acg::stv<4>(y + 4 * i, u);
   }
-  for (long long i = n4 * 4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] = a[i] + b[i];
+  for (long long i = n4 * 4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) acg::stf(y + i, acg::ldf(a + i) + acg::ldf(b + i));
 }
 
 struct CopyList {
   const float* src[ACG_COPY_MAX];
-  float* dst[ACG_COPY_MAX];
+  void* dst[ACG_COPY_MAX];
   long long rows[ACG_COPY_MAX];
-  int cols[ACG_COPY_MAX], pitch[ACG_COPY_MAX];
+  int cols[ACG_COPY_MAX], pitch[ACG_COPY_MAX], half[ACG_COPY_MAX];
 };
 
 // blockIdx.y = segment; float4 when the segment is dense and aligned, else one float per thread with 32-bit row math
 __global__ __launch_bounds__(256) void copy_many_k(const CopyList l) {
   const int sgm = blockIdx.y;
   const float* __restrict__ src = l.src[sgm];
-  float* __restrict__ dst = l.dst[sgm];
   const long long rows = l.rows[sgm];
   const int cols = l.cols[sgm], pitch = l.pitch[sgm];
   const long long n = rows * cols, stride = (long long)gridDim.x * 256;
+  if (l.half[sgm]) {   // float32 source -> bf16 destination
+    __bf16* __restrict__ dh = reinterpret_cast<__bf16*>(l.dst[sgm]);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+      const long long r = i / cols;
+      dh[r * pitch + (i - r * cols)] = (__bf16)src[i];
+    }
+    return;
+  }
+  float* __restrict__ dst = reinterpret_cast<float*>(l.dst[sgm]);
   if (pitch == cols && (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
     const float4* s4 = reinterpret_cast<const float4*>(src);
     float4* d4 = reinterpret_cast<float4*>(dst);
@@ -126,7 +137,7 @@ __global__ __launch_bounds__(256) void copy_many_k(const CopyList l) {
 extern "C" {
 
 int32_t acg_version(void) { return ACG_ABI_VERSION; }
-const char* acg_build_info(void) { return "hip gfx950 (fp32 MFMA 32x32x2)"; }
+const char* acg_build_info(void) { return "hip gfx950 (fp32 MFMA 32x32x2; bf16 MFMA 32x32x16)"; }
 const char* acg_last_error(void) { return acg::g_err; }
 
 int32_t acg_stream_edge_create(acg_edge_t* edge) {
@@ -154,42 +165,46 @@ int32_t acg_stream_edge(acg_edge_t edge, acg_stream_t from, acg_stream_t to) {
 
 int32_t acg_concat_actions_fwd(const void* x, const float* actions, void* y, int32_t B, int32_t hw, int32_t c, int32_t a,
                                int32_t y_pitch, int32_t dtype, acg_stream_t stream) {
-  ACG_REQUIRE_F32(dtype);
+  ACG_REQUIRE(dtype == ACG_F32 || dtype == ACG_BF16, ACG_ERR_UNSUPPORTED, "concat_actions_fwd: dtype %d", dtype);
   ACG_REQUIRE(B > 0 && hw > 0 && c > 0 && a > 0, ACG_ERR_INVALID_ARG, "concat_actions_fwd: non-positive size");
   ACG_REQUIRE(x && actions && y, ACG_ERR_INVALID_ARG, "concat_actions_fwd: null pointer");
   const int pitch = y_pitch > 0 ? y_pitch : c + a;
   ACG_REQUIRE(pitch >= c + a, ACG_ERR_INVALID_ARG, "concat_actions_fwd: pitch smaller than the row");
   const long long rows = (long long)B * hw;
-  ACG_LAUNCH(concat_k, dim3(grid_for(rows * (c + a))), dim3(256), 0, acg::to_stream(stream), (const float*)x,
-                     actions, (float*)y, rows, c, a, hw, pitch);
+  if (dtype == ACG_BF16)
+    ACG_LAUNCH((concat_k<__bf16, float, __bf16>), dim3(grid_for(rows * (c + a))), dim3(256), 0, acg::to_stream(stream), (const __bf16*)x,
+               actions, (__bf16*)y, rows, c, a, hw, pitch);
+  else
+    ACG_LAUNCH((concat_k<float, float, float>), dim3(grid_for(rows * (c + a))), dim3(256), 0, acg::to_stream(stream), (const float*)x,
+               actions, (float*)y, rows, c, a, hw, pitch);
   return acg::check_launch("concat_actions_fwd");
 }
 
 int32_t acg_concat_channels_fwd(const void* a, const void* b, void* y, int64_t rows, int32_t ca, int32_t cb, int32_t y_pitch,
                                 int32_t dtype, acg_stream_t stream) {
-  ACG_REQUIRE_F32(dtype);
   ACG_REQUIRE(rows > 0 && ca > 0 && cb >= 0, ACG_ERR_INVALID_ARG, "concat_channels_fwd: non-positive size");
   ACG_REQUIRE(a && (b || cb == 0) && y, ACG_ERR_INVALID_ARG, "concat_channels_fwd: null pointer");
   const int pitch = y_pitch > 0 ? y_pitch : ca + cb;
   ACG_REQUIRE(pitch >= ca + cb, ACG_ERR_INVALID_ARG, "concat_channels_fwd: pitch smaller than the row");
-  ACG_LAUNCH(concat_k, dim3(grid_for(rows * (ca + cb))), dim3(256), 0, acg::to_stream(stream), (const float*)a,
-                     (const float*)b, (float*)y, (long long)rows, ca, cb, 1, pitch);
+  ACG_WITH_TYPES_ANY(dtype, "concat_channels_fwd",
+                     ACG_LAUNCH((concat_k<TA, TA, TB>), dim3(grid_for(rows * (ca + cb))), dim3(256), 0, acg::to_stream(stream), (const TA*)a,
+                                (const TA*)b, (TB*)y, (long long)rows, ca, cb, 1, pitch));
   return acg::check_launch("concat_channels_fwd");
 }
 
 int32_t acg_slice_channels(const void* src, void* dst, float accumulate, int64_t rows, int32_t c_src, int32_t c_off,
                            int32_t c_dst, int32_t dtype, acg_stream_t stream) {
-  ACG_REQUIRE_F32(dtype);
   ACG_REQUIRE(rows > 0 && c_src > 0 && c_dst > 0, ACG_ERR_INVALID_ARG, "slice_channels: non-positive size");
   ACG_REQUIRE(c_off >= 0 && c_off + c_dst <= c_src, ACG_ERR_INVALID_ARG, "slice_channels: range outside source");
   ACG_REQUIRE(src && dst, ACG_ERR_INVALID_ARG, "slice_channels: null pointer");
-  ACG_LAUNCH(slice_k, dim3(grid_for(rows * c_dst)), dim3(256), 0, acg::to_stream(stream), (const float*)src,
-                     (float*)dst, accumulate, (long long)rows, c_src, c_off, c_dst);
+  ACG_WITH_TYPES(dtype, "slice_channels",
+                 ACG_LAUNCH((slice_k<TA, TB>), dim3(grid_for(rows * c_dst)), dim3(256), 0, acg::to_stream(stream), (const TA*)src, (TB*)dst,
+                            accumulate, (long long)rows, c_src, c_off, c_dst));
   return acg::check_launch("slice_channels");
 }
 
 int32_t acg_copy_many(const acg_copy_list* list, int32_t count, int32_t dtype, acg_stream_t stream) {
-  ACG_REQUIRE_F32(dtype);
+  ACG_REQUIRE_F32(dtype);     /* the sources; destinations per segment (dst_dtype) */
   ACG_REQUIRE(list && count >= 1 && count <= ACG_COPY_MAX, ACG_ERR_INVALID_ARG, "copy_many: 1..%d segments", ACG_COPY_MAX);
   CopyList l{};
   long long most = 0;
@@ -197,7 +212,8 @@ int32_t acg_copy_many(const acg_copy_list* list, int32_t count, int32_t dtype, a
     ACG_REQUIRE(list->src[i] && list->dst[i] && list->rows[i] > 0 && list->cols[i] > 0, ACG_ERR_INVALID_ARG, "copy_many: bad segment %d", i);
     const int pitch = list->dst_pitch[i] > 0 ? list->dst_pitch[i] : list->cols[i];
     ACG_REQUIRE(pitch >= list->cols[i], ACG_ERR_INVALID_ARG, "copy_many: segment %d pitch smaller than its row", i);
-    l.src[i] = (const float*)list->src[i]; l.dst[i] = (float*)list->dst[i];
+    ACG_REQUIRE(list->dst_dtype[i] == ACG_F32 || list->dst_dtype[i] == ACG_BF16, ACG_ERR_UNSUPPORTED, "copy_many: segment %d dtype", i);
+    l.src[i] = (const float*)list->src[i]; l.dst[i] = list->dst[i]; l.half[i] = list->dst_dtype[i] == ACG_BF16;
     l.rows[i] = list->rows[i]; l.cols[i] = list->cols[i]; l.pitch[i] = pitch;
     most = std::max<long long>(most, list->rows[i] * list->cols[i]);
   }
@@ -206,10 +222,12 @@ int32_t acg_copy_many(const acg_copy_list* list, int32_t count, int32_t dtype, a
 }
 
 int32_t acg_add(const void* a, const void* b, void* y, int64_t n, int32_t dtype, acg_stream_t stream) {
-  ACG_REQUIRE_F32(dtype);
+  ACG_REQUIRE(dtype == ACG_F32 || dtype == ACG_BF16, ACG_ERR_UNSUPPORTED, "add: dtype %d", dtype);
   ACG_REQUIRE(n > 0 && a && b && y, ACG_ERR_INVALID_ARG, "add: bad argument");
-  ACG_LAUNCH(add_k, dim3(grid_for(n / 4 + 1)), dim3(256), 0, acg::to_stream(stream), (const float*)a,
-                     (const float*)b, (float*)y, (long long)n);
+  if (dtype == ACG_BF16)
+    ACG_LAUNCH(add_k<__bf16>, dim3(grid_for(n / 4 + 1)), dim3(256), 0, acg::to_stream(stream), (const __bf16*)a, (const __bf16*)b, (__bf16*)y, (long long)n);
+  else
+    ACG_LAUNCH(add_k<float>, dim3(grid_for(n / 4 + 1)), dim3(256), 0, acg::to_stream(stream), (const float*)a, (const float*)b, (float*)y, (long long)n);
   return acg::check_launch("add");
 }
 

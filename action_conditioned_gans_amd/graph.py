@@ -132,6 +132,15 @@ class Graph:
         self._id = 0
         self._layouts = {}           # top-level scope -> (offsets dict, total numel, flat Tensor)
         self.collections = {}
+        # storage type of activation-class tensors (conv / BatchNorm outputs and their gradients): float32, or
+        # bfloat16 for the BASELINE config 3 / 5 pipeline (Session(dtype='bf16') sets it before the graph is built)
+        self.act_dtype = torch.float32
+        self.weight_copies = {}      # scope -> [(Variable, rm Tensor, tr Tensor)]: bf16 operand copies of the filters
+
+    @property
+    def cpad(self):
+        """Channel-pitch unit of activation tensors: one 16-byte gather = 4 floats or 8 bf16."""
+        return 8 if self.act_dtype == torch.bfloat16 else 4
 
     def _next_id(self):
         self._id += 1
@@ -196,9 +205,12 @@ def reset_default_graph():
     return _default[-1]
 
 
-def placeholder(shape, name=None, dtype=torch.float32, channel_pitch=None):
+def placeholder(shape, name=None, dtype=torch.float32, channel_pitch=None, act=False):
     """tf.placeholder.  ``channel_pitch`` stores the last dimension with that pitch (zero pad channels) so that 3-
-    or 6-channel images can be gathered with 16-byte loads by the first conv layer."""
+    or 6-channel images can be gathered with 16-byte loads by the first conv layer; ``act`` stores it in the graph's
+    activation type (fed float32 values are rounded on the way in)."""
+    if act:
+        dtype = get_default_graph().act_dtype
     if channel_pitch and channel_pitch != shape[-1]:
         ph = Placeholder(get_default_graph(), tuple(shape[:-1]) + (channel_pitch,), name=name, dtype=dtype)
         ph.valid_c = shape[-1]
@@ -353,7 +365,13 @@ class Session:
             if not torch.cuda.is_available():
                 raise RuntimeError('no GPU visible: the HIP path cannot run and there is no CPU fallback')
         if dtype not in ('f32', 'bf16'):
-            raise ValueError("dtype must be 'f32' or 'bf16' (bf16 matrix-core operands, fp32 storage and accumulation)")
+            raise ValueError("dtype must be 'f32' or 'bf16' (bf16 activations and matrix-core operands; fp32 master weights, "
+                             "weight gradients, statistics and losses)")
+        want = torch.bfloat16 if dtype == 'bf16' else torch.float32
+        if self.graph.act_dtype != want:
+            if self.graph.ops:
+                raise ValueError('Session(dtype=%r): the graph was already built for %s activations' % (dtype, self.graph.act_dtype))
+            self.graph.act_dtype = want
         self.rt = Runtime(lib, dev, world_size, rank, process_group, _lib.ACG_BF16 if dtype == 'bf16' else _lib.ACG_F32, comm)
         if dev.type == 'cuda':
             torch.cuda.set_device(dev)
@@ -362,6 +380,7 @@ class Session:
         self.pair_bwd = bool(pair_bwd)
         self._programs = {}
         self._initialized = False
+        self._weights_dirty = True     # bf16 operand copies of the filters are stale (initializer, set_value, restore)
 
     def __enter__(self):
         return self
@@ -403,6 +422,7 @@ class Session:
             buf = self._materialize(s)
             buf.fill_(s.init)
         self._initialized = True
+        self._weights_dirty = True
 
     # ---- variable access (checkpoint / parity tests)
     def get_value(self, var):
@@ -411,6 +431,22 @@ class Session:
     def set_value(self, var, value):
         self._materialize(var).copy_(torch.as_tensor(np.asarray(value) if not torch.is_tensor(value) else value)
                                      .to(torch.float32).reshape(var.shape))
+        self._weights_dirty = True
+
+    def _refresh_weight_copies(self):
+        """bf16 pipeline: the filter copies the conv kernels read (acg_weights_prepare_bf16) follow the float32 master
+        weights - inside a training program right behind the optimizer update, here after host-side writes."""
+        self._weights_dirty = False
+        if not self.graph.weight_copies:
+            return
+        from . import ops as O
+        for scope in self.graph.weight_copies:
+            for t3 in self.graph.weight_copies[scope]:
+                for t in t3:
+                    self._materialize(t)
+            fn = O.prepare_weights_launch(self.rt, self.graph, scope)
+            if fn is not None:
+                fn(self.rt.stream_ptr())
 
     # ---- compile
     @staticmethod
@@ -454,7 +490,7 @@ class Session:
             raise RuntimeError('Attempting to use uninitialized variables: run global_variables_initializer() first')
         ops = self._fold_clips(ops)
         for op in ops:
-            for t in op.inputs + op.outputs:
+            for t in op.inputs + op.outputs + list(getattr(op, 'extras', ())):
                 self._materialize(t)
         for k, op in enumerate(ops):           # pairing is decided per program: both ops fetched, nothing between them
             w = getattr(op, 'pair_w', None)
@@ -528,7 +564,7 @@ class Session:
             if tuple(src.shape) != tuple(dst.shape):
                 raise ValueError('Cannot feed value of shape %s for %r' % (tuple(src.shape), ph))
             if (self.rt.is_cuda and src.is_cuda and src.device == ph.buf.device and src.dtype == torch.float32
-                    and ph.dtype == torch.float32 and src.is_contiguous() and len(fused) < _lib.COPY_MAX):
+                    and ph.dtype in (torch.float32, torch.bfloat16) and src.is_contiguous() and len(fused) < _lib.COPY_MAX):
                 fused.append((src, ph))          # device-resident feeds: one launch for all of them (below)
             else:
                 dst.copy_(src.to(ph.dtype), non_blocking=True)
@@ -537,8 +573,10 @@ class Session:
             for i, (src, ph) in enumerate(fused):
                 cols = ph.valid_c if ph.valid_c is not None else ph.shape[-1]
                 cl.src[i], cl.dst[i] = src.data_ptr(), ph.buf.data_ptr()
-                cl.rows[i], cl.cols[i], cl.dst_pitch[i] = src.numel() // cols, cols, ph.shape[-1]
+                cl.rows[i], cl.cols[i], cl.dst_pitch[i], cl.dst_dtype[i] = src.numel() // cols, cols, ph.shape[-1], _lib.code(ph.dtype)
             self.rt.lib.copy_many(ctypes.byref(cl), len(fused), _lib.ACG_F32, self.rt.stream_ptr())
+        if self._weights_dirty and prog is not None:
+            self._refresh_weight_copies()
         self._execute(prog)
         results = []
         for t in prog.fetch_tensors:
@@ -547,7 +585,7 @@ class Session:
             elif device_fetch:
                 results.append(t.buf)
             else:
-                results.append(t.buf.detach().cpu().numpy().copy())
+                results.append(t.buf.detach().float().cpu().numpy().copy())
         if single:
             return results[0]
         return self._unflatten(fetches, iter(results))
@@ -570,6 +608,8 @@ class Session:
         for ph, val in (feed_dict or {}).items():
             dst = ph.buf if ph.valid_c is None else ph.buf[..., :ph.valid_c]
             dst.copy_(val if torch.is_tensor(val) else torch.from_numpy(np.ascontiguousarray(val)), non_blocking=True)
+        if self._weights_dirty:
+            self._refresh_weight_copies()
         stream = torch.cuda.current_stream(self.rt.device)
         records = []
         for _ in range(repeats):

@@ -30,6 +30,8 @@ def _with_actions(features, actions, name):
     if len(actions.shape) == 2:
         return O.concat_actions(features, actions, name=name)
     if len(actions.shape) == 4 and actions.shape[1:3] == features.shape[1:3]:
+        if O.half_mode():
+            raise NotImplementedError('bf16 graphs take the actions as [B, A] (tiled and concatenated in one fused op)')
         return O.concat([features, actions], axis=3, name=name)
     raise ValueError('actions %s cannot be concatenated with a %s feature map' % (actions.shape, features.shape))
 

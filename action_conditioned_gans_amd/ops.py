@@ -112,8 +112,74 @@ def zeros_initializer():
 # ================================================================================================
 # graph ops
 # ================================================================================================
-def _new(shape, name):
-    return G.Tensor(G.get_default_graph(), shape, name=name)
+def _new(shape, name, dtype=torch.float32):
+    return G.Tensor(G.get_default_graph(), shape, name=name, dtype=dtype)
+
+
+def act_dtype():
+    """Storage type of activation-class tensors in the graph being built (float32, or bfloat16: BASELINE configs 3 / 5)."""
+    return G.get_default_graph().act_dtype
+
+
+def half_mode():
+    return act_dtype() == torch.bfloat16
+
+
+def cpad(c):
+    """Channel pitch of an activation with ``c`` channels when it feeds a conv: rounded up to one 16-byte gather."""
+    u = G.get_default_graph().cpad
+    return -(-c // u) * u
+
+
+def _new_act(shape, name):
+    return _new(shape, name, act_dtype())
+
+
+def _code(t):
+    return _lib.code(t.dtype)
+
+
+def _code2(a, b):
+    return _lib.dtype2(_lib.code(a.dtype), _lib.code(b.dtype))
+
+
+def _wcopy(w, kind):
+    """bf16 pipeline: the bf16 operand copy of filter variable ``w`` [kh,kw,A,B] that a contraction reads - 'rm'
+    [taps,A,round8(B)] (conv dgrad, deconv fwd) or 'tr' [taps,B,round8(A)] (conv fwd, deconv dgrad); float32: ``w``."""
+    if not half_mode():
+        return w
+    if getattr(w, 'copies', None) is None:
+        g = G.get_default_graph()
+        kh, kw, a, b = w.shape
+        rm = g.new_state((kh * kw, a, -(-b // 8) * 8), 0.0, w.name + '/bf16_rm', dtype=torch.bfloat16)
+        tr = g.new_state((kh * kw, b, -(-a // 8) * 8), 0.0, w.name + '/bf16_tr', dtype=torch.bfloat16)
+        w.copies = {'rm': rm, 'tr': tr}
+        g.weight_copies.setdefault(w.scope, []).append((w, rm, tr))
+    return w.copies[kind]
+
+
+def prepare_weights_launch(rt, graph, scope):
+    """fn(stream) that refreshes every bf16 filter copy of ``scope`` from the float32 master weights in one launch
+    (acg_weights_prepare_bf16), or None when the scope has none.  Buffers must be materialised."""
+    entries = graph.weight_copies.get(scope) or []
+    if not entries:
+        return None
+    lists = []
+    for lo in range(0, len(entries), _lib.PREP_MAX):
+        chunk = entries[lo:lo + _lib.PREP_MAX]
+        pl = _lib.PrepList()
+        for i, (w, rm, tr) in enumerate(chunk):
+            kh, kw, a, b = w.shape
+            pl.src[i], pl.rm[i], pl.tr[i] = w.buf.data_ptr(), rm.buf.data_ptr(), tr.buf.data_ptr()
+            pl.taps[i], pl.a[i], pl.b[i] = kh * kw, a, b
+        lists.append((pl, len(chunk)))
+    fn = rt.lib.weights_prepare_bf16
+
+    def launch(s):
+        for pl, n in lists:
+            fn(ctypes.byref(pl), n, s)
+    launch._keep = lists
+    return launch
 
 
 def _check_nhwc(x, what):
@@ -149,6 +215,8 @@ class _ConvBase(G.Op):
 
     def _bind(self, rt, entry, a, b, out, accumulate=None):
         lib, d = rt.lib, self.desc
+        if a.dtype != (torch.bfloat16 if rt.conv_dtype == _lib.ACG_BF16 else torch.float32):
+            raise TypeError('%s: %s operand %r in a %s session' % (self.name, a.dtype, a, 'bf16' if rt.conv_dtype else 'f32'))
         ws, n = rt.workspace(lib.conv2d_workspace_bytes(ctypes.byref(d), self.which, rt.conv_dtype))
         self._keep = (ws, d)
         fn = getattr(lib, entry)
@@ -165,19 +233,26 @@ class Conv2dOp(_ConvBase):
         g = G.get_default_graph()
         self.desc, self.transposed = desc, transposed
         self.which = CONV_DGRAD if transposed else CONV_FWD
-        shape = (desc.batch, desc.in_h, desc.in_w, desc.in_c) if transposed else (desc.batch, desc.out_h, desc.out_w, desc.out_c)
-        super().__init__(g, name, [x, w], [_new(shape, name + ':0')])
+        c = desc.in_c if transposed else desc.out_c
+        shape = (desc.batch, desc.in_h, desc.in_w) if transposed else (desc.batch, desc.out_h, desc.out_w)
+        cphys = cpad(c) if half_mode() else c          # bf16 activations live at the channel pitch round8(C)
+        y = _new_act(shape + (cphys,), name + ':0')
+        if cphys != c:
+            y.valid_c = c
+        self.wop = _wcopy(w, 'rm' if transposed else 'tr')
+        self.extras = [self.wop]
+        super().__init__(g, name, [x, w], [y])
 
     def bind(self, rt):
         x, w = self.inputs
-        return self._bind(rt, 'deconv2d_fwd' if self.transposed else 'conv2d_fwd', x, w, self.outputs[0])
+        return self._bind(rt, 'deconv2d_fwd' if self.transposed else 'conv2d_fwd', x, self.wop, self.outputs[0])
 
     def grad(self, gouts, needs, ctx):
         x, w = self.inputs
         dy = gouts[0]
         dx = None
         if needs[0]:
-            dx = ConvDgradOp(dy, w, x.shape, self.desc, self.transposed, self.name + '/dgrad').outputs[0]
+            dx = ConvDgradOp(dy, w, x, self.desc, self.transposed, self.name + '/dgrad').outputs[0]
             dx.valid_c = x.valid_c
         if needs[1] and ctx.wants(w):
             dst, acc = ctx.slot(w)
@@ -192,13 +267,16 @@ class ConvDgradOp(_ConvBase):
     pair_w = None          # the layer's ConvWgradOp, when both gradients are built
     pair_active = False    # set per compiled program: this op launches both (acg_(de)conv2d_bwd_pair)
 
-    def __init__(self, dy, w, x_shape, desc, transposed, name):
+    def __init__(self, dy, w, x, desc, transposed, name):
         self.desc, self.transposed = desc, transposed
         self.which = CONV_FWD if transposed else CONV_DGRAD
-        super().__init__(G.get_default_graph(), name, [dy, w], [_new(x_shape, name + ':0')])
+        self.wop = _wcopy(w, 'tr' if transposed else 'rm')
+        self.extras = [self.wop]
+        super().__init__(G.get_default_graph(), name, [dy, w], [_new(x.shape, name + ':0', x.dtype)])
 
     def bind(self, rt):
         dy, w = self.inputs
+        w = self.wop
         if not self.pair_active:
             return self._bind(rt, 'deconv2d_dgrad' if self.transposed else 'conv2d_dgrad', dy, w, self.outputs[0])
         # ONE launch for dx and dw: the two contractions share the CUs instead of running one grid after the other
@@ -286,13 +364,21 @@ class BnActOp(G.Op):
 
     def __init__(self, x, beta, act, leak, eps, groups, name):
         g = G.get_default_graph()
-        c = x.shape[-1]
+        self.xp = x.shape[-1]                         # channel pitch of x (bf16 conv outputs: round8(C))
+        c = x.valid_c or self.xp
         self.act, self.leak, self.eps, self.groups = act, float(leak), float(eps), int(groups)
-        self.rows, self.c = x.numel // c, c
+        self.rows, self.c = x.numel // self.xp, c
         if self.rows % self.groups:
             raise ValueError('batch_norm: %d rows not divisible by %d groups' % (self.rows, self.groups))
         self.mean, self.rstd = _new((groups * c,), name + '/mean'), _new((groups * c,), name + '/rstd')
-        super().__init__(g, name, [x, beta], [_new(x.shape, name + ':0'), self.mean, self.rstd])
+        if act is None and half_mode():
+            # a layer without activation is a head (d/conv6: the logits the losses read): dense float32 output
+            y = _new(x.shape[:-1] + (c,), name + ':0')
+        else:
+            y = _new(x.shape, name + ':0', x.dtype)
+            y.valid_c = x.valid_c
+        self.yp = y.shape[-1]
+        super().__init__(g, name, [x, beta], [y, self.mean, self.rstd])
 
     def bind(self, rt):
         lib = rt.lib
@@ -300,8 +386,8 @@ class BnActOp(G.Op):
         self._keep = ws
         x, beta = self.inputs
         y, mean, rstd = self.outputs
-        args = (_p(x.buf), _p(beta.buf), _p(y.buf), _p(mean.buf), _p(rstd.buf), self.rows, self.c, self.groups, self.eps,
-                _ACT_CODE[self.act], self.leak, ACG_F32, _p(ws), n)
+        args = (_p(x.buf), _p(beta.buf), _p(y.buf), _p(mean.buf), _p(rstd.buf), self.rows, self.c, self.xp, self.yp, self.groups,
+                self.eps, _ACT_CODE[self.act], self.leak, _code2(x, y), _p(ws), n)
         fn = lib.bn_act_fwd
         return lambda s: fn(*args, s)
 
@@ -321,7 +407,9 @@ class BnActBwdOp(G.Op):
         x, beta = fwd.inputs
         if dbeta_dst is None:                      # beta frozen in this pass: private scratch slot
             dbeta_dst = _new((fwd.c,), name + '/dbeta_scratch')
-        super().__init__(g, name, [x, dy, beta, fwd.mean, fwd.rstd], [_new(x.shape, name + ':0'), dbeta_dst])
+        dx = _new(x.shape, name + ':0', x.dtype)
+        dx.valid_c = x.valid_c
+        super().__init__(g, name, [x, dy, beta, fwd.mean, fwd.rstd], [dx, dbeta_dst])
 
     def bind(self, rt):
         lib, f = rt.lib, self.fwd
@@ -330,7 +418,7 @@ class BnActBwdOp(G.Op):
         x, dy, beta, mean, rstd = self.inputs
         dx, dbeta = self.outputs
         args = (_p(x.buf), _p(dy.buf), _p(beta.buf), _p(mean.buf), _p(rstd.buf), _p(dx.buf), _p(dbeta.buf), self.accumulate,
-                f.rows, f.c, f.groups, _ACT_CODE[f.act], f.leak, ACG_F32, _p(ws), n)
+                f.rows, f.c, f.xp, f.yp, f.groups, _ACT_CODE[f.act], f.leak, _code2(x, dy), _p(ws), n)
         fn = lib.bn_act_bwd
         return lambda s: fn(*args, s)
 
@@ -460,20 +548,27 @@ class BnBwdApplySumsOp(G.Op):
 
 
 class BiasActOp(G.Op):
-    """y = act(x + bias); bias None gives the bare activation."""
+    """y = act(x + bias); bias None gives the bare activation.  ``head``: the layer's output is what the losses read
+    (frame, state): in a bf16 graph it becomes a dense float32 tensor, the conv output's pad channels dropped."""
 
-    def __init__(self, x, bias, act, leak, name):
+    def __init__(self, x, bias, act, leak, name, head=False):
         g = G.get_default_graph()
         self.act, self.leak = act, float(leak)
-        self.c = x.shape[-1]
-        self.rows = x.numel // self.c
-        super().__init__(g, name, [x] + ([bias] if bias is not None else []), [_new(x.shape, name + ':0')])
+        self.xp = x.shape[-1]                                  # channel pitch of x
+        self.c = x.valid_c or x.shape[-1]
+        self.rows = x.numel // self.xp
+        to_f32 = head and half_mode()
+        y = _new(x.shape[:-1] + (self.c,), name + ':0') if to_f32 else _new(x.shape, name + ':0', x.dtype)
+        if not to_f32:
+            y.valid_c = x.valid_c
+        self.yp = y.shape[-1]
+        super().__init__(g, name, [x] + ([bias] if bias is not None else []), [y])
         self.has_bias = bias is not None
 
     def bind(self, rt):
-        x = self.inputs[0]
+        x, y = self.inputs[0], self.outputs[0]
         pb = _p(self.inputs[1].buf) if self.has_bias else None
-        args = (_p(x.buf), pb, _p(self.outputs[0].buf), self.rows, self.c, _ACT_CODE[self.act], self.leak, ACG_F32)
+        args = (_p(x.buf), pb, _p(y.buf), self.rows, self.c, self.xp, self.yp, _ACT_CODE[self.act], self.leak, _code2(x, y))
         fn = rt.lib.bias_act_fwd
         return lambda s: fn(*args, s)
 
@@ -483,12 +578,14 @@ class BiasActOp(G.Op):
         if self.has_bias and needs[1] and ctx.wants(self.inputs[1]):
             dst, acc = ctx.slot(self.inputs[1])
         want_dx = needs[0]
-        if dst is None and self.act is None:
+        x, y = self.inputs[0], self.outputs[0]
+        same = x.dtype == y.dtype and x.shape == y.shape       # dx == dy when there is no activation either
+        if dst is None and self.act is None and same:
             return [dy if want_dx else None] + ([None] if self.has_bias else [])
         op = BiasActBwdOp(self, dy, dst, acc, want_dx, self.name + '/bwd')
         if dst is not None:
             ctx.wrote(self.inputs[1], op)
-        dx = (dy if self.act is None else op.dx) if want_dx else None
+        dx = (dy if (self.act is None and same) else op.dx) if want_dx else None
         return [dx] + ([None] if self.has_bias else [])
 
 
@@ -496,7 +593,11 @@ class BiasActBwdOp(G.Op):
     def __init__(self, fwd, dy, dbias_dst, accumulate, want_dx, name):
         g = G.get_default_graph()
         self.fwd, self.accumulate = fwd, float(accumulate)
-        self.dx = _new(dy.shape, name + ':0') if (want_dx and fwd.act is not None) else None
+        x, y = fwd.inputs[0], fwd.outputs[0]
+        same = x.dtype == y.dtype and x.shape == y.shape
+        self.dx = _new(x.shape, name + ':0', x.dtype) if (want_dx and (fwd.act is not None or not same)) else None
+        if self.dx is not None:
+            self.dx.valid_c = x.valid_c
         self.dbias = dbias_dst
         outs = [t for t in (self.dx, self.dbias) if t is not None]
         super().__init__(g, name, [fwd.outputs[0], dy], outs)
@@ -507,21 +608,27 @@ class BiasActBwdOp(G.Op):
         self._keep = ws
         y, dy = self.inputs
         args = (_p(y.buf), _p(dy.buf), _p(self.dx.buf) if self.dx is not None else None,
-                _p(self.dbias.buf) if self.dbias is not None else None, self.accumulate, f.rows, f.c,
-                _ACT_CODE[f.act], f.leak, ACG_F32, _p(ws), n)
+                _p(self.dbias.buf) if self.dbias is not None else None, self.accumulate, f.rows, f.c, f.xp, f.yp,
+                _ACT_CODE[f.act], f.leak, _code2(f.inputs[0], y), _p(ws), n)
         fn = lib.bias_act_bwd
         return lambda s: fn(*args, s)
 
 
 class DnaOp(G.Op):
-    def __init__(self, logits, image, ksize, name):
+    """softmax(logits + bias) and the k x k gather in one kernel; ``bias`` (may be None) is the bias variable of the
+    layer that produced the logits, folded in here instead of a pass of its own over the logits tensor."""
+
+    def __init__(self, logits, image, ksize, name, bias=None):
         self.ksize = int(ksize)
-        super().__init__(G.get_default_graph(), name, [logits, image], [_new(image.shape, name + ':0')])
+        self.has_bias = bias is not None
+        super().__init__(G.get_default_graph(), name, [logits, image] + ([bias] if bias is not None else []),
+                         [_new(image.shape, name + ':0')])
 
     def bind(self, rt):
-        lg, img = self.inputs
+        lg, img = self.inputs[:2]
         b, h, w, c = img.shape
-        args = (_p(lg.buf), _p(img.buf), _p(self.outputs[0].buf), b, h, w, c, self.ksize, ACG_F32)
+        pb = _p(self.inputs[2].buf) if self.has_bias else None
+        args = (_p(lg.buf), pb, _p(img.buf), _p(self.outputs[0].buf), b, h, w, c, self.ksize, _code(lg))
         fn = rt.lib.dna_fwd
         return lambda s: fn(*args, s)
 
@@ -529,19 +636,34 @@ class DnaOp(G.Op):
         if needs[1]:
             raise NotImplementedError('dna_gather: gradient w.r.t. the image is not part of the hot path '
                                       '(the image is a network input, train.py:53-54)')
-        return [DnaBwdOp(self, gouts[0], self.name + '/bwd').outputs[0] if needs[0] else None, None]
+        dst, acc = (None, 0.0)
+        if self.has_bias and needs[2] and ctx.wants(self.inputs[2]):
+            dst, acc = ctx.slot(self.inputs[2])
+        if not needs[0] and dst is None:
+            return [None] * len(self.inputs)
+        op = DnaBwdOp(self, gouts[0], dst, acc, self.name + '/bwd')
+        if dst is not None:
+            ctx.wrote(self.inputs[2], op)
+        return [op.outputs[0] if needs[0] else None, None] + ([None] if self.has_bias else [])
 
 
 class DnaBwdOp(G.Op):
-    def __init__(self, fwd, dout, name):
-        self.fwd = fwd
-        lg, img = fwd.inputs
-        super().__init__(G.get_default_graph(), name, [lg, img, dout], [_new(lg.shape, name + ':0')])
+    def __init__(self, fwd, dout, dbias_dst, accumulate, name):
+        self.fwd, self.accumulate, self.dbias = fwd, float(accumulate), dbias_dst
+        lg, img = fwd.inputs[:2]
+        dlg = _new(lg.shape, name + ':0', lg.dtype)
+        dlg.valid_c = lg.valid_c
+        super().__init__(G.get_default_graph(), name, [lg, img, dout] + list(fwd.inputs[2:]),
+                         [dlg] + ([dbias_dst] if dbias_dst is not None else []))
 
     def bind(self, rt):
-        lg, img, dout = self.inputs
+        lg, img, dout = self.inputs[:3]
         b, h, w, c = img.shape
-        args = (_p(lg.buf), _p(img.buf), _p(dout.buf), _p(self.outputs[0].buf), b, h, w, c, self.fwd.ksize, ACG_F32)
+        pb = _p(self.inputs[3].buf) if self.fwd.has_bias else None
+        ws, n = rt.workspace(rt.lib.dna_workspace_bytes(b, h, w, self.fwd.ksize)) if self.dbias is not None else (None, 0)
+        self._keep = ws
+        args = (_p(lg.buf), pb, _p(img.buf), _p(dout.buf), _p(self.outputs[0].buf), _p(self.dbias.buf) if self.dbias is not None else None,
+                self.accumulate, b, h, w, c, self.fwd.ksize, _code(lg), _p(ws) if ws is not None else None, n)
         fn = rt.lib.dna_bwd
         return lambda s: fn(*args, s)
 
@@ -616,8 +738,8 @@ class ConcatActionsOp(G.Op):
         if len(actions.shape) != 2 or actions.shape[0] != b:
             raise ValueError('concat_actions: actions must be [batch, A], got %s' % (actions.shape,))
         csum = c + actions.shape[1]
-        self.pitch = -(-csum // 4) * 4
-        y = _new((b, h, w, self.pitch), name + ':0')
+        self.pitch = cpad(csum)
+        y = _new((b, h, w, self.pitch), name + ':0', x.dtype)
         if self.pitch != csum:
             y.valid_c = csum
         super().__init__(G.get_default_graph(), name, [x, actions], [y])
@@ -625,7 +747,7 @@ class ConcatActionsOp(G.Op):
     def bind(self, rt):
         x, a = self.inputs
         b, h, w, c = x.shape
-        args = (_p(x.buf), _p(a.buf), _p(self.outputs[0].buf), b, h * w, c, a.shape[1], self.pitch, ACG_F32)
+        args = (_p(x.buf), _p(a.buf), _p(self.outputs[0].buf), b, h * w, c, a.shape[1], self.pitch, _code(x))
         fn = rt.lib.concat_actions_fwd
         return lambda s: fn(*args, s)
 
@@ -633,13 +755,14 @@ class ConcatActionsOp(G.Op):
         if needs[1]:
             raise NotImplementedError('concat_actions: actions are inputs, no gradient path')
         x = self.inputs[0]
-        return [SliceOp(gouts[0], 0, x.shape[-1], x.shape, self.name + '/bwd').outputs[0] if needs[0] else None, None]
+        return [SliceOp(gouts[0], 0, x.shape[-1], x.shape, self.name + '/bwd', x.dtype).outputs[0] if needs[0] else None, None]
 
 
 class ConcatChannelsOp(G.Op):
-    """a ++ b on the channel axis; ``pitch`` > ca+cb stores the result with zero pad channels (``valid_c`` set)."""
+    """a ++ b on the channel axis; ``pitch`` > ca+cb stores the result with zero pad channels (``valid_c`` set);
+    ``act``: the result is an activation (the conv-facing discriminator input: bf16 in a bf16 graph)."""
 
-    def __init__(self, a, b, name, out=None, pitch=0):
+    def __init__(self, a, b, name, out=None, pitch=0, act=False):
         if a.shape[:-1] != b.shape[:-1]:
             raise ValueError('concat: leading dimensions differ: %s vs %s' % (a.shape, b.shape))
         if a.valid_c or b.valid_c:
@@ -651,7 +774,9 @@ class ConcatChannelsOp(G.Op):
         if out is not None and out.shape != shape:
             raise ValueError('concat: out has shape %s, expected %s' % (out.shape, shape))
         self.pitch = pitch if pitch and pitch != csum else 0
-        y = out if out is not None else _new(shape, name + ':0')
+        if a.dtype != b.dtype:
+            raise ValueError('concat: %s vs %s' % (a.dtype, b.dtype))
+        y = out if out is not None else _new(shape, name + ':0', act_dtype() if act else a.dtype)
         if self.pitch:
             y.valid_c = csum
         super().__init__(G.get_default_graph(), name, [a, b], [y])
@@ -659,14 +784,14 @@ class ConcatChannelsOp(G.Op):
     def bind(self, rt):
         a, b = self.inputs
         args = (_p(a.buf), _p(b.buf), _p(self.outputs[0].buf), a.numel // a.shape[-1], a.shape[-1], b.shape[-1], self.pitch,
-                ACG_F32)
+                _code2(a, self.outputs[0]))
         fn = rt.lib.concat_channels_fwd
         return lambda s: fn(*args, s)
 
     def grad(self, gouts, needs, ctx):
         a, b = self.inputs
-        ga = SliceOp(gouts[0], 0, a.shape[-1], a.shape, self.name + '/bwd_a').outputs[0] if needs[0] else None
-        gb = SliceOp(gouts[0], a.shape[-1], b.shape[-1], b.shape, self.name + '/bwd_b').outputs[0] if needs[1] else None
+        ga = SliceOp(gouts[0], 0, a.shape[-1], a.shape, self.name + '/bwd_a', a.dtype).outputs[0] if needs[0] else None
+        gb = SliceOp(gouts[0], a.shape[-1], b.shape[-1], b.shape, self.name + '/bwd_b', b.dtype).outputs[0] if needs[1] else None
         return [ga, gb]
 
 
@@ -687,13 +812,13 @@ class JoinOp(G.Op):
         return out
 
 
-def batch_join(producers, part_shape, name='batch_join'):
+def batch_join(producers, part_shape, name='batch_join', act=False):
     """Join equally shaped tensors along the batch axis without a copy.
 
     ``producers`` are callables ``f(out)`` that build the op writing one part into the window ``out``.
-    Returns ``(whole, parts)``."""
+    Returns ``(whole, parts)``.  ``act``: the joined tensor is an activation (graph activation type)."""
     n = len(producers)
-    whole = _new((part_shape[0] * n,) + tuple(part_shape[1:]), name + ':0')
+    whole = _new((part_shape[0] * n,) + tuple(part_shape[1:]), name + ':0', act_dtype() if act else torch.float32)
     numel = 1
     for d in part_shape:
         numel *= d
@@ -708,27 +833,29 @@ def batch_join(producers, part_shape, name='batch_join'):
 
 
 class SliceOp(G.Op):
-    def __init__(self, src, c_off, c_dst, out_shape, name):
+    def __init__(self, src, c_off, c_dst, out_shape, name, dtype=None):
         self.c_off, self.c_dst = int(c_off), int(c_dst)
-        super().__init__(G.get_default_graph(), name, [src], [_new(out_shape, name + ':0')])
+        super().__init__(G.get_default_graph(), name, [src], [_new(out_shape, name + ':0', dtype or src.dtype)])
 
     def bind(self, rt):
         src = self.inputs[0]
         cs = src.shape[-1]
-        args = (_p(src.buf), _p(self.outputs[0].buf), 0.0, src.numel // cs, cs, self.c_off, self.c_dst, ACG_F32)
+        args = (_p(src.buf), _p(self.outputs[0].buf), 0.0, src.numel // cs, cs, self.c_off, self.c_dst, _code2(src, self.outputs[0]))
         fn = rt.lib.slice_channels
         return lambda s: fn(*args, s)
 
 
 class AddOp(G.Op):
     def __init__(self, a, b, name='grad_add'):
-        if a.numel != b.numel:
-            raise ValueError('add: %s vs %s' % (a.shape, b.shape))
-        super().__init__(G.get_default_graph(), name, [a, b], [_new(a.shape, name + ':0')])
+        if a.numel != b.numel or a.dtype != b.dtype:
+            raise ValueError('add: %s %s vs %s %s' % (a.shape, a.dtype, b.shape, b.dtype))
+        y = _new(a.shape, name + ':0', a.dtype)
+        y.valid_c = a.valid_c
+        super().__init__(G.get_default_graph(), name, [a, b], [y])
 
     def bind(self, rt):
         a, b = self.inputs
-        args = (_p(a.buf), _p(b.buf), _p(self.outputs[0].buf), a.numel, ACG_F32)
+        args = (_p(a.buf), _p(b.buf), _p(self.outputs[0].buf), a.numel, _code(a))
         fn = rt.lib.add
         return lambda s: fn(*args, s)
 
@@ -782,13 +909,15 @@ def batch_norm(inputs, decay=0.999, center=True, scale=False, epsilon=0.001, act
     if not is_training:
         raise ValueError('batch_norm: the reference never leaves training mode (moving averages are never updated)')
     act = _act_of(activation_fn)
-    c = inputs.shape[-1]
+    c = inputs.valid_c or inputs.shape[-1]
     with variable_scope(scope or 'BatchNorm', reuse=reuse):
         beta = G.get_default_graph().get_variable(_scope_name('beta'), (c,), zeros_initializer(), _scope_reuse())
         name = _scope_name()
     fused = act if act is not None else (None, 0.0)
     dp = G.get_default_graph().collections.get('data_parallel')
     if dp is not None and getattr(dp, 'sync_bn', False) and dp.active:
+        if half_mode():
+            raise NotImplementedError('synchronised BatchNorm (exact-global-batch validation mode) is float32 only')
         # statistics of the global batch: moments -> all-reduce (host) -> apply (SURVEY 8(e) caveat 1)
         mom = BnMomentsOp(inputs, groups, name + '/moments').outputs[0]
         gmom = BnMomentsAllReduceOp(mom, groups, c, name + '/moments_allreduce').outputs[0]
@@ -806,6 +935,11 @@ def _layer(inputs, num_outputs, kernel_size, stride, padding, activation_fn, nor
     cin = inputs.valid_c or cphys              # padded channel pitch: the filter sees the logical channels only
     pitch = cphys if cin != cphys else 0
     g = G.get_default_graph()
+    if half_mode():
+        if inputs.dtype != torch.bfloat16 or cphys != cpad(cin):
+            raise ValueError('%s: in a bf16 graph a conv layer reads a bf16 activation stored at the channel pitch round8(C) '
+                             '(got %s, %d channels at pitch %d)' % (scope or default_scope, inputs.dtype, cin, cphys))
+        pitch = 0                              # implied: the bf16 kernels address every activation at round8(C)
     with variable_scope(scope or default_scope, reuse=reuse):
         share = _scope_reuse()
         winit = weights_initializer or xavier_initializer()
@@ -829,9 +963,10 @@ def _layer(inputs, num_outputs, kernel_size, stride, padding, activation_fn, nor
             out = normalizer_fn(out, **params)
         else:
             bias = g.get_variable(_scope_name('biases'), (num_outputs,), biases_initializer or zeros_initializer(), share)
+            # a layer without BatchNorm is a head in the reference nets (frame, state, DNA logits): float32 result
             if act is not None:
-                return BiasActOp(out, bias, act[0], act[1], name + '/bias_act').outputs[0]
-            out = BiasActOp(out, bias, None, 0.0, name + '/bias').outputs[0]
+                return BiasActOp(out, bias, act[0], act[1], name + '/bias_act', head=True).outputs[0]
+            out = BiasActOp(out, bias, None, 0.0, name + '/bias', head=True).outputs[0]
         if activation_fn is not None:
             out = BiasActOp(out, None, act[0], act[1], name + '/act').outputs[0] if act is not None else activation_fn(out)
         return out
@@ -860,13 +995,21 @@ def dna_gather(logits, image, ksize=DNA_KERN_SIZE, name='dna'):
     """models.py:60-72 in one op: softmax over the k*k logits, then the per-pixel k x k gather of ``image``."""
     _check_nhwc(logits, 'dna_gather')
     _check_nhwc(image, 'dna_gather')
-    if logits.shape[:3] != image.shape[:3] or logits.shape[3] != ksize * ksize:
+    if logits.shape[:3] != image.shape[:3] or (logits.valid_c or logits.shape[3]) != ksize * ksize:
         raise ValueError('dna_gather: logits %s do not match image %s with ksize %d' % (logits.shape, image.shape, ksize))
     if not 1 <= ksize <= 11:
         raise ValueError('dna_gather: ksize outside 1..11')
     if not 1 <= image.shape[3] <= 4:
         raise ValueError('dna_gather: image channels outside 1..4')
-    return DnaOp(logits, image, ksize, _scope_name(name)).outputs[0]
+    bias = None
+    prod = logits.op
+    if isinstance(prod, BiasActOp) and prod.act is None and prod.has_bias:
+        # models.py:54-72: the logits come from a layer with a bias and neither BatchNorm nor activation - take its
+        # pre-bias output and fold the bias into the softmax kernel; the bias op itself is never fetched and gets pruned
+        logits, bias = prod.inputs[0], prod.inputs[1]
+    if half_mode() != (logits.dtype == torch.bfloat16):
+        raise ValueError('dna_gather: logits are %s in a %s graph' % (logits.dtype, act_dtype()))
+    return DnaOp(logits, image, ksize, _scope_name(name), bias=bias).outputs[0]
 
 
 RELU_SHIFT = 1e-12                                                # ops.py:13
@@ -894,6 +1037,8 @@ def cdna_transformation(prev_image, cdna_input, num_masks, color_channels, ksize
         raise ValueError('cdna_transformation: cdna_input must be [batch, features], got %s' % (cdna_input.shape,))
     if ksize not in (3, 5, 7) or not 1 <= num_masks <= 32 or not 1 <= color_channels <= 4:
         raise ValueError('cdna_transformation: supports ksize 3/5/7, 1..32 masks, 1..4 colour channels')
+    if half_mode():
+        raise NotImplementedError('cdna_transformation is float32 only (not on the hot path: no reference model calls it)')
     params = fully_connected(cdna_input, ksize * ksize * num_masks, activation_fn=None, scope='cdna_params', reuse=reuse)
     op = CdnaOp(params, prev_image, num_masks, ksize, RELU_SHIFT, _scope_name('cdna'))
     return list(op.outputs[:num_masks])
@@ -905,12 +1050,12 @@ def concat_actions(x, actions, name='concat_actions'):
     return ConcatActionsOp(x, actions, _scope_name(name)).outputs[0]
 
 
-def concat(values, axis=3, name='concat', out=None, pitch=0):
+def concat(values, axis=3, name='concat', out=None, pitch=0, act=False):
     """tf.concat on the channel axis (train.py:64,68); ``out`` lets the result land in a window of a larger tensor,
-    ``pitch`` stores it with zero pad channels up to that channel pitch."""
+    ``pitch`` stores it with zero pad channels up to that channel pitch, ``act`` in the graph's activation type."""
     if axis not in (3, -1) or len(values) != 2:
         raise ValueError('concat: only two tensors on the channel axis are supported')
-    return ConcatChannelsOp(values[0], values[1], _scope_name(name), out=out, pitch=pitch).outputs[0]
+    return ConcatChannelsOp(values[0], values[1], _scope_name(name), out=out, pitch=pitch, act=act).outputs[0]
 
 
 def repeat_batch(x, times, name='repeat_batch'):

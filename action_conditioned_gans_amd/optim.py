@@ -93,9 +93,19 @@ class StepOp(G.Op):
         super().__init__(flat_param.graph, opt.name + '/update', [flat_param, flat_grad] + slots, [], control_inputs=deps)
         self.opt, self.scope, self.var_names, self.grad_scale = opt, scope, list(var_names), grad_scale
         self.program_clip = None
+        self.extras = [t for t3 in flat_param.graph.weight_copies.get(scope, []) for t in t3[1:]]
 
     def bind(self, rt):
-        return self.opt._bind_step(rt, self, self.program_clip)
+        step = self.opt._bind_step(rt, self, self.program_clip)
+        # bf16 pipeline: the conv kernels read bf16 copies of the filters - refreshed right behind the update, one launch
+        prep = O.prepare_weights_launch(rt, self.graph, self.scope)
+        if prep is None:
+            return step
+
+        def launch(s):
+            step(s)
+            prep(s)
+        return launch
 
 
 class ClipOp(G.Op):
@@ -111,7 +121,14 @@ class ClipOp(G.Op):
     def bind(self, rt):
         args = (_p(self.var.buf), self.var.numel, self.lo, self.hi)
         fn = rt.lib.clip
-        return lambda s: fn(*args, s)
+        if getattr(self.var, 'copies', None) is None:
+            return lambda s: fn(*args, s)
+        prep = O.prepare_weights_launch(rt, self.graph, self.var.scope)    # a standalone clip changes a filter: refresh
+
+        def launch(s):
+            fn(*args, s)
+            prep(s)
+        return launch
 
 
 def clip_by_value_assign(var, lo, hi):

@@ -48,7 +48,7 @@ class Trainer:
 
         self.img_ph = G.placeholder((B, S, S, 3), name='current_frame')
         # the same frames with a channel pitch of 4 (zero pad channel): lets g/conv1 gather with 16-byte loads
-        self.img_ph.padded = self._img_pad = G.placeholder((B, S, S, 3), name='current_frame_pitch4', channel_pitch=4)
+        self.img_ph.padded = self._img_pad = G.placeholder((B, S, S, 3), name='current_frame_conv', channel_pitch=O.cpad(3), act=True)
         self.next_frame_ph = G.placeholder((B, S, S, 3), name='next_frame')
         self.action_ph = G.placeholder((B, ACTION_DIM), name='action')
         self.next_state = G.placeholder((B, STATE_DIM), name='next_state')
@@ -67,12 +67,12 @@ class Trainer:
         # launches.  The G step still uses the batch-B D(fake) graph (D(real) is pruned there anyway).
         if batched_d:
             d_in_both, (d_in_gen, d_in_real) = O.batch_join(
-                [lambda out: O.concat([self.img_ph, self.g_next_frame], axis=3, name='d_in_gen', out=out, pitch=8),
-                 lambda out: O.concat([self.img_ph, self.next_frame_ph], axis=3, name='d_in_real', out=out, pitch=8)],
-                (B, S, S, 8), name='d_in_both')          # 6 channels at a pitch of 8: 16-byte gathers in d/conv1
+                [lambda out: O.concat([self.img_ph, self.g_next_frame], axis=3, name='d_in_gen', out=out, pitch=8, act=True),
+                 lambda out: O.concat([self.img_ph, self.next_frame_ph], axis=3, name='d_in_real', out=out, pitch=8, act=True)],
+                (B, S, S, 8), name='d_in_both', act=True)          # 6 channels at a pitch of 8: 16-byte gathers in d/conv1
         else:
-            d_in_gen = O.concat([self.img_ph, self.g_next_frame], axis=3, name='d_in_gen', pitch=8)
-            d_in_real = O.concat([self.img_ph, self.next_frame_ph], axis=3, name='d_in_real', pitch=8)
+            d_in_gen = O.concat([self.img_ph, self.g_next_frame], axis=3, name='d_in_gen', pitch=8, act=True)
+            d_in_real = O.concat([self.img_ph, self.next_frame_ph], axis=3, name='d_in_real', pitch=8, act=True)
         self.d_out_gen = M.build_discriminator(d_in_gen, self.action_ph, reuse=False)
         if batched_d:
             with O.arg_scope([O.batch_norm], groups=2):

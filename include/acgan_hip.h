@@ -16,10 +16,14 @@
  *     safe to capture into a hipGraph.
  *   - Return 0 (ACG_OK) on success, an ACG_ERR_* code otherwise; the message is available
  *     from acg_last_error() (thread-local).  No global mutable state besides that.
- *   - `dtype` selects the arithmetic of the conv contractions: ACG_F32 = exact fp32 matrix cores;
- *     ACG_BF16 = operands rounded to bfloat16 (round-to-nearest-even) as they are staged for the bf16
- *     matrix cores, float32 accumulation.  Tensors are float32 in memory in both cases; every other
- *     entry point accepts ACG_F32 only.
+ *   - `dtype` is the STORAGE type of the activation-class tensors of a call (x, y, dy, dx ...): ACG_F32, or
+ *     ACG_BF16 = bfloat16 in memory (BASELINE configs 3 and 5).  bf16 activations are stored at the channel pitch
+ *     round8(C) with zero pad channels, so that every 16-byte unit is 8 channels of one pixel.  The conv entry
+ *     points then contract on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, float32 accumulation) and take
+ *     their filter operand from the bf16 copies made by acg_weights_prepare_bf16; weight gradients, BatchNorm
+ *     statistics, losses and optimizer state stay float32.  Where a call has two activation tensors of different
+ *     type, `dtype` carries both: ACG_DTYPE2(first, second), documented per entry (plain ACG_F32 / ACG_BF16 mean
+ *     "both").
  */
 #ifndef ACGAN_HIP_H
 #define ACGAN_HIP_H
@@ -37,6 +41,7 @@ typedef void* acg_stream_t; /* hipStream_t */
 
 enum { ACG_OK = 0, ACG_ERR_INVALID_ARG = 1, ACG_ERR_WORKSPACE = 2, ACG_ERR_LAUNCH = 3, ACG_ERR_UNSUPPORTED = 4 };
 enum { ACG_F32 = 0, ACG_BF16 = 1 };
+#define ACG_DTYPE2(first, second) ((first) | ((second) << 4) | 0x100)   /* two storage types in one dtype argument */
 enum { ACG_ACT_NONE = 0, ACG_ACT_RELU = 1, ACG_ACT_LRELU = 2, ACG_ACT_TANH = 3 };
 enum { ACG_CONV_FWD = 0, ACG_CONV_DGRAD = 1, ACG_CONV_WGRAD = 2 };
 
@@ -69,6 +74,21 @@ int32_t acg_conv_desc_init(acg_conv_desc* d, int32_t batch, int32_t in_h, int32_
                            int32_t kh, int32_t kw, int32_t out_c, int32_t stride, int32_t same_padding);
 
 size_t acg_conv2d_workspace_bytes(const acg_conv_desc* d, int32_t which /* ACG_CONV_* */, int32_t dtype);
+
+/* bf16 operand copies of the float32 master filters (dtype = ACG_BF16 conv entries).  A filter [kh,kw,A,B] - HWIO of
+ * a conv layer, TF's [kh,kw,Cout,Cin] of a conv2d_transpose layer - gets two copies, zero padded to multiples of 8:
+ *   rm [kh*kw][A][round8(B)]   the operand of acg_conv2d_dgrad and acg_deconv2d_fwd
+ *   tr [kh*kw][B][round8(A)]   the operand of acg_conv2d_fwd and acg_deconv2d_dgrad
+ * (each is k-fast for its contraction: one 16-byte load = 8 consecutive reduction indices).  All filters of a network
+ * in ONE launch, behind the optimizer update of train.py:100-102. */
+#define ACG_PREP_MAX 32
+typedef struct acg_prep_list {
+  const void* src[ACG_PREP_MAX]; /* float32 [taps][a][b] */
+  void* rm[ACG_PREP_MAX];
+  void* tr[ACG_PREP_MAX];
+  int32_t taps[ACG_PREP_MAX], a[ACG_PREP_MAX], b[ACG_PREP_MAX];
+} acg_prep_list;
+int32_t acg_weights_prepare_bf16(const acg_prep_list* list, int32_t count, acg_stream_t stream);
 
 /* Tuning hook (process-wide, not for production use): force the tile configuration (0: 128x128, 1: 128x64,
  * 2: 128x32, 3: 64x64) and/or the split-K factor chosen by the planner; -1 restores the heuristic.
@@ -166,36 +186,50 @@ int32_t acg_bn_act_bwd_sums(const void* x, const void* dy, const float* beta, co
  * launch while keeping separate batch statistics).  save_mean/save_rstd: [groups*channels].
  *   y = act((x - mean) * rsqrt(var + eps) + beta),  var biased.
  * bwd:  dbeta = dbeta_accumulate * dbeta + sum(dpre),  dx through mean and variance.
+ * dtype: storage of x / dx, or ACG_DTYPE2(x, y) with y / dy the second type (ACG_DTYPE2(ACG_BF16, ACG_F32): the
+ * loss-facing d/conv6 of a bf16 network keeps float32 logits).  Statistics, beta and dbeta are float32.
+ * x / dx rows are x_pitch elements apart, y / dy rows y_pitch (0 = dense = channels): the one-channel bf16 output of
+ * d/conv6 sits at a pitch of 8; pad channels are neither read nor written.
  * ---------------------------------------------------------------------------------------- */
 size_t acg_bn_workspace_bytes(int64_t rows, int32_t channels, int32_t groups);
 int32_t acg_bn_act_fwd(const void* x, const float* beta, void* y, float* save_mean, float* save_rstd,
-                       int64_t rows, int32_t channels, int32_t groups, float eps, int32_t act, float leak,
-                       int32_t dtype, void* workspace, size_t workspace_bytes, acg_stream_t stream);
+                       int64_t rows, int32_t channels, int32_t x_pitch, int32_t y_pitch, int32_t groups, float eps,
+                       int32_t act, float leak, int32_t dtype, void* workspace, size_t workspace_bytes,
+                       acg_stream_t stream);
 int32_t acg_bn_act_bwd(const void* x, const void* dy, const float* beta, const float* save_mean,
                        const float* save_rstd, void* dx, float* dbeta, float dbeta_accumulate,
-                       int64_t rows, int32_t channels, int32_t groups, int32_t act, float leak,
-                       int32_t dtype, void* workspace, size_t workspace_bytes, acg_stream_t stream);
+                       int64_t rows, int32_t channels, int32_t x_pitch, int32_t y_pitch, int32_t groups, int32_t act,
+                       float leak, int32_t dtype, void* workspace, size_t workspace_bytes, acg_stream_t stream);
 
 /* Layers built with normalizer_fn=None: y = act(x + bias)   (models.py:20-21,44-51,54-59).
- * bwd takes the forward OUTPUT y; dx may be NULL when act == ACG_ACT_NONE (dx == dy).
- * bias == NULL (fwd) / dbias == NULL (bwd) give the plain activation (ops.py:22-26 lrelu called on its own). */
+ * bwd takes the forward OUTPUT y; dx may be NULL when act == ACG_ACT_NONE and x, y share type and pitch (dx == dy).
+ * bias == NULL (fwd) / dbias == NULL (bwd) give the plain activation (ops.py:22-26 lrelu called on its own).
+ * x / dx rows are x_pitch elements apart, y / dy rows y_pitch (0 = dense = channels).  dtype = storage of x / dx, or
+ * ACG_DTYPE2(x, y): a bf16 conv output (pitch round8) becoming the float32 dense frame or state the losses read. */
 size_t acg_bias_workspace_bytes(int64_t rows, int32_t channels);
-int32_t acg_bias_act_fwd(const void* x, const float* bias, void* y, int64_t rows, int32_t channels,
-                         int32_t act, float leak, int32_t dtype, acg_stream_t stream);
+int32_t acg_bias_act_fwd(const void* x, const float* bias, void* y, int64_t rows, int32_t channels, int32_t x_pitch,
+                         int32_t y_pitch, int32_t act, float leak, int32_t dtype, acg_stream_t stream);
 int32_t acg_bias_act_bwd(const void* y, const void* dy, void* dx, float* dbias, float dbias_accumulate,
-                         int64_t rows, int32_t channels, int32_t act, float leak, int32_t dtype,
-                         void* workspace, size_t workspace_bytes, acg_stream_t stream);
+                         int64_t rows, int32_t channels, int32_t x_pitch, int32_t y_pitch, int32_t act, float leak,
+                         int32_t dtype, void* workspace, size_t workspace_bytes, acg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dynamic Neural Advection tail, models.py:60-72 (softmax + extract_image_patches + mul + sum):
  *   out[b,y,x,c] = sum_{i,j} softmax(logits[b,y,x,:])[i*k+j] * image[b, y-p+i, x-p+j, c],
  *   p = (k-1)/2, zero outside the image.   logits [B,H,W,k*k], image/out [B,H,W,C], C <= 4.
  * bwd produces dlogits only (the image is a network input, train.py:53-54).
+ * `bias` (float32 [k*k], may be NULL) folds in the bias of the layer that produces the logits - g/tconv4 has neither
+ * BatchNorm nor activation (models.py:54-59) - i.e. the kernels take softmax(logits + bias) and backward also yields
+ *   dbias = dbias_accumulate * dbias + sum over pixels of dlogits      (dbias may be NULL; workspace needed otherwise).
+ * dtype: storage of logits / dlogits; ACG_BF16 rows are round8(k*k) elements apart (pad taps are not written).
+ * image, out and dout are float32.
  * ---------------------------------------------------------------------------------------- */
-int32_t acg_dna_fwd(const void* logits, const void* image, void* out, int32_t batch, int32_t h, int32_t w,
-                    int32_t c, int32_t ksize, int32_t dtype, acg_stream_t stream);
-int32_t acg_dna_bwd(const void* logits, const void* image, const void* dout, void* dlogits, int32_t batch,
-                    int32_t h, int32_t w, int32_t c, int32_t ksize, int32_t dtype, acg_stream_t stream);
+size_t acg_dna_workspace_bytes(int32_t batch, int32_t h, int32_t w, int32_t ksize);
+int32_t acg_dna_fwd(const void* logits, const float* bias, const void* image, void* out, int32_t batch, int32_t h,
+                    int32_t w, int32_t c, int32_t ksize, int32_t dtype, acg_stream_t stream);
+int32_t acg_dna_bwd(const void* logits, const float* bias, const void* image, const void* dout, void* dlogits,
+                    float* dbias, float dbias_accumulate, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ksize,
+                    int32_t dtype, void* workspace, size_t workspace_bytes, acg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * CDNA transformation (reference ops.py:52-98, the unused sibling of the DNA tail).
@@ -223,11 +257,12 @@ int32_t acg_cdna_bwd(const void* params, const float* kern_norm, const void* ima
  * (0 = dense = c+a), pad channels are not written */
 int32_t acg_concat_actions_fwd(const void* x, const float* actions, void* y, int32_t batch, int32_t hw,
                                int32_t c, int32_t a, int32_t y_pitch, int32_t dtype, acg_stream_t stream);
-/* y[r,0:ca] = a[r,:], y[r,ca:ca+cb] = b[r,:]; y rows are y_pitch floats apart (0 = dense = ca+cb); pad channels
- * are not written.  cb may be 0 (b ignored): a plain re-pitching copy. */
+/* y[r,0:ca] = a[r,:], y[r,ca:ca+cb] = b[r,:]; y rows are y_pitch elements apart (0 = dense = ca+cb); pad channels
+ * are not written.  cb may be 0 (b ignored): a plain re-pitching copy.  dtype: storage of a, b and y, or
+ * ACG_DTYPE2(a and b, y) - ACG_DTYPE2(ACG_F32, ACG_BF16) builds the bf16 discriminator input from float32 frames. */
 int32_t acg_concat_channels_fwd(const void* a, const void* b, void* y, int64_t rows, int32_t ca, int32_t cb,
                                 int32_t y_pitch, int32_t dtype, acg_stream_t stream);
-/* dst[r,:] = accumulate * dst[r,:] + src[r, c_off : c_off + c_dst] */
+/* dst[r,:] = accumulate * dst[r,:] + src[r, c_off : c_off + c_dst]; dtype: storage of both, or ACG_DTYPE2(src, dst) */
 int32_t acg_slice_channels(const void* src, void* dst, float accumulate, int64_t rows, int32_t c_src,
                            int32_t c_off, int32_t c_dst, int32_t dtype, acg_stream_t stream);
 /* Stream-ordering edge "everything enqueued on `from` so far happens before what is enqueued on `to` from now on",
@@ -251,6 +286,7 @@ typedef struct acg_copy_list {
   int64_t rows[ACG_COPY_MAX];
   int32_t cols[ACG_COPY_MAX];
   int32_t dst_pitch[ACG_COPY_MAX];
+  int32_t dst_dtype[ACG_COPY_MAX]; /* ACG_F32, or ACG_BF16: the float32 source is rounded into a bf16 placeholder */
 } acg_copy_list;
 int32_t acg_copy_many(const acg_copy_list* list, int32_t count, int32_t dtype, acg_stream_t stream);
 /* y = a + b (gradient fan-in where one tensor feeds two consumers, models.py:40-53) */

@@ -155,6 +155,10 @@ int32_t acg_deconv2d_bwd_pair(const void* dy, const void* w, const void* x, void
   return slabs_only ? acg_deconv2d_wgrad_slabs(x, dy, adj, dtype, wsw, wsbw, s) : acg_deconv2d_wgrad(x, dy, dw, acc, adj, dtype, wsw, wsbw, s);
 }
 
+int32_t acg_weights_prepare_bf16(const acg_prep_list* l, int32_t count, acg_stream_t s) {
+  (void)l; (void)count; (void)s;
+  return fail(ACG_ERR_UNSUPPORTED, "cpu oracle: float32 only");
+}
 int32_t acg_splitk_reduce_many(const acg_reduce_list* l, int32_t count, acg_stream_t s) {
   (void)s;
   if (!l || count < 1 || count > ACG_REDUCE_MAX) return fail(ACG_ERR_INVALID_ARG, "splitk_reduce_many: 1..32 entries");
@@ -201,43 +205,45 @@ static double act_df(int act, double u, double leak) {
 /* slim.batch_norm training mode, SURVEY A.4 */
 size_t acg_bn_workspace_bytes(int64_t rows, int32_t channels, int32_t groups) { (void)rows; (void)channels; (void)groups; return 0; }
 int32_t acg_bn_act_fwd(const void* xv, const float* beta, void* yv, float* save_mean, float* save_rstd,
-                       int64_t rows, int32_t C, int32_t groups, float eps, int32_t act, float leak,
-                       int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
+                       int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t groups, float eps, int32_t act,
+                       float leak, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
   (void)ws; (void)wsb; (void)s; REQUIRE_F32(dtype);
   if (groups <= 0 || rows % groups) return fail(ACG_ERR_INVALID_ARG, "bn: rows not divisible by groups");
   const float* x = xv; float* y = yv; int64_t R = rows / groups;
+  const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
   for (int g = 0; g < groups; g++) for (int c = 0; c < C; c++) {
-    const float* xg = x + (size_t)g * R * C; float* yg = y + (size_t)g * R * C;
+    const float* xg = x + (size_t)g * R * XP; float* yg = y + (size_t)g * R * YP;
     double m = 0, v = 0;
-    for (int64_t r = 0; r < R; r++) m += xg[r * C + c];
+    for (int64_t r = 0; r < R; r++) m += xg[r * XP + c];
     m /= (double)R;
-    for (int64_t r = 0; r < R; r++) { double t = xg[r * C + c] - m; v += t * t; }
+    for (int64_t r = 0; r < R; r++) { double t = xg[r * XP + c] - m; v += t * t; }
     v /= (double)R;
     double rstd = 1.0 / sqrt(v + (double)eps);
     save_mean[g * C + c] = (float)m; save_rstd[g * C + c] = (float)rstd;
-    for (int64_t r = 0; r < R; r++) yg[r * C + c] = (float)act_f(act, (xg[r * C + c] - m) * rstd + beta[c], leak);
+    for (int64_t r = 0; r < R; r++) yg[r * YP + c] = (float)act_f(act, (xg[r * XP + c] - m) * rstd + beta[c], leak);
   }
   return ACG_OK;
 }
 
 int32_t acg_bn_act_bwd(const void* xv, const void* dyv, const float* beta, const float* save_mean,
                        const float* save_rstd, void* dxv, float* dbeta, float dbeta_acc,
-                       int64_t rows, int32_t C, int32_t groups, int32_t act, float leak,
+                       int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t groups, int32_t act, float leak,
                        int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
   (void)ws; (void)wsb; (void)s; REQUIRE_F32(dtype);
   if (groups <= 0 || rows % groups) return fail(ACG_ERR_INVALID_ARG, "bn: rows not divisible by groups");
   const float* x = xv; const float* dy = dyv; float* dx = dxv; int64_t R = rows / groups;
+  const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
   for (int c = 0; c < C; c++) {
     double db_total = 0;
     for (int g = 0; g < groups; g++) {
-      const float* xg = x + (size_t)g * R * C; const float* dyg = dy + (size_t)g * R * C; float* dxg = dx + (size_t)g * R * C;
+      const float* xg = x + (size_t)g * R * XP; const float* dyg = dy + (size_t)g * R * YP; float* dxg = dx + (size_t)g * R * XP;
       double m = save_mean[g * C + c], rstd = save_rstd[g * C + c], s1 = 0, s2 = 0;
-      for (int64_t r = 0; r < R; r++) { double xh = (xg[r * C + c] - m) * rstd;
-        double dp = dyg[r * C + c] * act_df(act, xh + beta[c], leak); s1 += dp; s2 += dp * xh; }
+      for (int64_t r = 0; r < R; r++) { double xh = (xg[r * XP + c] - m) * rstd;
+        double dp = dyg[r * YP + c] * act_df(act, xh + beta[c], leak); s1 += dp; s2 += dp * xh; }
       db_total += s1;
-      for (int64_t r = 0; r < R; r++) { double xh = (xg[r * C + c] - m) * rstd;
-        double dp = dyg[r * C + c] * act_df(act, xh + beta[c], leak);
-        dxg[r * C + c] = (float)(rstd * (dp - s1 / (double)R - xh * s2 / (double)R)); }
+      for (int64_t r = 0; r < R; r++) { double xh = (xg[r * XP + c] - m) * rstd;
+        double dp = dyg[r * YP + c] * act_df(act, xh + beta[c], leak);
+        dxg[r * XP + c] = (float)(rstd * (dp - s1 / (double)R - xh * s2 / (double)R)); }
     }
     dbeta[c] = (float)((dbeta_acc != 0.f ? (double)dbeta_acc * dbeta[c] : 0.0) + db_total);
   }
@@ -310,31 +316,34 @@ int32_t acg_bn_act_bwd_sums(const void* xv, const void* dyv, const float* beta, 
 }
 
 size_t acg_bias_workspace_bytes(int64_t rows, int32_t channels) { (void)rows; (void)channels; return 0; }
-int32_t acg_bias_act_fwd(const void* xv, const float* bias, void* yv, int64_t rows, int32_t C, int32_t act,
-                         float leak, int32_t dtype, acg_stream_t s) {
+int32_t acg_bias_act_fwd(const void* xv, const float* bias, void* yv, int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch,
+                         int32_t act, float leak, int32_t dtype, acg_stream_t s) {
   (void)s; REQUIRE_F32(dtype);
   const float* x = xv; float* y = yv;
+  const int xp = x_pitch > 0 ? x_pitch : C, yp = y_pitch > 0 ? y_pitch : C;
   for (int64_t r = 0; r < rows; r++) for (int c = 0; c < C; c++)
-    y[r * C + c] = (float)act_f(act, (double)x[r * C + c] + (bias ? bias[c] : 0.f), leak);
+    y[r * yp + c] = (float)act_f(act, (double)x[r * xp + c] + (bias ? bias[c] : 0.f), leak);
   return ACG_OK;
 }
 int32_t acg_bias_act_bwd(const void* yv, const void* dyv, void* dxv, float* dbias, float dbias_acc, int64_t rows,
-                         int32_t C, int32_t act, float leak, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
+                         int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t act, float leak, int32_t dtype, void* ws,
+                         size_t wsb, acg_stream_t s) {
   (void)ws; (void)wsb; (void)s; REQUIRE_F32(dtype);
   const float* y = yv; const float* dy = dyv; float* dx = dxv;
+  const int xp = x_pitch > 0 ? x_pitch : C, yp = y_pitch > 0 ? y_pitch : C;
   if (!dx && act != ACG_ACT_NONE) return fail(ACG_ERR_INVALID_ARG, "bias_act_bwd: dx NULL requires ACG_ACT_NONE");
   for (int c = 0; c < C; c++) {
     double sum = 0;
     for (int64_t r = 0; r < rows; r++) {
-      double yy = y[r * C + c], d;
+      double yy = y[r * yp + c], d;
       switch (act) {                                 /* derivative expressed through the OUTPUT y */
         case ACG_ACT_RELU: d = yy > 0 ? 1 : 0; break;
         case ACG_ACT_LRELU: d = 0.5 * (1 + leak) + 0.5 * (1 - leak) * sgn(yy); break;
         case ACG_ACT_TANH: d = 1 - yy * yy; break;
         default: d = 1;
       }
-      double g = dy[r * C + c] * d; sum += g;
-      if (dx) dx[r * C + c] = (float)g;
+      double g = dy[r * yp + c] * d; sum += g;
+      if (dx) dx[r * xp + c] = (float)g;
     }
     if (dbias) dbias[c] = (float)((dbias_acc != 0.f ? (double)dbias_acc * dbias[c] : 0.0) + sum);
   }
@@ -412,13 +421,16 @@ int32_t acg_cdna_bwd(const void* pv, const float* kern_norm, const void* iv, con
 
 /* ---- DNA tail: models.py:60-72, SURVEY A.7 */
 static int dna_check(int c, int k) { return c >= 1 && c <= 4 && k >= 1 && k <= 15; }
-int32_t acg_dna_fwd(const void* lv, const void* iv, void* ov, int32_t B, int32_t H, int32_t W, int32_t C,
+size_t acg_dna_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t k) { (void)B; (void)H; (void)W; (void)k; return 0; }
+int32_t acg_dna_fwd(const void* lv, const float* bias, const void* iv, void* ov, int32_t B, int32_t H, int32_t W, int32_t C,
                     int32_t k, int32_t dtype, acg_stream_t s) {
   (void)s; REQUIRE_F32(dtype);
   if (!dna_check(C, k)) return fail(ACG_ERR_INVALID_ARG, "dna: need 1<=c<=4, 1<=ksize<=15");
   const float* lg = lv; const float* img = iv; float* out = ov; int kk = k * k, p = (k - 1) / 2;
+  double l[225];
   for (int b = 0; b < B; b++) for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
-    const float* l = lg + (((size_t)b * H + y) * W + x) * kk;
+    const float* l0 = lg + (((size_t)b * H + y) * W + x) * kk;
+    for (int t = 0; t < kk; t++) l[t] = (double)l0[t] + (bias ? (double)bias[t] : 0.0);   /* softmax(logits + bias) */
     double mx = l[0], den = 0, acc[4] = {0, 0, 0, 0};
     for (int t = 1; t < kk; t++) if (l[t] > mx) mx = l[t];
     for (int t = 0; t < kk; t++) den += exp(l[t] - mx);
@@ -431,15 +443,17 @@ int32_t acg_dna_fwd(const void* lv, const void* iv, void* ov, int32_t B, int32_t
   }
   return ACG_OK;
 }
-int32_t acg_dna_bwd(const void* lv, const void* iv, const void* dov, void* dlv, int32_t B, int32_t H, int32_t W,
-                    int32_t C, int32_t k, int32_t dtype, acg_stream_t s) {
-  (void)s; REQUIRE_F32(dtype);
+int32_t acg_dna_bwd(const void* lv, const float* bias, const void* iv, const void* dov, void* dlv, float* dbias, float dbias_acc,
+                    int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
+  (void)s; (void)ws; (void)wsb; REQUIRE_F32(dtype);
   if (!dna_check(C, k)) return fail(ACG_ERR_INVALID_ARG, "dna: need 1<=c<=4, 1<=ksize<=15");
   const float* lg = lv; const float* img = iv; const float* dout = dov; float* dl = dlv; int kk = k * k, p = (k - 1) / 2;
-  double m[225], g[225];
+  double m[225], g[225], l[225], bsum[225];
+  for (int t = 0; t < kk; t++) bsum[t] = 0;
   for (int b = 0; b < B; b++) for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
     size_t pix = ((size_t)b * H + y) * W + x;
-    const float* l = lg + pix * kk; const float* dO = dout + pix * C;
+    const float* l0 = lg + pix * kk; const float* dO = dout + pix * C;
+    for (int t = 0; t < kk; t++) l[t] = (double)l0[t] + (bias ? (double)bias[t] : 0.0);
     double mx = l[0], den = 0, dot = 0;
     for (int t = 1; t < kk; t++) if (l[t] > mx) mx = l[t];
     for (int t = 0; t < kk; t++) { m[t] = exp(l[t] - mx); den += m[t]; }
@@ -449,8 +463,9 @@ int32_t acg_dna_bwd(const void* lv, const void* iv, const void* dov, void* dlv, 
         for (int c = 0; c < C; c++) g[t] += (double)dO[c] * img[(((size_t)b * H + yy) * W + xx) * C + c];
       dot += m[t] * g[t];
     }
-    for (int t = 0; t < kk; t++) dl[pix * kk + t] = (float)(m[t] * (g[t] - dot));
+    for (int t = 0; t < kk; t++) { const double v = m[t] * (g[t] - dot); dl[pix * kk + t] = (float)v; bsum[t] += v; }
   }
+  if (dbias) for (int t = 0; t < kk; t++) dbias[t] = (float)((dbias_acc != 0.f ? (double)dbias_acc * dbias[t] : 0.0) + bsum[t]);
   return ACG_OK;
 }
 
@@ -499,6 +514,7 @@ int32_t acg_copy_many(const acg_copy_list* l, int32_t count, int32_t dtype, acg_
     if (!l->src[i] || !l->dst[i] || l->rows[i] <= 0 || l->cols[i] <= 0) return fail(ACG_ERR_INVALID_ARG, "copy_many: bad segment");
     int pitch = l->dst_pitch[i] > 0 ? l->dst_pitch[i] : l->cols[i];
     if (pitch < l->cols[i]) return fail(ACG_ERR_INVALID_ARG, "copy_many: pitch smaller than the row");
+    if (l->dst_dtype[i] != ACG_F32) return fail(ACG_ERR_UNSUPPORTED, "cpu oracle: float32 only");
     const float* src = l->src[i]; float* dst = l->dst[i];
     for (int64_t r = 0; r < l->rows[i]; r++) for (int c = 0; c < l->cols[i]; c++) dst[r * pitch + c] = src[r * l->cols[i] + c];
   }

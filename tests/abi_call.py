@@ -41,13 +41,46 @@ class Abi:
         if self.device.type == 'cuda':
             torch.cuda.synchronize(self.device)
 
+    # ---- bf16 storage (conv_dtype == ACG_BF16): activations bf16 at pitch round8(C), filters as prepared copies
+    @property
+    def half(self):
+        return self.conv_dtype == L.ACG_BF16
+
+    def to16(self, x):
+        """fp32 [..., C] -> bf16 [..., round8(C)] with zero pad channels."""
+        c = x.shape[-1]
+        out = torch.zeros(*x.shape[:-1], (c + 7) // 8 * 8, dtype=torch.bfloat16, device=self.device)
+        out[..., :c] = x.to(self.device).to(torch.bfloat16)
+        return out
+
+    def from16(self, y, c):
+        return y[..., :c].float()
+
+    def prep_weights(self, w):
+        """acg_weights_prepare_bf16 on one filter [kh,kw,A,B] -> (rm [taps,A,B8], tr [taps,B,A8])."""
+        kh, kw, a, b = w.shape
+        w = w.to(self.device).float().contiguous()
+        rm = torch.full((kh * kw, a, (b + 7) // 8 * 8), float('nan'), dtype=torch.bfloat16, device=self.device)
+        tr = torch.full((kh * kw, b, (a + 7) // 8 * 8), float('nan'), dtype=torch.bfloat16, device=self.device)
+        pl = L.PrepList()
+        pl.src[0], pl.rm[0], pl.tr[0], pl.taps[0], pl.a[0], pl.b[0] = w.data_ptr(), rm.data_ptr(), tr.data_ptr(), kh * kw, a, b
+        self.lib.weights_prepare_bf16(ctypes.byref(pl), 1, self.stream())
+        self._keep16 = (w, rm, tr)
+        return rm, tr
+
     # ---- conv family (x NHWC, w HWIO)
     def conv2d_fwd(self, x, w, stride, padding):
         b, h, wd, c = x.shape
         pitch = c if c != w.shape[2] else 0            # x carries pad channels beyond the filter's Cin
         d = self.desc(b, h, wd, w.shape[2], w.shape[0], w.shape[1], w.shape[3], stride, padding, pitch)
-        y = self.empty(b, d.out_h, d.out_w, d.out_c)
         ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_FWD, self.conv_dtype))
+        if self.half:
+            d.in_pitch = 0
+            x16, (rm, tr) = self.to16(x[..., :d.in_c]), self.prep_weights(w)
+            y = torch.zeros(b, d.out_h, d.out_w, (d.out_c + 7) // 8 * 8, dtype=torch.bfloat16, device=self.device)
+            self.lib.conv2d_fwd(_p(x16), _p(tr), _p(y), ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
+            return self.from16(y, d.out_c)
+        y = self.empty(b, d.out_h, d.out_w, d.out_c)
         self.lib.conv2d_fwd(_p(x), _p(w), _p(y), ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
         return y
 
@@ -57,6 +90,12 @@ class Abi:
         d = self.desc(b, h, wd, w.shape[2], w.shape[0], w.shape[1], w.shape[3], stride, padding, pitch)
         dx = torch.zeros(*x_shape, device=self.device)
         ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_DGRAD, self.conv_dtype))
+        if self.half:
+            d.in_pitch = 0
+            dy16, (rm, tr) = self.to16(dy), self.prep_weights(w)
+            dx16 = torch.zeros(b, h, wd, (d.in_c + 7) // 8 * 8, dtype=torch.bfloat16, device=self.device)
+            self.lib.conv2d_dgrad(_p(dy16), _p(rm), _p(dx16), ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
+            return self.from16(dx16, d.in_c)
         self.lib.conv2d_dgrad(_p(dy), _p(w), _p(dx), ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
         return dx
 
@@ -67,6 +106,9 @@ class Abi:
         if dw is None:
             dw = self.empty(*w_shape)
         ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_WGRAD, self.conv_dtype))
+        if self.half:
+            d.in_pitch = 0
+            x, dy = self.to16(x[..., :d.in_c]), self.to16(dy)
         self.lib.conv2d_wgrad(_p(x), _p(dy), _p(dw), accumulate, ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
         return dw
 
@@ -80,8 +122,14 @@ class Abi:
 
     def deconv2d_fwd(self, x, w, stride):
         d = self._adj(x.shape, w.shape, stride)
-        y = self.empty(d.batch, d.in_h, d.in_w, d.in_c)
         ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_DGRAD, self.conv_dtype))
+        if self.half:
+            d.out_pitch = 0
+            x16, (rm, tr) = self.to16(x[..., :d.out_c]), self.prep_weights(w)
+            y = torch.zeros(d.batch, d.in_h, d.in_w, (d.in_c + 7) // 8 * 8, dtype=torch.bfloat16, device=self.device)
+            self.lib.deconv2d_fwd(_p(x16), _p(rm), _p(y), ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
+            return self.from16(y, d.in_c)
+        y = self.empty(d.batch, d.in_h, d.in_w, d.in_c)
         self.lib.deconv2d_fwd(_p(x), _p(w), _p(y), ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
         return y
 
@@ -89,6 +137,12 @@ class Abi:
         d = self._adj(x_shape, w.shape, stride)
         dx = torch.zeros(*x_shape, device=self.device)
         ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_FWD, self.conv_dtype))
+        if self.half:
+            d.out_pitch = 0
+            dy16, (rm, tr) = self.to16(dy), self.prep_weights(w)
+            dx16 = torch.zeros(*x_shape[:3], (d.out_c + 7) // 8 * 8, dtype=torch.bfloat16, device=self.device)
+            self.lib.deconv2d_dgrad(_p(dy16), _p(tr), _p(dx16), ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
+            return self.from16(dx16, d.out_c)
         self.lib.deconv2d_dgrad(_p(dy), _p(w), _p(dx), ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
         return dx
 
@@ -97,6 +151,9 @@ class Abi:
         if dw is None:
             dw = self.empty(*w_shape)
         ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_WGRAD, self.conv_dtype))
+        if self.half:
+            d.out_pitch = 0
+            x, dy = self.to16(x[..., :d.out_c]), self.to16(dy)
         self.lib.deconv2d_wgrad(_p(x), _p(dy), _p(dw), accumulate, ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
         return dw
 
@@ -146,25 +203,28 @@ class Abi:
         self.lib.splitk_reduce_many(ctypes.byref(rl), len(entries), self.stream())
 
     # ---- bn / bias
-    def bn_act_fwd(self, x, beta, act, groups=1, eps=1e-3, leak=0.2):
-        c = x.shape[-1]
-        rows = x.numel() // c
-        y = torch.empty_like(x)
+    def bn_act_fwd(self, x, beta, act, groups=1, eps=1e-3, leak=0.2, y_dtype=None, c=None):
+        """Storage types follow the tensors: x float32 or bfloat16, y like x unless ``y_dtype`` says otherwise.
+        ``c`` < x.shape[-1]: x rows carry pad channels (pitch x.shape[-1]); y is then dense [.., c]."""
+        xp = x.shape[-1]
+        c = c or xp
+        rows = x.numel() // xp
+        y = torch.zeros(*x.shape[:-1], c, dtype=y_dtype or x.dtype, device=self.device)
         mean, rstd = self.empty(groups * c), self.empty(groups * c)
         ws, n = self.ws(self.lib.bn_workspace_bytes(rows, c, groups))
-        self.lib.bn_act_fwd(_p(x), _p(beta), _p(y), _p(mean), _p(rstd), rows, c, groups, eps, ACT[act], leak,
-                            L.ACG_F32, _p(ws), n, self.stream())
+        self.lib.bn_act_fwd(_p(x), _p(beta), _p(y), _p(mean), _p(rstd), rows, c, xp, c, groups, eps, ACT[act], leak,
+                            L.dtype2(L.code(x.dtype), L.code(y.dtype)), _p(ws), n, self.stream())
         return y, mean, rstd
 
     def bn_act_bwd(self, x, dy, beta, mean, rstd, act, groups=1, leak=0.2, dbeta=None, accumulate=0.0):
-        c = x.shape[-1]
-        rows = x.numel() // c
-        dx = torch.empty_like(x)
+        xp, c = x.shape[-1], dy.shape[-1]
+        rows = x.numel() // xp
+        dx = torch.zeros_like(x)
         if dbeta is None:
             dbeta = self.empty(c)
         ws, n = self.ws(self.lib.bn_workspace_bytes(rows, c, groups))
-        self.lib.bn_act_bwd(_p(x), _p(dy), _p(beta), _p(mean), _p(rstd), _p(dx), _p(dbeta), accumulate, rows, c,
-                            groups, ACT[act], leak, L.ACG_F32, _p(ws), n, self.stream())
+        self.lib.bn_act_bwd(_p(x), _p(dy), _p(beta), _p(mean), _p(rstd), _p(dx), _p(dbeta), accumulate, rows, c, xp, c,
+                            groups, ACT[act], leak, L.dtype2(L.code(x.dtype), L.code(dy.dtype)), _p(ws), n, self.stream())
         return dx, dbeta
 
     # ---- synchronised BatchNorm entries (statistics supplied by the caller)
@@ -202,20 +262,24 @@ class Abi:
                                  _p(dbeta), 0.0, rows, c, groups, ACT[act], leak, L.ACG_F32, self.stream())
         return dx, dbeta
 
-    def bias_act_fwd(self, x, bias, act, leak=0.2):
-        c = x.shape[-1]
-        y = torch.empty_like(x)
-        self.lib.bias_act_fwd(_p(x), _p(bias), _p(y), x.numel() // c, c, ACT[act], leak, L.ACG_F32, self.stream())
+    def bias_act_fwd(self, x, bias, act, leak=0.2, c=None, y_dtype=None):
+        """``c`` < x.shape[-1]: x rows carry pad channels (pitch x.shape[-1]); y is dense [.., c] of ``y_dtype``."""
+        xp = x.shape[-1]
+        c = c or xp
+        y = torch.empty(*x.shape[:-1], c, dtype=y_dtype or x.dtype, device=self.device)
+        self.lib.bias_act_fwd(_p(x), _p(bias), _p(y), x.numel() // xp, c, xp, c, ACT[act], leak,
+                              L.dtype2(L.code(x.dtype), L.code(y.dtype)), self.stream())
         return y
 
-    def bias_act_bwd(self, y, dy, act, leak=0.2, want_dx=True):
+    def bias_act_bwd(self, y, dy, act, leak=0.2, want_dx=True, x_pitch=None, x_dtype=None):
         c = y.shape[-1]
         rows = y.numel() // c
-        dx = torch.empty_like(y) if want_dx else None
+        xp = x_pitch or c
+        dx = torch.zeros(*y.shape[:-1], xp, dtype=x_dtype or y.dtype, device=self.device) if want_dx else None
         dbias = self.empty(c)
         ws, n = self.ws(self.lib.bias_workspace_bytes(rows, c))
-        self.lib.bias_act_bwd(_p(y), _p(dy), _p(dx), _p(dbias), 0.0, rows, c, ACT[act], leak, L.ACG_F32, _p(ws), n,
-                              self.stream())
+        self.lib.bias_act_bwd(_p(y), _p(dy), _p(dx), _p(dbias), 0.0, rows, c, xp, c, ACT[act], leak,
+                              L.dtype2(L.code(x_dtype or y.dtype), L.code(y.dtype)), _p(ws), n, self.stream())
         return dx, dbias
 
     # ---- cdna
@@ -237,37 +301,43 @@ class Abi:
         return dpar, dimg
 
     # ---- dna
-    def dna_fwd(self, logits, img, k):
+    def dna_fwd(self, logits, img, k, bias=None):
+        """logits float32 [B,H,W,k*k] or bfloat16 [B,H,W,round8(k*k)]."""
         b, h, w, c = img.shape
         out = torch.empty_like(img)
-        self.lib.dna_fwd(_p(logits), _p(img), _p(out), b, h, w, c, k, L.ACG_F32, self.stream())
+        self.lib.dna_fwd(_p(logits), _p(bias), _p(img), _p(out), b, h, w, c, k, L.code(logits.dtype), self.stream())
         return out
 
-    def dna_bwd(self, logits, img, dout, k):
+    def dna_bwd(self, logits, img, dout, k, bias=None, want_dbias=False):
         b, h, w, c = img.shape
-        dl = torch.empty_like(logits)
-        self.lib.dna_bwd(_p(logits), _p(img), _p(dout), _p(dl), b, h, w, c, k, L.ACG_F32, self.stream())
-        return dl
+        dl = torch.zeros_like(logits)
+        dbias = self.empty(k * k) if want_dbias else None
+        ws, n = self.ws(self.lib.dna_workspace_bytes(b, h, w, k))
+        self.lib.dna_bwd(_p(logits), _p(bias), _p(img), _p(dout), _p(dl), _p(dbias), 0.0, b, h, w, c, k, L.code(logits.dtype),
+                         _p(ws), n, self.stream())
+        return (dl, dbias) if want_dbias else dl
 
     # ---- plumbing ops
-    def concat_actions(self, x, actions):
+    def concat_actions(self, x, actions, pitch=0):
         b, h, w, c = x.shape
         a = actions.shape[1]
-        y = self.empty(b, h, w, c + a)
-        self.lib.concat_actions_fwd(_p(x), _p(actions), _p(y), b, h * w, c, a, 0, L.ACG_F32, self.stream())
+        y = torch.zeros(b, h, w, pitch or (c + a), dtype=x.dtype, device=self.device)
+        self.lib.concat_actions_fwd(_p(x), _p(actions), _p(y), b, h * w, c, a, pitch, L.code(x.dtype), self.stream())
         return y
 
-    def concat_channels(self, a, b, pitch=0):
+    def concat_channels(self, a, b, pitch=0, y_dtype=None):
         ca, cb = a.shape[-1], (b.shape[-1] if b is not None else 0)
-        y = torch.zeros(*a.shape[:-1], pitch or (ca + cb), device=self.device)
-        self.lib.concat_channels_fwd(_p(a), _p(b), _p(y), a.numel() // ca, ca, cb, pitch, L.ACG_F32, self.stream())
+        y = torch.zeros(*a.shape[:-1], pitch or (ca + cb), dtype=y_dtype or a.dtype, device=self.device)
+        self.lib.concat_channels_fwd(_p(a), _p(b), _p(y), a.numel() // ca, ca, cb, pitch, L.dtype2(L.code(a.dtype), L.code(y.dtype)),
+                                     self.stream())
         return y
 
-    def slice_channels(self, src, off, cdst, dst=None, accumulate=0.0):
+    def slice_channels(self, src, off, cdst, dst=None, accumulate=0.0, dst_dtype=None):
         cs = src.shape[-1]
         if dst is None:
-            dst = self.empty(*src.shape[:-1], cdst)
-        self.lib.slice_channels(_p(src), _p(dst), accumulate, src.numel() // cs, cs, off, cdst, L.ACG_F32, self.stream())
+            dst = self.empty(*src.shape[:-1], cdst, dtype=dst_dtype or src.dtype)
+        self.lib.slice_channels(_p(src), _p(dst), accumulate, src.numel() // cs, cs, off, cdst,
+                                L.dtype2(L.code(src.dtype), L.code(dst.dtype)), self.stream())
         return dst
 
     def copy_many(self, pairs):
@@ -275,12 +345,12 @@ class Abi:
         cl = L.CopyList()
         for i, (src, dst) in enumerate(pairs):
             cl.src[i], cl.dst[i] = src.data_ptr(), dst.data_ptr()
-            cl.rows[i], cl.cols[i], cl.dst_pitch[i] = src.shape[0], src.shape[1], dst.shape[1]
+            cl.rows[i], cl.cols[i], cl.dst_pitch[i], cl.dst_dtype[i] = src.shape[0], src.shape[1], dst.shape[1], L.code(dst.dtype)
         self.lib.copy_many(ctypes.byref(cl), len(pairs), L.ACG_F32, self.stream())
 
     def add(self, a, b):
         y = torch.empty_like(a)
-        self.lib.add(_p(a), _p(b), _p(y), a.numel(), L.ACG_F32, self.stream())
+        self.lib.add(_p(a), _p(b), _p(y), a.numel(), L.code(a.dtype), self.stream())
         return y
 
     # ---- losses

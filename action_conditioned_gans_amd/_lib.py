@@ -70,6 +70,10 @@ SIGNATURES = {
     'acg_conv2d_splits': (c_int32, [_D, c_int32, c_int32]),
     'acg_conv2d_wgrad_slabs': (c_int32, [_P, _P, _D, c_int32, _P, c_size_t, _P]),
     'acg_deconv2d_wgrad_slabs': (c_int32, [_P, _P, _D, c_int32, _P, c_size_t, _P]),
+    'acg_conv2d_fwd_slabs': (c_int32, [_P, _P, _D, c_int32, _P, c_size_t, _P]),
+    'acg_conv2d_dgrad_slabs': (c_int32, [_P, _P, _D, c_int32, _P, c_size_t, _P]),
+    'acg_deconv2d_fwd_slabs': (c_int32, [_P, _P, _D, c_int32, _P, c_size_t, _P]),
+    'acg_deconv2d_dgrad_slabs': (c_int32, [_P, _P, _D, c_int32, _P, c_size_t, _P]),
     'acg_conv2d_bwd_pair': (c_int32, [_P, _P, _P, _P, _P, c_float, _D, c_int32, _P, c_size_t, _P, c_size_t, c_int32, _P]),
     'acg_deconv2d_bwd_pair': (c_int32, [_P, _P, _P, _P, _P, c_float, _D, c_int32, _P, c_size_t, _P, c_size_t, c_int32, _P]),
     'acg_splitk_reduce_many': (c_int32, [ctypes.POINTER(ReduceList), c_int32, _P]),
@@ -87,6 +91,11 @@ SIGNATURES = {
                                  c_int32, _P, c_size_t, _P]),
     'acg_bn_act_bwd': (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
                                  c_float, c_int32, _P, c_size_t, _P]),
+    'acg_bn_act_fwd_slabs': (c_int32, [_P, c_int32, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, c_float,
+                                       c_int32, _P, c_size_t, _P]),
+    'acg_bn_bwd_slabs_ok': (c_int32, [c_int64, c_int32]),
+    'acg_bn_act_bwd_slabs': (c_int32, [_P, _P, c_int32, _P, _P, _P, _P, _P, c_float, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                       c_float, c_int32, _P, c_size_t, _P]),
     'acg_bias_workspace_bytes': (c_size_t, [c_int64, c_int32]),
     'acg_bias_act_fwd': (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, _P]),
     'acg_bias_act_bwd': (c_int32, [_P, _P, _P, _P, c_float, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_int32,
@@ -141,7 +150,7 @@ def code(torch_dtype):
     if torch_dtype == torch.bfloat16:
         return ACG_BF16
     raise TypeError('no storage code for %s' % torch_dtype)
-VALUE_RETURNING = ('acg_version', 'acg_conv2d_splits')     # int32 results that are not status codes
+VALUE_RETURNING = ('acg_version', 'acg_conv2d_splits', 'acg_bn_bwd_slabs_ok')     # int32 results that are not status codes
 
 
 class AcgError(RuntimeError):

@@ -100,15 +100,37 @@ __device__ __forceinline__ void reduce_rsub_v(const VMap<V>& m, float (&a)[V], f
   }
 }
 
+// Split-K hand-off (acg_bn_act_fwd_slabs / acg_bn_act_bwd_slabs): the producing convolution left `splits` fp32 partial
+// slabs, each laid out like the tensor; the BatchNorm kernel that would read the tensor sums them itself - in slab
+// order, rounded to the tensor's storage type: the very values splitk_reduce would have written - and, where the tensor
+// is needed later (x: BatchNorm backward re-reads it), writes it back.  `slabs` == nullptr: the tensor is read as is.
+struct Slabs { const float* p; int splits; long long stride; };
+template <bool SL, int V, typename T>
+__device__ __forceinline__ void ld_or_sum(T* base, long long off, const Slabs& sl, bool write, float (&v)[V]) {
+  if constexpr (!SL) { ldv<V>(base + off, v); return; }
+#pragma unroll
+  for (int j = 0; j < V; ++j) v[j] = 0.f;
+#pragma unroll 4
+  for (int z = 0; z < sl.splits; ++z) {
+    float t[V];
+    ldv<V>(sl.p + (long long)z * sl.stride + off, t);
+#pragma unroll
+    for (int j = 0; j < V; ++j) v[j] += t[j];
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) v[j] = (float)(T)v[j];
+  if (write) stv<V>(base + off, v);
+}
+
 // partial layout: part[((g * nblk + b) * 2 + which) * C + c]
 // ---- BN forward ---------------------------------------------------------------------------------------
-template <int V, typename TX>
-__global__ __launch_bounds__(256) void bn_stats_partial(const TX* __restrict__ x, float* __restrict__ part,
-                                                        long long R, int C, int nblk, int XP) {
+template <int V, typename TX, bool SL = false>
+__global__ __launch_bounds__(256) void bn_stats_partial(TX* __restrict__ x, float* __restrict__ part,
+                                                        long long R, int C, int nblk, int XP, const Slabs sl) {
   __shared__ float sh[2 * V * 256];
   const VMap<V> m = vmap<V>(C);
   const int g = blockIdx.y, b = blockIdx.x;
-  const TX* xg = x + (long long)g * R * XP;
+  const long long gb = (long long)g * R * XP;
   const long long rpb = (R + nblk - 1) / nblk;
   const long long r0 = (long long)b * rpb, r1 = min(R, r0 + rpb);
   for (int ch = 0; ch < m.nchunk; ++ch) {
@@ -117,13 +139,13 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const TX* __restrict__ x
 #pragma unroll
     for (int j = 0; j < V; ++j) { s1[j] = 0.f; s2[j] = 0.f; pv[j] = 0.f; }
     if (m.active && cv < m.Cv) {
-      ldv<V>(xg + c, pv);   // shift by the group's first row: E[d^2]-E[d]^2 cannot cancel catastrophically
+      ld_or_sum<SL, V>(x, gb + c, sl, false, pv);   // shift by the group's first row: E[d^2]-E[d]^2 cannot cancel catastrophically
       // batches of 4 row passes, all loads of a batch issued before the first use (rows beyond r1 re-read
       // the last valid row with weight 0), so a block's few passes cost ~one memory round trip
       for (long long r = r0 + m.rsub; r < r1; r += kU * m.RPP) {
         float v[kU][V];
 #pragma unroll
-        for (int u = 0; u < kU; ++u) ldv<V>(xg + min(r + u * m.RPP, r1 - 1) * XP + c, v[u]);
+        for (int u = 0; u < kU; ++u) ld_or_sum<SL, V>(x, gb + min(r + u * m.RPP, r1 - 1) * XP + c, sl, r + u * m.RPP < r1, v[u]);
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
           const float w = r + u * m.RPP < r1 ? 1.f : 0.f;
@@ -365,18 +387,19 @@ __device__ __forceinline__ void block_sum(float (&v)[N], float* sh /* 4 * N floa
   for (int j = 0; j < N; ++j) v[j] = sh[j] + sh[N + j] + sh[2 * N + j] + sh[3 * N + j];
 }
 
-template <int V, int NR, typename TX, typename TY>
-__global__ __launch_bounds__(256) void bn_resident_fwd(const TX* __restrict__ x, const float* __restrict__ beta,
+template <int V, int NR, typename TX, typename TY, bool SL = false>
+__global__ __launch_bounds__(256) void bn_resident_fwd(TX* __restrict__ x, const float* __restrict__ beta,
                                                        TY* __restrict__ y, float* __restrict__ save_mean,
-                                                       float* __restrict__ save_rstd, int R, int C, float eps, int act, float leak, int XP, int YP) {
+                                                       float* __restrict__ save_rstd, int R, int C, float eps, int act, float leak, int XP, int YP,
+                                                       const Slabs sl) {
   __shared__ float sh[4 * 2 * V];
   const int c = blockIdx.x * V, g = blockIdx.y;
-  const TX* xg = x + (long long)g * R * XP + c;
+  const long long gb = (long long)g * R * XP + c;
   TY* yg = y + (long long)g * R * YP + c;
   float v[NR][V], pv[V], bt[V];
 #pragma unroll
-  for (int u = 0; u < NR; ++u) ldv<V>(xg + min((int)threadIdx.x + u * 256, R - 1) * XP, v[u]);
-  ldv<V>(xg, pv);      // shift by the group's first row, as in bn_stats_partial
+  for (int u = 0; u < NR; ++u) ld_or_sum<SL, V>(x, gb + (long long)min((int)threadIdx.x + u * 256, R - 1) * XP, sl, (int)threadIdx.x + u * 256 < R, v[u]);
+  ld_or_sum<SL, V>(x, gb, sl, false, pv);      // shift by the group's first row, as in bn_stats_partial
   ldv<V>(beta + c, bt);
   float s[2 * V];
 #pragma unroll
@@ -410,12 +433,12 @@ __global__ __launch_bounds__(256) void bn_resident_fwd(const TX* __restrict__ x,
 }
 
 // One block per V channels walks the groups in turn (dbeta is the sum over groups of its first reduction).
-template <int V, int NR, typename TX, typename TY>
+template <int V, int NR, typename TX, typename TY, bool SL = false>
 __global__ __launch_bounds__(256) void bn_resident_bwd(const TX* __restrict__ x, const TY* __restrict__ dy,
                                                        const float* __restrict__ beta, const float* __restrict__ save_mean,
                                                        const float* __restrict__ save_rstd, TX* __restrict__ dx,
                                                        float* __restrict__ dbeta, float dbeta_acc, int R, int C, int groups,
-                                                       int act, float leak, int XP, int YP) {
+                                                       int act, float leak, int XP, int YP, const Slabs sl) {
   __shared__ float sh[4 * 2 * V];
   const int c = blockIdx.x * V;
   float bt[V], tot[V];
@@ -428,7 +451,8 @@ __global__ __launch_bounds__(256) void bn_resident_bwd(const TX* __restrict__ x,
 #pragma unroll
     for (int u = 0; u < NR; ++u) {
       const int rq = min((int)threadIdx.x + u * 256, R - 1);
-      ldv<V>(x + base + rq * XP, xv[u]); ldv<V>(dy + ybase + rq * YP, dv[u]);
+      ldv<V>(x + base + rq * XP, xv[u]);
+      ld_or_sum<SL, V>(const_cast<TY*>(dy), ybase + (long long)rq * YP, sl, false, dv[u]);
     }
     ldv<V>(save_mean + g * C + c, mean); ldv<V>(save_rstd + g * C + c, rstd);
     float s[2 * V];
@@ -684,15 +708,16 @@ bool vec4_ok(int C, const void* a, const void* b, const void* c) {
 // layer of a bf16 network) exists for the scalar (V = 1) variants only.
 template <typename TX, typename TY>
 int bn_fwd_typed(const void* x, const float* beta, void* y, float* save_mean, float* save_rstd, long long R, int C, int groups,
-                 float eps, int act, float leak, float* part, bool v4, int XP, int YP, hipStream_t st) {
+                 float eps, int act, float leak, float* part, bool v4, int XP, int YP, hipStream_t st, const Slabs sl = Slabs{nullptr, 0, 0}) {
   constexpr bool same = std::is_same<TX, TY>::value;
-  const TX* xf = (const TX*)x;
+  TX* xf = (TX*)const_cast<void*>(x);
   TY* yf = (TY*)y;
   if (!same) v4 = false;
   const int V = v4 ? 4 : 1;
   if (const int nr = resident_nr(R, 32)) {
     const dim3 rg(C / V, groups);
-#define ACG_BN_RES_FWD(VV, NN) ACG_LAUNCH((bn_resident_fwd<VV, NN, TX, TY>), rg, dim3(256), 0, st, xf, beta, yf, save_mean, save_rstd, (int)R, C, eps, act, leak, XP, YP)
+#define ACG_BN_RES_FWD(VV, NN) do { if (sl.p) ACG_LAUNCH((bn_resident_fwd<VV, NN, TX, TY, true>), rg, dim3(256), 0, st, xf, beta, yf, save_mean, save_rstd, (int)R, C, eps, act, leak, XP, YP, sl); \
+    else ACG_LAUNCH((bn_resident_fwd<VV, NN, TX, TY, false>), rg, dim3(256), 0, st, xf, beta, yf, save_mean, save_rstd, (int)R, C, eps, act, leak, XP, YP, sl); } while (0)
 #define ACG_BN_RES_FWD_V(NN) do { if constexpr (same) { if (v4) ACG_BN_RES_FWD(4, NN); else ACG_BN_RES_FWD(1, NN); } else ACG_BN_RES_FWD(1, NN); } while (0)
     switch (nr) {
       case 1: ACG_BN_RES_FWD_V(1); break;
@@ -708,8 +733,13 @@ int bn_fwd_typed(const void* x, const float* beta, void* y, float* save_mean, fl
   }
   static const int stats_iters = env_int("ACG_BN_STATS_ITERS", 8);  // tuning hook
   const int nblk = vpartial_blocks(R, C, V, stats_iters);
-  if (same && v4) ACG_LAUNCH((bn_stats_partial<4, TX>), dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk, XP);
-  else ACG_LAUNCH((bn_stats_partial<1, TX>), dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk, XP);
+  if (sl.p) {
+    if (same && v4) ACG_LAUNCH((bn_stats_partial<4, TX, true>), dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk, XP, sl);
+    else ACG_LAUNCH((bn_stats_partial<1, TX, true>), dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk, XP, sl);
+  } else {
+    if (same && v4) ACG_LAUNCH((bn_stats_partial<4, TX, false>), dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk, XP, sl);
+    else ACG_LAUNCH((bn_stats_partial<1, TX, false>), dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk, XP, sl);
+  }
   if (int rc = acg::check_launch("bn_stats_partial")) return rc;
   const dim3 ag(tile_row_blocks(R, C, V), (C + 8 * V - 1) / (8 * V), groups);
   if constexpr (same) {
@@ -724,7 +754,7 @@ int bn_fwd_typed(const void* x, const float* beta, void* y, float* save_mean, fl
 template <typename TX, typename TY>
 int bn_bwd_typed(const void* x, const void* dy, const float* beta, const float* save_mean, const float* save_rstd, void* dx,
                  float* dbeta, float dbeta_acc, long long R, int C, int groups, int act, float leak, float* part, bool v4, int XP, int YP,
-                 hipStream_t st) {
+                 hipStream_t st, const Slabs sl = Slabs{nullptr, 0, 0}) {
   constexpr bool same = std::is_same<TX, TY>::value;
   const TX* xf = (const TX*)x;
   const TY* dyf = (const TY*)dy;
@@ -733,7 +763,8 @@ int bn_bwd_typed(const void* x, const void* dy, const float* beta, const float* 
   const int V = v4 ? 4 : 1;
   if (const int nr = resident_nr(R * groups, 16) ? resident_nr(R, 16) : 0) {
     const dim3 rg(C / V);
-#define ACG_BN_RES_BWD(VV, NN) ACG_LAUNCH((bn_resident_bwd<VV, NN, TX, TY>), rg, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, (int)R, C, groups, act, leak, XP, YP)
+#define ACG_BN_RES_BWD(VV, NN) do { if (sl.p) ACG_LAUNCH((bn_resident_bwd<VV, NN, TX, TY, true>), rg, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, (int)R, C, groups, act, leak, XP, YP, sl); \
+    else ACG_LAUNCH((bn_resident_bwd<VV, NN, TX, TY, false>), rg, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, (int)R, C, groups, act, leak, XP, YP, sl); } while (0)
 #define ACG_BN_RES_BWD_V(NN) do { if constexpr (same) { if (v4) ACG_BN_RES_BWD(4, NN); else ACG_BN_RES_BWD(1, NN); } else ACG_BN_RES_BWD(1, NN); } while (0)
     switch (nr) {
       case 1: ACG_BN_RES_BWD_V(1); break;
@@ -746,6 +777,7 @@ int bn_bwd_typed(const void* x, const void* dy, const float* beta, const float* 
 #undef ACG_BN_RES_BWD
     return acg::check_launch("bn_resident_bwd");
   }
+  if (sl.p) return acg::fail(ACG_ERR_UNSUPPORTED, "bn_act_bwd_slabs: %lld rows per group exceed the register-resident kernels (acg_bn_bwd_slabs_ok)", R);
   static const int bwd_iters = env_int("ACG_BN_BWD_ITERS", 4);      // tuning hook
   const int nblk = vpartial_blocks(R, C, V, bwd_iters);
   const dim3 ag(tile_row_blocks(R, C, V), (C + 8 * V - 1) / (8 * V), groups);
@@ -801,6 +833,41 @@ int32_t acg_bn_act_bwd(const void* x, const void* dy, const float* beta, const f
   ACG_WITH_TYPES(dtype, "bn_act_bwd", return (bn_bwd_typed<TA, TB>(x, dy, beta, save_mean, save_rstd, dx, dbeta, dbeta_acc, R, C, groups, act, leak, (float*)ws, v4, XP, YP, acg::to_stream(stream))));
 }
 
+int32_t acg_bn_act_fwd_slabs(const float* slabs, int32_t splits, void* x, const float* beta, void* y, float* save_mean, float* save_rstd,
+                             int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t groups, float eps, int32_t act, float leak,
+                             int32_t dtype, void* ws, size_t wsb, acg_stream_t stream) {
+  const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
+  ACG_REQUIRE(XP >= C && YP >= C, ACG_ERR_INVALID_ARG, "bn_act_fwd_slabs: pitch smaller than the row");
+  if (int rc = check_bn("bn_act_fwd_slabs", rows, C, groups)) return rc;
+  ACG_REQUIRE(slabs && splits >= 1 && x && beta && y && save_mean && save_rstd, ACG_ERR_INVALID_ARG, "bn_act_fwd_slabs: null pointer / splits < 1");
+  ACG_REQUIRE(act == ACG_ACT_NONE || act == ACG_ACT_RELU || act == ACG_ACT_LRELU, ACG_ERR_UNSUPPORTED, "bn_act_fwd_slabs: activation %d", act);
+  ACG_REQUIRE(ws && wsb >= acg_bn_workspace_bytes(rows, C, groups), ACG_ERR_WORKSPACE, "bn_act_fwd_slabs: workspace too small");
+  const long long R = rows / groups;
+  const bool v4 = vec4_ok(C, x, y, beta) && vec4_ok(C, save_mean, save_rstd, ws) && vec4_ok(C, slabs, slabs, slabs) && XP % 4 == 0 && YP % 4 == 0;
+  const Slabs sl{slabs, splits, (long long)rows * XP};
+  ACG_WITH_TYPES(dtype, "bn_act_fwd_slabs", return (bn_fwd_typed<TA, TB>(x, beta, y, save_mean, save_rstd, R, C, groups, eps, act, leak, (float*)ws, v4, XP, YP, acg::to_stream(stream), sl)));
+}
+
+int32_t acg_bn_bwd_slabs_ok(int64_t rows, int32_t groups) {
+  if (rows <= 0 || groups <= 0 || rows % groups) return 0;
+  return (resident_nr(rows, 16) && resident_nr(rows / groups, 16)) ? 1 : 0;
+}
+
+int32_t acg_bn_act_bwd_slabs(const void* x, const float* dy_slabs, int32_t splits, const float* beta, const float* save_mean,
+                             const float* save_rstd, void* dx, float* dbeta, float dbeta_acc, int64_t rows, int32_t C, int32_t x_pitch,
+                             int32_t y_pitch, int32_t groups, int32_t act, float leak, int32_t dtype, void* ws, size_t wsb, acg_stream_t stream) {
+  const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
+  ACG_REQUIRE(XP >= C && YP >= C, ACG_ERR_INVALID_ARG, "bn_act_bwd_slabs: pitch smaller than the row");
+  if (int rc = check_bn("bn_act_bwd_slabs", rows, C, groups)) return rc;
+  ACG_REQUIRE(x && dy_slabs && splits >= 1 && beta && save_mean && save_rstd && dx && dbeta, ACG_ERR_INVALID_ARG, "bn_act_bwd_slabs: null pointer / splits < 1");
+  ACG_REQUIRE(act == ACG_ACT_NONE || act == ACG_ACT_RELU || act == ACG_ACT_LRELU, ACG_ERR_UNSUPPORTED, "bn_act_bwd_slabs: activation %d", act);
+  ACG_REQUIRE(acg_bn_bwd_slabs_ok(rows, groups), ACG_ERR_UNSUPPORTED, "bn_act_bwd_slabs: tensor too large for the one-launch kernels (acg_bn_bwd_slabs_ok)");
+  const long long R = rows / groups;
+  const bool v4 = vec4_ok(C, x, dy_slabs, dx) && vec4_ok(C, save_mean, save_rstd, beta) && vec4_ok(C, beta, dbeta, dbeta) && XP % 4 == 0 && YP % 4 == 0;
+  const Slabs sl{dy_slabs, splits, (long long)rows * YP};
+  ACG_WITH_TYPES(dtype, "bn_act_bwd_slabs", return (bn_bwd_typed<TA, TB>(x, nullptr, beta, save_mean, save_rstd, dx, dbeta, dbeta_acc, R, C, groups, act, leak, (float*)ws, v4, XP, YP, acg::to_stream(stream), sl)));
+}
+
 int32_t acg_bn_moments(const void* x, float* moments, int64_t rows, int32_t C, int32_t groups, int32_t dtype, void* ws,
                        size_t wsb, acg_stream_t stream) {
   ACG_REQUIRE_F32(dtype);
@@ -811,8 +878,8 @@ int32_t acg_bn_moments(const void* x, float* moments, int64_t rows, int32_t C, i
   hipStream_t st = acg::to_stream(stream);
   const bool v4 = vec4_ok(C, x, x, ws);
   const int V = v4 ? 4 : 1, nblk = vpartial_blocks(R, C, V, 8);
-  if (v4) ACG_LAUNCH((bn_stats_partial<4, float>), dim3(nblk, groups), dim3(256), 0, st, (const float*)x, (float*)ws, R, C, nblk, C);
-  else ACG_LAUNCH((bn_stats_partial<1, float>), dim3(nblk, groups), dim3(256), 0, st, (const float*)x, (float*)ws, R, C, nblk, C);
+  if (v4) ACG_LAUNCH((bn_stats_partial<4, float>), dim3(nblk, groups), dim3(256), 0, st, (float*)const_cast<void*>(x), (float*)ws, R, C, nblk, C, Slabs{nullptr, 0, 0});
+  else ACG_LAUNCH((bn_stats_partial<1, float>), dim3(nblk, groups), dim3(256), 0, st, (float*)const_cast<void*>(x), (float*)ws, R, C, nblk, C, Slabs{nullptr, 0, 0});
   if (int rc = acg::check_launch("bn_stats_partial")) return rc;
   ACG_LAUNCH(bn_moments_finalize, dim3((groups * C + 255) / 256), dim3(256), 0, st, (const float*)ws, (const float*)x, moments, R, C, groups, nblk);
   return acg::check_launch("bn_moments_finalize");

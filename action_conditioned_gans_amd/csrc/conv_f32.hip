@@ -190,8 +190,10 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
   if (bf16) {
     // bf16: 128x128 tiles once they fill the chip (a K-step then carries 16 MFMAs per wave for the same 8 loads per
     // thread as two 64x64 blocks carry 8), 64x64 tiles + split-K below that
+    // (profiles/r2/b_tune_bf16_*.txt: 128x128 wins from ~256 tiles; weight gradients - few output tiles, parallelism
+    // from split-K - take it once K is long: nk >= 256)
     static const int big_min = env_int("ACG_PLAN16_BIG_TILES", 256);
-    const bool big = pl.N > 64 && tiles_for(128, 128) >= big_min;
+    const bool big = pl.N > 64 && pl.M >= 128 && (which == ACG_CONV_WGRAD ? pl.nk >= 256 : tiles_for(128, 128) >= big_min);
     pl.cfg = big ? 1 : 3; pl.bm = pl.bn = big ? 128 : 64;
     if (g_force_cfg == 1 || g_force_cfg == 3) { pl.cfg = g_force_cfg; pl.bm = pl.bn = g_force_cfg == 1 ? 128 : 64; }
     pl.ragged = false; pl.nvec = true;
@@ -201,8 +203,10 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
   static const int t_fd = env_int("ACG_PLAN_TARGET_FD", 0), t_w = env_int("ACG_PLAN_TARGET_W", 512), min_steps = env_int("ACG_PLAN_MIN_STEPS", 4);
   // bf16 K-steps are ~2x cheaper (matrix cores, loader-bound): two resident blocks per CU pay off there as well
   // (whole-step sweep: 507 vs 500 steps/s)
-  const long long target = which == ACG_CONV_WGRAD ? t_w : (t_fd > 0 ? t_fd : (bf16 ? 512 : 256));
-  long long s = target / pl.tiles;
+  // bf16: a K-step is ~4x cheaper than in fp32 while a slab round trip (fp32 slabs + the reduce launch) costs the same:
+  // split only below half a chip of tiles, up to one block per CU (weight gradients 1.5) - profiles/r2 sweeps
+  const long long target = bf16 ? (which == ACG_CONV_WGRAD ? 384 : 256) : (which == ACG_CONV_WGRAD ? t_w : (t_fd > 0 ? t_fd : 256));
+  long long s = (bf16 && pl.tiles >= 128) ? 1 : target / pl.tiles;
   s = std::min<long long>(s, std::max(1, pl.nk / min_steps));
   static const int max_splits = env_int("ACG_PLAN_MAX_SPLITS", 128), max_splits_w = env_int("ACG_PLAN_MAX_SPLITS_W", 128);
   s = std::min<long long>(s, which == ACG_CONV_WGRAD ? max_splits_w : max_splits);
@@ -210,7 +214,7 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
   // resident block hides the first one's load latencies (0.74 -> 0.53 us per K-step) and the slab reduction is small
   // next to a long K loop (profiles/r1/r_conv_tune_full.txt: 79.8 us unsplit, 67.1 us at 4 splits).
   s = std::max<long long>(s, 1);
-  if (which != ACG_CONV_WGRAD && pl.tiles * s <= 256 && pl.nk / s >= 50) s *= pl.nk / s >= 100 ? 4 : 2;
+  if (!bf16 && which != ACG_CONV_WGRAD && pl.tiles * s <= 256 && pl.nk / s >= 50) s *= pl.nk / s >= 100 ? 4 : 2;
   if (g_force_splits >= 1) s = std::min<long long>(g_force_splits, pl.nk);
   pl.splits = (int)std::max<long long>(s, 1);
   return pl;
@@ -304,10 +308,11 @@ int run(int which, const float* gsrc, const float* dense, float* out, float accu
 // Input gradient A (whichA = DGRAD, or FWD for a transposed layer) and weight gradient B of one layer: ONE launch when
 // the pair kernel covers the shapes (conv_f32_pair.hip), two otherwise; same results either way.
 int run_pair(int whichA, const float* gsrcA, const float* denseA, float* outA, const float* gsrcB, const float* denseB, float* outB,
-             float accumulateB, const acg_conv_desc* d, int dtype, void* wsA, size_t wsbA, void* wsB, size_t wsbB, bool slabs_only_B,
+             float accumulateB, const acg_conv_desc* d, int dtype, void* wsA, size_t wsbA, void* wsB, size_t wsbB, int slab_flags,
              acg_stream_t stream, const char* who) {
   Job ja, jb;
-  if (int rc = prepare(ja, whichA, gsrcA, denseA, outA, 0.f, d, dtype, wsA, wsbA, who, false)) return rc;
+  const bool slabs_only_B = (slab_flags & 1) != 0, slabs_only_A = (slab_flags & 2) != 0;
+  if (int rc = prepare(ja, whichA, gsrcA, denseA, outA, 0.f, d, dtype, wsA, wsbA, who, slabs_only_A)) return rc;
   if (int rc = prepare(jb, ACG_CONV_WGRAD, gsrcB, denseB, outB, accumulateB, d, dtype, wsB, wsbB, who, slabs_only_B)) return rc;
   hipStream_t st = acg::to_stream(stream);
   static const int enabled = env_int("ACG_CONV_PAIR", 1);       // 0: always two launches (A/B comparison)
@@ -368,11 +373,25 @@ int32_t acg_deconv2d_wgrad_slabs(const void* x, const void* dy, const acg_conv_d
   return run(ACG_CONV_WGRAD, (const float*)dy, (const float*)x, nullptr, 0.f, adj, dtype, ws, wsb, s, "deconv2d_wgrad_slabs", true);
 }
 
+// split-K hand-off to the consuming BatchNorm (acg_bn_act_fwd_slabs / acg_bn_act_bwd_slabs): the contraction only
+int32_t acg_conv2d_fwd_slabs(const void* x, const void* w, const acg_conv_desc* d, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
+  return run(ACG_CONV_FWD, (const float*)x, (const float*)w, nullptr, 0.f, d, dtype, ws, wsb, s, "conv2d_fwd_slabs", true);
+}
+int32_t acg_conv2d_dgrad_slabs(const void* dy, const void* w, const acg_conv_desc* d, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
+  return run(ACG_CONV_DGRAD, (const float*)dy, (const float*)w, nullptr, 0.f, d, dtype, ws, wsb, s, "conv2d_dgrad_slabs", true);
+}
+int32_t acg_deconv2d_fwd_slabs(const void* x, const void* w, const acg_conv_desc* adj, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
+  return run(ACG_CONV_DGRAD, (const float*)x, (const float*)w, nullptr, 0.f, adj, dtype, ws, wsb, s, "deconv2d_fwd_slabs", true);
+}
+int32_t acg_deconv2d_dgrad_slabs(const void* dy, const void* w, const acg_conv_desc* adj, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
+  return run(ACG_CONV_FWD, (const float*)dy, (const float*)w, nullptr, 0.f, adj, dtype, ws, wsb, s, "deconv2d_dgrad_slabs", true);
+}
+
 int32_t acg_conv2d_bwd_pair(const void* dy, const void* w, const void* x, void* dx, float* dw, float dw_accumulate,
                             const acg_conv_desc* d, int32_t dtype, void* ws_dgrad, size_t wsb_dgrad, void* ws_wgrad, size_t wsb_wgrad,
                             int32_t wgrad_slabs_only, acg_stream_t s) {
   return run_pair(ACG_CONV_DGRAD, (const float*)dy, (const float*)w, (float*)dx, (const float*)x, (const float*)dy, dw, dw_accumulate,
-                  d, dtype, ws_dgrad, wsb_dgrad, ws_wgrad, wsb_wgrad, wgrad_slabs_only != 0, s, "conv2d_bwd_pair");
+                  d, dtype, ws_dgrad, wsb_dgrad, ws_wgrad, wsb_wgrad, wgrad_slabs_only, s, "conv2d_bwd_pair");
 }
 int32_t acg_deconv2d_bwd_pair(const void* dy, const void* w, const void* x, void* dx, float* dw, float dw_accumulate,
                               const acg_conv_desc* adj, int32_t dtype, void* ws_dgrad, size_t wsb_dgrad, void* ws_wgrad, size_t wsb_wgrad,
@@ -380,7 +399,7 @@ int32_t acg_deconv2d_bwd_pair(const void* dy, const void* w, const void* x, void
   // transposed layer on the adjoint descriptor: its input gradient is the adjoint's FWD, its weight gradient the
   // adjoint's WGRAD with the roles of x and dy exchanged (acg_deconv2d_dgrad / acg_deconv2d_wgrad)
   return run_pair(ACG_CONV_FWD, (const float*)dy, (const float*)w, (float*)dx, (const float*)dy, (const float*)x, dw, dw_accumulate,
-                  adj, dtype, ws_dgrad, wsb_dgrad, ws_wgrad, wsb_wgrad, wgrad_slabs_only != 0, s, "deconv2d_bwd_pair");
+                  adj, dtype, ws_dgrad, wsb_dgrad, ws_wgrad, wsb_wgrad, wgrad_slabs_only, s, "deconv2d_bwd_pair");
 }
 
 int32_t acg_splitk_reduce_many(const acg_reduce_list* list, int32_t count, acg_stream_t stream) {

@@ -314,6 +314,11 @@ class Runtime:
         self.world_size, self.rank, self.process_group = world_size, rank, process_group
         self.is_cuda = self.device.type == 'cuda'
         self.side_stream = torch.cuda.Stream(self.device) if self.is_cuda else None
+        self.program_ops = frozenset()         # ids of the ops of the program being compiled (ops.py: hand-offs between neighbours)
+        # split-K slabs summed by the consuming BatchNorm kernel instead of by a launch of their own: bit-identical, but
+        # measured SLOWER (fp32 364 vs 383, bf16 567 vs 600 steps/s, profiles/r2): the one-launch BatchNorm kernels read 16
+        # bytes per row and block, and S slabs multiply exactly those poorly coalesced requests; kept as an option
+        self.slab_handoff = False
         self._comm = comm
         self._scratch = {}
 
@@ -355,7 +360,7 @@ class Session:
     """``tf.Session`` stand-in bound to one GPU (one process per GPU)."""
 
     def __init__(self, device='cuda:0', graph=None, use_hip_graphs=True, lib=None,
-                 world_size=1, rank=0, process_group=None, dtype='f32', pair_bwd=True, comm=None):
+                 world_size=1, rank=0, process_group=None, dtype='f32', pair_bwd=True, comm=None, slab_handoff=False):
         self.graph = graph or get_default_graph()
         dev = torch.device(device)
         if lib is None:
@@ -373,6 +378,7 @@ class Session:
                 raise ValueError('Session(dtype=%r): the graph was already built for %s activations' % (dtype, self.graph.act_dtype))
             self.graph.act_dtype = want
         self.rt = Runtime(lib, dev, world_size, rank, process_group, _lib.ACG_BF16 if dtype == 'bf16' else _lib.ACG_F32, comm)
+        self.rt.slab_handoff = bool(slab_handoff)
         if dev.type == 'cuda':
             torch.cuda.set_device(dev)
         self.use_hip_graphs = use_hip_graphs and dev.type == 'cuda'
@@ -492,6 +498,7 @@ class Session:
         for op in ops:
             for t in op.inputs + op.outputs + list(getattr(op, 'extras', ())):
                 self._materialize(t)
+        self.rt.program_ops = frozenset(id(o) for o in ops)
         for k, op in enumerate(ops):           # pairing is decided per program: both ops fetched, nothing between them
             w = getattr(op, 'pair_w', None)
             active = self.pair_bwd and w is not None and k + 1 < len(ops) and ops[k + 1] is w

@@ -243,8 +243,24 @@ class Conv2dOp(_ConvBase):
         self.extras = [self.wop]
         super().__init__(g, name, [x, w], [y])
 
+    bn_consumer = None      # the layer's BnActOp (set by _layer): candidate for the split-K hand-off
+    _slab = None            # (workspace, splits) while this program's BatchNorm sums the slabs itself
+
     def bind(self, rt):
         x, w = self.inputs
+        self._slab = None
+        bn = self.bn_consumer
+        if bn is not None and id(bn) in rt.program_ops and rt.slab_handoff:
+            # split over K and followed by its BatchNorm in this program: leave the partial slabs, the BatchNorm kernel
+            # sums them as it loads (acg_bn_act_fwd_slabs) - one launch less
+            lib, d = rt.lib, self.desc
+            splits = lib.conv2d_splits(ctypes.byref(d), self.which, rt.conv_dtype)
+            if splits > 1:
+                ws, n = rt.workspace(lib.conv2d_workspace_bytes(ctypes.byref(d), self.which, rt.conv_dtype))
+                self._keep, self._slab = (ws, d), (ws, splits)
+                fn = lib.deconv2d_fwd_slabs if self.transposed else lib.conv2d_fwd_slabs
+                pa, pb, dref, pws, dt = _p(x.buf), _p(self.wop.buf), ctypes.byref(d), _p(ws), rt.conv_dtype
+                return lambda s: fn(pa, pb, dref, dt, pws, n, s)
         return self._bind(rt, 'deconv2d_fwd' if self.transposed else 'conv2d_fwd', x, self.wop, self.outputs[0])
 
     def grad(self, gouts, needs, ctx):
@@ -274,17 +290,33 @@ class ConvDgradOp(_ConvBase):
         self.extras = [self.wop]
         super().__init__(G.get_default_graph(), name, [dy, w], [_new(x.shape, name + ':0', x.dtype)])
 
+    bn_bwd_consumer = None  # the BnActBwdOp that reads this op's output as its dy (set in BnActOp.grad)
+    _slab = None
+
     def bind(self, rt):
         dy, w = self.inputs
         w = self.wop
+        lib, d, dt = rt.lib, self.desc, rt.conv_dtype
+        self._slab = None
+        bn = self.bn_bwd_consumer
+        hand_off = False
+        if bn is not None and id(bn) in rt.program_ops and rt.slab_handoff and lib.bn_bwd_slabs_ok(bn.fwd.rows, bn.fwd.groups):
+            hand_off = lib.conv2d_splits(ctypes.byref(d), self.which, dt) > 1
         if not self.pair_active:
+            if hand_off:     # the consuming BatchNorm backward sums the slabs (acg_bn_act_bwd_slabs)
+                ws, n = rt.workspace(lib.conv2d_workspace_bytes(ctypes.byref(d), self.which, dt))
+                self._keep, self._slab = (ws, d), (ws, lib.conv2d_splits(ctypes.byref(d), self.which, dt))
+                fn = lib.deconv2d_dgrad_slabs if self.transposed else lib.conv2d_dgrad_slabs
+                pa, pb, dref, pws = _p(dy.buf), _p(w.buf), ctypes.byref(d), _p(ws)
+                return lambda s: fn(pa, pb, dref, dt, pws, n, s)
             return self._bind(rt, 'deconv2d_dgrad' if self.transposed else 'conv2d_dgrad', dy, w, self.outputs[0])
         # ONE launch for dx and dw: the two contractions share the CUs instead of running one grid after the other
         wg = self.pair_w
         x = wg.inputs[0]
-        lib, d, dt = rt.lib, self.desc, rt.conv_dtype
         wsd, nd = rt.workspace(lib.conv2d_workspace_bytes(ctypes.byref(d), self.which, dt))
         wsw, nw = rt.workspace(lib.conv2d_workspace_bytes(ctypes.byref(d), CONV_WGRAD, dt))
+        if hand_off:
+            self._slab = (wsd, lib.conv2d_splits(ctypes.byref(d), self.which, dt))
         slabs = 0
         if wg.deferred_to is not None:
             splits = lib.conv2d_splits(ctypes.byref(d), CONV_WGRAD, dt)
@@ -294,7 +326,7 @@ class ConvDgradOp(_ConvBase):
         self._keep = (wsd, wsw, d)
         fn = lib.deconv2d_bwd_pair if self.transposed else lib.conv2d_bwd_pair
         args = (_p(dy.buf), _p(w.buf), _p(x.buf), _p(self.outputs[0].buf), None if slabs else _p(wg.outputs[0].buf), wg.accumulate,
-                ctypes.byref(d), dt, _p(wsd), nd, _p(wsw), nw, slabs)
+                ctypes.byref(d), dt, _p(wsd), nd, _p(wsw), nw, slabs | (2 if hand_off else 0))
         return lambda s: fn(*args, s)
 
 
@@ -361,6 +393,7 @@ class WgradReduceOp(G.Op):
 
 class BnActOp(G.Op):
     """slim.batch_norm (batch statistics, beta only) fused with the layer activation."""
+    conv_producer = None     # the layer's Conv2dOp (set by _layer): source of the split-K hand-off
 
     def __init__(self, x, beta, act, leak, eps, groups, name):
         g = G.get_default_graph()
@@ -386,6 +419,14 @@ class BnActOp(G.Op):
         self._keep = ws
         x, beta = self.inputs
         y, mean, rstd = self.outputs
+        src = self.conv_producer
+        slab = src._slab if (src is not None and id(src) in rt.program_ops) else None
+        if slab is not None:      # the conv left its split-K slabs: sum them here and write x for the backward pass
+            sws, splits = slab
+            args = (_p(sws), splits, _p(x.buf), _p(beta.buf), _p(y.buf), _p(mean.buf), _p(rstd.buf), self.rows, self.c, self.xp, self.yp,
+                    self.groups, self.eps, _ACT_CODE[self.act], self.leak, _code2(x, y), _p(ws), n)
+            fn = lib.bn_act_fwd_slabs
+            return lambda s: fn(*args, s)
         args = (_p(x.buf), _p(beta.buf), _p(y.buf), _p(mean.buf), _p(rstd.buf), self.rows, self.c, self.xp, self.yp, self.groups,
                 self.eps, _ACT_CODE[self.act], self.leak, _code2(x, y), _p(ws), n)
         fn = lib.bn_act_fwd
@@ -397,10 +438,14 @@ class BnActOp(G.Op):
         op = BnActBwdOp(self, gouts[0], dst, acc, self.name + '/bwd')
         if dst is not None:
             ctx.wrote(beta, op)
+        if isinstance(gouts[0].op, ConvDgradOp) and gouts[0] is gouts[0].op.outputs[0]:
+            gouts[0].op.bn_bwd_consumer, op.dy_producer = op, gouts[0].op     # split-K hand-off candidate (backward)
         return [op.outputs[0] if needs[0] else None, None]
 
 
 class BnActBwdOp(G.Op):
+    dy_producer = None
+
     def __init__(self, fwd, dy, dbeta_dst, accumulate, name):
         g = G.get_default_graph()
         self.fwd, self.accumulate = fwd, float(accumulate)
@@ -417,6 +462,14 @@ class BnActBwdOp(G.Op):
         self._keep = ws
         x, dy, beta, mean, rstd = self.inputs
         dx, dbeta = self.outputs
+        src = self.dy_producer
+        slab = src._slab if (src is not None and id(src) in rt.program_ops) else None
+        if slab is not None:      # dy arrives as the producing dgrad's split-K slabs
+            sws, splits = slab
+            args = (_p(x.buf), _p(sws), splits, _p(beta.buf), _p(mean.buf), _p(rstd.buf), _p(dx.buf), _p(dbeta.buf), self.accumulate,
+                    f.rows, f.c, f.xp, f.yp, f.groups, _ACT_CODE[f.act], f.leak, _code2(x, dy), _p(ws), n)
+            fn = lib.bn_act_bwd_slabs
+            return lambda s: fn(*args, s)
         args = (_p(x.buf), _p(dy.buf), _p(beta.buf), _p(mean.buf), _p(rstd.buf), _p(dx.buf), _p(dbeta.buf), self.accumulate,
                 f.rows, f.c, f.xp, f.yp, f.groups, _ACT_CODE[f.act], f.leak, _code2(x, dy), _p(ws), n)
         fn = lib.bn_act_bwd
@@ -957,10 +1010,16 @@ def _layer(inputs, num_outputs, kernel_size, stride, padding, activation_fn, nor
         act = _act_of(activation_fn)
         if normalizer_fn is not None:
             params = dict(normalizer_params or {})
+            conv_op = out.op
+
+            def link(t):      # conv -> its BatchNorm: candidates for the split-K hand-off (Conv2dOp.bind)
+                if isinstance(t.op, BnActOp) and t.op.inputs[0] is conv_op.outputs[0]:
+                    conv_op.bn_consumer, t.op.conv_producer = t.op, conv_op
+                return t
             if getattr(normalizer_fn, '_acg_key', None) == 'batch_norm' and act is not None:
-                out = normalizer_fn(out, activation_fn=activation_fn, **params)      # fused BN + activation
+                out = link(normalizer_fn(out, activation_fn=activation_fn, **params))      # fused BN + activation
                 return out
-            out = normalizer_fn(out, **params)
+            out = link(normalizer_fn(out, **params))
         else:
             bias = g.get_variable(_scope_name('biases'), (num_outputs,), biases_initializer or zeros_initializer(), share)
             # a layer without BatchNorm is a head in the reference nets (frame, state, DNA logits): float32 result

@@ -140,11 +140,28 @@ int32_t acg_deconv2d_wgrad_slabs(const void* x, const void* dy, const acg_conv_d
                                  size_t workspace_bytes, acg_stream_t stream);
 int32_t acg_splitk_reduce_many(const acg_reduce_list* list, int32_t count, acg_stream_t stream);
 
+/* Split-K hand-off to the consuming BatchNorm.  A small layer is split over K to fill the chip and would need a
+ * launch of its own to sum the partial slabs; its output (forward) or input gradient (backward) is read next by the
+ * layer's BatchNorm kernel (models.py:10-15: every conv but three is followed by batch_norm), which can sum the slabs as it
+ * loads them: acg_(de)conv2d_fwd_slabs / _dgrad_slabs run the contraction only - `splits` float32 slabs, each laid out like
+ * the tensor, stay in the workspace (an error when acg_conv2d_splits == 1) - and acg_bn_act_fwd_slabs /
+ * acg_bn_act_bwd_slabs (below) take them.  Same values as the separate reduction, one launch less per layer and pass. */
+int32_t acg_conv2d_fwd_slabs(const void* x, const void* w, const acg_conv_desc* d, int32_t dtype, void* workspace,
+                             size_t workspace_bytes, acg_stream_t stream);
+int32_t acg_conv2d_dgrad_slabs(const void* dy, const void* w, const acg_conv_desc* d, int32_t dtype, void* workspace,
+                               size_t workspace_bytes, acg_stream_t stream);
+int32_t acg_deconv2d_fwd_slabs(const void* x, const void* w, const acg_conv_desc* adj, int32_t dtype, void* workspace,
+                               size_t workspace_bytes, acg_stream_t stream);
+int32_t acg_deconv2d_dgrad_slabs(const void* dy, const void* w, const acg_conv_desc* adj, int32_t dtype, void* workspace,
+                                 size_t workspace_bytes, acg_stream_t stream);
+
 /* A layer's input gradient and weight gradient in ONE launch (both consume dy, neither reads the other's result):
  * the same results as acg_(de)conv2d_dgrad followed by acg_(de)conv2d_wgrad - or, with wgrad_slabs_only != 0, by
  * acg_(de)conv2d_wgrad_slabs (dw may then be NULL) - bit for bit; the blocks of the two contractions share the CUs
  * instead of running one grid after the other.  Workspaces as for the separate entries (acg_conv2d_workspace_bytes
- * with ACG_CONV_DGRAD / ACG_CONV_WGRAD; for the transposed layer ACG_CONV_FWD / ACG_CONV_WGRAD on the adjoint). */
+ * with ACG_CONV_DGRAD / ACG_CONV_WGRAD; for the transposed layer ACG_CONV_FWD / ACG_CONV_WGRAD on the adjoint).
+ * wgrad_slabs_only is a bit set: 1 = leave the weight-gradient slabs (dw may be NULL), 2 = leave the input-gradient
+ * slabs for acg_bn_act_bwd_slabs (dx may be NULL; an error when that contraction is not split). */
 int32_t acg_conv2d_bwd_pair(const void* dy, const void* w, const void* x, void* dx, float* dw, float dw_accumulate,
                             const acg_conv_desc* d, int32_t dtype, void* ws_dgrad, size_t ws_dgrad_bytes, void* ws_wgrad,
                             size_t ws_wgrad_bytes, int32_t wgrad_slabs_only, acg_stream_t stream);
@@ -192,6 +209,20 @@ int32_t acg_bn_act_bwd_sums(const void* x, const void* dy, const float* beta, co
  * d/conv6 sits at a pitch of 8; pad channels are neither read nor written.
  * ---------------------------------------------------------------------------------------- */
 size_t acg_bn_workspace_bytes(int64_t rows, int32_t channels, int32_t groups);
+/* The same with the split-K hand-off described at acg_conv2d_fwd_slabs: forward reads x as the sum of `splits` float32
+ * slabs (each rows * x_pitch elements, summed in slab order and rounded to x's storage type - what the separate
+ * reduction would have stored) and WRITES x, which backward re-reads; backward reads dy as the sum of `splits` slabs
+ * (each rows * y_pitch elements) and stores it nowhere.  acg_bn_bwd_slabs_ok: 1 when backward can take slabs (tensors
+ * small enough for the one-launch kernels - the split layers are), else run the plain reduction + acg_bn_act_bwd. */
+int32_t acg_bn_act_fwd_slabs(const float* slabs, int32_t splits, void* x, const float* beta, void* y, float* save_mean,
+                             float* save_rstd, int64_t rows, int32_t channels, int32_t x_pitch, int32_t y_pitch, int32_t groups,
+                             float eps, int32_t act, float leak, int32_t dtype, void* workspace, size_t workspace_bytes,
+                             acg_stream_t stream);
+int32_t acg_bn_bwd_slabs_ok(int64_t rows, int32_t groups);
+int32_t acg_bn_act_bwd_slabs(const void* x, const float* dy_slabs, int32_t splits, const float* beta, const float* save_mean,
+                             const float* save_rstd, void* dx, float* dbeta, float dbeta_accumulate, int64_t rows,
+                             int32_t channels, int32_t x_pitch, int32_t y_pitch, int32_t groups, int32_t act, float leak,
+                             int32_t dtype, void* workspace, size_t workspace_bytes, acg_stream_t stream);
 int32_t acg_bn_act_fwd(const void* x, const float* beta, void* y, float* save_mean, float* save_rstd,
                        int64_t rows, int32_t channels, int32_t x_pitch, int32_t y_pitch, int32_t groups, float eps,
                        int32_t act, float leak, int32_t dtype, void* workspace, size_t workspace_bytes,

@@ -78,13 +78,18 @@ def _layer(params, net, spec, x, create=None):
         params[wname] = T.xavier_uniform_(shape, k * k * shape[2], k * k * shape[3], gen, dtype)
         bname = '%s/%s/%s' % (net, scope, 'BatchNorm/beta' if norm else 'biases')
         params[bname] = torch.zeros(cout, dtype=dtype)
-    w = params[wname]
-    y = T.conv2d(x, w, s, pad) if kind == 'c' else T.conv2d_transpose(x, w, s, pad)
+    # T.q_act / T.q_weight are identities unless bf16 storage is being emulated (tf_ops.bf16_storage): then the conv
+    # reads bf16 operands and writes a bf16 tensor, a BatchNorm'd + activated layer output is bf16 again, and the heads
+    # (bias layers, d/conv6 without activation) hand float32 to the losses
+    w = T.q_weight(params[wname])
+    x = T.q_act(x)
+    y = T.q_act(T.conv2d(x, w, s, pad) if kind == 'c' else T.conv2d_transpose(x, w, s, pad))
     if norm:
         y = T.batch_norm_train(y, params['%s/%s/BatchNorm/beta' % (net, scope)])
     else:
         y = y + params['%s/%s/biases' % (net, scope)]
-    return _ACT[act](y)
+    out = _ACT[act](y)
+    return T.q_act(out) if (norm and act is not None) else out
 
 
 def tile_actions(actions, size):
@@ -99,7 +104,7 @@ def generator(params, images, actions, create=None):
     out = images
     for spec in L['enc']:
         out = _layer(params, 'g', spec, out, create)
-    out = torch.cat([out, tile_actions(actions, out.shape[1]).to(out.dtype)], dim=3)
+    out = T.q_act(torch.cat([out, tile_actions(actions, out.shape[1]).to(out.dtype)], dim=3))
     for spec in L['dec']:
         out = _layer(params, 'g', spec, out, create)
     return out
@@ -111,7 +116,7 @@ def generator_transform(params, images, actions, ksize=5, create=None):
     out = images
     for spec in L['enc']:
         out = _layer(params, 'g', spec, out, create)
-    out = torch.cat([out, tile_actions(actions, out.shape[1]).to(out.dtype)], dim=3)
+    out = T.q_act(torch.cat([out, tile_actions(actions, out.shape[1]).to(out.dtype)], dim=3))
     for spec in L['dec1']:
         out = _layer(params, 'g', spec, out, create)
     st = out
@@ -129,7 +134,7 @@ def discriminator(params, inputs, actions, create=None):
     out = inputs
     for spec in L['pre']:
         out = _layer(params, 'd', spec, out, create)
-    out = torch.cat([out, tile_actions(actions, out.shape[1]).to(out.dtype)], dim=3)
+    out = T.q_act(torch.cat([out, tile_actions(actions, out.shape[1]).to(out.dtype)], dim=3))
     for spec in L['post']:
         out = _layer(params, 'd', spec, out, create)
     return out

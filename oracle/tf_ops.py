@@ -14,6 +14,57 @@ import torch
 import torch.nn.functional as F
 
 
+# --------------------------------------------------------------------------- bf16 storage emulation
+# BASELINE configs 3 and 5 keep activations (and their gradients) in bfloat16 in memory; everything is still computed
+# and accumulated in higher precision.  ``with bf16_storage():`` makes the model restatement (oracle/models.py) round
+# exactly the tensors the HIP pipeline stores as bf16 - conv operands and outputs, BatchNorm+activation outputs, the
+# action-concatenated maps, the discriminator input, and on the way back the gradients of those tensors - while
+# filters round in the forward pass only (master weights and weight gradients stay float32 there too).
+_BF16 = [False]
+
+
+class _RoundBoth(torch.autograd.Function):
+    """forward: x -> bf16(x) (round to nearest even); backward: g -> bf16(g).  A tensor that is stored as bf16."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+class _RoundFwd(torch.autograd.Function):
+    """forward: bf16 copy of a float32 master tensor; backward: identity (its gradient is accumulated in float32)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def q_act(x):
+    return _RoundBoth.apply(x) if _BF16[0] else x
+
+
+def q_weight(w):
+    return _RoundFwd.apply(w) if _BF16[0] else w
+
+
+class bf16_storage:
+    def __enter__(self):
+        self._prev = _BF16[0]
+        _BF16[0] = True
+
+    def __exit__(self, *a):
+        _BF16[0] = self._prev
+        return False
+
+
 # --------------------------------------------------------------------------- padding
 def same_pads(in_size, k, s):
     """TF 'SAME' geometry: (out, pad_before, pad_after).  SURVEY Appendix A.1."""

@@ -416,6 +416,153 @@ def case_dna(abi, shape, tol, seed=0):
     close(abi.dna_bwd(logits.to(dev), img.to(dev), dout.to(dev), k), dl_ref, tol * 4, tag + ' bwd')
 
 
+def case_dna_bias(abi, shape, tol, seed=0):
+    """softmax(logits + bias) with the bias of the producing layer folded into the kernel (models.py:54-72), and
+    dbias = sum over pixels of dlogits, accumulated into a running gradient."""
+    b, h, w, c, k = shape
+    logits = randn((b, h, w, k * k), seed, 2.0)
+    bias = randn((k * k,), seed + 3, 1.0)
+    img = uniform((b, h, w, c), seed + 1)
+    ld, bd = logits.double().requires_grad_(True), bias.double().requires_grad_(True)
+    out_ref = T.dna_gather(ld + bd, img.double(), k)
+    dout = randn(tuple(out_ref.shape), seed + 2)
+    dl_ref, db_ref = torch.autograd.grad(out_ref, [ld, bd], dout.double())
+    dev = abi.device
+    tag = 'dna+bias%s' % (shape,)
+    close(abi.dna_fwd(logits.to(dev), img.to(dev), k, bias=bias.to(dev)), out_ref, tol, tag + ' fwd')
+    dl, db = abi.dna_bwd(logits.to(dev), img.to(dev), dout.to(dev), k, bias=bias.to(dev), want_dbias=True)
+    close(dl, dl_ref, tol * 4, tag + ' dlogits')
+    close(db, db_ref, tol * 8, tag + ' dbias')
+
+
+def r16(t):
+    """Round to bfloat16 and back (what a bf16 tensor holds)."""
+    return t.to(torch.bfloat16).float()
+
+
+def case_dna_bf16(abi, shape, tol_f32, tol_bf16, seed=0):
+    """bf16 logits at the pitch round8(k*k), float32 image / frame; dlogits come back as bf16 with zero pad taps."""
+    b, h, w, c, k = shape
+    kk, lp = k * k, (k * k + 7) // 8 * 8
+    logits = r16(randn((b, h, w, kk), seed, 2.0))
+    bias = randn((kk,), seed + 3, 1.0)
+    img = uniform((b, h, w, c), seed + 1)
+    ld, bd = logits.double().requires_grad_(True), bias.double().requires_grad_(True)
+    out_ref = T.dna_gather(ld + bd, img.double(), k)
+    dout = randn(tuple(out_ref.shape), seed + 2)
+    dl_ref, db_ref = torch.autograd.grad(out_ref, [ld, bd], dout.double())
+    dev = abi.device
+    l16 = torch.zeros(b, h, w, lp, dtype=torch.bfloat16, device=dev)
+    l16[..., :kk] = logits.to(dev).to(torch.bfloat16)
+    tag = 'dna bf16%s' % (shape,)
+    close(abi.dna_fwd(l16, img.to(dev), k, bias=bias.to(dev)), out_ref, tol_f32, tag + ' fwd')
+    dl, db = abi.dna_bwd(l16, img.to(dev), dout.to(dev), k, bias=bias.to(dev), want_dbias=True)
+    assert dl.dtype == torch.bfloat16 and (dl[..., kk:] == 0).all(), tag + ': pad taps of dlogits must stay zero'
+    close(dl[..., :kk].float(), dl_ref, tol_bf16, tag + ' dlogits')
+    close(db, db_ref, tol_bf16, tag + ' dbias')      # sums of float32 values formed before the bf16 rounding of dlogits
+
+
+def case_bn_bf16(abi, shape, tol, seed=0):
+    """bf16 x / y / dy / dx (BASELINE configs 3 and 5): statistics, beta and dbeta stay float32.  Reference: fp64
+    BatchNorm of the bf16-rounded inputs; outputs carry one bf16 rounding."""
+    lead, c, groups, act = shape
+    x = r16(randn(lead + (c,), seed, 1.5) + 0.7)
+    beta = randn((c,), seed + 1, 0.3)
+    xd, bd = x.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y_ref = _bn_ref(xd, bd, act, groups)
+    dy = r16(randn(tuple(y_ref.shape), seed + 2))
+    dx_ref, db_ref = torch.autograd.grad(y_ref, [xd, bd], dy.double())
+    dev = abi.device
+    xg, bg, dyg = x.to(dev).to(torch.bfloat16), beta.to(dev), dy.to(dev).to(torch.bfloat16)
+    tag = 'bn bf16%s' % (shape,)
+    y, mean, rstd = abi.bn_act_fwd(xg, bg, act, groups)
+    assert y.dtype == torch.bfloat16
+    close(y.float(), y_ref, tol, tag + ' fwd')
+    dx, dbeta = abi.bn_act_bwd(xg, dyg, bg, mean, rstd, act, groups)
+    close(dx.float(), dx_ref, tol, tag + ' dx')
+    close(dbeta, db_ref, 2e-4, tag + ' dbeta')
+
+
+def case_bn_head_bf16(abi, tol, seed=0):
+    """The loss-facing layer of a bf16 network (d/conv6: one channel at a pitch of 8): bf16 x / dx with pad channels,
+    dense float32 y / dy."""
+    for lead, c, groups in [((4, 2, 2), 1, 2), ((6, 3, 3), 5, 1)]:
+        x = r16(randn(lead + (c,), seed, 1.5) + 0.3)
+        beta = randn((c,), seed + 1, 0.3)
+        xd, bd = x.double().requires_grad_(True), beta.double().requires_grad_(True)
+        y_ref = _bn_ref(xd, bd, None, groups)
+        dy = randn(tuple(y_ref.shape), seed + 2)
+        dx_ref, db_ref = torch.autograd.grad(y_ref, [xd, bd], dy.double())
+        dev = abi.device
+        xp = torch.zeros(*lead, 8, dtype=torch.bfloat16, device=dev)
+        xp[..., :c] = x.to(dev).to(torch.bfloat16)
+        y, mean, rstd = abi.bn_act_fwd(xp, beta.to(dev), None, groups, y_dtype=torch.float32, c=c)
+        assert y.dtype == torch.float32 and y.shape[-1] == c
+        close(y, y_ref, 2e-5, 'bn head fwd')
+        dx, dbeta = abi.bn_act_bwd(xp, dy.to(dev), beta.to(dev), mean, rstd, None, groups)
+        assert dx.dtype == torch.bfloat16 and (dx[..., c:] == 0).all()
+        close(dx[..., :c].float(), dx_ref, tol, 'bn head dx')
+        close(dbeta, db_ref, 2e-4, 'bn head dbeta')
+
+
+def case_bias_bf16(abi, tol, seed=0):
+    """bias (+ tanh) heads of a bf16 network: bf16 conv output at pitch 8 in, dense float32 frame / state out; backward
+    returns the bf16 gradient at pitch 8 and the float32 bias gradient."""
+    for lead, c, act in [((2, 16, 16), 3, 'tanh'), ((4, 1, 1), 5, None)]:
+        x = r16(randn(lead + (c,), seed))
+        bias = randn((c,), seed + 1, 0.5)
+        xd, bd = x.double().requires_grad_(True), bias.double().requires_grad_(True)
+        y_ref = {'tanh': torch.tanh, None: lambda t: t}[act](xd + bd)
+        dy = randn(tuple(y_ref.shape), seed + 2)
+        dx_ref, db_ref = torch.autograd.grad(y_ref, [xd, bd], dy.double())
+        dev = abi.device
+        xp = torch.zeros(*lead, 8, dtype=torch.bfloat16, device=dev)
+        xp[..., :c] = x.to(dev).to(torch.bfloat16)
+        y = abi.bias_act_fwd(xp, bias.to(dev), act, c=c, y_dtype=torch.float32)
+        close(y, y_ref, 2e-5, 'bias bf16 %s fwd' % act)
+        dx, db = abi.bias_act_bwd(y, dy.to(dev), act, x_pitch=8, x_dtype=torch.bfloat16)
+        assert dx.dtype == torch.bfloat16 and (dx[..., c:] == 0).all()
+        close(dx[..., :c].float(), dx_ref, tol, 'bias bf16 %s dx' % act)
+        close(db, db_ref, 1e-4, 'bias bf16 %s dbias' % act)
+
+
+def case_plumbing_bf16(abi):
+    """The channel plumbing of a bf16 network: exact copies / roundings, no arithmetic."""
+    dev = abi.device
+    x = r16(randn((2, 4, 4, 256), 0))
+    a = randn((2, 10), 1)
+    ref = torch.cat([x, r16(a).reshape(2, 1, 1, 10).expand(2, 4, 4, 10)], dim=3)
+    y = abi.concat_actions(x.to(dev).to(torch.bfloat16), a.to(dev), pitch=272)
+    assert y.dtype == torch.bfloat16 and (y[..., 266:] == 0).all()
+    assert torch.equal(y[..., :266].float().cpu(), ref), 'concat_actions bf16'
+    p, q = randn((2, 8, 8, 3), 2), randn((2, 8, 8, 3), 3)
+    cat = abi.concat_channels(p.to(dev), q.to(dev), pitch=8, y_dtype=torch.bfloat16)      # float32 frames -> bf16 D input
+    assert cat.dtype == torch.bfloat16 and torch.equal(cat[..., :6].float().cpu(), r16(torch.cat([p, q], dim=3))) and (cat[..., 6:] == 0).all()
+    back = abi.slice_channels(cat, 3, 3, dst_dtype=torch.float32)                         # bf16 gradient -> float32 frame gradient
+    assert back.dtype == torch.float32 and torch.equal(back.cpu(), r16(q)), 'slice bf16 -> f32'
+    same = abi.slice_channels(y, 0, 256)
+    assert same.dtype == torch.bfloat16 and torch.equal(same.float().cpu(), x), 'slice bf16 -> bf16'
+    u, v = r16(randn((3, 5, 7, 8), 5)), r16(randn((3, 5, 7, 8), 6))
+    s2 = abi.add(u.to(dev).to(torch.bfloat16), v.to(dev).to(torch.bfloat16))
+    assert torch.equal(s2.float().cpu(), r16(u + v)), 'add bf16'
+    src = randn((6, 3), 7).to(dev)
+    dst = torch.zeros(6, 8, dtype=torch.bfloat16, device=dev)
+    abi.copy_many([(src, dst)])
+    assert torch.equal(dst[:, :3].float().cpu(), r16(src.cpu())) and (dst[:, 3:] == 0).all(), 'copy_many f32 -> bf16'
+
+
+def case_weights_prepare(abi):
+    """acg_weights_prepare_bf16: both operand layouts, zero padded to multiples of 8."""
+    for shape in [(5, 5, 3, 32), (5, 5, 266, 128), (2, 2, 512, 1), (4, 4, 16, 5), (5, 5, 25, 128)]:
+        w = randn(shape, 11, 0.1)
+        rm, tr = abi.prep_weights(w)
+        abi.sync()
+        kh, kw, a, b = shape
+        wr = r16(w).reshape(kh * kw, a, b)
+        assert torch.equal(rm[:, :, :b].float().cpu(), wr) and (rm[:, :, b:] == 0).all(), 'rm %s' % (shape,)
+        assert torch.equal(tr[:, :, :a].float().cpu(), wr.permute(0, 2, 1)) and (tr[:, :, a:] == 0).all(), 'tr %s' % (shape,)
+
+
 def case_dna_extreme_logits(abi, tol):
     """softmax must be max-subtracted: logits of +-80 overflow a naive exp in fp32."""
     logits = randn((1, 6, 6, 25), 3, 1.0)

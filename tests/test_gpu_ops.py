@@ -37,6 +37,47 @@ def test_deconv_bf16(hip_abi_bf16, shape):
     C.case_conv_bf16(hip_abi_bf16, shape, TOL_BF16, TOL_CONV, transposed=True)
 
 
+@pytest.mark.parametrize('shape', [(32, 64, 64, 64, 128, 5, 2, 'SAME')], ids=str)
+def test_conv_bf16_big_tiles(hip_abi_bf16, shape):
+    """Large enough for the planner's 128x128 tiles in all three contractions (256 output tiles; wgrad: long K)."""
+    C.case_conv_bf16(hip_abi_bf16, shape, TOL_BF16, TOL_CONV)
+
+
+def test_deconv_bf16_big_tiles(hip_abi_bf16):
+    C.case_conv_bf16(hip_abi_bf16, (16, 32, 32, 128, 128, 5, 2), TOL_BF16, TOL_CONV, transposed=True)
+
+
+@pytest.mark.parametrize('shape', C.BN_SHAPES[:2] + C.BN_SHAPES[3:7] + [((32, 16, 16), 128, 2, 'lrelu'), ((32, 32, 32), 64, 1, 'relu')], ids=str)
+def test_bn_bf16(hip_abi, shape):
+    C.case_bn_bf16(hip_abi, shape, 6e-3)
+
+
+def test_bn_head_bf16(hip_abi):
+    C.case_bn_head_bf16(hip_abi, 6e-3)
+
+
+def test_bias_bf16(hip_abi):
+    C.case_bias_bf16(hip_abi, 6e-3)
+
+
+@pytest.mark.parametrize('shape', C.DNA_SHAPES, ids=str)
+def test_dna_bias(hip_abi, shape):
+    C.case_dna_bias(hip_abi, shape, TOL)
+
+
+@pytest.mark.parametrize('shape', C.DNA_SHAPES + [(2, 128, 128, 3, 11)], ids=str)
+def test_dna_bf16(hip_abi, shape):
+    C.case_dna_bf16(hip_abi, shape, TOL, 6e-3)
+
+
+def test_plumbing_bf16(hip_abi):
+    C.case_plumbing_bf16(hip_abi)
+
+
+def test_weights_prepare(hip_abi):
+    C.case_weights_prepare(hip_abi)
+
+
 def test_deconv_pitched(hip_abi):
     C.case_deconv_pitched(hip_abi, TOL_CONV)
 

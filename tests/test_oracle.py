@@ -66,6 +66,12 @@ def test_copy_many(oracle_abi):
     C.case_copy_many(oracle_abi)
 
 
+@pytest.mark.parametrize('shape', [C.DNA_SHAPES[i] for i in (0, 1, 3, 4, 8)], ids=str)
+def test_dna_bias(oracle_abi, shape):
+    """The C restatement of softmax(logits + bias) and its dbias against the torch restatement (autograd)."""
+    C.case_dna_bias(oracle_abi, shape, TOL)
+
+
 def test_dna_extreme(oracle_abi):
     C.case_dna_extreme_logits(oracle_abi, TOL)
 

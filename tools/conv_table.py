@@ -18,15 +18,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--other', action='store_true', help='table of the NON-conv ops instead (time, tensor bytes moved, GB/s)')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
+    ap.add_argument('--img', type=int, default=64)
+    ap.add_argument('--ksize', type=int, default=5)
     args = ap.parse_args()
-    B = args.batch
+    B, S = args.batch, args.img
     G.reset_default_graph()
     optim.set_data_parallel(1)
-    sess = G.Session(device='cuda:0')
-    tr = T.Trainer(sess, True, 'bce', 'adam', True, batch_size=B)
+    sess = G.Session(device='cuda:0', dtype=args.dtype)
+    tr = T.Trainer(sess, True, 'bce', 'adam', True, batch_size=B, img_size=S, ksize=args.ksize)
     sess.run(G.global_variables_initializer())
     rng = np.random.default_rng(0)
-    x, y = (rng.uniform(-1, 1, (B, 64, 64, 3)).astype(np.float32) for _ in range(2))
+    x, y = (rng.uniform(-1, 1, (B, S, S, 3)).astype(np.float32) for _ in range(2))
     a, s = rng.standard_normal((B, 10)).astype(np.float32), rng.standard_normal((B, 5)).astype(np.float32)
     import ctypes
     rows = []
@@ -57,14 +60,15 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 if args.other:    # bytes = every input and output tensor once (the algorithmic traffic of an elementwise/reduction op)
-                    by = 4.0 * sum(t.numel for t in list(op.inputs) + list(op.outputs))
+                    by = float(sum(t.numel * (2 if t.dtype == torch.bfloat16 else 4) for t in list(op.inputs) + list(op.outputs)))
                     shape = 'x'.join(str(v) for v in (op.inputs[0].shape if op.inputs else ()))
                     rows.append((tag, op.name, type(op).__name__ + ' ' + shape, by, e0.elapsed_time(e1) * 1e3 / 60))
                     continue
                 d = op.desc
                 fl = 2.0 * d.batch * d.out_h * d.out_w * d.kh * d.kw * d.in_c * d.out_c
                 paired = getattr(op, 'pair_active', False)     # this launch also ran the layer's weight gradient (same FLOPs again)
-                rows.append((tag, op.name + ('+wgrad' if paired else ''), type(op).__name__ + ('+W' if paired else ''), fl * (2 if paired else 1),
+                splits = sess.rt.lib.conv2d_splits(ctypes.byref(d), op.which, sess.rt.conv_dtype)
+                rows.append((tag, op.name + ('+wgrad' if paired else ''), type(op).__name__ + ('+W' if paired else '') + ' s%d' % splits, fl * (2 if paired else 1),
                              e0.elapsed_time(e1) * 1e3 / 60))
     tot_us = sum(r[4] for r in rows)
     if args.other:
@@ -75,9 +79,10 @@ def main():
         return
     tot_fl = sum(r[3] for r in rows)
     print('# %d conv launches (+W: input gradient and weight gradient of a layer in one launch), %.1f us, %.2f GFLOP, %.1f TFLOP/s average' % (len(rows), tot_us, tot_fl / 1e9, tot_fl / tot_us / 1e6))
-    print('# step op kind GFLOP us TFLOP/s us_above_90TF')
-    for tag, name, kind, fl, us in sorted(rows, key=lambda r: -(r[4] - r[3] / 90e6)):
-        print('%s %-44s %-14s %6.2f %7.1f %6.1f %7.1f' % (tag, name[:44], kind, fl / 1e9, us, fl / us / 1e6, us - fl / 90e6))
+    line = 90e6 if args.dtype == 'f32' else 750e6      # 90 TFLOP/s (fp32) / 750 TFLOP/s (bf16: 30 % of the dense peak)
+    print('# step op kind+splits GFLOP us TFLOP/s us_above_line')
+    for tag, name, kind, fl, us in sorted(rows, key=lambda r: -(r[4] - r[3] / line)):
+        print('%s %-44s %-18s %6.2f %7.1f %6.1f %7.1f' % (tag, name[:44], kind, fl / 1e9, us, fl / us / 1e6, us - fl / line))
 
 
 if __name__ == '__main__':

@@ -51,13 +51,21 @@ def main():
     ap.add_argument('--cfgs', default='-1,2,3', help='tile configurations to try (-1 = planner)')
     ap.add_argument('--unbatched-d', action='store_true')
     ap.add_argument('--top', type=int, default=6, help='rows printed per layer')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='bf16: tile configurations 1 (128x128) and 3 (64x64)')
+    ap.add_argument('--img', type=int, default=64)
+    ap.add_argument('--ksize', type=int, default=5)
     args = ap.parse_args()
+    half = args.dtype == 'bf16'
+    dt = _lib.ACG_BF16 if half else _lib.ACG_F32
+    if half:
+        CFG.clear()
+        CFG.update({1: '128x128', 3: '64x64'})
     lib = _lib.get()
     dev = torch.device('cuda:0')
     G.reset_default_graph()
     optim.set_data_parallel(1)
-    sess = G.Session(device=dev)
-    T.Trainer(sess, True, 'bce', 'adam', not args.plain, batch_size=args.batch, batched_d=not args.unbatched_d)
+    sess = G.Session(device=dev, dtype=args.dtype)
+    T.Trainer(sess, True, 'bce', 'adam', not args.plain, batch_size=args.batch, batched_d=not args.unbatched_d, img_size=args.img, ksize=args.ksize)
     seen = {}
     for op in G.get_default_graph().ops:
         if isinstance(op, O._ConvBase):
@@ -72,12 +80,16 @@ def main():
             continue
         d = op.desc
         flops = 2.0 * d.batch * d.out_h * d.out_w * d.kh * d.kw * d.in_c * d.out_c
-        nx = d.batch * d.in_h * d.in_w * max(d.in_c, d.in_pitch)
-        ny = d.batch * d.out_h * d.out_w * max(d.out_c, d.out_pitch)
-        nw = d.kh * d.kw * d.in_c * d.out_c
-        x = torch.randn(nx, device=dev)
-        y = torch.randn(ny, device=dev)
-        w = torch.randn(nw, device=dev)
+        r8 = lambda c: -(-c // 8) * 8     # noqa: E731
+        nx = d.batch * d.in_h * d.in_w * (r8(d.in_c) if half else max(d.in_c, d.in_pitch))
+        ny = d.batch * d.out_h * d.out_w * (r8(d.out_c) if half else max(d.out_c, d.out_pitch))
+        nw = d.kh * d.kw * (max(d.in_c * r8(d.out_c), d.out_c * r8(d.in_c)) if half else d.in_c * d.out_c)
+        tdt = torch.bfloat16 if half else torch.float32
+        x = torch.randn(nx, device=dev).to(tdt)
+        y = torch.randn(ny, device=dev).to(tdt)
+        w = (torch.randn(nw, device=dev) * 0.05).to(tdt)       # bf16: stands in for either prepared filter copy
+        if which == _lib.CONV_WGRAD:
+            w = torch.zeros(d.kh * d.kw * d.in_c * d.out_c, device=dev)
         if which == _lib.CONV_FWD:
             a, b, out, fn = x, w, y, lib.conv2d_fwd
         elif which == _lib.CONV_DGRAD:
@@ -88,7 +100,7 @@ def main():
         for cfg in cfgs:
             for sp in ([-1] if cfg == -1 else splits_list):
                 lib.debug_conv_plan(cfg, sp)
-                nbytes = lib.conv2d_workspace_bytes(ctypes.byref(d), which, 0)
+                nbytes = lib.conv2d_workspace_bytes(ctypes.byref(d), which, dt)
                 if nbytes > (2 << 30):
                     continue
                 ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
@@ -97,9 +109,9 @@ def main():
                 def call():
                     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
                     if which == _lib.CONV_WGRAD:
-                        fn(pa, pb, po, 0.0, ctypes.byref(d), 0, pw, nbytes, stream)
+                        fn(pa, pb, po, 0.0, ctypes.byref(d), dt, pw, nbytes, stream)
                     else:
-                        fn(pa, pb, po, ctypes.byref(d), 0, pw, nbytes, stream)
+                        fn(pa, pb, po, ctypes.byref(d), dt, pw, nbytes, stream)
                 us = time_graph(call, reps=args.reps)
                 results.append((us, cfg, sp))
         lib.debug_conv_plan(-1, -1)

@@ -63,7 +63,6 @@ SIGNATURES = {
     'acg_last_error': (c_char_p, []),
     'acg_conv_desc_init': (c_int32, [_D] + [c_int32] * 9),
     'acg_conv2d_workspace_bytes': (c_size_t, [_D, c_int32, c_int32]),
-    'acg_debug_conv_plan': (c_int32, [c_int32, c_int32]),
     'acg_conv2d_fwd': (c_int32, _conv),
     'acg_conv2d_dgrad': (c_int32, _conv),
     'acg_conv2d_wgrad': (c_int32, _wgrad),
@@ -160,13 +159,14 @@ class AcgError(RuntimeError):
 class Library:
     """A loaded C-ABI library; every int-returning entry point is checked and raises AcgError."""
 
-    def __init__(self, path):
+    def __init__(self, path, extra=None):
         self.path = path
         self._cdll = ctypes.CDLL(path)
-        missing = [n for n in SIGNATURES if not hasattr(self._cdll, n)]
+        sigs = dict(SIGNATURES, **(extra or {}))
+        missing = [n for n in sigs if not hasattr(self._cdll, n)]
         if missing:
             raise AcgError('%s does not export %s' % (path, ', '.join(missing)))
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in sigs.items():
             fn = getattr(self._cdll, name)
             fn.restype, fn.argtypes = res, args
             if res is c_int32 and name not in VALUE_RETURNING:
@@ -193,13 +193,22 @@ def get():
     """The process-wide HIP library; raises if it was not built."""
     global _LIB
     if _LIB is None:
-        path = os.environ.get('ACG_HIP_LIB', LIB_PATH)     # kernel experiments: an alternative build of the same ABI
-        if path != LIB_PATH:
-            _LIB = Library(path)
-            return _LIB
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 '%s not found: the HIP kernels are not built and there is no fallback path. '
                 'Run `python -c "import __graft_entry__ as g; g.build()"` first.' % LIB_PATH)
         _LIB = Library(LIB_PATH)
+    return _LIB
+
+
+TUNING_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), 'libacgan_hip_tuning.so')
+
+
+def load_tuning():
+    """tools/ only: the -DACG_TUNING build (`make -C action_conditioned_gans_amd/csrc tuning`) with acg_debug_conv_plan
+    and the ACG_* environment knobs, installed as the process's library.  The package itself never loads it."""
+    global _LIB
+    if not os.path.exists(TUNING_LIB_PATH):
+        raise RuntimeError('%s not built: make -C action_conditioned_gans_amd/csrc tuning' % TUNING_LIB_PATH)
+    _LIB = Library(TUNING_LIB_PATH, extra={'acg_debug_conv_plan': (c_int32, [c_int32, c_int32])})
     return _LIB

@@ -27,10 +27,14 @@ constexpr int kMaxPartialBlocks = 512;
 #endif
 constexpr int kU = ACG_BN_U;   // row passes whose loads a thread keeps in flight together (two-launch BatchNorm kernels)
 
+#ifdef ACG_TUNING        // tuning builds only (see conv_f32.hip)
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
 }
+#else
+constexpr int env_int(const char*, int dflt) { return dflt; }
+#endif
 constexpr int kMaxC = 1024;
 
 struct ColMap {

@@ -144,13 +144,18 @@ int validate(const acg_conv_desc* d, const char* who) {
   return ACG_OK;
 }
 
-// Tuning hook (acg_debug_conv_plan): force a tile configuration / split-K factor; -1 = heuristic.
-int g_force_cfg = -1, g_force_splits = -1;
-
+// Tuning hooks exist in -DACG_TUNING builds only (libacgan_hip_tuning.so, `make tuning`, used by tools/): the shipped
+// library has no process-wide mutable state and reads no environment variable.
+#ifdef ACG_TUNING
+int g_force_cfg = -1, g_force_splits = -1;   // acg_debug_conv_plan: force a tile configuration / split-K factor; -1 = heuristic
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
 }
+#else
+constexpr int g_force_cfg = -1, g_force_splits = -1;
+constexpr int env_int(const char*, int dflt) { return dflt; }
+#endif
 
 Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
   Plan pl{};
@@ -348,10 +353,12 @@ int32_t acg_conv_desc_init(acg_conv_desc* d, int32_t batch, int32_t in_h, int32_
   return ACG_OK;
 }
 
+#ifdef ACG_TUNING
 int32_t acg_debug_conv_plan(int32_t cfg, int32_t splits) {
   g_force_cfg = cfg; g_force_splits = splits;
   return ACG_OK;
 }
+#endif
 
 size_t acg_conv2d_workspace_bytes(const acg_conv_desc* d, int32_t which, int32_t dtype) {
   if (!d || validate(d, "conv2d_workspace_bytes") != ACG_OK || which < 0 || which > 2) return 0;

@@ -20,7 +20,7 @@ class Saver:
     def _tensors(self):
         items = {'var:' + n: v for n, v in self.graph.variables.items()}
         for s in self.graph.state:
-            if s.name and not s.name.endswith('/flat_grad'):
+            if s.name and not s.name.endswith(('/flat_grad', '/bf16_rm', '/bf16_tr')):     # gradients and derived copies are not state
                 items['state:' + s.name] = s
         return items
 
@@ -48,6 +48,7 @@ class Saver:
             if tuple(arr.shape) != t.shape:
                 raise ValueError('checkpoint tensor %s has shape %s, graph expects %s' % (key, arr.shape, t.shape))
             sess._materialize(t).copy_(torch.from_numpy(arr).to(t.dtype))
+        sess._weights_dirty = True          # bf16 sessions: the filter copies follow the restored master weights
 
 
 def latest_checkpoint(checkpoint_dir):

@@ -152,8 +152,26 @@ class Trainer:
         gen_next_state = res[1] if self.g_state_out is not None else None      # defect D4
         return gen_next_frames, gen_next_state, self._named(summ)
 
-    def test_sequence(self, input_images, test_next_frame, test_actions, steps=None):
-        """Recursive rollout (train.py:157-176): feed each prediction (and predicted state) back in."""
+    def test_sequence(self, input_images, test_next_frame, test_actions, steps=None, literal=False):
+        """Recursive rollout: feed each prediction (and predicted state) back in.
+
+        Default: the evaluation block of the reference's training loop (train.py:285-298) - T-1 steps, step j commanded
+        by ``test_actions[:, j]`` and scored against ``test_next_frame[:, j + 1]`` (defect D7: own states); returns
+        ``(predicted [B, steps, H, W, 3], summaries of step 0)``.
+        ``literal=True``: the reference's method of this name exactly as written (train.py:157-176) - SIX steps, step j
+        reads ``test_actions[:, 2 j, :5]`` and ``test_next_frame[:, 2 j]`` (the sequences must hold >= 11 frames),
+        and the second return value is ``current_frame[1:7]``, samples 1..6 of the last prediction."""
+        if literal:
+            predicted = []
+            current_frame = input_images[:, 0]
+            current_state = test_actions[:, 0, 5:]
+            for j in range(0, 6):
+                acs = np.concatenate((test_actions[:, j * 2, :5], current_state), axis=1).astype(np.float32)
+                out, st, _ = self.test(current_frame, test_next_frame[:, j * 2], acs)
+                predicted.append(out)
+                current_frame = out
+                current_state = st if st is not None else test_actions[:, j * 2, 5:]      # plain generator: no state head (D4)
+            return np.transpose(np.array(predicted), (1, 0, 2, 3, 4)), current_frame[1:7]
         steps = steps if steps is not None else test_next_frame.shape[1] - 1
         predicted, summ0 = [], None
         current_frame = input_images[:, 0]

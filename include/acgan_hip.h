@@ -90,10 +90,12 @@ typedef struct acg_prep_list {
 } acg_prep_list;
 int32_t acg_weights_prepare_bf16(const acg_prep_list* list, int32_t count, acg_stream_t stream);
 
-/* Tuning hook (process-wide, not for production use): force the tile configuration (0: 128x128, 1: 128x64,
- * 2: 128x32, 3: 64x64) and/or the split-K factor chosen by the planner; -1 restores the heuristic.
- * Affects acg_conv2d_workspace_bytes too, so query the workspace after setting it. */
+#ifdef ACG_TUNING
+/* Tuning builds only (libacgan_hip_tuning.so, `make tuning`; absent from libacgan_hip.so, which has no process-wide
+ * mutable state): force the tile configuration (fp32: 2 = 128x32, 3 = 64x64; bf16: 1 = 128x128, 3 = 64x64) and/or the
+ * split-K factor chosen by the planner; -1 restores the heuristic.  Affects acg_conv2d_workspace_bytes too. */
 int32_t acg_debug_conv_plan(int32_t cfg, int32_t splits);
+#endif
 
 /* slim.conv2d's tf.nn.conv2d: models.py:12-15,34-37,42-51,82-88. */
 int32_t acg_conv2d_fwd(const void* x, const void* w, void* y, const acg_conv_desc* d, int32_t dtype,

@@ -57,7 +57,6 @@ size_t acg_conv2d_workspace_bytes(const acg_conv_desc* d, int32_t which, int32_t
   const int32_t sp = acg_conv2d_splits(d, which, dtype);
   return sp > 1 ? (size_t)sp * d->kh * d->kw * d->in_c * d->out_c * sizeof(float) : 0;
 }
-int32_t acg_debug_conv_plan(int32_t cfg, int32_t splits) { (void)cfg; (void)splits; return ACG_OK; }
 
 #define XPITCH(d) ((d)->in_pitch > 0 ? (d)->in_pitch : (d)->in_c)
 #define XI(d, b, y, x, c) ((((size_t)(b) * (d)->in_h + (y)) * (d)->in_w + (x)) * XPITCH(d) + (c))

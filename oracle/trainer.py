@@ -109,7 +109,8 @@ class OracleTrainer:
         p = self._with_grad(self.g_names)
         out = self._g_losses(p, img, next_frame, actions, state)
         grads = torch.autograd.grad(out['g_l2_loss'], [p[n] for n in self.g_names], allow_unused=True)
-        self.g_pretrain_opt.apply(self.p, {n: g for n, g in zip(self.g_names, grads) if g is not None})
+        self.last_grads = {n: g for n, g in zip(self.g_names, grads) if g is not None}
+        self.g_pretrain_opt.apply(self.p, self.last_grads)
         return out['g_loss'].detach()
 
     def train_g(self, img, next_frame, actions, state, return_all=False):
@@ -151,6 +152,15 @@ class OracleTrainer:
         """Recursive rollout (reference train.py:157-176 / the eval block at :285-298): the predicted frame and the
         predicted state are fed back in; the commanded action of step j comes from the data.
         frames, next_frames: [B,T,H,W,3]; actions: [B,T,10] (action 0:5, state 5:10).  Returns [B,steps,H,W,3], PSNRs."""
+        if steps == 'literal':      # the reference's own test_sequence (train.py:157-176): six steps, stride-2 indexing
+            cur, state, out = frames[:, 0], actions[:, 0, 5:], []
+            for j in range(6):
+                acs = torch.cat([actions[:, j * 2, :5], state], dim=1)
+                frame, st, _ = self.test(cur, next_frames[:, j * 2], acs)
+                out.append(frame)
+                cur = frame
+                state = st if st is not None else actions[:, j * 2, 5:]
+            return torch.stack(out, dim=1), cur[1:7]
         steps = steps if steps is not None else next_frames.shape[1] - 1
         cur, state = frames[:, 0], actions[:, 0, 5:]
         out, psnrs = [], []

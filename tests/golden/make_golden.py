@@ -5,9 +5,10 @@ the ORACLE (against accidental change) and give the GPU suite fixed targets; the
 the reference itself.  Usage:  python tests/golden/make_golden.py   (from the repo root)
 
 Each case stores small tensors only: generated frame / state / logits / loss scalars with the initial
-parameters, per-variable gradient L2 norms of one D step and one G step, and - for the RMSProp case -
-per-variable parameter L2 norms after 1 D step + 1 G step.  Parameters themselves are re-created from
-the seed (oracle.models.init_params) and are not stored.
+parameters; per variable the gradient L2 norm AND a strided elementwise sample (sample_index) of the gradient
+of one D step, one G step and one pre-training step; the same sample of every parameter after 1 D step +
+1 G step (RMSProp: plus the L2 norm; Adam: compared where the gradient is clearly signed, see
+tests/train_cases.py).  Parameters themselves are re-created from the seed (oracle.models.init_params).
 """
 import os
 import sys
@@ -42,6 +43,23 @@ def inputs(batch, img=64):
     return x, y, a, s
 
 
+def sample_index(numel, n=193):
+    """<= n element indices of a flattened variable: a stride coprime to the usual power-of-two extents, so the sample
+    walks through every axis (taps, input channels, output channels) instead of one column."""
+    if numel <= n:
+        return np.arange(numel)
+    stride = numel // n
+    stride += 1 - stride % 2            # odd
+    while stride % 3 == 0 or stride % 5 == 0:
+        stride += 2
+    return (np.arange(n) * stride) % numel
+
+
+def sample(t):
+    flat = t.detach().reshape(-1).numpy()
+    return flat[sample_index(flat.size)].astype(np.float64)
+
+
 def make_case(name):
     adv, loss, opt, dna, batch, ksize = CASES[name]
     params = OM.init_params(dna, batch=batch, ksize=ksize, seed=PARAM_SEED, dtype=torch.float32)
@@ -61,15 +79,26 @@ def make_case(name):
     out['d_out_gen'], out['d_out_real'] = d['d_out_gen'].numpy(), d['d_out_real'].numpy()
     for k, g in tr.last_grads.items():
         out['dgrad_norm/' + k] = np.float64(g.norm())
+        out['dgrad_sample/' + k] = sample(g)
     g = tr.train_g(td(x), td(y), td(a), td(s), return_all=True)
     for k in ('g_loss', 'g_l2_loss', 'g_adv_loss', 'gdl'):
         if g.get(k) is not None:
             out[k] = np.float64(g[k])
     for k, gr in tr.last_grads.items():
         out['ggrad_norm/' + k] = np.float64(gr.norm())
-    if opt == 'rmsprop':
-        for k, v in tr.p.items():
+        out['ggrad_sample/' + k] = sample(gr)
+    for k, v in tr.p.items():                    # parameters after 1 D step + 1 G step
+        out['param_sample/' + k] = sample(v)
+        if opt == 'rmsprop':
             out['param_norm/' + k] = np.float64(v.norm())
+    # pre-training step (train.py:114-121: g_pretrain_opt on g_l2_loss) from the initial parameters, own optimizer state
+    tp = OracleTrainer(params, adv, loss, opt, dna, ksize)
+    out['pretrain_g_loss'] = np.float64(tp.pretrain_g(td(x), td(y), td(a), td(s)))
+    for k, gr in tp.last_grads.items():
+        out['pretrain_grad_sample/' + k] = sample(gr)
+    for k, v in tp.p.items():
+        if k.startswith('g/'):
+            out['pretrain_param_sample/' + k] = sample(v)
     return out
 
 

@@ -20,8 +20,12 @@ def uniform(shape, seed):
     return (torch.rand(shape, generator=_rng(seed), dtype=torch.float64) * 2 - 1).float()
 
 
-def close(got, want, tol, what):
-    """max abs error relative to the reference tensor's scale (north_star: 1e-3 rel, fp32)."""
+def close(got, want, tol, what, elementwise=True):
+    """Two bars.  (1) max abs error relative to the reference tensor's scale (north_star: 1e-3 rel, fp32).  (2) element
+    by element: |err| <= 4 tol |want| + 2 tol rms(want) - relative to each element, with an absolute floor at the
+    tensor's RMS instead of its maximum (accumulation error scales with the sum of |products|, so a cancelled, near-zero
+    output cannot be held to its own magnitude); outliers, scale or sign errors confined to small elements fail here
+    while passing (1)."""
     got = got.detach().double().cpu()
     want = want.detach().double().cpu()
     assert got.shape == want.shape, '%s: shape %s vs %s' % (what, tuple(got.shape), tuple(want.shape))
@@ -29,6 +33,10 @@ def close(got, want, tol, what):
     scale = max(want.abs().max().item(), 1e-30)
     err = (got - want).abs().max().item() / scale
     assert err <= tol, '%s: rel err %.3e > %.1e (scale %.3e)' % (what, err, tol, scale)
+    if elementwise and tol > 0 and want.numel() > 1:
+        rms = max(want.pow(2).mean().sqrt().item(), 1e-30)
+        bad = (got - want).abs() > 4 * tol * want.abs() + 2 * tol * rms
+        assert not bad.any(), '%s: %d of %d elements beyond the elementwise bar (tol %.1e, rms %.3e)' % (what, int(bad.sum()), want.numel(), tol, rms)
     return err
 
 

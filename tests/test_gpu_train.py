@@ -21,6 +21,13 @@ def test_trainer_matches_golden(name):
     TC.case_golden(gpu_session, name, 1e-3)
 
 
+@pytest.mark.parametrize('name', ['c2_dna_bce_adam', 'plain_adv_bce_rmsprop', 'c1_plain_l1'])
+def test_pretrain_step_matches_golden(name):
+    """Trainer.pretrain_g (train.py:114-121) against the oracle's pre-training step: loss, elementwise gradient samples and
+    the generator weights after the update."""
+    TC.case_pretrain_golden(gpu_session, name, 1e-3)
+
+
 @pytest.mark.parametrize('name', ['c2_dna_bce_adam', 'c4_dna_wass_rmsprop'])
 def test_hip_graph_replay_equals_eager(name):
     """Run 1 is eager, run 2 captures, run 3+ replays: the weights must match an all-eager session bit for bit."""
@@ -177,6 +184,56 @@ def test_rollout_matches_oracle(name):
     for j in range(T_ - 1):
         assert TC.rel(pred[:, j], want[:, j].numpy()) <= 1e-3, j
     assert abs(summ['g_psnr'] - psnrs[0]) <= 1e-3 * abs(psnrs[0])
+
+
+def test_test_sequence_literal_matches_reference_indexing():
+    """Trainer.test_sequence(literal=True) is the reference's method as written (train.py:157-176): six steps, step j
+    commanded by actions[:, 2 j] and fed next_frame[:, 2 j], second result current_frame[1:7] - against the oracle's
+    restatement of the same lines."""
+    from oracle.trainer import OracleTrainer
+    from oracle import models as OM
+    name = 'c2_dna_bce_adam'
+    adv, loss, opt, dna, batch, ksize = TC.MG.CASES[name]
+    sess, tr = TC.build_trainer(gpu_session, name, batch=8)
+    rng = np.random.default_rng(6)
+    frames = rng.uniform(-1, 1, (8, 11, 64, 64, 3)).astype(np.float32)
+    acts = rng.standard_normal((8, 11, 10)).astype(np.float32)
+    pred, tail = tr.test_sequence(frames, frames, acts, literal=True)
+    params = OM.init_params(dna, batch=8, ksize=ksize, seed=TC.MG.PARAM_SEED, dtype=torch.float32)
+    ot = OracleTrainer({k: v.double() for k, v in params.items()}, adv, loss, opt, dna, ksize)
+    want, wtail = ot.test_sequence(torch.from_numpy(frames).double(), torch.from_numpy(frames).double(), torch.from_numpy(acts).double(),
+                                   steps='literal')
+    assert pred.shape == (8, 6, 64, 64, 3) and tail.shape == (6, 64, 64, 3)
+    for j in range(6):
+        assert TC.rel(pred[:, j], want[:, j].numpy()) <= 1e-3, j
+    assert TC.rel(tail, wtail.numpy()) <= 1e-3
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_checkpoint_roundtrip_on_the_gpu(tmp_path, dtype):
+    """Saver (train.py:215,274; test.py:29-30) on CUDA sessions: weights and optimizer slots (Adam m, v, step counter)
+    are saved, restored into a FRESH session, and the resumed run continues bit-identically - also through the
+    captured HIP graphs and, in a bf16 session, the refreshed bf16 filter copies."""
+    from action_conditioned_gans_amd.saver import Saver, latest_checkpoint
+    x, y, a, s = TC.MG.inputs(2)
+    sess, tr = TC.build_trainer(gpu_session, 'c2_dna_bce_adam', dtype=dtype)
+    for _ in range(3):
+        tr.train_d(x, y, a)
+        tr.train_g(x, y, a, s)
+    Saver().save(sess, str(tmp_path / 'model100'))
+    assert latest_checkpoint(str(tmp_path)) == str(tmp_path / 'model100')
+    for _ in range(3):
+        tr.train_d(x, y, a)
+        frames = tr.train_g(x, y, a, s)
+    want = {n: sess.get_value(v) for n, v in G.get_default_graph().variables.items()}
+    sess2, tr2 = TC.build_trainer(gpu_session, 'c2_dna_bce_adam', dtype=dtype)
+    Saver().restore(sess2, str(tmp_path / 'model100'))
+    for _ in range(3):
+        tr2.train_d(x, y, a)
+        frames2 = tr2.train_g(x, y, a, s)
+    for n, v in G.get_default_graph().variables.items():
+        assert torch.equal(sess2.get_value(v), want[n]), n
+    assert np.array_equal(frames, frames2)
 
 
 def test_device_resident_feeds_equal_host_feeds():

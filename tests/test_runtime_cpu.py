@@ -24,6 +24,11 @@ def test_trainer_matches_golden(name):
     TC.case_golden(cpu_session, name, 1e-5)
 
 
+@pytest.mark.parametrize('name', ['c2_dna_bce_adam', 'plain_adv_bce_rmsprop'])
+def test_pretrain_step_matches_golden(name):
+    TC.case_pretrain_golden(cpu_session, name, 1e-5)
+
+
 def test_oracle_still_matches_golden():
     """Pins the fp64 restatement itself: regenerating a fixture must reproduce the committed file."""
     import make_golden as MG
@@ -215,12 +220,16 @@ def test_c_abi_exports_every_declared_symbol():
     import re, os, ctypes
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     header = open(os.path.join(root, 'include', 'acgan_hip.h')).read()
+    tuning = re.findall(r'#ifdef ACG_TUNING(.*?)#endif', header, flags=re.S)
+    header = re.sub(r'#ifdef ACG_TUNING.*?#endif', '', header, flags=re.S)     # tuning builds only: not part of the shipped ABI
     declared = set(re.findall(r'\b(acg_[a-z0-9_]+)\s*\(', header))
     declared -= {'acg_conv_desc', 'acg_stream_t', 'acg_edge_t'}
     assert declared == set(_lib.SIGNATURES), sorted(declared ^ set(_lib.SIGNATURES))
     hip = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(hip, name), 'libacgan_hip.so lacks ' + name
+    for name in set(re.findall(r'\b(acg_[a-z0-9_]+)\s*\(', ' '.join(tuning))):
+        assert not hasattr(hip, name), 'the shipped library exports the tuning hook ' + name
     assert _lib.get().version() == _lib.ABI_VERSION
     assert cbind.load().version() == _lib.ABI_VERSION
 

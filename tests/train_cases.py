@@ -62,6 +62,80 @@ def check_norms(got, gold, prefix, tol, what):
             assert abs(got[n] - want) <= tol * want + 1e-6 * scale, '%s %s: %g vs %g' % (what, n, got[n], want)
 
 
+def flat_grad_samples(sess, step_op):
+    """The golden generator's strided elementwise sample (make_golden.sample_index) of every variable's gradient."""
+    g = G.get_default_graph()
+    offs, _, _ = g.layout(step_op.scope)
+    flat = step_op.inputs[1].buf.detach().double().cpu().numpy()
+    return {n: flat[o:o + g.variables[n].numel][MG.sample_index(g.variables[n].numel)] for n, o in offs.items()}
+
+
+def param_samples(sess, scope=None):
+    g = G.get_default_graph()
+    return {n: sess.get_value(v).double().reshape(-1).numpy()[MG.sample_index(v.numel)] for n, v in g.variables.items()
+            if scope is None or n.startswith(scope)}
+
+
+def check_samples(got, gold, prefix, tol, what):
+    """Elementwise: every sampled gradient element within tol of its golden value relative to that element, with an
+    absolute floor of tol x the sample's rms (a permuted, transposed or sign-flipped gradient keeps its norm and fails
+    here).  Analytically (near-)zero gradients are bounded instead."""
+    ref = {k[len(prefix):]: np.asarray(v, np.float64) for k, v in gold.items() if k.startswith(prefix)}
+    assert ref, 'no golden entries for ' + prefix
+    scale = max(max(float(np.sqrt(np.mean(v * v))) for v in ref.values()), 1e-2)     # floor: every gradient may be analytically zero (wass D step)
+    for n, want in ref.items():
+        rms = float(np.sqrt(np.mean(want * want)))
+        if rms < 1e-7 * scale:
+            assert np.abs(got[n]).max() <= 1e-4 * scale, '%s %s: should be ~0' % (what, n)
+            continue
+        err = np.abs(got[n] - want)
+        bad = err > tol * np.abs(want) + tol * rms
+        assert not bad.any(), '%s %s: %d of %d sampled elements off (worst %.3g at |want| %.3g, rms %.3g)' % (
+            what, n, int(bad.sum()), want.size, float(err.max()), float(np.abs(want[err.argmax()])), rms)
+
+
+def check_adam_params(got, gold, grad_prefix, param_prefix, what, lr=1e-3):
+    """Weights after ONE Adam step, where they are well defined: TF's first Adam step moves a weight by
+    lr * g / (|g| + eps / sqrt(1 - beta2)), i.e. by ~lr * sign(g) - rounding noise decides the direction of an
+    analytically zero gradient, so compare the elements whose golden gradient is clearly signed."""
+    n_checked = 0
+    for k, want in gold.items():
+        if not k.startswith(param_prefix):
+            continue
+        n = k[len(param_prefix):]
+        gk = grad_prefix + n
+        if gk not in gold or n not in got:
+            continue
+        g = np.abs(np.asarray(gold[gk], np.float64))
+        mask = g > max(1e-3 * g.max(), 1e-5)
+        if not mask.any():
+            continue
+        err = np.abs(got[n] - np.asarray(want, np.float64))[mask]
+        assert err.max() <= 0.02 * lr + 1e-7, '%s %s: weight off by %.3g after one Adam step (lr %g)' % (what, n, err.max(), lr)
+        n_checked += int(mask.sum())
+    assert n_checked > 0, what + ': nothing compared'
+
+
+def case_pretrain_golden(make_session, name, tol):
+    """Trainer.pretrain_g (train.py:114-121: g_pretrain_opt on g_l2_loss only) against the golden pre-training step:
+    returned g_loss, gradient samples, and the generator weights after the step."""
+    adv, loss, opt, dna, batch, ksize = MG.CASES[name]
+    gold = golden(name)
+    x, y, a, s = MG.inputs(batch)
+    sess, tr = build_trainer(make_session, name)
+    got_loss = tr.pretrain_g(x, y, a, s)
+    assert abs(got_loss - gold['pretrain_g_loss']) <= tol * abs(gold['pretrain_g_loss']), (got_loss, gold['pretrain_g_loss'])
+    check_samples(flat_grad_samples(sess, tr.g_pretrain_opt_op), gold, 'pretrain_grad_sample/', 10 * tol, 'pretrain grad')
+    got = param_samples(sess, 'g/')
+    if opt == 'rmsprop':
+        for n, v in got.items():
+            want = np.asarray(gold['pretrain_param_sample/' + n], np.float64)
+            assert np.abs(v - want).max() <= 1e-3 * 5e-5 + 1e-7, n       # RMSProp moves a weight by <= lr / sqrt(0.1)
+    else:
+        check_adam_params(got, gold, 'pretrain_grad_sample/', 'pretrain_param_sample/', 'pretrain weights')
+    return sess, tr
+
+
 def case_golden(make_session, name, tol):
     """frames / losses / gradients / (RMSProp) updated weights against the golden vectors."""
     adv, loss, opt, dna, batch, ksize = MG.CASES[name]
@@ -80,6 +154,7 @@ def case_golden(make_session, name, tol):
     assert abs(dsumm['discriminator_direct_loss'] - gold['d_direct_loss']) <= tol * dscale
     assert abs(dsumm['discriminator_gen_loss'] - gold['d_gen_loss']) <= tol * dscale
     check_norms(flat_grad_norms(sess, tr.d_opt_op), gold, 'dgrad_norm/', 10 * tol, 'D grad')
+    check_samples(flat_grad_samples(sess, tr.d_opt_op), gold, 'dgrad_sample/', 10 * tol, 'D grad')
     # G step (values are those of the forward pass inside the step, i.e. before the update)
     fetch = [tr.g_opt_op, tr.g_loss, tr.g_l2_loss] + ([tr.g_adv_loss] if adv else [])
     res = sess.run(fetch, tr._feed(x, y, a, s))
@@ -88,6 +163,11 @@ def case_golden(make_session, name, tol):
     if adv:
         assert abs(res[3][0] - gold['g_adv_loss']) <= tol * max(abs(gold['g_adv_loss']), 1e-2)
     check_norms(flat_grad_norms(sess, tr.g_opt_op), gold, 'ggrad_norm/', 10 * tol, 'G grad')
+    check_samples(flat_grad_samples(sess, tr.g_opt_op), gold, 'ggrad_sample/', 10 * tol, 'G grad')
+    if opt == 'adam':      # weights after 1 D step (+ clip) + 1 G step, where Adam's sign-like first step is well defined
+        got_p = param_samples(sess)
+        check_adam_params({n: v for n, v in got_p.items() if n.startswith('g/')}, gold, 'ggrad_sample/', 'param_sample/', 'G weights (Adam)')
+        check_adam_params({n: v for n, v in got_p.items() if n.startswith('d/')}, gold, 'dgrad_sample/', 'param_sample/', 'D weights (Adam)')
     if opt == 'rmsprop':
         g = G.get_default_graph()
         got = {n: float(sess.get_value(v).double().norm()) for n, v in g.variables.items()}

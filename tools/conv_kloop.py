@@ -47,7 +47,7 @@ def main():
     ap.add_argument('--modes', default='fwd,dgrad,wgrad')
     ap.add_argument('--data', default='randn', help='randn | zeros | ones | small (randn * 1e-3): operand values (the MFMA rate turned out to depend on them)')
     args = ap.parse_args()
-    lib = _lib.get()
+    lib = _lib.load_tuning()
     dev = torch.device('cuda:0')
     print('# cfg %d dtype %d; rows: blocks  [Cin -> nk: us]  fit fixed us + per K-step us (floor 0.43 us fp32 64x64)' % (args.cfg, args.dtype))
     for which, wname in ((_lib.CONV_FWD, 'fwd'), (_lib.CONV_DGRAD, 'dgrad'), (_lib.CONV_WGRAD, 'wgrad')):

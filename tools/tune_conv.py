@@ -60,7 +60,7 @@ def main():
     if half:
         CFG.clear()
         CFG.update({1: '128x128', 3: '64x64'})
-    lib = _lib.get()
+    lib = _lib.load_tuning()
     dev = torch.device('cuda:0')
     G.reset_default_graph()
     optim.set_data_parallel(1)

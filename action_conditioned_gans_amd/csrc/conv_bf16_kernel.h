@@ -372,6 +372,11 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
   const bool to_bf16 = MODE != MODE_WGRAD && p.splits == 1;
   float* const outf = p.out + (p.splits > 1 ? (long long)bz * p.out_numel : 0ll);
   __bf16* const outh = reinterpret_cast<__bf16*>(p.out);
+  if constexpr (MODE != MODE_WGRAD) {
+    // (A packed variant - neighbouring lanes trade registers over DPP so that each stores 4 bytes, half the store
+    // instructions - measured SLOWER in the same session: conv stack of config 5 2246 vs 2088 us, of config 3 908 vs 864 us,
+    // profiles/r2/c_epilogue_ab.txt; the plain 2-byte stores below stay.)
+  }
 #pragma unroll
   for (int a = 0; a < TA; ++a)
 #pragma unroll

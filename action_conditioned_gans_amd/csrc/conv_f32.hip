@@ -72,33 +72,66 @@ __global__ __launch_bounds__(256) void splitk_reduce_bf16(const float* __restric
 }
 
 // fp32 master weights [taps][A][B] -> the two bf16 operand layouts of the bf16 conv kernels, zero padded to multiples
-// of 8: rm [taps][A][B8] (k-fast along B) and tr [taps][B][A8] (k-fast along A).  All filters of a scope in ONE launch.
+// of 8: rm [taps][A][B8] (k-fast along B) and tr [taps][B][A8] (k-fast along A).  All filters of a scope in ONE launch:
+// entry e owns blocks [first_block[e], first_block[e+1]); the first n_rm[e] of them write rm - one 16-byte oct per
+// thread and step, reading 8 consecutive floats - the rest write tr through 32 x 32 LDS tile transposes, so that both
+// the float32 reads (along B) and the bf16 writes (along A) are coalesced.
 struct PrepList {
   const float* src[ACG_PREP_MAX];
   __bf16* rm[ACG_PREP_MAX];
   __bf16* tr[ACG_PREP_MAX];
   int taps[ACG_PREP_MAX], A[ACG_PREP_MAX], B[ACG_PREP_MAX];
-  int first_block[ACG_PREP_MAX + 1];
+  int first_block[ACG_PREP_MAX + 1], n_rm[ACG_PREP_MAX];
 };
 __global__ __launch_bounds__(256) void weights_prepare_bf16(const PrepList l, int count) {
+  __shared__ float tile[32][33];
   int e = 0;
   while (e + 1 < count && (int)blockIdx.x >= l.first_block[e + 1]) ++e;
   const int A = l.A[e], B = l.B[e], A8 = (A + 7) & ~7, B8 = (B + 7) & ~7, taps = l.taps[e];
   const float* __restrict__ src = l.src[e];
-  const long long nrm = (long long)taps * A * B8, ntr = (long long)taps * B * A8;
-  const long long stride = (long long)(l.first_block[e + 1] - l.first_block[e]) * 256;
-  for (long long i = (long long)((int)blockIdx.x - l.first_block[e]) * 256 + threadIdx.x; i < nrm + ntr; i += stride) {
-    if (i < nrm) {
-      const int b = (int)(i % B8);
-      const long long ta = i / B8;
-      l.rm[e][i] = b < B ? (__bf16)src[ta * B + b] : (__bf16)0.f;
-    } else {
-      const long long j = i - nrm;
-      const int a = (int)(j % A8);
-      const long long tb = j / A8;
-      const int b = (int)(tb % B);
-      const long long t = tb / B;
-      l.tr[e][j] = a < A ? (__bf16)src[(t * A + a) * B + b] : (__bf16)0.f;
+  const int blk = (int)blockIdx.x - l.first_block[e], nrm = l.n_rm[e], ntr = l.first_block[e + 1] - l.first_block[e] - nrm;
+  if (blk < nrm) {
+    const int ob = B8 >> 3;                                   // octs per (tap, a) row
+    const long long nocts = (long long)taps * A * ob;
+    const bool fast = (B & 7) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+    for (long long i = (long long)blk * 256 + threadIdx.x; i < nocts; i += (long long)nrm * 256) {
+      const long long ta = i / ob;
+      const int b0 = (int)(i - ta * ob) * 8;
+      float v[8];
+      if (fast) {
+        const f4 lo = *reinterpret_cast<const f4*>(src + ta * B + b0), hi = *reinterpret_cast<const f4*>(src + ta * B + b0 + 4);
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = b0 + u < B ? src[ta * B + b0 + u] : 0.f;
+      }
+      bf8 o;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) o[u] = (__bf16)v[u];
+      *reinterpret_cast<bf8*>(l.rm[e] + ta * B8 + b0) = o;
+    }
+    return;
+  }
+  // tr: tiles of 32 (a) x 32 (b) of one tap; pad columns a in [A, A8) are written as zeros by the tiles that cover them
+  const int ta_n = (A8 + 31) / 32, tb_n = (B + 31) / 32;
+  const long long ntiles = (long long)taps * ta_n * tb_n;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8 threads
+  for (long long t = blk - nrm; t < ntiles; t += ntr) {
+    const int tb = (int)(t % tb_n);
+    const long long r = t / tb_n;
+    const int ta = (int)(r % ta_n), tap = (int)(r / ta_n);
+    const int a0 = ta * 32, b0 = tb * 32;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int a = a0 + ty + 8 * k, b = b0 + tx;
+      tile[ty + 8 * k][tx] = (a < A && b < B) ? src[((long long)tap * A + a) * B + b] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int b = b0 + ty + 8 * k, a = a0 + tx;
+      if (b < B && a < A8) l.tr[e][((long long)tap * B + b) * A8 + a] = (__bf16)tile[tx][ty + 8 * k];
     }
   }
 }
@@ -211,7 +244,8 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
   // bf16: a K-step is ~4x cheaper than in fp32 while a slab round trip (fp32 slabs + the reduce launch) costs the same:
   // split only below half a chip of tiles, up to one block per CU (weight gradients 1.5) - profiles/r2 sweeps
   const long long target = bf16 ? (which == ACG_CONV_WGRAD ? 384 : 256) : (which == ACG_CONV_WGRAD ? t_w : (t_fd > 0 ? t_fd : 256));
-  long long s = (bf16 && pl.tiles >= 128) ? 1 : target / pl.tiles;
+  long long s = target / pl.tiles;
+  if (bf16 && pl.tiles >= 128) s = (pl.tiles < 256 && pl.nk >= 64) ? 2 : 1;     // half a chip of tiles with a long K: two blocks per tile
   s = std::min<long long>(s, std::max(1, pl.nk / min_steps));
   static const int max_splits = env_int("ACG_PLAN_MAX_SPLITS", 128), max_splits_w = env_int("ACG_PLAN_MAX_SPLITS_W", 128);
   s = std::min<long long>(s, which == ACG_CONV_WGRAD ? max_splits_w : max_splits);
@@ -437,9 +471,11 @@ int32_t acg_weights_prepare_bf16(const acg_prep_list* list, int32_t count, acg_s
                 "weights_prepare_bf16: bad entry %d", i);
     l.src[i] = (const float*)list->src[i]; l.rm[i] = (__bf16*)list->rm[i]; l.tr[i] = (__bf16*)list->tr[i];
     l.taps[i] = list->taps[i]; l.A[i] = list->a[i]; l.B[i] = list->b[i];
-    const long long n = (long long)l.taps[i] * ((long long)l.A[i] * ((l.B[i] + 7) & ~7) + (long long)l.B[i] * ((l.A[i] + 7) & ~7));
+    const long long nocts = (long long)l.taps[i] * l.A[i] * (((l.B[i] + 7) & ~7) / 8);
+    const long long ntiles = (long long)l.taps[i] * ((((l.A[i] + 7) & ~7) + 31) / 32) * ((l.B[i] + 31) / 32);
     l.first_block[i] = blocks;
-    blocks += (int)std::max<long long>(1, std::min<long long>(acg::ceil_div(n, 256 * 4), 1024));
+    l.n_rm[i] = (int)std::max<long long>(1, std::min<long long>(acg::ceil_div(nocts, 256 * 2), 512));
+    blocks += l.n_rm[i] + (int)std::max<long long>(1, std::min<long long>(ntiles, 1024));
   }
   l.first_block[count] = blocks;
   ACG_LAUNCH(weights_prepare_bf16, dim3(blocks), dim3(256), 0, acg::to_stream(stream), l, (int)count);

@@ -399,9 +399,12 @@ __global__ __launch_bounds__(256) void dna_dbias_sum(const float* __restrict__ p
 #endif
 
 // grid of the kernel that serves ksize k (also the number of dbias partial rows)
+#ifndef ACG_DNA_TY
+#define ACG_DNA_TY 4            // tile rows of dna_kernel (64 x TY pixels, one thread each)
+#endif
 dim3 dna_grid(int k, int B, int H, int W) {
   if (k >= ACG_DNA_ROWS_MIN) return dim3((W + 63) / 64, H, B);
-  return dim3((W + TX - 1) / TX, (H + 3) / 4, B);
+  return dim3((W + TX - 1) / TX, (H + ACG_DNA_TY - 1) / ACG_DNA_TY, B);
 }
 
 template <int K, bool BWD, typename TL>
@@ -412,7 +415,7 @@ int launch_k(const TL* logits, const float* bias, const float* img, const float*
     if (C == 3) ACG_LAUNCH((dna_rows_kernel<K, BWD, 3, TL>), grid, dim3(256), 0, st, logits, bias, img, dout, out, bpart, H, W, C);
     else ACG_LAUNCH((dna_rows_kernel<K, BWD, 0, TL>), grid, dim3(256), 0, st, logits, bias, img, dout, out, bpart, H, W, C);
   } else {
-    constexpr int TY = 4;
+    constexpr int TY = ACG_DNA_TY;
     if (C == 3) ACG_LAUNCH((dna_kernel<K, TY, BWD, 3, TL>), grid, dim3(TX * TY), 0, st, logits, bias, img, dout, out, bpart, H, W, C);
     else ACG_LAUNCH((dna_kernel<K, TY, BWD, 0, TL>), grid, dim3(TX * TY), 0, st, logits, bias, img, dout, out, bpart, H, W, C);
   }

@@ -22,8 +22,10 @@ def main():
     ap.add_argument('--ksize', type=int, default=5)
     ap.add_argument('--reps', type=int, default=50)
     ap.add_argument('--cdna', action='store_true', help='time the CDNA transformation (10 masks, k=5) instead')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='storage of logits / dlogits')
+    ap.add_argument('--lib', default=None, help='an alternative build of the library (kernel experiments)')
     args = ap.parse_args()
-    lib, dev = _lib.get(), torch.device('cuda:0')
+    lib, dev = (_lib.Library(args.lib) if args.lib else _lib.get()), torch.device('cuda:0')
     k, S, C = args.ksize, args.img, 3
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
@@ -54,15 +56,23 @@ def main():
                 print('cdna_%s k=%d masks=%d B=%-5d %7.2f MB  %8.2f us  %7.1f GB/s  (%.1f%% of 8 TB/s)' % (
                     name, k, M, B, nbytes / 1e6, us, nbytes / us / 1e3, 100 * nbytes / us / 1e3 / 8000))
         return
+    half = args.dtype == 'bf16'
+    dt, es, lp = (1, 2, (k * k + 7) // 8 * 8) if half else (0, 4, k * k)
     for B in [int(b) for b in args.batches.split(',')]:
-        logits = torch.randn(B, S, S, k * k, device=dev)
+        logits = torch.randn(B, S, S, lp, device=dev).to(torch.bfloat16 if half else torch.float32)
+        bias = torch.randn(k * k, device=dev)
+        dbias = torch.zeros(k * k, device=dev)
         img = torch.rand(B, S, S, C, device=dev) * 2 - 1
         out = torch.empty_like(img)
         dout = torch.randn_like(img)
-        dl = torch.empty_like(logits)
+        dl = torch.zeros_like(logits)
+        nws = lib.dna_workspace_bytes(B, S, S, k)
+        ws = torch.zeros(max(nws, 16), dtype=torch.uint8, device=dev)
+        # algorithmic bytes: k*k logits (+ k*k dlogits) at their storage size, 2C float32 image / frame values
         for name, fn, nbytes in (
-                ('fwd', lambda: lib.dna_fwd(p(logits), p(img), p(out), B, S, S, C, k, 0, stream), B * S * S * (k * k + 2 * C) * 4),
-                ('bwd', lambda: lib.dna_bwd(p(logits), p(img), p(dout), p(dl), B, S, S, C, k, 0, stream), B * S * S * (2 * k * k + 2 * C) * 4)):
+                ('fwd', lambda: lib.dna_fwd(p(logits), p(bias), p(img), p(out), B, S, S, C, k, dt, stream), B * S * S * (k * k * es + 2 * C * 4)),
+                ('bwd', lambda: lib.dna_bwd(p(logits), p(bias), p(img), p(dout), p(dl), p(dbias), 0.0, B, S, S, C, k, dt, p(ws), nws, stream),
+                 B * S * S * (2 * k * k * es + 2 * C * 4))):
             for _ in range(5):
                 fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

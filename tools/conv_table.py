@@ -21,7 +21,11 @@ def main():
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
     ap.add_argument('--img', type=int, default=64)
     ap.add_argument('--ksize', type=int, default=5)
+    ap.add_argument('--lib', default=None, help='an alternative build of the library (kernel A/B experiments)')
     args = ap.parse_args()
+    if args.lib:
+        from action_conditioned_gans_amd import _lib
+        _lib._LIB = _lib.Library(args.lib)
     B, S = args.batch, args.img
     G.reset_default_graph()
     optim.set_data_parallel(1)

@@ -597,14 +597,14 @@ class Session:
             return results[0]
         return self._unflatten(fetches, iter(results))
 
-    def profile_ops(self, fetches, feed_dict=None, repeats=3, relaunch=None):
-        """Instrumented eager pass of a fetch: every device op is bracketed by events recorded on the
-        launch stream.  Returns [(op, mean milliseconds)] in program order.  Executes the program
-        ``repeats`` times for real (optimizer steps included).
-        An event pair around ONE eager launch also times the gap the event records themselves open (~4 us here, more
-        than some kernels).  For ops accepted by ``relaunch(op)`` - which must be idempotent - the op is launched two
-        more times back to back behind the first bracket and its time is that of one of those launches: kernel plus
-        one inter-kernel gap, which is what a launch costs inside the replayed graph."""
+    def profile_ops(self, fetches, feed_dict=None, repeats=3, relaunch=None, in_graph=10):
+        """Instrumented pass of a fetch.  Returns [(op, mean milliseconds)] in program order.  Executes the program
+        ``repeats`` times for real (optimizer steps included), every device op bracketed by events recorded on the
+        launch stream.  An event pair around ONE eager launch also times the gap the event records themselves open
+        (~4 us here, more than some kernels), so the ops accepted by ``relaunch(op)`` - which must be idempotent - are
+        timed the way the training step runs them instead: ``in_graph`` launches of the op captured into a small HIP
+        graph, replayed once untimed and once between two events; the op's time is that replay / in_graph - kernel(s)
+        plus one in-graph launch boundary, on the launch stream."""
         if not self.rt.is_cuda:
             raise RuntimeError('profile_ops needs a GPU session')
         flat = self._flatten(fetches)
@@ -618,25 +618,35 @@ class Session:
         if self._weights_dirty:
             self._refresh_weight_copies()
         stream = torch.cuda.current_stream(self.rt.device)
-        records = []
-        for _ in range(repeats):
+        records, graphs = [], {}
+        for rep in range(repeats):
             for kind, seg in prog.segments:
                 if kind == 'host':
                     seg()
                     continue
                 sp = self.rt.stream_ptr()
                 for op, fn in seg:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(stream)
-                    fn(sp)
-                    e1.record(stream)
                     if relaunch is not None and relaunch(op):
-                        e2 = torch.cuda.Event(enable_timing=True)
-                        fn(sp)
-                        fn(sp)
-                        e2.record(stream)
-                        records.append((op, e1, e2, 0.5))
+                        fn(sp)                                   # the launch that belongs to the program
+                        if id(op) not in graphs:
+                            torch.cuda.synchronize(self.rt.device)
+                            gr = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(gr, capture_error_mode='thread_local'):
+                                csp = self.rt.stream_ptr()
+                                for _ in range(in_graph):
+                                    fn(csp)
+                            gr.replay()
+                            graphs[id(op)] = gr
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(stream)
+                        graphs[id(op)].replay()
+                        e1.record(stream)
+                        records.append((op, e0, e1, 1.0 / in_graph))
                     else:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(stream)
+                        fn(sp)
+                        e1.record(stream)
                         records.append((op, e0, e1, 1.0))
         torch.cuda.synchronize(self.rt.device)
         totals, order = {}, []

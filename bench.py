@@ -67,6 +67,12 @@ def conv_flops(op):
     return 2.0 * d.batch * d.out_h * d.out_w * d.kh * d.kw * d.in_c * d.out_c
 
 
+def conv_bytes(op):
+    """Algorithmic HBM bytes of one contraction: each operand and the result once, at their storage sizes."""
+    size = lambda t: t.numel * (2 if t.dtype == torch.bfloat16 else 4)      # noqa: E731
+    return float(sum(size(getattr(op, 'wop', t) if i == 1 and hasattr(op, 'wop') else t) for i, t in enumerate(op.inputs)) + sum(size(t) for t in op.outputs))
+
+
 def cpu_baseline(args, n_critic):
     """The CPU restatement of the reference step on this host (the checker, timed - never shipped)."""
     from oracle import models as OM
@@ -209,12 +215,13 @@ def main():
         x, y, a, s = pool[0]
         zero_state = torch.zeros(B, 5, device=device)
         recs = []
-        # conv and DNA launches are idempotent: timed as one of two extra back-to-back launches (graph.profile_ops)
+        # conv and DNA launches are idempotent: timed as launches inside a small captured HIP graph, the way the step runs
+        # them (graph.profile_ops)
         relaunch = lambda op: isinstance(op, (O._ConvBase, O.DnaOp, O.DnaBwdOp))   # noqa: E731
         recs += sess.profile_ops([tr.d_opt_op, tr.clip_d], tr._feed(x, y, a, zero_state), repeats=args.profile_repeats, relaunch=relaunch) * n_critic
         recs += sess.profile_ops([tr.g_opt_op, tr.g_next_frame], tr._feed(x, y, a, s), repeats=args.profile_repeats, relaunch=relaunch)
-        conv_ms = conv_fl = 0.0
-        n_conv = 0
+        conv_ms = conv_fl = conv_by = 0.0
+        n_conv = n_launch = 0
         dna_ms = dna_bytes = 0.0
         for op, ms in recs:
             kind = type(op).__name__
@@ -222,39 +229,50 @@ def main():
             if isinstance(op, O._ConvBase):
                 conv_ms += ms
                 conv_fl += conv_flops(op)
+                conv_by += conv_bytes(op)
                 n_conv += 1
+                n_launch += 1
                 if getattr(op, 'pair_active', False):      # this launch also ran the layer's weight gradient
                     conv_fl += conv_flops(op.pair_w)
+                    conv_by += conv_bytes(op.pair_w)
                     n_conv += 1
             elif isinstance(op, O.WgradReduceOp):      # the deferred slab reductions of the weight gradients: conv time
                 conv_ms += ms
-            elif kind == 'DnaOp':
+            elif kind == 'DnaOp':      # k*k logits at their storage size + C image values in + C frame values out
                 b, h, w, c = op.inputs[1].shape
                 dna_ms += ms
-                dna_bytes += b * h * w * (op.ksize * op.ksize + 2 * c) * 4.0
+                dna_bytes += b * h * w * (op.ksize * op.ksize * (2.0 if args.dtype == 'bf16' else 4.0) + 2 * c * 4.0)
         if conv_ms > 0:
             ach = conv_fl / (conv_ms * 1e-3) / 1e12
             peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == 'bf16' else PEAK_F32_MFMA_TFLOPS
-            # HBM-side bytes per conv launch: not measurable from inside this process - taken from the committed PMC
-            # summary of this same workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950
-            # note of MI355X_MICROARCH.md), fp32 config-2 only; null otherwise
-            traffic, traffic_note = None, None
-            pmc = os.path.join(ROOT, 'profiles', 'r1', 'zz_pmc_traffic_final.json')
-            if args.dtype == 'f32' and dna and B == 32 and S == 64 and args.ksize == 5 and os.path.exists(pmc):
+            # HBM-side bytes per launch cannot be measured from inside this process: they come from the committed PMC
+            # summary of this same command line (tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+            # passes, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md); null when no summary matches the workload
+            traffic, traffic_note, pmc_dna = None, None, None
+            tag = '%s_b%d_s%d_k%d%s' % (args.dtype, B, S, args.ksize, '' if dna else '_plain')
+            pmc = os.path.join(ROOT, 'profiles', 'r2', 'pmc_traffic_%s.json' % tag)
+            if adv and args.loss == 'bce' and os.path.exists(pmc):
                 with open(pmc) as f:
-                    c = json.load(f)['conv_mfma_f32']
-                traffic = round(c['fetch_bytes_per_launch'] + c['write_bytes_per_launch'])     # bytes per launch
-                traffic_note = ('HBM-side bytes per conv launch (FETCH_SIZE x2 + WRITE_SIZE) from profiles/r1/zz_pmc_traffic_final.txt, '
-                                'separate --pmc passes of this bench; algorithmic %d bytes per launch' % round(c['algorithmic_bytes_per_launch']))
+                    pj = json.load(f)
+                c = pj.get('conv')
+                if c:
+                    traffic = round(c['fetch_bytes_per_launch'] + c['write_bytes_per_launch'])     # bytes per launch
+                    traffic_note = ('HBM-side bytes per conv launch (FETCH_SIZE x2 + WRITE_SIZE) from profiles/r2/pmc_traffic_%s.txt, separate '
+                                    '--pmc passes of this command; algorithmic (operands + result once) %d bytes per launch' % (tag, round(conv_by / max(n_launch, 1))))
+                pmc_dna = pj.get('dna_fwd')
             roof = {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': peak, 'unit': 'TFLOP/s',
                     'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_note': traffic_note,
-                    'kernel': 'conv_mfma_f32<*> (+splitk_reduce, +splitk_reduce_many): %d conv/deconv fwd+dgrad+wgrad launches per step' % n_conv,
+                    'kernel': '%s (+splitk_reduce*): %d conv/deconv fwd+dgrad+wgrad contractions per step' % (
+                        'conv_mfma_bf16<*>' if args.dtype == 'bf16' else 'conv_mfma_f32<*> / conv_pair_f32<*>', n_conv),
                     'algorithmic_gflop_per_step': round(conv_fl / 1e9, 2), 'ms_per_step_in_kernel': round(conv_ms, 4),
-                    'avg_launch_us': round(conv_ms * 1e3 / max(n_conv, 1), 2)}
+                    'avg_launch_us': round(conv_ms * 1e3 / max(n_launch, 1), 2), 'launches_per_step': n_launch,
+                    'algorithmic_bytes_per_launch': round(conv_by / max(n_launch, 1))}
         if dna_ms > 0:
             gbs = dna_bytes / (dna_ms * 1e-3) / 1e9
             roof_dna = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                        'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': None, 'kernel': 'dna_kernel<K,TY,fwd>',
+                        'frac': round(gbs / PEAK_HBM_GBS, 4),
+                        'traffic': round(pmc_dna['fetch_bytes_per_launch'] + pmc_dna['write_bytes_per_launch']) if (conv_ms > 0 and pmc_dna) else None,
+                        'kernel': 'dna_rows_kernel<K,fwd>' if args.ksize >= 6 else 'dna_kernel<K,4,fwd>',
                         'algorithmic_mb_per_step': round(dna_bytes / 1e6, 2), 'ms_per_step_in_kernel': round(dna_ms, 4)}
 
     if rank != 0:

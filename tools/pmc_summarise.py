@@ -13,9 +13,20 @@ import sys
 def short(name):
     name = re.sub(r'^void ', '', name)
     name = re.sub(r'\(anonymous namespace\)::|acgconv::', '', name)
+    m = re.search(r'\d+(dna_kernel|dna_rows_kernel)I.*?Lb([01])E', name)   # mangled (anonymous-namespace kernels come through mangled)
+    if m:
+        return 'dna_bwd' if m.group(2) == '1' else 'dna_fwd'
+    m = re.search(r'_ZN12_GLOBAL__N_1\d+([a-z_0-9]+?)I', name)
+    if m:
+        name = m.group(1)
+    m = re.match(r'(dna_kernel|dna_rows_kernel)<([^>]*)>', name)      # forward / backward are one template: split them
+    if m:
+        bwd = re.search(r'\(bool\)\s*(1|true)|, true,', m.group(2)) is not None
+        return 'dna_bwd' if bwd else 'dna_fwd'
     name = re.sub(r'\(.*$', '', name)                       # drop the argument list
-    if name.startswith('conv_mfma_f32'):
-        return 'conv_mfma_f32'
+    for k in ('conv_mfma_f32', 'conv_pair_f32', 'conv_mfma_bf16'):
+        if name.startswith(k):
+            return k
     return name[:34]
 
 
@@ -48,8 +59,13 @@ def main():
     for k, n, f_mb, w_mb in rows:
         print('%-36s %8d   %12.2f %26.2f %16.2f' % (k, n, f_mb, w_mb, f_mb + w_mb))
     out = {}
+    conv = [r for r in rows if r[0] in ('conv_mfma_f32', 'conv_pair_f32', 'conv_mfma_bf16')]
+    if conv:        # all conv contraction launches together (a paired launch counts once)
+        n = sum(r[1] for r in conv)
+        out['conv'] = {'launches': n, 'fetch_bytes_per_launch': round(sum(r[1] * r[2] for r in conv) * 1e6 / n),
+                       'write_bytes_per_launch': round(sum(r[1] * r[3] for r in conv) * 1e6 / n)}
     for k, n, f_mb, w_mb in rows:
-        if k in ('conv_mfma_f32', 'splitk_reduce', 'splitk_reduce_many'):
+        if k in ('conv_mfma_f32', 'conv_pair_f32', 'conv_mfma_bf16', 'splitk_reduce', 'splitk_reduce_bf16', 'splitk_reduce_many', 'dna_fwd', 'dna_bwd'):
             out[k] = {'launches': n, 'fetch_bytes_per_launch': round(f_mb * 1e6), 'write_bytes_per_launch': round(w_mb * 1e6)}
     sys.stderr.write(json.dumps(out, indent=1) + '\n')
 

@@ -74,8 +74,17 @@ def _share_unique_id(uid_bytes, world_size, rank, process_group):
     key = 'acg/rccl_unique_id/%s' % os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')
     if rank == 0:
         store.set(key, uid_bytes)
+        import time
+        t0 = time.time()
+        while store.add(key + '/ack', 0) < world_size - 1:      # the server lives in THIS process: stay until every rank has read
+            if time.time() - t0 > 600:
+                raise CommError('unique-id bootstrap: %d of %d ranks did not fetch the id within 600 s'
+                                % (world_size - 1 - store.add(key + '/ack', 0), world_size - 1))
+            time.sleep(0.01)
         return uid_bytes
-    return bytes(store.get(key))
+    got = bytes(store.get(key))
+    store.add(key + '/ack', 1)
+    return got
 
 
 class Communicator:

@@ -709,18 +709,32 @@ class Session:
                     self._launch_segment(seg)
             return
         if prog.graphs is None:
-            prog.graphs = []
+            graphs = []
             torch.cuda.synchronize(rt.device)
-            for kind, seg in prog.segments:
-                if kind == 'host':
-                    prog.graphs.append(None)
-                    continue
-                gr = torch.cuda.CUDAGraph()
-                # thread_local: HIP calls of OTHER threads (none of ours; a host library's helper thread at worst) neither
-                # see nor invalidate this thread's capture
-                with torch.cuda.graph(gr, capture_error_mode='thread_local'):
-                    self._launch_segment(seg)     # current stream = the capture stream
-                prog.graphs.append(gr)
+            try:
+                for kind, seg in prog.segments:
+                    if kind == 'host':
+                        graphs.append(None)
+                        continue
+                    gr = torch.cuda.CUDAGraph()
+                    # thread_local: HIP calls of OTHER threads (none of ours; a host library's helper thread at worst)
+                    # neither see nor invalidate this thread's capture
+                    with torch.cuda.graph(gr, capture_error_mode='thread_local'):
+                        self._launch_segment(seg)     # current stream = the capture stream
+                    graphs.append(gr)
+            except Exception as e:      # a launch that cannot be captured on this stack: say so once, run this program eagerly
+                import sys
+                sys.stderr.write('[acgan] HIP-graph capture failed (%s: %s); this program is launched eagerly from now on\n'
+                                 % (type(e).__name__, str(e).splitlines()[0] if str(e) else ''))
+                torch.cuda.synchronize(rt.device)
+                prog.eager = True
+                for kind, seg in prog.segments:
+                    if kind == 'host':
+                        seg()
+                    else:
+                        self._launch_segment(seg)
+                return
+            prog.graphs = graphs
         for (kind, seg), gr in zip(prog.segments, prog.graphs):
             if kind == 'host':
                 seg()

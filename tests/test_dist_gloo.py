@@ -220,3 +220,33 @@ def test_exact_global_batch_mode_reproduces_one_device():
     # a different, if equally legitimate, computation
     off = np.abs(plain['g_grad'].astype(np.float64) / 2.0 - ref['g_grad']).max() / np.abs(ref['g_grad']).max()
     assert off > 1e-2, off
+
+
+# ---- bootstrap of the RCCL communicator (comm.py): the 128-byte unique id travels over CPU channels only ------------
+def _uid_worker(rank, world, port, outdir, via):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from action_conditioned_gans_amd import comm as C
+    uid = bytes(range(128)) if rank == 0 else None
+    if via == 'gloo':
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+        got = C._share_unique_id(uid, world, rank, None)
+        dist.barrier()
+        dist.destroy_process_group()
+    else:       # no process group at all: a TCPStore at MASTER_ADDR / MASTER_PORT
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        os.environ.pop('TORCHELASTIC_USE_AGENT_STORE', None)
+        got = C._share_unique_id(uid, world, rank, None)
+    with open(os.path.join(outdir, 'uid_%s_%d' % (via, rank)), 'wb') as f:
+        f.write(got)
+
+
+@pytest.mark.parametrize('via', ['gloo', 'store'])
+def test_rccl_unique_id_bootstrap_over_cpu_channels(via):
+    """What every rank needs before ncclCommInitRank: rank 0's unique id, delivered through an initialised gloo group
+    or, without any process group, a TCPStore - never through ProcessGroupNCCL."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_uid_worker, args=(2, _free_port(), d, via), nprocs=2, join=True)
+        for r in (0, 1):
+            assert open(os.path.join(d, 'uid_%s_%d' % (via, r)), 'rb').read() == bytes(range(128)), (via, r)

@@ -61,6 +61,17 @@ __global__ __launch_bounds__(256) void concat_k(const TI* __restrict__ a, const 
   }
 }
 
+// y[r, ca : ca + cb] = b[r / rows_per_b, :] only: the features y[r, 0:ca] were written in place by their producer
+template <typename TO>
+__global__ __launch_bounds__(256) void tile_actions_k(const float* __restrict__ b, TO* __restrict__ y, unsigned rows, int ca, int cb,
+                                                      unsigned rows_per_b, int pitch) {
+  const unsigned n = rows * (unsigned)cb;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const unsigned r = i / (unsigned)cb, j = i - r * (unsigned)cb;
+    acg::stf(y + (size_t)r * pitch + ca + j, b[(size_t)(r / rows_per_b) * cb + j]);
+  }
+}
+
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void slice_k(const TI* __restrict__ src, TO* __restrict__ dst, float acc,
                                                long long rows, int c_src, int c_off, int c_dst) {
@@ -167,10 +178,16 @@ int32_t acg_concat_actions_fwd(const void* x, const float* actions, void* y, int
                                int32_t y_pitch, int32_t dtype, acg_stream_t stream) {
   ACG_REQUIRE(dtype == ACG_F32 || dtype == ACG_BF16, ACG_ERR_UNSUPPORTED, "concat_actions_fwd: dtype %d", dtype);
   ACG_REQUIRE(B > 0 && hw > 0 && c > 0 && a > 0, ACG_ERR_INVALID_ARG, "concat_actions_fwd: non-positive size");
-  ACG_REQUIRE(x && actions && y, ACG_ERR_INVALID_ARG, "concat_actions_fwd: null pointer");
+  ACG_REQUIRE(actions && y, ACG_ERR_INVALID_ARG, "concat_actions_fwd: null pointer");
   const int pitch = y_pitch > 0 ? y_pitch : c + a;
   ACG_REQUIRE(pitch >= c + a, ACG_ERR_INVALID_ARG, "concat_actions_fwd: pitch smaller than the row");
   const long long rows = (long long)B * hw;
+  if (!x) {      // the features are already in y (their producer wrote them at this pitch): only the tiled actions
+    ACG_REQUIRE(rows * a < (1ll << 31), ACG_ERR_UNSUPPORTED, "concat_actions_fwd: tensor too large");
+    if (dtype == ACG_BF16) ACG_LAUNCH(tile_actions_k<__bf16>, dim3(grid_for(rows * a)), dim3(256), 0, acg::to_stream(stream), actions, (__bf16*)y, (unsigned)rows, c, a, (unsigned)hw, pitch);
+    else ACG_LAUNCH(tile_actions_k<float>, dim3(grid_for(rows * a)), dim3(256), 0, acg::to_stream(stream), actions, (float*)y, (unsigned)rows, c, a, (unsigned)hw, pitch);
+    return acg::check_launch("concat_actions_fwd");
+  }
   if (dtype == ACG_BF16)
     ACG_LAUNCH((concat_k<__bf16, float, __bf16>), dim3(grid_for(rows * (c + a))), dim3(256), 0, acg::to_stream(stream), (const __bf16*)x,
                actions, (__bf16*)y, rows, c, a, hw, pitch);

@@ -787,20 +787,30 @@ class ConcatActionsOp(G.Op):
     the consuming conv / deconv gathers it with 16-byte loads."""
 
     def __init__(self, x, actions, name):
-        b, h, w, c = x.shape
+        b, h, w = x.shape[:3]
+        c = x.valid_c or x.shape[3]
         if len(actions.shape) != 2 or actions.shape[0] != b:
             raise ValueError('concat_actions: actions must be [batch, A], got %s' % (actions.shape,))
         csum = c + actions.shape[1]
-        self.pitch = cpad(csum)
+        self.pitch, self.c = cpad(csum), c
         y = _new((b, h, w, self.pitch), name + ':0', x.dtype)
         if self.pitch != csum:
             y.valid_c = csum
+        # Producer-side concat (models.py:16,38,84): when x is the output of a fused BatchNorm + activation, that kernel
+        # writes its result straight into the concatenated tensor (its y pitch becomes this tensor's pitch), this op only
+        # adds the tiled action channels, and backward hands the gradient of the concatenated tensor to the BatchNorm
+        # backward as it is (dy at this pitch) - no copy of the feature map in either direction.
+        self.in_place = isinstance(x.op, BnActOp) and x is x.op.outputs[0] and x.view_of is None and x.dtype == y.dtype
+        if self.in_place:
+            x.op.yp = self.pitch
+            x.view_of, x.shape, x.valid_c = (y, 0), y.shape, c
         super().__init__(G.get_default_graph(), name, [x, actions], [y])
 
     def bind(self, rt):
         x, a = self.inputs
-        b, h, w, c = x.shape
-        args = (_p(x.buf), _p(a.buf), _p(self.outputs[0].buf), b, h * w, c, a.shape[1], self.pitch, _code(x))
+        b, h, w = x.shape[:3]
+        px = None if self.in_place else _p(x.buf)
+        args = (px, _p(a.buf), _p(self.outputs[0].buf), b, h * w, self.c, a.shape[1], self.pitch, _code(self.outputs[0]))
         fn = rt.lib.concat_actions_fwd
         return lambda s: fn(*args, s)
 
@@ -808,7 +818,13 @@ class ConcatActionsOp(G.Op):
         if needs[1]:
             raise NotImplementedError('concat_actions: actions are inputs, no gradient path')
         x = self.inputs[0]
-        return [SliceOp(gouts[0], 0, x.shape[-1], x.shape, self.name + '/bwd', x.dtype).outputs[0] if needs[0] else None, None]
+        if not needs[0]:
+            return [None, None]
+        if self.in_place:      # d(concat) IS dy of the BatchNorm, read at the concat pitch (a window, not a copy)
+            g = gouts[0].view(0, gouts[0].shape, name=self.name + '/bwd:view')
+            g.valid_c = self.c
+            return [g, None]
+        return [SliceOp(gouts[0], 0, x.shape[-1], x.shape, self.name + '/bwd', x.dtype).outputs[0], None]
 
 
 class ConcatChannelsOp(G.Op):

@@ -286,8 +286,9 @@ int32_t acg_cdna_bwd(const void* params, const float* kern_norm, const void* ima
 /* ------------------------------------------------------------------------------------------
  * Channel plumbing: tf.tile + tf.concat at train.py:48-50,64,68 and models.py:16,38,84.
  * ---------------------------------------------------------------------------------------- */
-/* y[b,s,0:c] = x[b,s,:],  y[b,s,c:c+a] = actions[b,:]   for s in [0,hw); y rows are y_pitch floats apart
- * (0 = dense = c+a), pad channels are not written */
+/* y[b,s,0:c] = x[b,s,:],  y[b,s,c:c+a] = actions[b,:]   for s in [0,hw); y rows are y_pitch elements apart
+ * (0 = dense = c+a), pad channels are not written.  x == NULL: the features are in y already (their producer - the
+ * layer's BatchNorm - wrote them at this pitch), only the tiled actions are added. */
 int32_t acg_concat_actions_fwd(const void* x, const float* actions, void* y, int32_t batch, int32_t hw,
                                int32_t c, int32_t a, int32_t y_pitch, int32_t dtype, acg_stream_t stream);
 /* y[r,0:ca] = a[r,:], y[r,ca:ca+cb] = b[r,:]; y rows are y_pitch elements apart (0 = dense = ca+cb); pad channels

@@ -497,7 +497,7 @@ int32_t acg_concat_actions_fwd(const void* xv, const float* actions, void* yv, i
   if (py < (size_t)(c + a)) return fail(ACG_ERR_INVALID_ARG, "concat_actions: pitch smaller than the row");
   for (int b = 0; b < B; b++) for (int p = 0; p < hw; p++) {
     size_t r = (size_t)b * hw + p;
-    memcpy(y + r * py, x + r * c, sizeof(float) * c);
+    if (x) memcpy(y + r * py, x + r * c, sizeof(float) * c);     /* x NULL: the producer wrote the features in place */
     memcpy(y + r * py + c, actions + (size_t)b * a, sizeof(float) * a);
   }
   return ACG_OK;

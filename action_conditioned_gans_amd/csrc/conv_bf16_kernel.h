@@ -418,6 +418,24 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16(const ConvArgs p) {
   conv16_body<MODE, BM, BN>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
 }
 
+// A layer's input gradient (DGRAD, or FWD on the adjoint descriptor of a transposed layer) and its weight gradient out
+// of ONE grid, as conv_pair_f32 does for fp32: both consume dy, neither reads the other's result; one launch boundary
+// less and each contraction's blocks fill the other's tail.  Blocks [0, nA) run A with the grid (gxA, gyA, *).
+template <int MODE_A, int BMA, int BNA, int BMB, int BNB>
+__global__ __launch_bounds__(256) void conv_pair_bf16(const ConvArgs a, const ConvArgs b, const PairGeom g) {
+  constexpr int LA = conv16_lds_bytes<MODE_A, BMA, BNA>(), LB = conv16_lds_bytes<MODE_WGRAD, BMB, BNB>();
+  __shared__ __align__(16) char smem[LA > LB ? LA : LB];
+  const int L = (int)blockIdx.x;
+  if (L < g.nA) {
+    const int t = L / g.gxA;
+    conv16_body<MODE_A, BMA, BNA>(a, L - t * g.gxA, t % g.gyA, t / g.gyA, g.gxA, smem);
+  } else {
+    const int l = L - g.nA, bz = l / g.gxB;
+    conv16_body<MODE_WGRAD, BMB, BNB>(b, l - bz * g.gxB, 0, bz, g.gxB, smem);
+  }
+}
+int launch_pair16(int modeA, const Plan& pa, const ConvArgs& a, const Plan& pb, const ConvArgs& b, hipStream_t st);
+
 template <int MODE>
 int launch_mode16(const Plan& pl, const ConvArgs& a, hipStream_t st);
 

@@ -355,7 +355,10 @@ int run_pair(int whichA, const float* gsrcA, const float* denseA, float* outA, c
   if (int rc = prepare(jb, ACG_CONV_WGRAD, gsrcB, denseB, outB, accumulateB, d, dtype, wsB, wsbB, who, slabs_only_B)) return rc;
   hipStream_t st = acg::to_stream(stream);
   static const int enabled = env_int("ACG_CONV_PAIR", 1);       // 0: always two launches (A/B comparison)
-  if (enabled && g_force_cfg < 0 && pair_supported(whichA, ja.pl, jb.pl)) {
+  if (enabled && g_force_cfg < 0 && ja.pl.bf16 && jb.pl.bf16 && (whichA == ACG_CONV_FWD || whichA == ACG_CONV_DGRAD) &&
+      (long long)ja.pl.tiles * ja.pl.splits + (long long)jb.pl.tiles * jb.pl.splits < (1ll << 30)) {
+    if (int rc = launch_pair16(whichA == ACG_CONV_FWD ? MODE_FWD : MODE_DGRAD, ja.pl, ja.a, jb.pl, jb.a, st)) return rc;
+  } else if (enabled && g_force_cfg < 0 && pair_supported(whichA, ja.pl, jb.pl)) {
     if (int rc = launch_pair(whichA, ja.pl, ja.a, jb.pl, jb.a, st)) return rc;
   } else {
     if (int rc = launch(ja, st)) return rc;

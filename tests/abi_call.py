@@ -173,8 +173,17 @@ class Abi:
         wsd, nd = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), which_d, self.conv_dtype))
         wsw, nw = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_WGRAD, self.conv_dtype))
         fn = self.lib.deconv2d_bwd_pair if transposed else self.lib.conv2d_bwd_pair
-        fn(_p(dy), _p(w), _p(x), _p(dx), None if slabs_only else _p(dw), accumulate, ctypes.byref(d), self.conv_dtype, _p(wsd), nd, _p(wsw), nw,
-           1 if slabs_only else 0, self.stream())
+        if self.half:          # bf16 tensors at pitch round8(C); dgrad of a conv reads the 'rm' copy, of a deconv the 'tr' copy
+            d.in_pitch = d.out_pitch = 0
+            cx = d.out_c if transposed else d.in_c
+            x16, dy16, (rm, tr) = self.to16(x[..., :cx]), self.to16(dy), self.prep_weights(w)
+            dx16 = torch.zeros(*x.shape[:3], (cx + 7) // 8 * 8, dtype=torch.bfloat16, device=self.device)
+            fn(_p(dy16), _p(tr if transposed else rm), _p(x16), _p(dx16), None if slabs_only else _p(dw), accumulate, ctypes.byref(d),
+               self.conv_dtype, _p(wsd), nd, _p(wsw), nw, 1 if slabs_only else 0, self.stream())
+            dx = self.from16(dx16, cx)
+        else:
+            fn(_p(dy), _p(w), _p(x), _p(dx), None if slabs_only else _p(dw), accumulate, ctypes.byref(d), self.conv_dtype, _p(wsd), nd,
+               _p(wsw), nw, 1 if slabs_only else 0, self.stream())
         if slabs_only:
             return dx, (wsw, self.lib.conv2d_splits(ctypes.byref(d), L.CONV_WGRAD, self.conv_dtype))
         return dx, dw

@@ -125,6 +125,37 @@ def case_conv_bf16(abi, shape, tol, tol_w, seed=0, transposed=False):
         close(abi.conv2d_wgrad(xg, dyg, tuple(wt.shape), s, pad), dw_ref, tol_w, tag + ' wgrad')
 
 
+def case_bwd_pair_bf16(abi, tol, tol_w):
+    """bf16 acg_(de)conv2d_bwd_pair (conv_pair_bf16: both gradients of a layer out of one grid) against the separate
+    entries, for every tile pairing the planner produces (64/64, 64/128, 128/64, 128/128) and an accumulating dw."""
+    dev = abi.device
+    layers = [((2, 16, 16, 32), (5, 5, 32, 64), 2, 'SAME', False),       # 64x64 / 64x64
+              ((8, 32, 32, 64), (5, 5, 64, 128), 2, 'SAME', False),      # larger, split wgrad
+              ((4, 9, 7, 24), (3, 3, 24, 40), 1, 'SAME', False),         # ragged edges
+              ((2, 8, 8, 64), (5, 5, 32, 64), 2, None, True),            # transposed layer (FWD on the adjoint + WGRAD)
+              ((32, 32, 32, 128), (5, 5, 128, 128), 1, 'SAME', False)]   # 128x128 tiles on both sides
+    for i, (xs, ws_, stride, padding, transposed) in enumerate(layers):
+        x = uniform(xs, 170 + i).to(dev)
+        w = randn(ws_, 180 + i, 0.1).to(dev)
+        if transposed:
+            dy = randn((xs[0], xs[1] * stride, xs[2] * stride, ws_[2]), 190 + i).to(dev)
+            dx_ref = abi.deconv2d_dgrad(dy, w, tuple(xs), stride)
+            dw_plain = lambda dw, acc: abi.deconv2d_wgrad(x, dy, ws_, stride, dw=dw, accumulate=acc)    # noqa: E731
+        else:
+            d = abi.desc(xs[0], xs[1], xs[2], ws_[2], ws_[0], ws_[1], ws_[3], stride, padding)
+            dy = randn((xs[0], d.out_h, d.out_w, ws_[3]), 190 + i).to(dev)
+            dx_ref = abi.conv2d_dgrad(dy, w, tuple(xs), stride, padding)
+            dw_plain = lambda dw, acc: abi.conv2d_wgrad(x, dy, ws_, stride, padding, dw=dw, accumulate=acc)    # noqa: E731
+        init = randn(ws_, 200 + i).to(dev)
+        for acc in (0.0, 1.0):
+            dw_ref = dw_plain(init.clone(), acc)
+            dx, dw = abi.bwd_pair(x, dy, w, stride, padding, transposed, accumulate=acc, dw=init.clone())
+            abi.sync()
+            tag = 'bf16 pair layer %d acc %g' % (i, acc)
+            close(dx, dx_ref.double().cpu(), tol, tag + ' dx')
+            close(dw, dw_ref.double().cpu(), tol_w, tag + ' dw')
+
+
 def case_conv_pitched(abi, tol, seed=0):
     """3- and 6-channel inputs stored with a channel pitch of 4 / 8 (in_pitch): same results as the dense tensor,
     pad channels of dx untouched."""

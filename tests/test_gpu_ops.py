@@ -37,6 +37,10 @@ def test_deconv_bf16(hip_abi_bf16, shape):
     C.case_conv_bf16(hip_abi_bf16, shape, TOL_BF16, TOL_CONV, transposed=True)
 
 
+def test_bwd_pair_bf16(hip_abi_bf16):
+    C.case_bwd_pair_bf16(hip_abi_bf16, TOL_BF16, TOL_CONV)
+
+
 @pytest.mark.parametrize('shape', [(32, 64, 64, 64, 128, 5, 2, 'SAME')], ids=str)
 def test_conv_bf16_big_tiles(hip_abi_bf16, shape):
     """Large enough for the planner's 128x128 tiles in all three contractions (256 output tiles; wgrad: long K)."""

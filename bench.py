@@ -51,6 +51,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-repeats', type=int, default=3)
     ap.add_argument('--cpu-steps', type=int, default=20)
+    ap.add_argument('--lib', default=None, help='experiment: an alternative build of the library (e.g. the tuning build, whose knobs read the environment)')
     ap.add_argument('--slab-handoff', action='store_true', help='experiment: the consuming BatchNorm kernels sum the split-K slabs instead of separate reduction launches (bit-identical; measured slower)')
     ap.add_argument('--no-pair', action='store_true', help='experiment: a layer\'s dgrad and wgrad as two launches instead of one')
     ap.add_argument('--dp-collectives', default=None, choices=['stream', 'side'], help='gradient all-reduces (ncclAllReduce captured into the step\'s HIP graph) on the compute stream in program order, or on a side HIP stream overlapping the rest of backward; default: side with more than one rank')
@@ -124,6 +125,9 @@ def main():
         args.dp_collectives = 'side' if world > 1 else 'stream'
 
     from action_conditioned_gans_amd import graph as G, ops as O, optim, train as T
+    if args.lib:
+        from action_conditioned_gans_amd import _lib
+        _lib._LIB = _lib.Library(args.lib)
 
     B, S, dna, adv = args.batch, args.img, not args.plain, not args.no_adv
     n_critic = 5 if args.loss == 'wass' else 1

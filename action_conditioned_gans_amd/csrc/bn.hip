@@ -209,7 +209,8 @@ template <int V, typename TX, typename TY>
 __global__ __launch_bounds__(256) void bn_apply_fwd(const TX* __restrict__ x, const float* __restrict__ beta,
                                                     const float* __restrict__ part, TY* __restrict__ y,
                                                     float* __restrict__ save_mean, float* __restrict__ save_rstd,
-                                                    long long R, int C, int nblk, float eps, int act, float leak, int XP, int YP) {
+                                                    long long R, int C, int nblk, float eps, int act, float leak, int XP, int YP,
+                                                    int shifted) {
   __shared__ float sh[4 * 8 * 2 * V];
   const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3, g = blockIdx.z;
   const int c = (blockIdx.y * 8 + cq) * V;
@@ -220,7 +221,12 @@ __global__ __launch_bounds__(256) void bn_apply_fwd(const TX* __restrict__ x, co
   const TX* xg = x + (long long)g * R * XP;
   TY* yg = y + (long long)g * R * YP;
   float pv[V], mean[V], rstd[V], bt[V];
-  ldv<V>(xg + c, pv);
+  if (shifted) {       // partials of bn_stats_partial: sums of (x - first row of the group)
+    ldv<V>(xg + c, pv);
+  } else {             // partials out of the producing convolution's epilogue (acg_bn_act_fwd_partials): plain sums
+#pragma unroll
+    for (int j = 0; j < V; ++j) pv[j] = 0.f;
+  }
   ldv<V>(beta + c, bt);
 #pragma unroll
   for (int j = 0; j < V; ++j) {
@@ -747,10 +753,10 @@ int bn_fwd_typed(const void* x, const float* beta, void* y, float* save_mean, fl
   if (int rc = acg::check_launch("bn_stats_partial")) return rc;
   const dim3 ag(tile_row_blocks(R, C, V), (C + 8 * V - 1) / (8 * V), groups);
   if constexpr (same) {
-    if (v4) ACG_LAUNCH((bn_apply_fwd<4, TX, TY>), ag, dim3(256), 0, st, xf, beta, (const float*)part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP);
-    else ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, xf, beta, (const float*)part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP);
+    if (v4) ACG_LAUNCH((bn_apply_fwd<4, TX, TY>), ag, dim3(256), 0, st, xf, beta, (const float*)part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, 1);
+    else ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, xf, beta, (const float*)part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, 1);
   } else {
-    ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, xf, beta, (const float*)part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP);
+    ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, xf, beta, (const float*)part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, 1);
   }
   return acg::check_launch("bn_apply_fwd");
 }
@@ -799,6 +805,26 @@ int bn_bwd_typed(const void* x, const void* dy, const float* beta, const float* 
   return acg::check_launch("bn_apply_bwd");
 }
 
+// BatchNorm + activation whose statistics arrive as per-tile partial sums out of the producing convolution's epilogue
+// (acg_conv2d_fwd_stats / acg_deconv2d_fwd_stats): the apply pass alone - ONE launch, x is read once.
+template <typename TX, typename TY>
+int bn_fwd_partials_typed(const void* x, const float* beta, const float* part, int nblk, void* y, float* save_mean, float* save_rstd,
+                          long long R, int C, int groups, float eps, int act, float leak, bool v4, int XP, int YP, hipStream_t st) {
+  constexpr bool same = std::is_same<TX, TY>::value;
+  const TX* xf = (const TX*)x;
+  TY* yf = (TY*)y;
+  if (!same) v4 = false;
+  const int V = v4 ? 4 : 1;
+  const dim3 ag(tile_row_blocks(R, C, V), (C + 8 * V - 1) / (8 * V), groups);
+  if constexpr (same) {
+    if (v4) ACG_LAUNCH((bn_apply_fwd<4, TX, TY>), ag, dim3(256), 0, st, xf, beta, part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, 0);
+    else ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, xf, beta, part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, 0);
+  } else {
+    ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, xf, beta, part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, 0);
+  }
+  return acg::check_launch("bn_apply_fwd");
+}
+
 }  // namespace
 
 extern "C" {
@@ -821,6 +847,19 @@ int32_t acg_bn_act_fwd(const void* x, const float* beta, void* y, float* save_me
   const long long R = rows / groups;
   const bool v4 = vec4_ok(C, x, y, beta) && vec4_ok(C, save_mean, save_rstd, ws) && XP % 4 == 0 && YP % 4 == 0;
   ACG_WITH_TYPES(dtype, "bn_act_fwd", return (bn_fwd_typed<TA, TB>(x, beta, y, save_mean, save_rstd, R, C, groups, eps, act, leak, (float*)ws, v4, XP, YP, acg::to_stream(stream))));
+}
+
+int32_t acg_bn_act_fwd_partials(const void* x, const float* beta, const float* partials, int32_t nblk, void* y, float* save_mean,
+                                float* save_rstd, int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t groups, float eps,
+                                int32_t act, float leak, int32_t dtype, acg_stream_t stream) {
+  const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
+  ACG_REQUIRE(XP >= C && YP >= C, ACG_ERR_INVALID_ARG, "bn_act_fwd_partials: pitch smaller than the row");
+  if (int rc = check_bn("bn_act_fwd_partials", rows, C, groups)) return rc;
+  ACG_REQUIRE(x && beta && partials && nblk >= 1 && y && save_mean && save_rstd, ACG_ERR_INVALID_ARG, "bn_act_fwd_partials: null pointer / nblk < 1");
+  ACG_REQUIRE(act == ACG_ACT_NONE || act == ACG_ACT_RELU || act == ACG_ACT_LRELU, ACG_ERR_UNSUPPORTED, "bn_act_fwd_partials: activation %d", act);
+  const long long R = rows / groups;
+  const bool v4 = vec4_ok(C, x, y, beta) && vec4_ok(C, save_mean, save_rstd, partials) && XP % 4 == 0 && YP % 4 == 0;
+  ACG_WITH_TYPES(dtype, "bn_act_fwd_partials", return (bn_fwd_partials_typed<TA, TB>(x, beta, partials, nblk, y, save_mean, save_rstd, R, C, groups, eps, act, leak, v4, XP, YP, acg::to_stream(stream))));
 }
 
 int32_t acg_bn_act_bwd(const void* x, const void* dy, const float* beta, const float* save_mean, const float* save_rstd,

@@ -270,10 +270,32 @@ struct Job {
   bool slabs_only;
 };
 
+// BatchNorm statistics out of the epilogue (ConvArgs::stats): partial blocks per group, 0 when this plan cannot provide
+// them - a split contraction holds partial sums only; a tile must not straddle two groups; the parity classes of a
+// DGRAD (a transposed layer's forward) must be of one size, or the smaller ones would leave partial blocks unwritten.
+constexpr int kMaxStatsBlocks = 4096;
+int stats_blocks(const Plan& pl, const acg_conv_desc& d, int which, int groups, int* tiles_per_group) {
+  if (which == ACG_CONV_WGRAD || pl.splits != 1 || groups < 1) return 0;
+  const long long tiles_m = acg::ceil_div(pl.M, pl.bm);
+  long long nblk = 0, tpg = 0;
+  if (which == ACG_CONV_DGRAD) {
+    if (groups != 1 || d.in_h % d.stride_h || d.in_w % d.stride_w) return 0;
+    tpg = tiles_m; nblk = tiles_m * pl.classes;
+  } else if (groups == 1) {
+    tpg = nblk = tiles_m;
+  } else {
+    if (pl.M % groups || (pl.M / groups) % pl.bm) return 0;
+    tpg = nblk = pl.M / groups / pl.bm;
+  }
+  if (nblk < 1 || nblk > kMaxStatsBlocks) return 0;
+  if (tiles_per_group) *tiles_per_group = (int)tpg;
+  return (int)nblk;
+}
+
 // slabs_only (weight gradients whose reduction is deferred to acg_splitk_reduce_many): the contraction leaves its
 // `splits` partial slabs in the workspace and `out` is not touched.
 int prepare(Job& j, int which, const float* gsrc, const float* dense, float* out, float accumulate, const acg_conv_desc* d,
-            int dtype, void* ws, size_t ws_bytes, const char* who, bool slabs_only) {
+            int dtype, void* ws, size_t ws_bytes, const char* who, bool slabs_only, float* stats = nullptr, int stats_groups = 0) {
   ACG_REQUIRE(dtype == ACG_F32 || dtype == ACG_BF16, ACG_ERR_UNSUPPORTED, "%s: dtype %d", who, dtype);
   if (int rc = validate(d, who)) return rc;
   ACG_REQUIRE(gsrc && dense && (out || slabs_only), ACG_ERR_INVALID_ARG, "%s: null tensor pointer", who);
@@ -307,6 +329,12 @@ int prepare(Job& j, int which, const float* gsrc, const float* dense, float* out
   a.splits = pl.splits;
   { const FastDiv fw = fast_div(d->out_w), fh = fast_div(d->out_h); a.mg_ow = fw.magic; a.sh_ow = fw.shift; a.mg_oh = fh.magic; a.sh_oh = fh.shift;
     const FastDiv fc = fast_div(which == ACG_CONV_DGRAD ? (h ? cout8 : (d->out_c + 3) & ~3) : (h ? cin8 : (d->in_c + 3) & ~3)); a.mg_cp = fc.magic; a.sh_cp = fc.shift; }
+  if (stats != nullptr) {
+    int tpg = 0;
+    const int nblk = stats_blocks(pl, *d, which, stats_groups, &tpg);
+    ACG_REQUIRE(nblk > 0, ACG_ERR_UNSUPPORTED, "%s: this shape provides no BatchNorm partials (acg_conv2d_stats_blocks == 0)", who);
+    a.stats = stats; a.stats_nblk = nblk; a.stats_tpg = tpg;
+  }
   j.which = which; j.pl = pl; j.a = a; j.ws = ws; j.out = out; j.accumulate = accumulate; j.slabs_only = slabs_only;
   return ACG_OK;
 }
@@ -336,9 +364,10 @@ int reduce(const Job& j, hipStream_t st) {
 }
 
 int run(int which, const float* gsrc, const float* dense, float* out, float accumulate, const acg_conv_desc* d, int dtype,
-        void* ws, size_t ws_bytes, acg_stream_t stream, const char* who, bool slabs_only = false) {
+        void* ws, size_t ws_bytes, acg_stream_t stream, const char* who, bool slabs_only = false, float* stats = nullptr,
+        int stats_groups = 0) {
   Job j;
-  if (int rc = prepare(j, which, gsrc, dense, out, accumulate, d, dtype, ws, ws_bytes, who, slabs_only)) return rc;
+  if (int rc = prepare(j, which, gsrc, dense, out, accumulate, d, dtype, ws, ws_bytes, who, slabs_only, stats, stats_groups)) return rc;
   hipStream_t st = acg::to_stream(stream);
   if (int rc = launch(j, st)) return rc;
   return reduce(j, st);
@@ -406,6 +435,21 @@ size_t acg_conv2d_workspace_bytes(const acg_conv_desc* d, int32_t which, int32_t
 int32_t acg_conv2d_splits(const acg_conv_desc* d, int32_t which, int32_t dtype) {
   if (!d || validate(d, "conv2d_splits") != ACG_OK || which < 0 || which > 2) return 0;
   return make_plan(*d, which, dtype == ACG_BF16).splits;
+}
+
+int32_t acg_conv2d_stats_blocks(const acg_conv_desc* d, int32_t which, int32_t dtype, int32_t groups) {
+  if (!d || validate(d, "conv2d_stats_blocks") != ACG_OK || which < 0 || which > 2) return 0;
+  return stats_blocks(make_plan(*d, which, dtype == ACG_BF16), *d, which, groups, nullptr);
+}
+int32_t acg_conv2d_fwd_stats(const void* x, const void* w, void* y, const acg_conv_desc* d, int32_t dtype, void* ws, size_t wsb,
+                             float* partials, int32_t groups, acg_stream_t s) {
+  ACG_REQUIRE(partials != nullptr, ACG_ERR_INVALID_ARG, "conv2d_fwd_stats: null partials");
+  return run(ACG_CONV_FWD, (const float*)x, (const float*)w, (float*)y, 0.f, d, dtype, ws, wsb, s, "conv2d_fwd_stats", false, partials, groups);
+}
+int32_t acg_deconv2d_fwd_stats(const void* x, const void* w, void* y, const acg_conv_desc* adj, int32_t dtype, void* ws, size_t wsb,
+                               float* partials, int32_t groups, acg_stream_t s) {
+  ACG_REQUIRE(partials != nullptr, ACG_ERR_INVALID_ARG, "deconv2d_fwd_stats: null partials");
+  return run(ACG_CONV_DGRAD, (const float*)x, (const float*)w, (float*)y, 0.f, adj, dtype, ws, wsb, s, "deconv2d_fwd_stats", false, partials, groups);
 }
 
 int32_t acg_conv2d_wgrad_slabs(const void* x, const void* dy, const acg_conv_desc* d, int32_t dtype, void* ws, size_t wsb,

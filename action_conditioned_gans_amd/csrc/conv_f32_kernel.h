@@ -54,6 +54,12 @@ struct ConvArgs {
   int splits;
   unsigned mg_ow, mg_oh, mg_cp;   // magic multipliers: r / OW = (r * mg_ow) >> sh_ow for 0 <= r < 2^31 (host: fast_div)
   int sh_ow, sh_oh, sh_cp;        // _cp: division by the gathered channel count padded to a multiple of 4
+  // FWD / DGRAD with splits == 1, optional: the layer's BatchNorm statistics out of the epilogue.  Each block leaves the
+  // per-channel sum and sum of squares of ITS tile rows (of the values as stored) at
+  // stats[((g * stats_nblk + b) * 2 + {0,1}) * N + n], the partial-block layout bn_apply_fwd sums (bn.hip);
+  // FWD: g = tile_row / stats_tpg, b = tile_row % stats_tpg; DGRAD (one group): b = class * stats_tpg + tile_row.
+  float* stats;
+  int stats_nblk, stats_tpg;
 };
 
 // Division by a launch-constant through multiply-high (Granlund-Montgomery, N = 31): a runtime integer division is
@@ -581,6 +587,35 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
       }
   }
   // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) --------------
+  if constexpr (MODE != MODE_WGRAD) {
+    if (p.stats != nullptr) {     // BatchNorm statistics of this tile (ConvArgs::stats): lane -> half pair -> waves of a column
+      float* const red = reinterpret_cast<float*>(smem);        // the A tiles are dead after the K loop's last barrier
+#pragma unroll
+      for (int b = 0; b < TB; ++b) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int a = 0; a < TA; ++a)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const float v = m0 + row < M ? acc[a][b][r] : 0.f;
+            s1 += v; s2 += v * v;
+          }
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (lk == 0) { red[(wr * BN + wn0 + 32 * b + lrow) * 2] = s1; red[(wr * BN + wn0 + 32 * b + lrow) * 2 + 1] = s2; }
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < N) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) { a1 += red[(w * BN + tid) * 2]; a2 += red[(w * BN + tid) * 2 + 1]; }
+        int g = 0, blk;
+        if constexpr (MODE == MODE_DGRAD) { blk = by * p.stats_tpg + tm; } else { g = tm / p.stats_tpg; blk = tm - g * p.stats_tpg; }
+        float* const o = p.stats + ((long long)g * p.stats_nblk + blk) * 2 * N + n0 + tid;
+        o[0] = a1; o[N] = a2;
+      }
+    }
+  }
   float* outp = p.out + (p.splits > 1 ? (long long)bz * p.out_numel : 0ll);
 #pragma unroll
   for (int a = 0; a < TA; ++a)

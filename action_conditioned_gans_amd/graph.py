@@ -319,6 +319,7 @@ class Runtime:
         # measured SLOWER (fp32 364 vs 383, bf16 567 vs 600 steps/s, profiles/r2): the one-launch BatchNorm kernels read 16
         # bytes per row and block, and S slabs multiply exactly those poorly coalesced requests; kept as an option
         self.slab_handoff = False
+        self.epilogue_stats = True
         self._comm = comm
         self._scratch = {}
 
@@ -360,7 +361,7 @@ class Session:
     """``tf.Session`` stand-in bound to one GPU (one process per GPU)."""
 
     def __init__(self, device='cuda:0', graph=None, use_hip_graphs=True, lib=None,
-                 world_size=1, rank=0, process_group=None, dtype='f32', pair_bwd=True, comm=None, slab_handoff=False):
+                 world_size=1, rank=0, process_group=None, dtype='f32', pair_bwd=True, comm=None, slab_handoff=False, epilogue_stats=True):
         self.graph = graph or get_default_graph()
         dev = torch.device(device)
         if lib is None:
@@ -379,6 +380,7 @@ class Session:
             self.graph.act_dtype = want
         self.rt = Runtime(lib, dev, world_size, rank, process_group, _lib.ACG_BF16 if dtype == 'bf16' else _lib.ACG_F32, comm)
         self.rt.slab_handoff = bool(slab_handoff)
+        self.rt.epilogue_stats = bool(epilogue_stats)     # BatchNorm statistics out of the producing conv's epilogue (ops.Conv2dOp.bind)
         if dev.type == 'cuda':
             torch.cuda.set_device(dev)
         self.use_hip_graphs = use_hip_graphs and dev.type == 'cuda'

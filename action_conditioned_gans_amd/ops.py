@@ -241,15 +241,33 @@ class Conv2dOp(_ConvBase):
             y.valid_c = c
         self.wop = _wcopy(w, 'rm' if transposed else 'tr')
         self.extras = [self.wop]
+        self._part = {}
         super().__init__(g, name, [x, w], [y])
 
-    bn_consumer = None      # the layer's BnActOp (set by _layer): candidate for the split-K hand-off
+    bn_consumer = None      # the layer's BnActOp (set by _layer): takes its statistics, or the split-K slabs, from this op
     _slab = None            # (workspace, splits) while this program's BatchNorm sums the slabs itself
+    _stats = None           # (partials, blocks per group) while this program's BatchNorm takes its statistics from the epilogue
 
     def bind(self, rt):
         x, w = self.inputs
-        self._slab = None
+        self._slab = self._stats = None
         bn = self.bn_consumer
+        if bn is not None and id(bn) in rt.program_ops and rt.epilogue_stats and type(bn) is BnActOp:
+            # followed by its BatchNorm in this program and not split: the epilogue leaves per-tile channel sums, the
+            # BatchNorm runs its apply pass alone (acg_(de)conv2d_fwd_stats -> acg_bn_act_fwd_partials): one launch and one
+            # read of the activation less
+            lib, d, dt = rt.lib, self.desc, rt.conv_dtype
+            nblk = lib.conv2d_stats_blocks(ctypes.byref(d), self.which, dt, bn.groups)
+            if nblk > 0:
+                size = bn.groups * nblk * 2 * bn.c
+                part = self._part.get((rt.device, size))     # one buffer for every program this op is compiled into
+                if part is None:
+                    part = self._part[(rt.device, size)] = torch.zeros(size, dtype=torch.float32, device=rt.device)
+                ws, n = rt.workspace(lib.conv2d_workspace_bytes(ctypes.byref(d), self.which, dt))
+                self._keep, self._stats = (ws, d, part), (part, nblk)
+                fn = lib.deconv2d_fwd_stats if self.transposed else lib.conv2d_fwd_stats
+                args = (_p(x.buf), _p(self.wop.buf), _p(self.outputs[0].buf), ctypes.byref(d), dt, _p(ws), n, _p(part), bn.groups)
+                return lambda s: fn(*args, s)
         if bn is not None and id(bn) in rt.program_ops and rt.slab_handoff:
             # split over K and followed by its BatchNorm in this program: leave the partial slabs, the BatchNorm kernel
             # sums them as it loads (acg_bn_act_fwd_slabs) - one launch less
@@ -420,6 +438,13 @@ class BnActOp(G.Op):
         x, beta = self.inputs
         y, mean, rstd = self.outputs
         src = self.conv_producer
+        stats = src._stats if (src is not None and id(src) in rt.program_ops) else None
+        if stats is not None:     # the conv's epilogue left the per-tile channel sums: the apply pass alone
+            part, nblk = stats
+            args = (_p(x.buf), _p(beta.buf), _p(part), nblk, _p(y.buf), _p(mean.buf), _p(rstd.buf), self.rows, self.c, self.xp, self.yp,
+                    self.groups, self.eps, _ACT_CODE[self.act], self.leak, _code2(x, y))
+            fn = lib.bn_act_fwd_partials
+            return lambda s: fn(*args, s)
         slab = src._slab if (src is not None and id(src) in rt.program_ops) else None
         if slab is not None:      # the conv left its split-K slabs: sum them here and write x for the backward pass
             sws, splits = slab

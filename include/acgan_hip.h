@@ -142,6 +142,21 @@ int32_t acg_deconv2d_wgrad_slabs(const void* x, const void* dy, const acg_conv_d
                                  size_t workspace_bytes, acg_stream_t stream);
 int32_t acg_splitk_reduce_many(const acg_reduce_list* list, int32_t count, acg_stream_t stream);
 
+/* BatchNorm statistics out of the producing convolution (models.py:10-15,31-44,80-87: every conv / conv2d_transpose but
+ * three feeds slim.batch_norm, whose first pass re-reads the whole activation for its per-channel mean and variance).
+ * acg_(de)conv2d_fwd_stats are acg_(de)conv2d_fwd that also leave, per row tile of the output, the per-channel sum and
+ * sum of squares of the values as stored:
+ *   partials[((g * nblk + b) * 2 + {0: sum, 1: sum of squares}) * out_channels + c],  g < groups, b < nblk
+ * with nblk = acg_conv2d_stats_blocks(desc, which, dtype, groups) (which = ACG_CONV_FWD for a conv layer, ACG_CONV_DGRAD on
+ * the adjoint descriptor for a transposed layer; 0 = this shape cannot: it is split over K, a tile would straddle two
+ * groups, or the stride classes of a transposed layer differ in size - use the plain entry and acg_bn_act_fwd).
+ * acg_bn_act_fwd_partials (below) consumes them: BatchNorm + activation in ONE launch. */
+int32_t acg_conv2d_stats_blocks(const acg_conv_desc* d, int32_t which, int32_t dtype, int32_t groups);
+int32_t acg_conv2d_fwd_stats(const void* x, const void* w, void* y, const acg_conv_desc* d, int32_t dtype, void* workspace,
+                             size_t workspace_bytes, float* partials, int32_t groups, acg_stream_t stream);
+int32_t acg_deconv2d_fwd_stats(const void* x, const void* w, void* y, const acg_conv_desc* adj, int32_t dtype, void* workspace,
+                               size_t workspace_bytes, float* partials, int32_t groups, acg_stream_t stream);
+
 /* Split-K hand-off to the consuming BatchNorm.  A small layer is split over K to fill the chip and would need a
  * launch of its own to sum the partial slabs; its output (forward) or input gradient (backward) is read next by the
  * layer's BatchNorm kernel (models.py:10-15: every conv but three is followed by batch_norm), which can sum the slabs as it
@@ -225,6 +240,12 @@ int32_t acg_bn_act_bwd_slabs(const void* x, const float* dy_slabs, int32_t split
                              const float* save_rstd, void* dx, float* dbeta, float dbeta_accumulate, int64_t rows,
                              int32_t channels, int32_t x_pitch, int32_t y_pitch, int32_t groups, int32_t act, float leak,
                              int32_t dtype, void* workspace, size_t workspace_bytes, acg_stream_t stream);
+/* BatchNorm + activation from the partial sums of acg_(de)conv2d_fwd_stats (plain sums over each block's rows; `nblk`
+ * blocks per group): mean = sum / rows_per_group, var = sumsq / rows_per_group - mean^2 (float64 combine), then the
+ * same apply pass as acg_bn_act_fwd.  No workspace. */
+int32_t acg_bn_act_fwd_partials(const void* x, const float* beta, const float* partials, int32_t nblk, void* y, float* save_mean,
+                                float* save_rstd, int64_t rows, int32_t channels, int32_t x_pitch, int32_t y_pitch,
+                                int32_t groups, float eps, int32_t act, float leak, int32_t dtype, acg_stream_t stream);
 int32_t acg_bn_act_fwd(const void* x, const float* beta, void* y, float* save_mean, float* save_rstd,
                        int64_t rows, int32_t channels, int32_t x_pitch, int32_t y_pitch, int32_t groups, float eps,
                        int32_t act, float leak, int32_t dtype, void* workspace, size_t workspace_bytes,

@@ -154,6 +154,49 @@ int32_t acg_deconv2d_bwd_pair(const void* dy, const void* w, const void* x, void
   return slabs_only ? acg_deconv2d_wgrad_slabs(x, dy, adj, dtype, wsw, wsbw, s) : acg_deconv2d_wgrad(x, dy, dw, acc, adj, dtype, wsw, wsbw, s);
 }
 
+/* include/acgan_hip.h "BatchNorm statistics out of the producing convolution": the restatement runs the layer, then sums
+ * its output rows in two blocks per group (one when the row count is odd), so callers see a multi-block partial layout. */
+static int32_t stats_rows(const acg_conv_desc* d, int32_t which, int64_t* rows, int* C, int* pitch) {
+  if (which == ACG_CONV_FWD) { *rows = (int64_t)d->batch * d->out_h * d->out_w; *C = d->out_c; *pitch = d->out_pitch > 0 ? d->out_pitch : d->out_c; return 1; }
+  if (which == ACG_CONV_DGRAD) { *rows = (int64_t)d->batch * d->in_h * d->in_w; *C = d->in_c; *pitch = d->in_pitch > 0 ? d->in_pitch : d->in_c; return 1; }
+  return 0;
+}
+int32_t acg_conv2d_stats_blocks(const acg_conv_desc* d, int32_t which, int32_t dtype, int32_t groups) {
+  int64_t rows; int C, pitch;
+  if (!d || dtype != ACG_F32 || groups < 1 || !stats_rows(d, which, &rows, &C, &pitch)) return 0;
+  if (which == ACG_CONV_DGRAD && groups != 1) return 0;
+  if (rows % groups) return 0;
+  return (rows / groups) % 2 == 0 ? 2 : 1;
+}
+static void stats_of(const float* y, const acg_conv_desc* d, int32_t which, int32_t groups, float* part) {
+  int64_t rows; int C, pitch;
+  stats_rows(d, which, &rows, &C, &pitch);
+  const int nblk = acg_conv2d_stats_blocks(d, which, ACG_F32, groups);
+  const int64_t R = rows / groups, per = R / nblk;
+  for (int g = 0; g < groups; g++) for (int b = 0; b < nblk; b++) for (int c = 0; c < C; c++) {
+    double s1 = 0, s2 = 0;
+    for (int64_t r = g * R + b * per; r < g * R + (b + 1) * per; r++) { double v = y[r * pitch + c]; s1 += v; s2 += v * v; }
+    part[((size_t)(g * nblk + b) * 2) * C + c] = (float)s1;
+    part[((size_t)(g * nblk + b) * 2 + 1) * C + c] = (float)s2;
+  }
+}
+int32_t acg_conv2d_fwd_stats(const void* x, const void* w, void* y, const acg_conv_desc* d, int32_t dtype, void* ws, size_t wsb,
+                             float* partials, int32_t groups, acg_stream_t s) {
+  if (!partials || acg_conv2d_stats_blocks(d, ACG_CONV_FWD, dtype, groups) < 1) return fail(ACG_ERR_UNSUPPORTED, "conv2d_fwd_stats: no partials for this shape");
+  int rc = acg_conv2d_fwd(x, w, y, d, dtype, ws, wsb, s);
+  if (rc) return rc;
+  stats_of(y, d, ACG_CONV_FWD, groups, partials);
+  return ACG_OK;
+}
+int32_t acg_deconv2d_fwd_stats(const void* x, const void* w, void* y, const acg_conv_desc* adj, int32_t dtype, void* ws, size_t wsb,
+                               float* partials, int32_t groups, acg_stream_t s) {
+  if (!partials || acg_conv2d_stats_blocks(adj, ACG_CONV_DGRAD, dtype, groups) < 1) return fail(ACG_ERR_UNSUPPORTED, "deconv2d_fwd_stats: no partials for this shape");
+  int rc = acg_deconv2d_fwd(x, w, y, adj, dtype, ws, wsb, s);
+  if (rc) return rc;
+  stats_of(y, adj, ACG_CONV_DGRAD, groups, partials);
+  return ACG_OK;
+}
+
 /* split-K hand-off entries: the restatement never splits forward / input-gradient contractions (acg_conv2d_splits) */
 int32_t acg_conv2d_fwd_slabs(const void* x, const void* w, const acg_conv_desc* d, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
   (void)x; (void)w; (void)d; (void)dtype; (void)ws; (void)wsb; (void)s; return fail(ACG_ERR_UNSUPPORTED, "cpu oracle: contraction is not split"); }
@@ -237,6 +280,26 @@ int32_t acg_bn_act_fwd(const void* xv, const float* beta, void* yv, float* save_
     m /= (double)R;
     for (int64_t r = 0; r < R; r++) { double t = xg[r * XP + c] - m; v += t * t; }
     v /= (double)R;
+    double rstd = 1.0 / sqrt(v + (double)eps);
+    save_mean[g * C + c] = (float)m; save_rstd[g * C + c] = (float)rstd;
+    for (int64_t r = 0; r < R; r++) yg[r * YP + c] = (float)act_f(act, (xg[r * XP + c] - m) * rstd + beta[c], leak);
+  }
+  return ACG_OK;
+}
+
+int32_t acg_bn_act_fwd_partials(const void* xv, const float* beta, const float* partials, int32_t nblk, void* yv, float* save_mean,
+                                float* save_rstd, int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t groups, float eps,
+                                int32_t act, float leak, int32_t dtype, acg_stream_t s) {
+  (void)s; REQUIRE_F32(dtype);
+  if (groups <= 0 || rows % groups || nblk < 1) return fail(ACG_ERR_INVALID_ARG, "bn partials: rows not divisible by groups / nblk < 1");
+  const float* x = xv; float* y = yv; int64_t R = rows / groups;
+  const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
+  for (int g = 0; g < groups; g++) for (int c = 0; c < C; c++) {
+    const float* xg = x + (size_t)g * R * XP; float* yg = y + (size_t)g * R * YP;
+    double s1 = 0, s2 = 0;
+    for (int b = 0; b < nblk; b++) { s1 += partials[((size_t)(g * nblk + b) * 2) * C + c]; s2 += partials[((size_t)(g * nblk + b) * 2 + 1) * C + c]; }
+    double m = s1 / (double)R, v = s2 / (double)R - m * m;
+    if (v < 0) v = 0;
     double rstd = 1.0 / sqrt(v + (double)eps);
     save_mean[g * C + c] = (float)m; save_rstd[g * C + c] = (float)rstd;
     for (int64_t r = 0; r < R; r++) yg[r * YP + c] = (float)act_f(act, (xg[r * XP + c] - m) * rstd + beta[c], leak);

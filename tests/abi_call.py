@@ -236,6 +236,41 @@ class Abi:
                             groups, ACT[act], leak, L.dtype2(L.code(x.dtype), L.code(dy.dtype)), _p(ws), n, self.stream())
         return dx, dbeta
 
+    # ---- BatchNorm statistics out of the producing convolution's epilogue
+    def conv_bn_fused(self, x, w, beta, stride, padding, act, groups=1, transposed=False, eps=1e-3, leak=0.2):
+        """acg_(de)conv2d_fwd_stats + acg_bn_act_fwd_partials -> (conv output, y, mean, rstd) as float32, or None when
+        acg_conv2d_stats_blocks says this shape provides no partials."""
+        if transposed:
+            d = self._adj(x.shape, tuple(w.shape), stride)
+            which, c, oshape = L.CONV_DGRAD, d.in_c, (d.batch, d.in_h, d.in_w)
+        else:
+            b, h, wd, cin = x.shape
+            d = self.desc(b, h, wd, w.shape[2], w.shape[0], w.shape[1], w.shape[3], stride, padding)
+            which, c, oshape = L.CONV_FWD, d.out_c, (b, d.out_h, d.out_w)
+        nblk = self.lib.conv2d_stats_blocks(ctypes.byref(d), which, self.conv_dtype, groups)
+        if nblk <= 0:
+            return None
+        part = torch.full((groups * nblk * 2 * c,), float('nan'), device=self.device)
+        ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), which, self.conv_dtype))
+        fn = self.lib.deconv2d_fwd_stats if transposed else self.lib.conv2d_fwd_stats
+        rows = oshape[0] * oshape[1] * oshape[2]
+        mean, rstd = self.empty(groups * c), self.empty(groups * c)
+        if self.half:
+            cp = (c + 7) // 8 * 8
+            x16, (rm, tr) = self.to16(x), self.prep_weights(w)
+            conv = torch.zeros(*oshape, cp, dtype=torch.bfloat16, device=self.device)
+            fn(_p(x16), _p(rm if transposed else tr), _p(conv), ctypes.byref(d), self.conv_dtype, _p(ws), n, _p(part), groups, self.stream())
+            y = torch.zeros(*oshape, cp, dtype=torch.bfloat16, device=self.device)
+            self.lib.bn_act_fwd_partials(_p(conv), _p(beta), _p(part), nblk, _p(y), _p(mean), _p(rstd), rows, c, cp, cp, groups, eps,
+                                         ACT[act], leak, L.dtype2(L.ACG_BF16, L.ACG_BF16), self.stream())
+            return self.from16(conv, c), self.from16(y, c), mean, rstd
+        conv = self.empty(*oshape, c)
+        fn(_p(x), _p(w), _p(conv), ctypes.byref(d), self.conv_dtype, _p(ws), n, _p(part), groups, self.stream())
+        y = self.empty(*oshape, c)
+        self.lib.bn_act_fwd_partials(_p(conv), _p(beta), _p(part), nblk, _p(y), _p(mean), _p(rstd), rows, c, c, c, groups, eps, ACT[act],
+                                     leak, L.dtype2(L.ACG_F32, L.ACG_F32), self.stream())
+        return conv, y, mean, rstd
+
     # ---- synchronised BatchNorm entries (statistics supplied by the caller)
     def bn_moments(self, x, groups=1):
         c = x.shape[-1]

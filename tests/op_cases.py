@@ -156,6 +156,47 @@ def case_bwd_pair_bf16(abi, tol, tol_w):
             close(dw, dw_ref.double().cpu(), tol_w, tag + ' dw')
 
 
+STATS_LAYERS = [   # (x shape, w shape, stride, padding, transposed, groups, act)
+    ((4, 16, 16, 8), (5, 5, 8, 16), 2, 'SAME', False, 1, 'relu'),
+    ((8, 32, 32, 3), (5, 5, 3, 32), 2, 'SAME', False, 1, 'relu'),        # g/conv1-like: N = 32 (the 128 x 32 tile in fp32)
+    ((8, 32, 32, 6), (5, 5, 6, 64), 2, 'SAME', False, 2, 'lrelu'),       # d/conv1-like: two groups (fake | real)
+    ((6, 18, 14, 12), (3, 3, 12, 40), 1, 'SAME', False, 1, None),        # ragged rows and columns
+    ((8, 16, 16, 32), (5, 5, 24, 32), 2, None, True, 1, 'relu'),         # transposed layer: four stride classes
+    ((32, 32, 32, 64), (5, 5, 64, 128), 2, 'SAME', False, 2, 'lrelu'),   # d/conv2-like
+]
+
+
+def case_conv_bn_stats(abi, tol, tol_stat, min_fused=1):
+    """acg_(de)conv2d_fwd_stats + acg_bn_act_fwd_partials against the float64 conv followed by slim batch_norm + activation:
+    the conv output, the normalised output and the saved mean / rstd.  ``min_fused``: how many of the layers must actually
+    take the fused path (acg_conv2d_stats_blocks > 0) - the split ones legitimately do not."""
+    fused = 0
+    r = (lambda t: t.bfloat16().float()) if abi.half else (lambda t: t)
+    for i, (xs, ws_, stride, padding, transposed, groups, act) in enumerate(STATS_LAYERS):
+        x, w = uniform(xs, 300 + i), randn(ws_, 310 + i, 0.1)
+        c = ws_[2] if transposed else ws_[3]
+        beta = randn((c,), 320 + i, 0.5)
+        got = abi.conv_bn_fused(x.to(abi.device), w.to(abi.device), beta.to(abi.device), stride, padding, act, groups, transposed)
+        if got is None:
+            continue
+        fused += 1
+        conv, y, mean, rstd = got
+        abi.sync()
+        xr, wr = r(x).double(), r(w).double()
+        ref = T.conv2d_transpose(xr, wr, stride, 'SAME') if transposed else T.conv2d(xr, wr, stride, padding)
+        tag = 'conv+bn stats layer %d' % i
+        close(conv, ref, tol, tag + ' conv')
+        stored = r(ref.float()).double()                      # BatchNorm sees the tensor as stored
+        rows = stored.reshape(groups, -1, c)
+        m, v = rows.mean(1), rows.var(1, unbiased=False)
+        close(mean, m.reshape(-1), tol_stat, tag + ' mean')
+        close(rstd, (1.0 / torch.sqrt(v + 1e-3)).reshape(-1), tol_stat, tag + ' rstd')
+        pre = (rows - m[:, None, :]) / torch.sqrt(v[:, None, :] + 1e-3) + beta.double()
+        want = {'relu': torch.relu, 'lrelu': lambda t: torch.where(t > 0, t, 0.2 * t), None: lambda t: t}[act](pre).reshape(stored.shape)
+        close(y, want, tol * 4 if abi.half else tol, tag + ' y')
+    assert fused >= min_fused, 'only %d of %d layers took the fused path' % (fused, len(STATS_LAYERS))
+
+
 def case_conv_pitched(abi, tol, seed=0):
     """3- and 6-channel inputs stored with a channel pitch of 4 / 8 (in_pitch): same results as the dense tensor,
     pad channels of dx untouched."""

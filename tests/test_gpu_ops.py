@@ -37,6 +37,15 @@ def test_deconv_bf16(hip_abi_bf16, shape):
     C.case_conv_bf16(hip_abi_bf16, shape, TOL_BF16, TOL_CONV, transposed=True)
 
 
+def test_conv_bn_stats(hip_abi):
+    """BatchNorm statistics out of the conv epilogue (acg_(de)conv2d_fwd_stats -> acg_bn_act_fwd_partials)."""
+    C.case_conv_bn_stats(hip_abi, TOL_CONV, 1e-4, min_fused=4)
+
+
+def test_conv_bn_stats_bf16(hip_abi_bf16):
+    C.case_conv_bn_stats(hip_abi_bf16, TOL_BF16, 2e-3, min_fused=4)
+
+
 def test_bwd_pair_bf16(hip_abi_bf16):
     C.case_bwd_pair_bf16(hip_abi_bf16, TOL_BF16, TOL_CONV)
 

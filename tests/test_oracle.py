@@ -54,6 +54,10 @@ def test_sync_bn_entries(oracle_abi, shape, act, groups):
     C.case_sync_bn_entries(oracle_abi, shape, act, groups, TOL)
 
 
+def test_conv_bn_stats(oracle_abi):
+    C.case_conv_bn_stats(oracle_abi, TOL, TOL, min_fused=6)
+
+
 def test_bwd_pair(oracle_abi):
     C.case_bwd_pair(oracle_abi, TOL, exact=False)
 

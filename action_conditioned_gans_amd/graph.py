@@ -109,6 +109,8 @@ class Op:
         self.inputs, self.outputs = list(inputs), list(outputs)
         self.control_inputs = list(control_inputs)
         self.index = float(graph._next_id())
+        if graph._side_default and not self.host:
+            self.side_stream = True      # built inside Graph.side_branch(): a chain that runs beside the main one
         for o in self.outputs:
             if o.op is None:
                 o.op = self
@@ -130,6 +132,7 @@ class Graph:
         self.variables = {}          # name -> Variable, creation order
         self.state = []              # state slots with constant init (optimizer slots, counters)
         self._id = 0
+        self._side_default = False   # inside side_branch(): new ops are flagged side_stream
         self._layouts = {}           # top-level scope -> (offsets dict, total numel, flat Tensor)
         self.collections = {}
         # storage type of activation-class tensors (conv / BatchNorm outputs and their gradients): float32, or
@@ -141,6 +144,19 @@ class Graph:
     def cpad(self):
         """Channel-pitch unit of activation tensors: one 16-byte gather = 4 floats or 8 bf16."""
         return 8 if self.act_dtype == torch.bfloat16 else 4
+
+    @contextlib.contextmanager
+    def side_branch(self, on=True):
+        """Ops built inside (and, through build_gradients, their gradient ops) form a SIDE chain: independent of what the
+        main chain does next - the DNA generator's state head next to its frame decoder, models.py:44-51 vs 53-72 - so a
+        GPU session enqueues them on its second HIP stream (Session._launch_segment: one fork edge where the chain
+        starts, one join in front of the first op that needs a result) and, inside a captured program, they are a
+        parallel branch of the HIP graph.  Small latency-bound kernels then hide behind the main chain's large ones."""
+        prev, self._side_default = self._side_default, bool(on)
+        try:
+            yield
+        finally:
+            self._side_default = prev
 
     def _next_id(self):
         self._id += 1
@@ -273,7 +289,9 @@ def build_gradients(graph, heads, var_list, flat_grad, offsets, add_op):
         needs = [(not isinstance(i, Variable)) and i.akey() in reach for i in head.inputs]
         if not any(needs):
             continue
-        for t, g in head.seed(weights, needs):
+        with graph.side_branch(head.side_stream):
+            seeds = list(head.seed(weights, needs))
+        for t, g in seeds:
             r = t.akey()
             pending[r] = g if r not in pending else add_op(pending[r], g)
     ctx = GradContext(graph, var_list, flat_grad, offsets)
@@ -285,7 +303,8 @@ def build_gradients(graph, heads, var_list, flat_grad, offsets, add_op):
                  for i in op.inputs]
         if not any(needs):
             continue
-        gins = op.grad(gouts, needs, ctx)
+        with graph.side_branch(op.side_stream):      # the gradient ops of a side chain are a side chain
+            gins = op.grad(gouts, needs, ctx)
         for i, g in zip(op.inputs, gins):
             if g is None or isinstance(i, Variable):
                 continue
@@ -361,7 +380,7 @@ class Session:
     """``tf.Session`` stand-in bound to one GPU (one process per GPU)."""
 
     def __init__(self, device='cuda:0', graph=None, use_hip_graphs=True, lib=None,
-                 world_size=1, rank=0, process_group=None, dtype='f32', pair_bwd=True, comm=None, slab_handoff=False, epilogue_stats=True):
+                 world_size=1, rank=0, process_group=None, dtype='f32', pair_bwd=True, comm=None, slab_handoff=False, epilogue_stats=True, side_branches=False):
         self.graph = graph or get_default_graph()
         dev = torch.device(device)
         if lib is None:
@@ -386,6 +405,10 @@ class Session:
         self.use_hip_graphs = use_hip_graphs and dev.type == 'cuda'
         # a layer's input gradient and weight gradient in ONE launch (acg_conv2d_bwd_pair) when they are neighbours in a program
         self.pair_bwd = bool(pair_bwd)
+        # side chains (Graph.side_branch) on the second stream.  OFF by default: they then stay where they were built, on
+        # the main stream - measured faster on this stack (profiles/r2/m_side_branch_ab.txt: a parallel branch of the HIP
+        # graph costs more in fork / join edges than the state head's ~70 us of small kernels hide; bit-identical results)
+        self.side_branches = bool(side_branches) and dev.type == 'cuda'
         self._programs = {}
         self._initialized = False
         self._weights_dirty = True     # bf16 operand copies of the filters are stale (initializer, set_value, restore)
@@ -500,6 +523,7 @@ class Session:
         for op in ops:
             for t in op.inputs + op.outputs + list(getattr(op, 'extras', ())):
                 self._materialize(t)
+        ops = self._hoist_side_chains(ops) if self.side_branches else ops
         self.rt.program_ops = frozenset(id(o) for o in ops)
         for k, op in enumerate(ops):           # pairing is decided per program: both ops fetched, nothing between them
             w = getattr(op, 'pair_w', None)
@@ -533,6 +557,25 @@ class Session:
         prog = _Program(segments, fetch_tensors, list(feeds))
         prog.eager = any(getattr(op, 'no_graph', False) for op in ops)     # an op that cannot be captured: eager launch list
         return prog
+
+    @staticmethod
+    def _hoist_side_chains(ops):
+        """Side-chain ops (Graph.side_branch) move to the earliest position their producers allow, keeping their own
+        order: the chain is then forked from the main stream as soon as its inputs exist and overlaps everything the main
+        chain does after that point, instead of waiting for the main ops that merely precede it in creation order."""
+        if not any(o.side_stream and not getattr(o, 'is_collective', False) for o in ops):
+            return ops
+        out, pos_floor = [], 0
+        for op in ops:
+            if not op.side_stream or getattr(op, 'is_collective', False) or op.run_last:
+                out.append(op)
+                continue
+            where = {id(o): k for k, o in enumerate(out)}
+            deps = [t.op for t in op.inputs if t.op is not None] + list(op.control_inputs)
+            p = max([where[id(d)] + 1 for d in deps if id(d) in where] + [pos_floor])
+            out.insert(p, op)
+            pos_floor = p + 1
+        return out
 
     @staticmethod
     def _fold_clips(ops):
@@ -665,12 +708,16 @@ class Session:
         return next(it)
 
     def _launch_segment(self, seg):
-        """Enqueue one device segment.  Ops flagged ``side_stream`` (the gradient all-reduces of
-        ``collectives='side'``) go to the session's second HIP stream: ordered behind everything enqueued so far by
-        one edge, and joined back into the main stream in front of the first op that depends on them (the optimizer
-        update) - a fork/join that is captured into the program's HIP graph like any other dependency."""
+        """Enqueue one device segment.  Ops flagged ``side_stream`` (the gradient all-reduces of ``collectives='side'``;
+        the chains built inside Graph.side_branch) go to the session's second HIP stream.  A side op is ordered behind the
+        main stream by ONE edge at the point where it first needs something the side stream has not seen (always for the
+        first one: that edge also pulls the side stream into a capture), and the side stream is joined back in front of
+        the first main op that reads a side result, waits on one (control input) or is flagged ``joins_side`` (the
+        optimizer steps and the deferred weight-gradient reduction, which consume what side ops left in buffers).
+        Fork and join are captured into the program's HIP graph like any other dependency: a parallel branch."""
         rt = self.rt
-        if not (rt.is_cuda and any(op.side_stream for op, _ in seg)):
+        use_side = rt.is_cuda and any(op.side_stream and (self.side_branches or getattr(op, 'is_collective', False)) for op, _ in seg)
+        if not use_side:
             sp = rt.stream_ptr()
             for _, fn in seg:
                 fn(sp)
@@ -680,22 +727,33 @@ class Session:
         sp_main = ctypes.c_void_p(main.cuda_stream)
         sp_side = ctypes.c_void_p(side.cuda_stream)
         pending = set()                 # ids of side-stream ops not yet joined into the main stream
+        unseen = set()                  # ids of main-stream ops enqueued since the last fork edge
+        forked = False
         edges = iter(rt.edge_pool(2 * len(seg) + 2))
         edge = rt.lib.stream_edge
+
+        def deps(op):
+            return [t.op for t in op.inputs if t.op is not None] + list(op.control_inputs)
+
+        def launched(op):               # a paired input gradient also runs its layer's weight gradient (ops.ConvDgradOp)
+            return (id(op), id(op.pair_w)) if getattr(op, 'pair_active', False) else (id(op),)
 
         def join():
             edge(next(edges), sp_side, sp_main)
             pending.clear()
         for op, fn in seg:
-            if op.side_stream:
-                edge(next(edges), sp_main, sp_side)
+            if op.side_stream and (self.side_branches or getattr(op, 'is_collective', False)):
+                if not forked or (unseen and getattr(op, 'is_collective', False)) or any(id(d) in unseen for d in deps(op)):
+                    edge(next(edges), sp_main, sp_side)
+                    forked = True
+                    unseen.clear()
                 fn(sp_side)
-                pending.add(id(op))
+                pending.update(launched(op))
             else:
-                if pending and (any(id(c) in pending for c in op.control_inputs) or
-                                any(t.op is not None and id(t.op) in pending for t in op.inputs)):
+                if pending and (getattr(op, 'joins_side', False) or any(id(d) in pending for d in deps(op))):
                     join()
                 fn(sp_main)
+                unseen.update(launched(op))
         if pending:
             join()
 

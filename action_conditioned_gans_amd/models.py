@@ -14,6 +14,7 @@ Deviations from the reference text, which does not run as committed (SURVEY sect
 with 16-byte loads.  Actions may be given as ``[B, A]`` (tiled and concatenated in one fused op) or already tiled
 ``[B, h, w, A]`` as the reference Trainer passes them (train.py:48-50).
 """
+from . import graph as G
 from . import ops as O
 
 G_PLAIN = {'encoder': (('conv1', 64), ('conv2', 128), ('conv3', 256), ('conv4', 512)),
@@ -70,15 +71,19 @@ def build_generator_transform(images, actions, batch_size=None, reuse=False, col
         net = _with_actions(net, actions, 'actions')
         net = _stack(net, G_DNA['decoder_a'], O.deconv2d)
 
-        state = _stack(net, G_DNA['state'], O.conv2d, size=3)
-        sk = state.shape[1]           # 4 at 64x64: the reference's 4x4 VALID head (models.py:44-51)
-        state = O.conv2d(state, 5, [sk, sk], activation_fn=None, stride=1, padding='VALID', normalizer_fn=None,
-                         scope='sconv5')
+        # the state head reads the decoder's 16x16 features and nothing of what the frame decoder does next: a side chain
+        # (five tiny latency-bound layers that hide behind tconv3 / tconv4 / the DNA gather, forward and backward)
+        with G.get_default_graph().side_branch():
+            state = _stack(net, G_DNA['state'], O.conv2d, size=3)
+            sk = state.shape[1]           # 4 at 64x64: the reference's 4x4 VALID head (models.py:44-51)
+            state = O.conv2d(state, 5, [sk, sk], activation_fn=None, stride=1, padding='VALID', normalizer_fn=None,
+                             scope='sconv5')
+            state = O.squeeze(state)
 
         net = _stack(net, G_DNA['decoder_b'], O.deconv2d)
         logits = O.deconv2d(net, ksize * ksize, [5, 5], activation_fn=None, normalizer_fn=None, scope='tconv4')
         frame = O.dna_gather(logits, images, ksize)
-        return frame, O.squeeze(state)
+        return frame, state
 
 
 def build_discriminator(inputs, actions, reuse=False):

@@ -381,9 +381,12 @@ class WgradReduceOp(G.Op):
     a weight gradient before the optimizer update (or the all-reduce of its bucket), and a launch costs ~4-5 us in the
     step's HIP graph whatever its size.  Bit-identical to the per-layer reductions it replaces."""
 
+    joins_side = True
+
     def __init__(self, wgrads, name):
         g = G.get_default_graph()
         super().__init__(g, name, [], [], control_inputs=wgrads)
+        self.side_stream = False
         self.index = max(o.index for o in wgrads) + 0.25      # right behind the last of its layers
         self.pending = []                                     # filled by the ConvWgradOps as they are bound
         for o in wgrads:

@@ -68,6 +68,9 @@ class AllReduceOp(G.Op):
     hands it - the compute stream (collectives='stream') or the session's side stream (collectives='side',
     ``side_stream`` makes graph._launch_segment fork and join around it).  A device op like any kernel launch."""
 
+    is_collective = True     # never part of a hoisted side chain; forks behind EVERY main op enqueued so far (its bucket's writers)
+    joins_side = True        # on the main stream: side-chain weight gradients of its bucket must have landed
+
     def __init__(self, flat_grad, start, end, after, name, side):
         super().__init__(flat_grad.graph, name, [], [], control_inputs=after)
         self.flat_grad, self.start, self.end = flat_grad, start, end
@@ -88,6 +91,7 @@ class AllReduceOp(G.Op):
 class StepOp(G.Op):
     """One fused optimizer launch over the flat buffers of a scope."""
     is_optimizer_step = True
+    joins_side = True        # reads every gradient of its scope, whichever stream produced it
 
     def __init__(self, opt, scope, var_names, flat_param, flat_grad, slots, deps, grad_scale):
         super().__init__(flat_param.graph, opt.name + '/update', [flat_param, flat_grad] + slots, [], control_inputs=deps)
@@ -111,6 +115,7 @@ class StepOp(G.Op):
 class ClipOp(G.Op):
     """p.assign(tf.clip_by_value(p, lo, hi)) (train.py:89).  Ordered after the update of the same
     program (defect D6), and folded into the optimizer kernel when it covers the optimizer's scope."""
+    joins_side = True
     is_clip = True
     run_last = True
 

@@ -87,7 +87,9 @@ class Trainer:
         l1, gdl = O.frame_losses(self.g_out, self.next_frame_ph)
         g_l2_loss = l1 / B
         if arg_transform:
-            g_l2_loss = g_l2_loss * L2_WEIGHT + O.l2_norm(self.g_state_out, self.next_state, name='g_state_loss') / B
+            with G.get_default_graph().side_branch():      # the state head's loss belongs to its side chain (models.py)
+                state_loss = O.l2_norm(self.g_state_out, self.next_state, name='g_state_loss')
+            g_l2_loss = g_l2_loss * L2_WEIGHT + state_loss / B
         self.g_l2_loss = g_l2_loss
         self.summaries = {}
         if arg_adv:

@@ -407,6 +407,32 @@ def test_splitk_handoff_to_batchnorm(dtype):
     assert TC.rel(f1, f0) <= (1e-4 if dtype == 'f32' else 2e-2)
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_side_branch_is_bit_identical(dtype):
+    """The DNA generator's state head runs as a side chain (Graph.side_branch): on the session's second HIP stream, a
+    parallel branch of the step's HIP graph, hoisted to where its inputs exist.  Same kernels on the same data, only
+    the schedule differs: weights and frames after three D + G steps (eager, capture, replay) must equal those of a
+    session that keeps everything on one stream, bit for bit - a missing fork or join edge shows up here."""
+    x, y, a, s = TC.MG.inputs(2)
+    xs, ys = np.tile(x, (4, 1, 1, 1)), np.tile(y, (4, 1, 1, 1))
+    as_, ss = np.tile(a, (4, 1)), np.tile(s, (4, 1))
+    finals = []
+    for side in (False, True):
+        sess, tr = TC.build_trainer(gpu_session, 'dna_k6_bce_rmsprop', batch=8, dtype=dtype, side_branches=side)
+        for _ in range(3):
+            tr.train_d(xs, ys, as_)
+            frames = tr.train_g(xs, ys, as_, ss)
+        torch.cuda.synchronize()
+        g = G.get_default_graph()
+        n_side = sum(1 for o in g.ops if o.side_stream)
+        assert n_side >= 10, n_side          # sconv3-5 with BatchNorm / bias, the state loss, and their gradient ops
+        finals.append(({n: sess.get_value(v) for n, v in g.variables.items()}, frames))
+    (p0, f0), (p1, f1) = finals
+    for n in p0:
+        assert torch.equal(p0[n], p1[n]), n
+    assert np.array_equal(f0, f1)
+
+
 def test_data_parallel_machinery_on_one_rank():
     """The multi-GPU path cannot be launched from here, so drive everything but the peers on ONE rank: this process's
     own RCCL communicator of size 1 (comm.py), the per-bucket ncclAllReduce captured into the step's HIP graphs - on the

@@ -215,6 +215,31 @@ def test_checkpoint_roundtrip_and_rollout(tmp_path):
     assert pred.shape == (2, 3, 64, 64, 3) and np.isfinite(pred).all() and 'g_psnr' in summ
 
 
+def test_side_chain_flags_and_hoisting():
+    """Graph.side_branch: the DNA state head, its loss and all their gradient ops are flagged for the side stream, nothing
+    else is; Session._hoist_side_chains moves them to where their producers allow without breaking any dependency."""
+    sess, tr = TC.build_trainer(cpu_session, 'c2_dna_bce_adam', batch=2)
+    g = G.get_default_graph()
+    side = [o for o in g.ops if o.side_stream]
+    assert side and all(('sconv' in o.name or 'g_state_loss' in o.name) for o in side), [o.name for o in side][:8]
+    assert all(o.side_stream for o in g.ops if 'sconv' in o.name and not o.name.startswith('g_opt')), \
+        [o.name for o in g.ops if 'sconv' in o.name and not o.side_stream]
+    needed = [o for o in g.ops if not isinstance(o, G.InitOp)]
+    ops = sorted(needed, key=lambda o: (o.run_last, o.index))
+    out = sess._hoist_side_chains(list(ops))
+    assert sorted(map(id, out)) == sorted(map(id, ops))
+    where = {id(o): k for k, o in enumerate(out)}
+    for o in out:
+        for d in [t.op for t in o.inputs if t.op is not None] + list(o.control_inputs):
+            if id(d) in where:
+                assert where[id(d)] < where[id(o)], (d.name, o.name)
+    names = [o.name for o in out]
+    first_bwd_side = min(k for k, o in enumerate(out) if o.side_stream and o.name.endswith('g_state_loss/grad'))
+    dna_bwd = names.index('g/dna/bwd')
+    assert first_bwd_side < dna_bwd, (first_bwd_side, dna_bwd)      # the backward side chain starts before the frame decoder's
+    assert [o for o in out if o.side_stream] == [o for o in ops if o.side_stream]      # its own order is kept
+
+
 def test_c_abi_exports_every_declared_symbol():
     """include/acgan_hip.h <-> both libraries: every declared entry point is exported (no compute here)."""
     import re, os, ctypes

@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B inside ONE box: BatchNorm statistics out of the conv epilogue (default) vs a statistics pass of its own (--no-epilogue-stats).
+# A/B of one bench.py flag inside ONE box, two repeats, the three workloads:  tools/ab_flag.sh OUTDIR --some-flag
 set -e
-OUT=$1; mkdir -p $OUT
+OUT=$1; FLAG=$2; mkdir -p $OUT
 for rep in 1 2; do
-for f in "" "--no-epilogue-stats"; do
+for f in "" "$FLAG"; do
   python3 bench.py --no-cpu-baseline $f > $OUT/f32_${rep}_${f#--}.json 2>$OUT/err.txt
   python3 bench.py --dtype bf16 --no-cpu-baseline $f > $OUT/c3_${rep}_${f#--}.json 2>>$OUT/err.txt
   python3 bench.py --dtype bf16 --img 128 --ksize 11 --seq_len 16 --steps 10 --no-cpu-baseline $f > $OUT/c5_${rep}_${f#--}.json 2>>$OUT/err.txt

@@ -80,7 +80,7 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
   }
   const int tiles_n = (N + BN - 1) / BN;
   int bid = bx;
-  {
+  if constexpr (MODE != MODE_WGRAD) {      // (weight gradients are placed by wgrad_xcd_map in the kernel wrappers)
     const int nwg = gx, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
   }
@@ -444,7 +444,13 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
 template <int MODE, int BM, int BN>
 __global__ __launch_bounds__(256) void conv_mfma_bf16(const ConvArgs p) {
   __shared__ __align__(16) char smem[conv16_lds_bytes<MODE, BM, BN>()];
-  conv16_body<MODE, BM, BN>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
+  if constexpr (MODE == MODE_WGRAD) {      // grid (tiles, 1, splits)
+    int tile, split;
+    wgrad_xcd_map((int)(blockIdx.x + gridDim.x * blockIdx.z), (int)gridDim.x, (int)gridDim.z, tile, split);
+    conv16_body<MODE, BM, BN>(p, tile, 0, split, (int)gridDim.x, smem);
+  } else {
+    conv16_body<MODE, BM, BN>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
+  }
 }
 
 // A layer's input gradient (DGRAD, or FWD on the adjoint descriptor of a transposed layer) and its weight gradient out
@@ -459,8 +465,9 @@ __global__ __launch_bounds__(256) void conv_pair_bf16(const ConvArgs a, const Co
     const int t = L / g.gxA;
     conv16_body<MODE_A, BMA, BNA>(a, L - t * g.gxA, t % g.gyA, t / g.gyA, g.gxA, smem);
   } else {
-    const int l = L - g.nA, bz = l / g.gxB;
-    conv16_body<MODE_WGRAD, BMB, BNB>(b, l - bz * g.gxB, 0, bz, g.gxB, smem);
+    int tile, split;
+    wgrad_xcd_map(L - g.nA, g.gxB, b.splits, tile, split);
+    conv16_body<MODE_WGRAD, BMB, BNB>(b, tile, 0, split, g.gxB, smem);
   }
 }
 int launch_pair16(int modeA, const Plan& pa, const ConvArgs& a, const Plan& pb, const ConvArgs& b, hipStream_t st);

@@ -254,6 +254,11 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
   // next to a long K loop (profiles/r1/r_conv_tune_full.txt: 79.8 us unsplit, 67.1 us at 4 splits).
   s = std::max<long long>(s, 1);
   if (!bf16 && which != ACG_CONV_WGRAD && pl.tiles * s <= 256 && pl.nk / s >= 50) s *= pl.nk / s >= 100 ? 4 : 2;
+  // Weight gradients: every output tile of one K range gathers the SAME pixels (at its own taps), so the blocks of a split
+  // are placed on ONE XCD and share that range in its L2 (wgrad_xcd_map, conv_f32_kernel.h) - which needs the split count
+  // to be a multiple of the 8 XCDs.
+  static const int xcd_splits = env_int("ACG_PLAN_WGRAD_XCD", 1);
+  if (xcd_splits && bf16 && which == ACG_CONV_WGRAD && s >= 6 && (s + 7) / 8 * 8 <= pl.nk) s = (s + 7) / 8 * 8;   // (fp32: the swept split counts stay - rounding them cost 1.3 % of the step)
   if (g_force_splits >= 1) s = std::min<long long>(g_force_splits, pl.nk);
   pl.splits = (int)std::max<long long>(s, 1);
   return pl;

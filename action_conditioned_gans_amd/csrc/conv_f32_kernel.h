@@ -75,6 +75,22 @@ __device__ __forceinline__ int div_fast(int r, unsigned magic, int shift) {
   return (int)(((unsigned long long)(unsigned)r * magic) >> shift);
 }
 
+// Weight-gradient blocks: block l of gx * splits (x fastest) -> (tile, split).  The hardware deals workgroups round-robin
+// over the 8 XCDs in dispatch order, so blocks l, l+8, l+16 ... share an XCD; all gx tiles of one split read the same
+// pixel range of both operands (each at its own filter taps): give them to ONE XCD, so that range comes out of HBM / the
+// Infinity Cache once instead of once per XCD (measured: g/tconv4's pair at 128x128 fetched 878 MB per launch, 6x its
+// operands).  Splits that are not a multiple of 8 keep the plain order.  Placement only: results do not change.
+__device__ __forceinline__ void wgrad_xcd_map(int l, int gx, int splits, int& tile, int& split) {
+  if ((splits & 7) == 0) {
+    const int x8 = l & 7, q = l >> 3, grp = q / gx;
+    tile = q - grp * gx;
+    split = grp * 8 + x8;
+  } else {
+    split = l / gx;
+    tile = l - split * gx;
+  }
+}
+
 struct alignas(16) RowInfo {
   int base;            // element offset of the row's (tap 0, channel 0) source element (may be virtual)
   unsigned mask_lo, mask_hi;  // bit t set <=> filter tap t reads inside the tensor
@@ -204,7 +220,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
   // give every XCD a CONTIGUOUS run of tiles - neighbours in the run share A rows / filter columns in that L2.
   // Bijective for any grid size; placement affects speed only.
   int bid = bx;
-  {
+  if constexpr (MODE != MODE_WGRAD) {      // (weight gradients are placed by wgrad_xcd_map in the kernel wrappers)
     const int nwg = gx, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
   }
@@ -656,7 +672,13 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
 template <int MODE, int BM, int BN, int WM, int WN, bool RAGGED, bool NVEC>
 __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
   __shared__ __align__(16) char smem[conv_lds_bytes<MODE, BM, BN>()];
-  conv_body<MODE, BM, BN, WM, WN, RAGGED, NVEC>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
+  if constexpr (MODE == MODE_WGRAD) {      // grid (tiles, 1, splits)
+    int tile, split;
+    wgrad_xcd_map((int)(blockIdx.x + gridDim.x * blockIdx.z), (int)gridDim.x, (int)gridDim.z, tile, split);
+    conv_body<MODE, BM, BN, WM, WN, RAGGED, NVEC>(p, tile, 0, split, (int)gridDim.x, smem);
+  } else {
+    conv_body<MODE, BM, BN, WM, WN, RAGGED, NVEC>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
+  }
 }
 
 
@@ -678,8 +700,9 @@ __global__ __launch_bounds__(256) void conv_pair_f32(const ConvArgs a, const Con
     const int t = L / g.gxA;
     conv_body<MODE_A, BMA, BNA, WMA, WNA, RAGGED, true>(a, L - t * g.gxA, t % g.gyA, t / g.gyA, g.gxA, smem);
   } else {
-    const int l = L - g.nA, bz = l / g.gxB;
-    conv_body<MODE_WGRAD, BMB, BNB, WMB, WNB, RAGGED, true>(b, l - bz * g.gxB, 0, bz, g.gxB, smem);
+    int tile, split;
+    wgrad_xcd_map(L - g.nA, g.gxB, b.splits, tile, split);
+    conv_body<MODE_WGRAD, BMB, BNB, WMB, WNB, RAGGED, true>(b, tile, 0, split, g.gxB, smem);
   }
 }
 

@@ -555,6 +555,15 @@ class Session:
         for ph in feeds:
             self._materialize(ph)
         prog = _Program(segments, fetch_tensors, list(feeds))
+        # placeholders this program reads (directly, or as the storage a view aliases): a feed for any other placeholder is
+        # validated but not copied - Trainer.train_d feeds next_state like the reference does, and the D step never reads it
+        read = set()
+        for op in ops:
+            for t in list(op.inputs) + list(getattr(op, 'extras', ())):
+                read.add(id(t))
+                read.add(id(t.root()))
+        prog.used_feeds = frozenset(id(ph) for ph in feeds
+                                    if id(ph) in read or any(t is not None and t.root() is ph for t in fetch_tensors))
         prog.eager = any(getattr(op, 'no_graph', False) for op in ops)     # an op that cannot be captured: eager launch list
         return prog
 
@@ -615,6 +624,8 @@ class Session:
             dst = ph.buf if ph.valid_c is None else ph.buf[..., :ph.valid_c]     # pad channels stay zero
             if tuple(src.shape) != tuple(dst.shape):
                 raise ValueError('Cannot feed value of shape %s for %r' % (tuple(src.shape), ph))
+            if id(ph) not in prog.used_feeds:
+                continue
             if (self.rt.is_cuda and src.is_cuda and src.device == ph.buf.device and src.dtype == torch.float32
                     and ph.dtype in (torch.float32, torch.bfloat16) and src.is_contiguous() and len(fused) < _lib.COPY_MAX):
                 fused.append((src, ph))          # device-resident feeds: one launch for all of them (below)

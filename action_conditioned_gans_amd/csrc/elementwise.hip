@@ -50,14 +50,16 @@ __global__ __launch_bounds__(256) void concat_k(const TI* __restrict__ a, const 
     const unsigned n32 = (unsigned)n, st32 = (unsigned)stride, ucy = (unsigned)cy, urpb = (unsigned)rows_per_b;
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n32; i += st32) {
       const unsigned r = i / ucy, c = i - r * ucy;
-      acg::stf(y + (size_t)r * pitch + c, c < (unsigned)ca ? acg::ldf(a + (size_t)r * ca + c) : acg::ldf(b + (size_t)(r / urpb) * cb + (c - ca)));
+      if (c >= (unsigned)ca) acg::stf(y + (size_t)r * pitch + c, acg::ldf(b + (size_t)(r / urpb) * cb + (c - ca)));
+      else if (a != nullptr) acg::stf(y + (size_t)r * pitch + c, acg::ldf(a + (size_t)r * ca + c));
     }
     return;
   }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     const long long r = i / cy;
     const int c = (int)(i - r * cy);
-    acg::stf(y + r * pitch + c, c < ca ? acg::ldf(a + r * ca + c) : acg::ldf(b + (r / rows_per_b) * cb + (c - ca)));
+    if (c >= ca) acg::stf(y + r * pitch + c, acg::ldf(b + (r / rows_per_b) * cb + (c - ca)));
+    else if (a != nullptr) acg::stf(y + r * pitch + c, acg::ldf(a + r * ca + c));
   }
 }
 
@@ -200,7 +202,7 @@ int32_t acg_concat_actions_fwd(const void* x, const float* actions, void* y, int
 int32_t acg_concat_channels_fwd(const void* a, const void* b, void* y, int64_t rows, int32_t ca, int32_t cb, int32_t y_pitch,
                                 int32_t dtype, acg_stream_t stream) {
   ACG_REQUIRE(rows > 0 && ca > 0 && cb >= 0, ACG_ERR_INVALID_ARG, "concat_channels_fwd: non-positive size");
-  ACG_REQUIRE(a && (b || cb == 0) && y, ACG_ERR_INVALID_ARG, "concat_channels_fwd: null pointer");
+  ACG_REQUIRE((a || cb > 0) && (b || cb == 0) && y, ACG_ERR_INVALID_ARG, "concat_channels_fwd: null pointer");
   const int pitch = y_pitch > 0 ? y_pitch : ca + cb;
   ACG_REQUIRE(pitch >= ca + cb, ACG_ERR_INVALID_ARG, "concat_channels_fwd: pitch smaller than the row");
   ACG_WITH_TYPES_ANY(dtype, "concat_channels_fwd",

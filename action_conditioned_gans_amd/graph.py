@@ -133,6 +133,7 @@ class Graph:
         self.state = []              # state slots with constant init (optimizer slots, counters)
         self._id = 0
         self._side_default = False   # inside side_branch(): new ops are flagged side_stream
+        self.feed_aliases = {}       # id(placeholder) -> [(tensor, channel offset)]: also written by that placeholder's feed
         self._layouts = {}           # top-level scope -> (offsets dict, total numel, flat Tensor)
         self.collections = {}
         # storage type of activation-class tensors (conv / BatchNorm outputs and their gradients): float32, or
@@ -144,6 +145,14 @@ class Graph:
     def cpad(self):
         """Channel-pitch unit of activation tensors: one 16-byte gather = 4 floats or 8 bf16."""
         return 8 if self.act_dtype == torch.bfloat16 else 4
+
+    def add_feed_alias(self, placeholder, dst, c_off):
+        """Whenever ``placeholder`` ([..., C] float32) is fed, its value is ALSO written into channels
+        [c_off, c_off + C) of ``dst`` (same leading dimensions, any channel pitch, float32 or bf16) - by the same feed copy,
+        for every program that reads ``dst`` (ops.ConcatChannelsOp: a concatenation whose inputs are fed needs no launch)."""
+        if placeholder.shape[:-1] != dst.shape[:-1] or c_off + placeholder.shape[-1] > dst.shape[-1]:
+            raise ValueError('feed alias: %r does not fit %r at channel %d' % (placeholder, dst, c_off))
+        self.feed_aliases.setdefault(id(placeholder), []).append((dst, int(c_off)))
 
     @contextlib.contextmanager
     def side_branch(self, on=True):
@@ -322,6 +331,9 @@ class _Program:
         self.graphs = None           # captured HIP graphs, one per 'dev' segment
         self.eager = False           # always launched eagerly (contains stream-ordered collectives)
         self.runs = 0
+        self.missing_feeds = []
+        self.used_feeds = frozenset()
+        self.alias_copies = {}
 
 
 class Runtime:
@@ -559,11 +571,31 @@ class Session:
         # validated but not copied - Trainer.train_d feeds next_state like the reference does, and the D step never reads it
         read = set()
         for op in ops:
+            fed = getattr(op, 'fed_inputs', ())
             for t in list(op.inputs) + list(getattr(op, 'extras', ())):
+                if any(t is f for f in fed):
+                    continue                      # this op takes the value through a feed alias, not from the placeholder
                 read.add(id(t))
                 read.add(id(t.root()))
         prog.used_feeds = frozenset(id(ph) for ph in feeds
                                     if id(ph) in read or any(t is not None and t.root() is ph for t in fetch_tensors))
+        # TF: "You must feed a value for placeholder tensor ..." - every placeholder the program reads, directly or through
+        # a feed alias, has to be in the feed dict
+        fed_ids = {id(ph) for ph in feeds}
+        needed = {}
+        for op in ops:
+            for t in op.inputs:
+                r = t.root()
+                if isinstance(r, Placeholder):
+                    needed[id(r)] = r
+        prog.missing_feeds = sorted(r.name for i, r in needed.items() if i not in fed_ids)      # Session.run raises on these
+        # feed aliases whose destination this program reads
+        prog.alias_copies = {}
+        for ph in feeds:
+            for dst, c_off in self.graph.feed_aliases.get(id(ph), ()):
+                if id(dst) in read or id(dst.root()) in read:
+                    self._materialize(dst)
+                    prog.alias_copies.setdefault(id(ph), []).append((dst, c_off))
         prog.eager = any(getattr(op, 'no_graph', False) for op in ops)     # an op that cannot be captured: eager launch list
         return prog
 
@@ -618,25 +650,28 @@ class Session:
         if prog is None:
             prog = self._compile(flat, list(feed_dict.keys()))
             self._programs[key] = prog
+        if prog.missing_feeds:
+            raise ValueError('You must feed a value for placeholder tensor(s) %s' % ', '.join(prog.missing_feeds))
         fused = []
         for ph, val in feed_dict.items():
             src = val if torch.is_tensor(val) else torch.from_numpy(np.ascontiguousarray(val))
             dst = ph.buf if ph.valid_c is None else ph.buf[..., :ph.valid_c]     # pad channels stay zero
             if tuple(src.shape) != tuple(dst.shape):
                 raise ValueError('Cannot feed value of shape %s for %r' % (tuple(src.shape), ph))
-            if id(ph) not in prog.used_feeds:
-                continue
-            if (self.rt.is_cuda and src.is_cuda and src.device == ph.buf.device and src.dtype == torch.float32
-                    and ph.dtype in (torch.float32, torch.bfloat16) and src.is_contiguous() and len(fused) < _lib.COPY_MAX):
-                fused.append((src, ph))          # device-resident feeds: one launch for all of them (below)
-            else:
-                dst.copy_(src.to(ph.dtype), non_blocking=True)
+            targets = ([(ph, 0)] if id(ph) in prog.used_feeds else []) + prog.alias_copies.get(id(ph), [])
+            cols = src.shape[-1]
+            for t, c_off in targets:
+                if (self.rt.is_cuda and src.is_cuda and src.device == t.buf.device and src.dtype == torch.float32
+                        and t.dtype in (torch.float32, torch.bfloat16) and src.is_contiguous() and len(fused) < _lib.COPY_MAX):
+                    fused.append((src, t, c_off))          # device-resident feeds: one launch for all of them (below)
+                else:
+                    t.buf.view(-1, t.shape[-1])[:, c_off:c_off + cols].copy_(src.reshape(-1, cols).to(t.dtype), non_blocking=True)
         if fused:
             cl = _lib.CopyList()
-            for i, (src, ph) in enumerate(fused):
-                cols = ph.valid_c if ph.valid_c is not None else ph.shape[-1]
-                cl.src[i], cl.dst[i] = src.data_ptr(), ph.buf.data_ptr()
-                cl.rows[i], cl.cols[i], cl.dst_pitch[i], cl.dst_dtype[i] = src.numel() // cols, cols, ph.shape[-1], _lib.code(ph.dtype)
+            for i, (src, t, c_off) in enumerate(fused):
+                cols = src.shape[-1]
+                cl.src[i], cl.dst[i] = src.data_ptr(), t.buf.data_ptr() + c_off * t.buf.element_size()
+                cl.rows[i], cl.cols[i], cl.dst_pitch[i], cl.dst_dtype[i] = src.numel() // cols, cols, t.shape[-1], _lib.code(t.dtype)
             self.rt.lib.copy_many(ctypes.byref(cl), len(fused), _lib.ACG_F32, self.rt.stream_ptr())
         if self._weights_dirty and prog is not None:
             self._refresh_weight_copies()

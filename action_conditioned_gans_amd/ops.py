@@ -876,12 +876,25 @@ class ConcatChannelsOp(G.Op):
         y = out if out is not None else _new(shape, name + ':0', act_dtype() if act else a.dtype)
         if self.pitch:
             y.valid_c = csum
-        super().__init__(G.get_default_graph(), name, [a, b], [y])
+        g = G.get_default_graph()
+        # channels that come straight from a fed placeholder are written by the feed copy itself (Graph.add_feed_alias):
+        # both discriminator inputs start with the fed current frame, the real one is fed frames only (train.py:64,68)
+        fed_a = isinstance(a, G.Placeholder) and a.dtype == torch.float32
+        fed_b = fed_a and isinstance(b, G.Placeholder) and b.dtype == torch.float32
+        self.fed_inputs = ([a] if fed_a else []) + ([b] if fed_b else [])
+        if fed_a:
+            g.add_feed_alias(a, y, 0)
+        if fed_b:
+            g.add_feed_alias(b, y, a.shape[-1])
+        super().__init__(g, name, [a, b], [y])
 
     def bind(self, rt):
         a, b = self.inputs
-        args = (_p(a.buf), _p(b.buf), _p(self.outputs[0].buf), a.numel // a.shape[-1], a.shape[-1], b.shape[-1], self.pitch,
-                _code2(a, self.outputs[0]))
+        if len(self.fed_inputs) == 2:
+            return None                       # nothing left to launch
+        pa = None if self.fed_inputs else _p(a.buf)
+        args = (pa, _p(b.buf), _p(self.outputs[0].buf), a.numel // a.shape[-1], a.shape[-1], b.shape[-1], self.pitch,
+                _code2(b, self.outputs[0]))
         fn = rt.lib.concat_channels_fwd
         return lambda s: fn(*args, s)
 

@@ -313,7 +313,9 @@ int32_t acg_cdna_bwd(const void* params, const float* kern_norm, const void* ima
 int32_t acg_concat_actions_fwd(const void* x, const float* actions, void* y, int32_t batch, int32_t hw,
                                int32_t c, int32_t a, int32_t y_pitch, int32_t dtype, acg_stream_t stream);
 /* y[r,0:ca] = a[r,:], y[r,ca:ca+cb] = b[r,:]; y rows are y_pitch elements apart (0 = dense = ca+cb); pad channels
- * are not written.  cb may be 0 (b ignored): a plain re-pitching copy.  dtype: storage of a, b and y, or
+ * are not written.  cb may be 0 (b ignored): a plain re-pitching copy.  a may be NULL (with cb > 0): channels 0:ca of y
+ * were written by someone else - the host's feed copy puts the fed frame there (train.py:64,68: both discriminator inputs
+ * start with the fed current frame) - and only b's channels are written.  dtype: storage of a, b and y, or
  * ACG_DTYPE2(a and b, y) - ACG_DTYPE2(ACG_F32, ACG_BF16) builds the bf16 discriminator input from float32 frames. */
 int32_t acg_concat_channels_fwd(const void* a, const void* b, void* y, int64_t rows, int32_t ca, int32_t cb,
                                 int32_t y_pitch, int32_t dtype, acg_stream_t stream);

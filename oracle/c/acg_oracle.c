@@ -571,7 +571,8 @@ int32_t acg_concat_channels_fwd(const void* av, const void* bv, void* yv, int64_
   const float* a = av; const float* b = bv; float* y = yv;
   const int64_t py = y_pitch > 0 ? y_pitch : ca + cb;
   if (py < ca + cb) return fail(ACG_ERR_INVALID_ARG, "concat_channels: pitch smaller than the row");
-  for (int64_t r = 0; r < rows; r++) { memcpy(y + r * py, a + r * ca, sizeof(float) * ca);
+  if (!a && cb <= 0) return fail(ACG_ERR_INVALID_ARG, "concat_channels: null pointer");
+  for (int64_t r = 0; r < rows; r++) { if (a) memcpy(y + r * py, a + r * ca, sizeof(float) * ca);
                                        if (cb > 0) memcpy(y + r * py + ca, b + r * cb, sizeof(float) * cb); }
   return ACG_OK;
 }

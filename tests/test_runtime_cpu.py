@@ -215,6 +215,28 @@ def test_checkpoint_roundtrip_and_rollout(tmp_path):
     assert pred.shape == (2, 3, 64, 64, 3) and np.isfinite(pred).all() and 'g_psnr' in summ
 
 
+def test_feeds_missing_unused_and_aliased():
+    """TF feed semantics of the session: a placeholder the program reads must be fed (ValueError, as TF's "You must feed a value
+    for placeholder tensor"); a fed placeholder the program does not read is validated and ignored (the D step is fed next_state
+    like the reference does); a concatenation of fed placeholders is written by the feed itself (Graph.add_feed_alias)."""
+    sess, tr = TC.build_trainer(cpu_session, 'c2_dna_bce_adam', batch=2)
+    x, y, a, s = TC.MG.inputs(2)
+    with pytest.raises(ValueError, match='must feed'):
+        sess.run(tr.g_next_frame, {tr.img_ph: x, tr._img_pad: x})                 # actions missing
+    with pytest.raises(ValueError, match='shape'):
+        bad = tr._feed(x, y, a)
+        bad[tr.next_state] = np.zeros((2, 4), np.float32)
+        sess.run([tr.d_opt_op, tr.clip_d], bad)
+    tr.train_d(x, y, a)                                                           # next_state fed, unused: fine
+    g = G.get_default_graph()
+    real = [o for o in g.ops if o.name == 'd_in_real'][0]
+    gen = [o for o in g.ops if o.name == 'd_in_gen'][0]
+    assert len(real.fed_inputs) == 2 and len(gen.fed_inputs) == 1
+    got = sess._materialize(real.outputs[0])
+    assert torch.equal(got[..., 0:3], torch.from_numpy(x)) and torch.equal(got[..., 3:6], torch.from_numpy(y)) and bool((got[..., 6:] == 0).all())
+    assert torch.equal(sess._materialize(gen.outputs[0])[..., 0:3], torch.from_numpy(x))
+
+
 def test_side_chain_flags_and_hoisting():
     """Graph.side_branch: the DNA state head, its loss and all their gradient ops are flagged for the side stream, nothing
     else is; Session._hoist_side_chains moves them to where their producers allow without breaking any dependency."""

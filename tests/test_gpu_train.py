@@ -408,6 +408,40 @@ def test_splitk_handoff_to_batchnorm(dtype):
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_epilogue_statistics_match_the_statistics_pass(dtype):
+    """Session(epilogue_stats=True), the default: BatchNorm statistics come out of the producing conv's epilogue
+    (acg_(de)conv2d_fwd_stats -> acg_bn_act_fwd_partials) instead of a pass over the activation.  Same values summed in a
+    different order (per row tile, then float64), so the gradients and frames of the first D + G step must agree with the
+    statistics-pass run to rounding level, and the fused path must actually have been taken."""
+    from action_conditioned_gans_amd import ops as O
+    x, y, a, s = TC.MG.inputs(2)
+    xs, ys = np.tile(x, (4, 1, 1, 1)), np.tile(y, (4, 1, 1, 1))
+    as_, ss = np.tile(a, (4, 1)), np.tile(s, (4, 1))
+    finals = []
+    for fused in (False, True):
+        sess, tr = TC.build_trainer(gpu_session, 'c2_dna_bce_adam', batch=8, dtype=dtype, epilogue_stats=fused)
+        tr.train_d(xs, ys, as_)
+        frames = tr.train_g(xs, ys, as_, ss)
+        torch.cuda.synchronize()
+        g = G.get_default_graph()
+        n = sum(1 for o in g.ops if isinstance(o, O.Conv2dOp) and o._stats is not None)
+        assert (n >= 3) if fused else (n == 0), (fused, n)      # batch 8: most small layers are split over K and keep the pass
+        grads = [op.inputs[1].buf.detach().double().cpu().clone() for op in (tr.d_opt_op, tr.g_opt_op)]
+        finals.append((grads, frames))
+    (g0, f0), (g1, f1) = finals
+    # the gradients of the first D and G step (the weights behind them are an Adam step apart whatever the gradient's size, so
+    # they are the wrong thing to compare): whole-buffer relative error at accumulation-order level
+    # (bf16: a last-bit change of a statistic re-rounds every activation behind it, and rounding noise is the bf16 gradient's
+    # error floor - the bf16-vs-oracle tests of this file sit at cosine 0.984 - so the bound there is that floor)
+    tol = 2e-5 if dtype == 'f32' else 0.1          # measured: 2.7e-6 / 1.1e-6 (float32), 4.4e-2 / 2.4e-3 (bf16: D, G)
+    for a0, a1, who in zip(g0, g1, ('d', 'g')):
+        err = float((a0 - a1).norm() / a0.norm())
+        print('epilogue statistics vs pass, %s, %s gradient: relative difference %.3g' % (dtype, who, err))
+        assert err <= tol, (who, err)
+    assert TC.rel(f1, f0) <= (1e-4 if dtype == 'f32' else 3e-2)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_side_branch_is_bit_identical(dtype):
     """The DNA generator's state head runs as a side chain (Graph.side_branch): on the session's second HIP stream, a
     parallel branch of the step's HIP graph, hoisted to where its inputs exist.  Same kernels on the same data, only

@@ -48,7 +48,7 @@ class PrepList(ctypes.Structure):
 class CopyList(ctypes.Structure):
     """struct acg_copy_list (ACG_COPY_MAX = 8 segments)."""
     _fields_ = [('src', c_void_p * 8), ('dst', c_void_p * 8), ('rows', c_int64 * 8), ('cols', c_int32 * 8),
-                ('dst_pitch', c_int32 * 8), ('dst_dtype', c_int32 * 8)]
+                ('dst_pitch', c_int32 * 8), ('dst_dtype', c_int32 * 8), ('src_div', c_int32 * 8), ('src_mod', c_int32 * 8)]
 
 
 _P = c_void_p

@@ -115,6 +115,7 @@ struct CopyList {
   void* dst[ACG_COPY_MAX];
   long long rows[ACG_COPY_MAX];
   int cols[ACG_COPY_MAX], pitch[ACG_COPY_MAX], half[ACG_COPY_MAX];
+  int div[ACG_COPY_MAX], mod[ACG_COPY_MAX];      // source row of destination row r: (r / div) % mod (mod 0: no wrap)
 };
 
 // blockIdx.y = segment; float4 when the segment is dense and aligned, else one float per thread with 32-bit row math
@@ -124,6 +125,18 @@ __global__ __launch_bounds__(256) void copy_many_k(const CopyList l) {
   const long long rows = l.rows[sgm];
   const int cols = l.cols[sgm], pitch = l.pitch[sgm];
   const long long n = rows * cols, stride = (long long)gridDim.x * 256;
+  const int dv = l.div[sgm], md = l.mod[sgm];
+  if (dv > 1 || md > 0) {          // tiled source rows (the action vector over a feature map): small, 32-bit row math
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+      const unsigned r = (unsigned)(i / cols), c = (unsigned)(i - (long long)r * cols);
+      unsigned sr = r / (unsigned)dv;
+      if (md > 0) sr %= (unsigned)md;
+      const float v = src[(size_t)sr * cols + c];
+      if (l.half[sgm]) reinterpret_cast<__bf16*>(l.dst[sgm])[(size_t)r * pitch + c] = (__bf16)v;
+      else reinterpret_cast<float*>(l.dst[sgm])[(size_t)r * pitch + c] = v;
+    }
+    return;
+  }
   if (l.half[sgm]) {   // float32 source -> bf16 destination
     __bf16* __restrict__ dh = reinterpret_cast<__bf16*>(l.dst[sgm]);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
@@ -234,6 +247,8 @@ int32_t acg_copy_many(const acg_copy_list* list, int32_t count, int32_t dtype, a
     ACG_REQUIRE(list->dst_dtype[i] == ACG_F32 || list->dst_dtype[i] == ACG_BF16, ACG_ERR_UNSUPPORTED, "copy_many: segment %d dtype", i);
     l.src[i] = (const float*)list->src[i]; l.dst[i] = list->dst[i]; l.half[i] = list->dst_dtype[i] == ACG_BF16;
     l.rows[i] = list->rows[i]; l.cols[i] = list->cols[i]; l.pitch[i] = pitch;
+    ACG_REQUIRE(list->src_div[i] >= 0 && list->src_mod[i] >= 0 && list->rows[i] < (1ll << 31), ACG_ERR_INVALID_ARG, "copy_many: segment %d tiling", i);
+    l.div[i] = list->src_div[i] > 0 ? list->src_div[i] : 1; l.mod[i] = list->src_mod[i];
     most = std::max<long long>(most, list->rows[i] * list->cols[i]);
   }
   ACG_LAUNCH(copy_many_k, dim3(grid_for(most / 4 + 1), count), dim3(256), 0, acg::to_stream(stream), l);

@@ -146,13 +146,17 @@ class Graph:
         """Channel-pitch unit of activation tensors: one 16-byte gather = 4 floats or 8 bf16."""
         return 8 if self.act_dtype == torch.bfloat16 else 4
 
-    def add_feed_alias(self, placeholder, dst, c_off):
+    def add_feed_alias(self, placeholder, dst, c_off, tile=None):
         """Whenever ``placeholder`` ([..., C] float32) is fed, its value is ALSO written into channels
         [c_off, c_off + C) of ``dst`` (same leading dimensions, any channel pitch, float32 or bf16) - by the same feed copy,
-        for every program that reads ``dst`` (ops.ConcatChannelsOp: a concatenation whose inputs are fed needs no launch)."""
-        if placeholder.shape[:-1] != dst.shape[:-1] or c_off + placeholder.shape[-1] > dst.shape[-1]:
+        for every program that reads ``dst`` (ops.ConcatChannelsOp: a concatenation whose inputs are fed needs no launch).
+        ``tile`` = (div, mod): row r of ``dst`` takes row (r // div) % mod of the [B, C] placeholder instead - tf.tile of
+        the action vector over a feature map, shared by the sub-batches of a joined batch (ops.ConcatActionsOp)."""
+        if tile is None and placeholder.shape[:-1] != dst.shape[:-1]:
+            raise ValueError('feed alias: %r does not fit %r' % (placeholder, dst))
+        if c_off + placeholder.shape[-1] > dst.shape[-1]:
             raise ValueError('feed alias: %r does not fit %r at channel %d' % (placeholder, dst, c_off))
-        self.feed_aliases.setdefault(id(placeholder), []).append((dst, int(c_off)))
+        self.feed_aliases.setdefault(id(placeholder), []).append((dst, int(c_off), tile))
 
     @contextlib.contextmanager
     def side_branch(self, on=True):
@@ -522,8 +526,9 @@ class Session:
             if id(op) in needed:
                 continue
             needed[id(op)] = op
+            fed = getattr(op, 'fed_inputs', ())
             for t in op.inputs:
-                if t.op is not None and id(t.op) not in needed:
+                if t.op is not None and id(t.op) not in needed and not any(t is f for f in fed):
                     stack.append(t.op)
             stack.extend(c for c in op.control_inputs if id(c) not in needed)
         ops = sorted(needed.values(), key=lambda o: (o.run_last, o.index))
@@ -592,10 +597,10 @@ class Session:
         # feed aliases whose destination this program reads
         prog.alias_copies = {}
         for ph in feeds:
-            for dst, c_off in self.graph.feed_aliases.get(id(ph), ()):
+            for dst, c_off, tile in self.graph.feed_aliases.get(id(ph), ()):
                 if id(dst) in read or id(dst.root()) in read:
                     self._materialize(dst)
-                    prog.alias_copies.setdefault(id(ph), []).append((dst, c_off))
+                    prog.alias_copies.setdefault(id(ph), []).append((dst, c_off, tile))
         prog.eager = any(getattr(op, 'no_graph', False) for op in ops)     # an op that cannot be captured: eager launch list
         return prog
 
@@ -658,20 +663,26 @@ class Session:
             dst = ph.buf if ph.valid_c is None else ph.buf[..., :ph.valid_c]     # pad channels stay zero
             if tuple(src.shape) != tuple(dst.shape):
                 raise ValueError('Cannot feed value of shape %s for %r' % (tuple(src.shape), ph))
-            targets = ([(ph, 0)] if id(ph) in prog.used_feeds else []) + prog.alias_copies.get(id(ph), [])
+            targets = ([(ph, 0, None)] if id(ph) in prog.used_feeds else []) + prog.alias_copies.get(id(ph), [])
             cols = src.shape[-1]
-            for t, c_off in targets:
+            for t, c_off, tile in targets:
                 if (self.rt.is_cuda and src.is_cuda and src.device == t.buf.device and src.dtype == torch.float32
                         and t.dtype in (torch.float32, torch.bfloat16) and src.is_contiguous() and len(fused) < _lib.COPY_MAX):
-                    fused.append((src, t, c_off))          # device-resident feeds: one launch for all of them (below)
+                    fused.append((src, t, c_off, tile))    # device-resident feeds: one launch for all of them (below)
                 else:
-                    t.buf.view(-1, t.shape[-1])[:, c_off:c_off + cols].copy_(src.reshape(-1, cols).to(t.dtype), non_blocking=True)
+                    rows2d = src.reshape(-1, cols)
+                    if tile is not None:                   # (r // div) % mod: the tiled action vector
+                        idx = (torch.arange(t.numel // t.shape[-1], device=rows2d.device) // tile[0]) % tile[1]
+                        rows2d = rows2d[idx]
+                    t.buf.view(-1, t.shape[-1])[:, c_off:c_off + cols].copy_(rows2d.to(t.dtype), non_blocking=True)
         if fused:
             cl = _lib.CopyList()
-            for i, (src, t, c_off) in enumerate(fused):
+            for i, (src, t, c_off, tile) in enumerate(fused):
                 cols = src.shape[-1]
                 cl.src[i], cl.dst[i] = src.data_ptr(), t.buf.data_ptr() + c_off * t.buf.element_size()
-                cl.rows[i], cl.cols[i], cl.dst_pitch[i], cl.dst_dtype[i] = src.numel() // cols, cols, t.shape[-1], _lib.code(t.dtype)
+                cl.rows[i] = src.numel() // cols if tile is None else t.numel // t.shape[-1]
+                cl.cols[i], cl.dst_pitch[i], cl.dst_dtype[i] = cols, t.shape[-1], _lib.code(t.dtype)
+                cl.src_div[i], cl.src_mod[i] = (0, 0) if tile is None else tile
             self.rt.lib.copy_many(ctypes.byref(cl), len(fused), _lib.ACG_F32, self.rt.stream_ptr())
         if self._weights_dirty and prog is not None:
             self._refresh_weight_copies()

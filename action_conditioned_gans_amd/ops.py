@@ -829,12 +829,40 @@ class ConcatActionsOp(G.Op):
         # adds the tiled action channels, and backward hands the gradient of the concatenated tensor to the BatchNorm
         # backward as it is (dy at this pitch) - no copy of the feature map in either direction.
         self.in_place = isinstance(x.op, BnActOp) and x is x.op.outputs[0] and x.view_of is None and x.dtype == y.dtype
+        g = G.get_default_graph()
+        self.fed_inputs = []
         if self.in_place:
             x.op.yp = self.pitch
             x.view_of, x.shape, x.valid_c = (y, 0), y.shape, c
-        super().__init__(G.get_default_graph(), name, [x, actions], [y])
+            # ... and when the actions are a fed placeholder (possibly repeated for a joined batch, repeat_batch), the
+            # feed copy tiles them into the action channels (Graph.add_feed_alias): then this op launches nothing
+            ph = self._fed_source(actions)
+            if ph is not None:
+                g.add_feed_alias(ph, y, c, tile=(h * w, ph.shape[0]))
+                self.fed_inputs = [actions]
+        super().__init__(g, name, [x, actions], [y])
+
+    @staticmethod
+    def _fed_source(actions):
+        """The float32 [B, A] placeholder behind ``actions``: the tensor itself, or repeat_batch(placeholder, 2)."""
+        t = actions
+        while t.alias_of is not None:
+            t = t.alias_of
+        if isinstance(t, G.Placeholder):
+            return t if (t.dtype == torch.float32 and len(t.shape) == 2 and t.shape[1] == actions.shape[1]) else None
+        op = t.op
+        if isinstance(op, ConcatChannelsOp) and op.inputs[0] is op.inputs[1] and t is op.outputs[0]:
+            src = op.inputs[0]
+            while src.alias_of is not None:
+                src = src.alias_of
+            if (isinstance(src, G.Placeholder) and src.dtype == torch.float32 and len(src.shape) == 2
+                    and src.shape[1] == actions.shape[1] and src.shape[0] * 2 == actions.shape[0]):
+                return src
+        return None
 
     def bind(self, rt):
+        if self.fed_inputs:
+            return None
         x, a = self.inputs
         b, h, w = x.shape[:3]
         px = None if self.in_place else _p(x.buf)

@@ -344,6 +344,11 @@ typedef struct acg_copy_list {
   int32_t cols[ACG_COPY_MAX];
   int32_t dst_pitch[ACG_COPY_MAX];
   int32_t dst_dtype[ACG_COPY_MAX]; /* ACG_F32, or ACG_BF16: the float32 source is rounded into a bf16 placeholder */
+  /* destination row r reads source row (r / src_div) % src_mod (0 = 1 / no wrap: a plain copy).  tf.tile of the action
+   * vector over a feature map (train.py:48-50: [B,10] -> [B,h,w,10]) is src_div = h*w; the same vector shared by the
+   * fake and the real half of a joined batch is src_mod = B.  rows[i] counts DESTINATION rows. */
+  int32_t src_div[ACG_COPY_MAX];
+  int32_t src_mod[ACG_COPY_MAX];
 } acg_copy_list;
 int32_t acg_copy_many(const acg_copy_list* list, int32_t count, int32_t dtype, acg_stream_t stream);
 /* y = a + b (gradient fan-in where one tensor feeds two consumers, models.py:40-53) */

@@ -599,7 +599,9 @@ int32_t acg_copy_many(const acg_copy_list* l, int32_t count, int32_t dtype, acg_
     if (pitch < l->cols[i]) return fail(ACG_ERR_INVALID_ARG, "copy_many: pitch smaller than the row");
     if (l->dst_dtype[i] != ACG_F32) return fail(ACG_ERR_UNSUPPORTED, "cpu oracle: float32 only");
     const float* src = l->src[i]; float* dst = l->dst[i];
-    for (int64_t r = 0; r < l->rows[i]; r++) for (int c = 0; c < l->cols[i]; c++) dst[r * pitch + c] = src[r * l->cols[i] + c];
+    const int64_t dv = l->src_div[i] > 0 ? l->src_div[i] : 1, md = l->src_mod[i];
+    for (int64_t r = 0; r < l->rows[i]; r++) { int64_t sr = r / dv; if (md > 0) sr %= md;
+      for (int c = 0; c < l->cols[i]; c++) dst[r * pitch + c] = src[sr * l->cols[i] + c]; }
   }
   return ACG_OK;
 }

@@ -235,6 +235,17 @@ def test_feeds_missing_unused_and_aliased():
     got = sess._materialize(real.outputs[0])
     assert torch.equal(got[..., 0:3], torch.from_numpy(x)) and torch.equal(got[..., 3:6], torch.from_numpy(y)) and bool((got[..., 6:] == 0).all())
     assert torch.equal(sess._materialize(gen.outputs[0])[..., 0:3], torch.from_numpy(x))
+    # the tiled action channels of the concatenated feature maps come from the feed as well (g: [B,4,4,256+10]; d on the joined
+    # batch: [2B,16,16,128+10], the same actions for the fake and the real half)
+    cats = [o for o in g.ops if isinstance(o, O.ConcatActionsOp)]
+    assert len(cats) >= 2 and all(o.fed_inputs for o in cats), [(o.name, bool(o.fed_inputs)) for o in cats]
+    for o in cats:
+        t = sess._materialize(o.outputs[0])
+        if t.shape[0] == 0 or id(o) not in sess.rt.program_ops:
+            continue
+        want = torch.from_numpy(a)[torch.arange(t.shape[0]) % 2]
+        got_a = t[..., o.c:o.c + a.shape[1]]
+        assert torch.equal(got_a, want[:, None, None, :].expand_as(got_a)), o.name
 
 
 def test_side_chain_flags_and_hoisting():

@@ -105,8 +105,9 @@ SIGNATURES = {
     'acg_bias_act_bwd': (c_int32, [_P, _P, _P, _P, c_float, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_int32,
                                    _P, c_size_t, _P]),
     'acg_dna_workspace_bytes': (c_size_t, [c_int32] * 4),
-    'acg_dna_fwd': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
-    'acg_dna_bwd': (c_int32, [_P, _P, _P, _P, _P, _P, c_float, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_size_t, _P]),
+    'acg_dna_fwd': (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
+    'acg_dna_bwd': (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P, c_float, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P,
+                              c_size_t, _P]),
     'acg_cdna_workspace_bytes': (c_size_t, [c_int32] * 6),
     'acg_cdna_fwd': (c_int32, [_P, _P, _P, _P] + [c_int32] * 6 + [c_float, c_int32, _P]),
     'acg_cdna_bwd': (c_int32, [_P, _P, _P, _P, _P, _P] + [c_int32] * 6 + [c_float, c_int32, _P, c_size_t, _P]),

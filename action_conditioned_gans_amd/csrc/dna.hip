@@ -21,6 +21,22 @@ namespace {
 
 constexpr int TX = 64;
 
+// The frame's second home (train.py:63-66: D(fake) reads concat(current frame, generated frame)): forward also writes the
+// frame into channels [off, off + C) of a pitched tensor of the conv storage type - the discriminator's input - and backward
+// adds the gradient that arrives through those channels to dout; ptr == nullptr: none.
+struct Second {
+  void* ptr;
+  int pitch, off, half;
+};
+__device__ __forceinline__ void second_store(const Second& s2, long long pix, int c, float v) {
+  if (s2.half) reinterpret_cast<__bf16*>(s2.ptr)[pix * s2.pitch + s2.off + c] = (__bf16)v;
+  else reinterpret_cast<float*>(s2.ptr)[pix * s2.pitch + s2.off + c] = v;
+}
+__device__ __forceinline__ float second_load(const Second& s2, long long pix, int c) {
+  return s2.half ? (float)reinterpret_cast<const __bf16*>(s2.ptr)[pix * s2.pitch + s2.off + c]
+                 : reinterpret_cast<const float*>(s2.ptr)[pix * s2.pitch + s2.off + c];
+}
+
 template <typename TL>
 __host__ __device__ constexpr int logit_pitch(int kk) { return sizeof(TL) == 2 ? (kk + 7) & ~7 : kk; }
 
@@ -28,7 +44,8 @@ __host__ __device__ constexpr int logit_pitch(int kk) { return sizeof(TL) == 2 ?
 template <int K, int TY, bool BWD, int CC, typename TL>
 __global__ __launch_bounds__(TX* TY) void dna_kernel(const TL* __restrict__ logits, const float* __restrict__ bias,
                                                      const float* __restrict__ img, const float* __restrict__ dout,
-                                                     void* __restrict__ outv, float* __restrict__ bpart, int H, int W, int Crt) {
+                                                     void* __restrict__ outv, float* __restrict__ bpart, int H, int W, int Crt,
+                                                     const Second s2) {
   constexpr int KK = K * K, S = KK | 1, NT = TX * TY, P = (K - 1) / 2, LP = logit_pitch<TL>(KK);
   constexpr int WW = TX + K - 1, WH = TY + K - 1;
   constexpr bool F32 = sizeof(TL) == 4;
@@ -123,9 +140,21 @@ __global__ __launch_bounds__(TX* TY) void dna_kernel(const TL* __restrict__ logi
       if (C > 1) o[1] = a1 * inv;
       if (C > 2) o[2] = a2 * inv;
       if (C > 3) o[3] = a3 * inv;
+      if (s2.ptr) {
+        second_store(s2, pix, 0, a0 * inv);
+        if (C > 1) second_store(s2, pix, 1, a1 * inv);
+        if (C > 2) second_store(s2, pix, 2, a2 * inv);
+        if (C > 3) second_store(s2, pix, 3, a3 * inv);
+      }
     } else {
       const float* dO = dout + pix * C;
-      const float d0 = dO[0], d1 = C > 1 ? dO[1] : 0.f, d2 = C > 2 ? dO[2] : 0.f, d3 = C > 3 ? dO[3] : 0.f;
+      float d0 = dO[0], d1 = C > 1 ? dO[1] : 0.f, d2 = C > 2 ? dO[2] : 0.f, d3 = C > 3 ? dO[3] : 0.f;
+      if (s2.ptr) {
+        d0 += second_load(s2, pix, 0);
+        if (C > 1) d1 += second_load(s2, pix, 1);
+        if (C > 2) d2 += second_load(s2, pix, 2);
+        if (C > 3) d3 += second_load(s2, pix, 3);
+      }
       auto gfun = [&](int i, int j) {
         const float* wp = wbase + (i * WW + j) * C;
         float g = d0 * wp[0];
@@ -213,7 +242,8 @@ __global__ __launch_bounds__(TX* TY) void dna_kernel(const TL* __restrict__ logi
 template <int K, bool BWD, int CC, typename TL>
 __global__ __launch_bounds__(256) void dna_rows_kernel(const TL* __restrict__ logits, const float* __restrict__ bias,
                                                        const float* __restrict__ img, const float* __restrict__ dout,
-                                                       void* __restrict__ outv, float* __restrict__ bpart, int H, int W, int Crt) {
+                                                       void* __restrict__ outv, float* __restrict__ bpart, int H, int W, int Crt,
+                                                       const Second s2) {
   // E taps per lane and load: one float, or two adjacent bf16 (so that a 16-lane row still reads 64-byte runs)
   constexpr int E = sizeof(TL) == 2 ? 2 : 1;
   constexpr int KK = K * K, P = (K - 1) / 2, R = (KK + 16 * E - 1) / (16 * E), WW = 64 + K - 1, LP = logit_pitch<TL>(KK);
@@ -297,7 +327,7 @@ __global__ __launch_bounds__(256) void dna_rows_kernel(const TL* __restrict__ lo
     float den = 0.f, a[4] = {0.f, 0.f, 0.f, 0.f}, d[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (BWD) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) d[c] = c < C ? dout[pix * C + c] : 0.f;
+      for (int c = 0; c < 4; ++c) d[c] = c < C ? dout[pix * C + c] + (s2.ptr ? second_load(s2, pix, c) : 0.f) : 0.f;
     }
     float g[R][E];
 #pragma unroll
@@ -331,7 +361,10 @@ __global__ __launch_bounds__(256) void dna_rows_kernel(const TL* __restrict__ lo
       for (int c = 0; c < 4; ++c) {
         if (c < C) {
           const float v = row_sum(a[c]);
-          if (l16 == c) out[pix * C + c] = v * inv;
+          if (l16 == c) {
+            out[pix * C + c] = v * inv;
+            if (s2.ptr) second_store(s2, pix, c, v * inv);
+          }
         }
       }
     } else {
@@ -409,24 +442,24 @@ dim3 dna_grid(int k, int B, int H, int W) {
 
 template <int K, bool BWD, typename TL>
 int launch_k(const TL* logits, const float* bias, const float* img, const float* dout, void* out, float* bpart, int B, int H, int W,
-             int C, hipStream_t st) {
+             int C, hipStream_t st, const Second& s2) {
   const dim3 grid = dna_grid(K, B, H, W);
   if constexpr (K >= ACG_DNA_ROWS_MIN) {
-    if (C == 3) ACG_LAUNCH((dna_rows_kernel<K, BWD, 3, TL>), grid, dim3(256), 0, st, logits, bias, img, dout, out, bpart, H, W, C);
-    else ACG_LAUNCH((dna_rows_kernel<K, BWD, 0, TL>), grid, dim3(256), 0, st, logits, bias, img, dout, out, bpart, H, W, C);
+    if (C == 3) ACG_LAUNCH((dna_rows_kernel<K, BWD, 3, TL>), grid, dim3(256), 0, st, logits, bias, img, dout, out, bpart, H, W, C, s2);
+    else ACG_LAUNCH((dna_rows_kernel<K, BWD, 0, TL>), grid, dim3(256), 0, st, logits, bias, img, dout, out, bpart, H, W, C, s2);
   } else {
     constexpr int TY = ACG_DNA_TY;
-    if (C == 3) ACG_LAUNCH((dna_kernel<K, TY, BWD, 3, TL>), grid, dim3(TX * TY), 0, st, logits, bias, img, dout, out, bpart, H, W, C);
-    else ACG_LAUNCH((dna_kernel<K, TY, BWD, 0, TL>), grid, dim3(TX * TY), 0, st, logits, bias, img, dout, out, bpart, H, W, C);
+    if (C == 3) ACG_LAUNCH((dna_kernel<K, TY, BWD, 3, TL>), grid, dim3(TX * TY), 0, st, logits, bias, img, dout, out, bpart, H, W, C, s2);
+    else ACG_LAUNCH((dna_kernel<K, TY, BWD, 0, TL>), grid, dim3(TX * TY), 0, st, logits, bias, img, dout, out, bpart, H, W, C, s2);
   }
   return acg::check_launch(BWD ? "dna_bwd" : "dna_fwd");
 }
 
 template <bool BWD, typename TL>
 int dispatch(int k, const void* logits, const float* bias, const float* img, const float* dout, void* out, float* bpart, int B, int H,
-             int W, int C, hipStream_t st) {
+             int W, int C, hipStream_t st, const Second& s2) {
   switch (k) {
-#define ACG_DNA_CASE(KV) case KV: return launch_k<KV, BWD, TL>((const TL*)logits, bias, img, dout, out, bpart, B, H, W, C, st);
+#define ACG_DNA_CASE(KV) case KV: return launch_k<KV, BWD, TL>((const TL*)logits, bias, img, dout, out, bpart, B, H, W, C, st, s2);
     ACG_DNA_CASE(1) ACG_DNA_CASE(2) ACG_DNA_CASE(3) ACG_DNA_CASE(4) ACG_DNA_CASE(5) ACG_DNA_CASE(6)
     ACG_DNA_CASE(7) ACG_DNA_CASE(8) ACG_DNA_CASE(9) ACG_DNA_CASE(10) ACG_DNA_CASE(11)
 #undef ACG_DNA_CASE
@@ -453,25 +486,40 @@ size_t acg_dna_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t k) {
   return ((size_t)g.x * g.y * g.z + kSegs) * (size_t)(k * k) * sizeof(float);
 }
 
-int32_t acg_dna_fwd(const void* logits, const float* bias, const void* image, void* out, int32_t B, int32_t H, int32_t W,
-                    int32_t C, int32_t k, int32_t dtype, acg_stream_t stream) {
+namespace {
+int second_of(const char* who, const void* ptr, int pitch, int off, int dt, int C, Second* s2) {
+  s2->ptr = const_cast<void*>(ptr); s2->pitch = pitch; s2->off = off; s2->half = dt == ACG_BF16;
+  if (!ptr) return ACG_OK;
+  ACG_REQUIRE(dt == ACG_F32 || dt == ACG_BF16, ACG_ERR_UNSUPPORTED, "%s: second tensor dtype %d", who, dt);
+  ACG_REQUIRE(off >= 0 && pitch >= off + C, ACG_ERR_INVALID_ARG, "%s: second tensor: %d channels at offset %d do not fit pitch %d", who, C, off, pitch);
+  return ACG_OK;
+}
+}  // namespace
+
+int32_t acg_dna_fwd(const void* logits, const float* bias, const void* image, void* out, void* out2, int32_t out2_pitch,
+                    int32_t out2_offset, int32_t out2_dtype, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype,
+                    acg_stream_t stream) {
   if (int rc = check("dna_fwd", B, H, W, C, k, dtype)) return rc;
   ACG_REQUIRE(logits && image && out, ACG_ERR_INVALID_ARG, "dna_fwd: null pointer");
-  if (dtype == ACG_BF16) return dispatch<false, __bf16>(k, logits, bias, (const float*)image, nullptr, out, nullptr, B, H, W, C, acg::to_stream(stream));
-  return dispatch<false, float>(k, logits, bias, (const float*)image, nullptr, out, nullptr, B, H, W, C, acg::to_stream(stream));
+  Second s2;
+  if (int rc = second_of("dna_fwd", out2, out2_pitch, out2_offset, out2_dtype, C, &s2)) return rc;
+  if (dtype == ACG_BF16) return dispatch<false, __bf16>(k, logits, bias, (const float*)image, nullptr, out, nullptr, B, H, W, C, acg::to_stream(stream), s2);
+  return dispatch<false, float>(k, logits, bias, (const float*)image, nullptr, out, nullptr, B, H, W, C, acg::to_stream(stream), s2);
 }
 
-int32_t acg_dna_bwd(const void* logits, const float* bias, const void* image, const void* dout, void* dlogits, float* dbias,
-                    float dbias_acc, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype, void* ws, size_t wsb,
-                    acg_stream_t stream) {
+int32_t acg_dna_bwd(const void* logits, const float* bias, const void* image, const void* dout, const void* dout2, int32_t dout2_pitch,
+                    int32_t dout2_offset, int32_t dout2_dtype, void* dlogits, float* dbias, float dbias_acc, int32_t B, int32_t H,
+                    int32_t W, int32_t C, int32_t k, int32_t dtype, void* ws, size_t wsb, acg_stream_t stream) {
   if (int rc = check("dna_bwd", B, H, W, C, k, dtype)) return rc;
   ACG_REQUIRE(logits && image && dout && dlogits, ACG_ERR_INVALID_ARG, "dna_bwd: null pointer");
+  Second s2;
+  if (int rc = second_of("dna_bwd", dout2, dout2_pitch, dout2_offset, dout2_dtype, C, &s2)) return rc;
   ACG_REQUIRE(!dbias || (ws && wsb >= acg_dna_workspace_bytes(B, H, W, k)), ACG_ERR_WORKSPACE, "dna_bwd: workspace too small for dbias");
   hipStream_t st = acg::to_stream(stream);
   float* bpart = dbias ? (float*)ws : nullptr;
   int rc;
-  if (dtype == ACG_BF16) rc = dispatch<true, __bf16>(k, logits, bias, (const float*)image, (const float*)dout, dlogits, bpart, B, H, W, C, st);
-  else rc = dispatch<true, float>(k, logits, bias, (const float*)image, (const float*)dout, dlogits, bpart, B, H, W, C, st);
+  if (dtype == ACG_BF16) rc = dispatch<true, __bf16>(k, logits, bias, (const float*)image, (const float*)dout, dlogits, bpart, B, H, W, C, st, s2);
+  else rc = dispatch<true, float>(k, logits, bias, (const float*)image, (const float*)dout, dlogits, bpart, B, H, W, C, st, s2);
   if (rc || !dbias) return rc;
   const dim3 g = dna_grid(k, B, H, W);
   const int nblk = (int)(g.x * g.y * g.z), KK = k * k, tb = (KK + 31) / 32;

@@ -705,11 +705,17 @@ class DnaOp(G.Op):
         super().__init__(G.get_default_graph(), name, [logits, image] + ([bias] if bias is not None else []),
                          [_new(image.shape, name + ':0')])
 
+    second = None       # (ConcatChannelsOp, its output, channel offset): the frame's second home, written by this kernel too
+
     def bind(self, rt):
         lg, img = self.inputs[:2]
         b, h, w, c = img.shape
         pb = _p(self.inputs[2].buf) if self.has_bias else None
-        args = (_p(lg.buf), pb, _p(img.buf), _p(self.outputs[0].buf), b, h, w, c, self.ksize, _code(lg))
+        p2, pitch2, off2, dt2 = None, 0, 0, 0
+        if self.second is not None and id(self.second[0]) in rt.program_ops:      # only where someone reads that tensor
+            _, y2, off2 = self.second
+            p2, pitch2, dt2 = _p(y2.buf), y2.shape[-1], _code(y2)
+        args = (_p(lg.buf), pb, _p(img.buf), _p(self.outputs[0].buf), p2, pitch2, off2, dt2, b, h, w, c, self.ksize, _code(lg))
         fn = rt.lib.dna_fwd
         return lambda s: fn(*args, s)
 
@@ -722,19 +728,30 @@ class DnaOp(G.Op):
             dst, acc = ctx.slot(self.inputs[2])
         if not needs[0] and dst is None:
             return [None] * len(self.inputs)
-        op = DnaBwdOp(self, gouts[0], dst, acc, self.name + '/bwd')
+        # dout = (gradient of the frame losses) + (the frame channels of d(discriminator input)): when that sum is an AddOp over
+        # a SliceOp of the pitched gradient, the kernel reads the window itself (acg_dna_bwd dout2) and the slice and add
+        # launches drop out of every program (nothing else reads them)
+        dout, dout2 = gouts[0], None
+        if isinstance(dout.op, AddOp) and dout is dout.op.outputs[0]:
+            parts = list(dout.op.inputs)
+            for k, t in enumerate(parts):
+                if isinstance(t.op, SliceOp) and t is t.op.outputs[0] and t.op.c_dst == self.outputs[0].shape[-1] and parts[1 - k].dtype == torch.float32:
+                    dout, dout2 = parts[1 - k], (t.op.inputs[0], t.op.c_off)
+                    break
+        op = DnaBwdOp(self, dout, dst, acc, self.name + '/bwd', dout2=dout2)
         if dst is not None:
             ctx.wrote(self.inputs[2], op)
         return [op.outputs[0] if needs[0] else None, None] + ([None] if self.has_bias else [])
 
 
 class DnaBwdOp(G.Op):
-    def __init__(self, fwd, dout, dbias_dst, accumulate, name):
+    def __init__(self, fwd, dout, dbias_dst, accumulate, name, dout2=None):
         self.fwd, self.accumulate, self.dbias = fwd, float(accumulate), dbias_dst
+        self.dout2 = dout2                      # (pitched gradient tensor, channel offset) added to dout by the kernel
         lg, img = fwd.inputs[:2]
         dlg = _new(lg.shape, name + ':0', lg.dtype)
         dlg.valid_c = lg.valid_c
-        super().__init__(G.get_default_graph(), name, [lg, img, dout] + list(fwd.inputs[2:]),
+        super().__init__(G.get_default_graph(), name, [lg, img, dout] + list(fwd.inputs[2:]) + ([dout2[0]] if dout2 is not None else []),
                          [dlg] + ([dbias_dst] if dbias_dst is not None else []))
 
     def bind(self, rt):
@@ -743,7 +760,12 @@ class DnaBwdOp(G.Op):
         pb = _p(self.inputs[3].buf) if self.fwd.has_bias else None
         ws, n = rt.workspace(rt.lib.dna_workspace_bytes(b, h, w, self.fwd.ksize)) if self.dbias is not None else (None, 0)
         self._keep = ws
-        args = (_p(lg.buf), pb, _p(img.buf), _p(dout.buf), _p(self.outputs[0].buf), _p(self.dbias.buf) if self.dbias is not None else None,
+        p2, pitch2, off2, dt2 = None, 0, 0, 0
+        if self.dout2 is not None:
+            t2, off2 = self.dout2
+            p2, pitch2, dt2 = _p(t2.buf), t2.shape[-1], _code(t2)
+        args = (_p(lg.buf), pb, _p(img.buf), _p(dout.buf), p2, pitch2, off2, dt2, _p(self.outputs[0].buf),
+                _p(self.dbias.buf) if self.dbias is not None else None,
                 self.accumulate, b, h, w, c, self.fwd.ksize, _code(lg), _p(ws) if ws is not None else None, n)
         fn = rt.lib.dna_bwd
         return lambda s: fn(*args, s)
@@ -914,11 +936,16 @@ class ConcatChannelsOp(G.Op):
             g.add_feed_alias(a, y, 0)
         if fed_b:
             g.add_feed_alias(b, y, a.shape[-1])
+        # ... and a generated frame that comes out of the DNA kernel is written here by that kernel (acg_dna_fwd out2)
+        self.by_producer = fed_a and not fed_b and isinstance(b.op, DnaOp) and b is b.op.outputs[0] and b.op.second is None
         super().__init__(g, name, [a, b], [y])
+        if self.by_producer:
+            b.op.second = (self, y, a.shape[-1])
+            b.op.extras = list(getattr(b.op, 'extras', ())) + [y]
 
     def bind(self, rt):
         a, b = self.inputs
-        if len(self.fed_inputs) == 2:
+        if len(self.fed_inputs) == 2 or self.by_producer:
             return None                       # nothing left to launch
         pa = None if self.fed_inputs else _p(a.buf)
         args = (pa, _p(b.buf), _p(self.outputs[0].buf), a.numel // a.shape[-1], a.shape[-1], b.shape[-1], self.pitch,

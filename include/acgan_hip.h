@@ -277,13 +277,19 @@ int32_t acg_bias_act_bwd(const void* y, const void* dy, void* dx, float* dbias, 
  *   dbias = dbias_accumulate * dbias + sum over pixels of dlogits      (dbias may be NULL; workspace needed otherwise).
  * dtype: storage of logits / dlogits; ACG_BF16 rows are round8(k*k) elements apart (pad taps are not written).
  * image, out and dout are float32.
+ * out2 / dout2 (may be NULL): the frame's second home.  train.py:63-66 feeds D concat(current frame, generated frame):
+ * forward ALSO writes the frame into channels [out2_offset, out2_offset + c) of out2 - a tensor of out2_dtype (ACG_F32 /
+ * ACG_BF16) whose pixels are out2_pitch elements apart, i.e. the discriminator's input - and backward adds the gradient
+ * that comes back through those channels of dout2 (same addressing) to dout: no concat, slice or add launch.
  * ---------------------------------------------------------------------------------------- */
 size_t acg_dna_workspace_bytes(int32_t batch, int32_t h, int32_t w, int32_t ksize);
-int32_t acg_dna_fwd(const void* logits, const float* bias, const void* image, void* out, int32_t batch, int32_t h,
-                    int32_t w, int32_t c, int32_t ksize, int32_t dtype, acg_stream_t stream);
-int32_t acg_dna_bwd(const void* logits, const float* bias, const void* image, const void* dout, void* dlogits,
-                    float* dbias, float dbias_accumulate, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ksize,
-                    int32_t dtype, void* workspace, size_t workspace_bytes, acg_stream_t stream);
+int32_t acg_dna_fwd(const void* logits, const float* bias, const void* image, void* out, void* out2, int32_t out2_pitch,
+                    int32_t out2_offset, int32_t out2_dtype, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ksize,
+                    int32_t dtype, acg_stream_t stream);
+int32_t acg_dna_bwd(const void* logits, const float* bias, const void* image, const void* dout, const void* dout2,
+                    int32_t dout2_pitch, int32_t dout2_offset, int32_t dout2_dtype, void* dlogits, float* dbias,
+                    float dbias_accumulate, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ksize, int32_t dtype,
+                    void* workspace, size_t workspace_bytes, acg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * CDNA transformation (reference ops.py:52-98, the unused sibling of the DNA tail).

@@ -504,10 +504,12 @@ int32_t acg_cdna_bwd(const void* pv, const float* kern_norm, const void* iv, con
 /* ---- DNA tail: models.py:60-72, SURVEY A.7 */
 static int dna_check(int c, int k) { return c >= 1 && c <= 4 && k >= 1 && k <= 15; }
 size_t acg_dna_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t k) { (void)B; (void)H; (void)W; (void)k; return 0; }
-int32_t acg_dna_fwd(const void* lv, const float* bias, const void* iv, void* ov, int32_t B, int32_t H, int32_t W, int32_t C,
-                    int32_t k, int32_t dtype, acg_stream_t s) {
+int32_t acg_dna_fwd(const void* lv, const float* bias, const void* iv, void* ov, void* o2v, int32_t o2_pitch, int32_t o2_off, int32_t o2_dtype,
+                    int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype, acg_stream_t s) {
   (void)s; REQUIRE_F32(dtype);
   if (!dna_check(C, k)) return fail(ACG_ERR_INVALID_ARG, "dna: need 1<=c<=4, 1<=ksize<=15");
+  if (o2v && (o2_dtype != ACG_F32 || o2_off < 0 || o2_pitch < o2_off + C)) return fail(ACG_ERR_INVALID_ARG, "dna: second output");
+  float* out2 = o2v;
   const float* lg = lv; const float* img = iv; float* out = ov; int kk = k * k, p = (k - 1) / 2;
   double l[225];
   for (int b = 0; b < B; b++) for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
@@ -521,20 +523,25 @@ int32_t acg_dna_fwd(const void* lv, const float* bias, const void* iv, void* ov,
       double m = exp(l[i * k + j] - mx) / den;
       for (int c = 0; c < C; c++) acc[c] += m * img[(((size_t)b * H + yy) * W + xx) * C + c];
     }
-    for (int c = 0; c < C; c++) out[(((size_t)b * H + y) * W + x) * C + c] = (float)acc[c];
+    for (int c = 0; c < C; c++) { out[(((size_t)b * H + y) * W + x) * C + c] = (float)acc[c];
+      if (out2) out2[(((size_t)b * H + y) * W + x) * o2_pitch + o2_off + c] = (float)acc[c]; }
   }
   return ACG_OK;
 }
-int32_t acg_dna_bwd(const void* lv, const float* bias, const void* iv, const void* dov, void* dlv, float* dbias, float dbias_acc,
+int32_t acg_dna_bwd(const void* lv, const float* bias, const void* iv, const void* dov, const void* d2v, int32_t d2_pitch, int32_t d2_off,
+                    int32_t d2_dtype, void* dlv, float* dbias, float dbias_acc,
                     int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
   (void)s; (void)ws; (void)wsb; REQUIRE_F32(dtype);
   if (!dna_check(C, k)) return fail(ACG_ERR_INVALID_ARG, "dna: need 1<=c<=4, 1<=ksize<=15");
+  if (d2v && (d2_dtype != ACG_F32 || d2_off < 0 || d2_pitch < d2_off + C)) return fail(ACG_ERR_INVALID_ARG, "dna: second gradient");
+  const float* dout2 = d2v;
   const float* lg = lv; const float* img = iv; const float* dout = dov; float* dl = dlv; int kk = k * k, p = (k - 1) / 2;
   double m[225], g[225], l[225], bsum[225];
   for (int t = 0; t < kk; t++) bsum[t] = 0;
   for (int b = 0; b < B; b++) for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
     size_t pix = ((size_t)b * H + y) * W + x;
-    const float* l0 = lg + pix * kk; const float* dO = dout + pix * C;
+    const float* l0 = lg + pix * kk; double dO[4] = {0, 0, 0, 0};
+    for (int c = 0; c < C; c++) dO[c] = (double)dout[pix * C + c] + (dout2 ? (double)dout2[pix * d2_pitch + d2_off + c] : 0.0);
     for (int t = 0; t < kk; t++) l[t] = (double)l0[t] + (bias ? (double)bias[t] : 0.0);
     double mx = l[0], den = 0, dot = 0;
     for (int t = 1; t < kk; t++) if (l[t] > mx) mx = l[t];
@@ -542,7 +549,7 @@ int32_t acg_dna_bwd(const void* lv, const float* bias, const void* iv, const voi
     for (int i = 0; i < k; i++) for (int j = 0; j < k; j++) {
       int t = i * k + j, yy = y - p + i, xx = x - p + j; m[t] /= den; g[t] = 0;
       if (yy >= 0 && yy < H && xx >= 0 && xx < W)
-        for (int c = 0; c < C; c++) g[t] += (double)dO[c] * img[(((size_t)b * H + yy) * W + xx) * C + c];
+        for (int c = 0; c < C; c++) g[t] += dO[c] * img[(((size_t)b * H + yy) * W + xx) * C + c];
       dot += m[t] * g[t];
     }
     for (int t = 0; t < kk; t++) { const double v = m[t] * (g[t] - dot); dl[pix * kk + t] = (float)v; bsum[t] += v; }

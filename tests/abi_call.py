@@ -345,19 +345,23 @@ class Abi:
         return dpar, dimg
 
     # ---- dna
-    def dna_fwd(self, logits, img, k, bias=None):
-        """logits float32 [B,H,W,k*k] or bfloat16 [B,H,W,round8(k*k)]."""
+    def dna_fwd(self, logits, img, k, bias=None, out2=None, out2_off=0):
+        """logits float32 [B,H,W,k*k] or bfloat16 [B,H,W,round8(k*k)].  ``out2`` [B,H,W,pitch] (float32 / bfloat16): the frame is
+        also written into its channels [out2_off, out2_off + C)."""
         b, h, w, c = img.shape
         out = torch.empty_like(img)
-        self.lib.dna_fwd(_p(logits), _p(bias), _p(img), _p(out), b, h, w, c, k, L.code(logits.dtype), self.stream())
+        self.lib.dna_fwd(_p(logits), _p(bias), _p(img), _p(out), _p(out2), out2.shape[-1] if out2 is not None else 0, out2_off,
+                         L.code(out2.dtype) if out2 is not None else 0, b, h, w, c, k, L.code(logits.dtype), self.stream())
         return out
 
-    def dna_bwd(self, logits, img, dout, k, bias=None, want_dbias=False):
+    def dna_bwd(self, logits, img, dout, k, bias=None, want_dbias=False, dout2=None, dout2_off=0):
+        """``dout2`` [B,H,W,pitch]: its channels [dout2_off, dout2_off + C) are added to dout."""
         b, h, w, c = img.shape
         dl = torch.zeros_like(logits)
         dbias = self.empty(k * k) if want_dbias else None
         ws, n = self.ws(self.lib.dna_workspace_bytes(b, h, w, k))
-        self.lib.dna_bwd(_p(logits), _p(bias), _p(img), _p(dout), _p(dl), _p(dbias), 0.0, b, h, w, c, k, L.code(logits.dtype),
+        self.lib.dna_bwd(_p(logits), _p(bias), _p(img), _p(dout), _p(dout2), dout2.shape[-1] if dout2 is not None else 0, dout2_off,
+                         L.code(dout2.dtype) if dout2 is not None else 0, _p(dl), _p(dbias), 0.0, b, h, w, c, k, L.code(logits.dtype),
                          _p(ws), n, self.stream())
         return (dl, dbias) if want_dbias else dl
 

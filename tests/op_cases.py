@@ -197,6 +197,32 @@ def case_conv_bn_stats(abi, tol, tol_stat, min_fused=1):
     assert fused >= min_fused, 'only %d of %d layers took the fused path' % (fused, len(STATS_LAYERS))
 
 
+def case_dna_second(abi, tol):
+    """acg_dna_fwd out2 / acg_dna_bwd dout2 (the frame's second home, train.py:63-66): forward writes the frame also into channels
+    [3, 6) of an 8-pitched tensor (float32 and bfloat16), leaving the other channels alone; backward with a gradient window equals
+    backward of the explicit sum."""
+    dev = abi.device
+    for (b, h, w, c, k) in [(2, 16, 12, 3, 5), (1, 9, 20, 3, 6), (1, 8, 8, 3, 11)]:
+        lg, img = randn((b, h, w, k * k), 500 + k).to(dev), uniform((b, h, w, c), 510 + k).to(dev)
+        bias = randn((k * k,), 520 + k, 0.3).to(dev)
+        for dt in ([torch.float32, torch.bfloat16] if dev.type == 'cuda' else [torch.float32]):
+            out2 = torch.full((b, h, w, 8), 7.0, dtype=dt, device=dev)
+            out = abi.dna_fwd(lg, img, k, bias=bias, out2=out2, out2_off=3)
+            ref = abi.dna_fwd(lg, img, k, bias=bias)
+            abi.sync()
+            assert torch.equal(out.cpu(), ref.cpu()), 'dna second output changed the frame'
+            assert torch.equal(out2[..., 3:6].float().cpu(), ref.to(dt).float().cpu()), 'dna second output %s' % dt
+            assert bool((out2[..., :3] == 7).all()) and bool((out2[..., 6:] == 7).all()), 'dna second output wrote outside its channels'
+            dout = randn((b, h, w, c), 530 + k).to(dev)
+            d2 = torch.zeros(b, h, w, 8, dtype=dt, device=dev)
+            d2[..., 3:6] = randn((b, h, w, c), 540 + k).to(dev).to(dt)
+            d2[..., :3] = 5.0                                        # must not be read
+            got = abi.dna_bwd(lg, img, dout, k, bias=bias, dout2=d2, dout2_off=3)
+            want = abi.dna_bwd(lg, img, dout + d2[..., 3:6].float(), k, bias=bias)
+            abi.sync()
+            close(got, want.double().cpu(), tol, 'dna second gradient %s k=%d' % (dt, k))
+
+
 def case_conv_pitched(abi, tol, seed=0):
     """3- and 6-channel inputs stored with a channel pitch of 4 / 8 (in_pitch): same results as the dense tensor,
     pad channels of dx untouched."""

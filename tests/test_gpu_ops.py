@@ -46,6 +46,11 @@ def test_conv_bn_stats_bf16(hip_abi_bf16):
     C.case_conv_bn_stats(hip_abi_bf16, TOL_BF16, 2e-3, min_fused=4)
 
 
+def test_dna_second(hip_abi):
+    """The frame's second home: acg_dna_fwd out2 / acg_dna_bwd dout2, float32 and bf16 tensors, both kernel families."""
+    C.case_dna_second(hip_abi, 1e-5)
+
+
 def test_bwd_pair_bf16(hip_abi_bf16):
     C.case_bwd_pair_bf16(hip_abi_bf16, TOL_BF16, TOL_CONV)
 

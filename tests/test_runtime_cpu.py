@@ -235,6 +235,16 @@ def test_feeds_missing_unused_and_aliased():
     got = sess._materialize(real.outputs[0])
     assert torch.equal(got[..., 0:3], torch.from_numpy(x)) and torch.equal(got[..., 3:6], torch.from_numpy(y)) and bool((got[..., 6:] == 0).all())
     assert torch.equal(sess._materialize(gen.outputs[0])[..., 0:3], torch.from_numpy(x))
+    # the generated frame reaches D's input out of the DNA kernel (acg_dna_fwd out2), and its gradient goes back into the DNA
+    # backward as a window of d(D input) (dout2): no concat, slice or add op is launched for it
+    assert gen.by_producer and gen.bind(sess.rt) is None
+    tr.train_g(x, y, a, s)
+    frame = sess._materialize(tr.g_next_frame)
+    assert torch.equal(sess._materialize(gen.outputs[0])[..., 3:6], frame)
+    bwd = [o for o in g.ops if o.name == 'g/dna/bwd'][0]
+    assert bwd.dout2 is not None and bwd.dout2[1] == 3
+    names = {o.name for o in g.ops if id(o) in sess.rt.program_ops}
+    assert 'g/dna/bwd' in names and not any(n.startswith('d_in_gen/bwd') for n in names), sorted(n for n in names if 'd_in' in n)
     # the tiled action channels of the concatenated feature maps come from the feed as well (g: [B,4,4,256+10]; d on the joined
     # batch: [2B,16,16,128+10], the same actions for the fake and the real half)
     cats = [o for o in g.ops if isinstance(o, O.ConcatActionsOp)]
@@ -243,7 +253,7 @@ def test_feeds_missing_unused_and_aliased():
         t = sess._materialize(o.outputs[0])
         if t.shape[0] == 0 or id(o) not in sess.rt.program_ops:
             continue
-        want = torch.from_numpy(a)[torch.arange(t.shape[0]) % 2]
+        want = torch.from_numpy(a)[torch.arange(t.shape[0]) % 2]          # (the joined batch repeats the two samples)
         got_a = t[..., o.c:o.c + a.shape[1]]
         assert torch.equal(got_a, want[:, None, None, :].expand_as(got_a)), o.name
 

@@ -70,8 +70,8 @@ def main():
         ws = torch.zeros(max(nws, 16), dtype=torch.uint8, device=dev)
         # algorithmic bytes: k*k logits (+ k*k dlogits) at their storage size, 2C float32 image / frame values
         for name, fn, nbytes in (
-                ('fwd', lambda: lib.dna_fwd(p(logits), p(bias), p(img), p(out), B, S, S, C, k, dt, stream), B * S * S * (k * k * es + 2 * C * 4)),
-                ('bwd', lambda: lib.dna_bwd(p(logits), p(bias), p(img), p(dout), p(dl), p(dbias), 0.0, B, S, S, C, k, dt, p(ws), nws, stream),
+                ('fwd', lambda: lib.dna_fwd(p(logits), p(bias), p(img), p(out), None, 0, 0, 0, B, S, S, C, k, dt, stream), B * S * S * (k * k * es + 2 * C * 4)),
+                ('bwd', lambda: lib.dna_bwd(p(logits), p(bias), p(img), p(dout), None, 0, 0, 0, p(dl), p(dbias), 0.0, B, S, S, C, k, dt, p(ws), nws, stream),
                  B * S * S * (2 * k * k * es + 2 * C * 4))):
             for _ in range(5):
                 fn()

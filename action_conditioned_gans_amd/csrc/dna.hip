@@ -23,7 +23,8 @@ constexpr int TX = 64;
 
 // The frame's second home (train.py:63-66: D(fake) reads concat(current frame, generated frame)): forward also writes the
 // frame into channels [off, off + C) of a pitched tensor of the conv storage type - the discriminator's input - and backward
-// adds the gradient that arrives through those channels to dout; ptr == nullptr: none.
+// adds the gradient that arrives through those channels to dout; ptr == nullptr: none.  When the tensor is exactly
+// concat(image, frame) at a pitch of 8 (off == C == 3), forward writes the WHOLE pixel - image channels and zero pad included.
 struct Second {
   void* ptr;
   int pitch, off, half;
@@ -31,6 +32,24 @@ struct Second {
 __device__ __forceinline__ void second_store(const Second& s2, long long pix, int c, float v) {
   if (s2.half) reinterpret_cast<__bf16*>(s2.ptr)[pix * s2.pitch + s2.off + c] = (__bf16)v;
   else reinterpret_cast<float*>(s2.ptr)[pix * s2.pitch + s2.off + c] = v;
+}
+// concat(image, frame) as ONE vector store per pixel when the second home is exactly that (3 + 3 channels at a pitch of 8:
+// the discriminator input of train.py:63-66, the image channels being the pixel's own window centre) - three scalar stores
+// at a 32-byte stride cost the forward kernel a quarter of its time; other layouts take the scalar path
+__device__ __forceinline__ void second_store_pixel(const Second& s2, long long pix, int C, const float* img_c, const float (&f)[4]) {
+  if (C == 3 && s2.off == 3 && s2.pitch == 8) {
+    if (s2.half) {
+      typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+      const bf8v v = {(__bf16)img_c[0], (__bf16)img_c[1], (__bf16)img_c[2], (__bf16)f[0], (__bf16)f[1], (__bf16)f[2], (__bf16)0.f, (__bf16)0.f};
+      *reinterpret_cast<bf8v*>(reinterpret_cast<__bf16*>(s2.ptr) + pix * 8) = v;
+    } else {
+      float4* o = reinterpret_cast<float4*>(reinterpret_cast<float*>(s2.ptr) + pix * 8);
+      o[0] = make_float4(img_c[0], img_c[1], img_c[2], f[0]);
+      o[1] = make_float4(f[1], f[2], 0.f, 0.f);
+    }
+    return;
+  }
+  for (int c = 0; c < C; ++c) second_store(s2, pix, c, f[c]);
 }
 __device__ __forceinline__ float second_load(const Second& s2, long long pix, int c) {
   return s2.half ? (float)reinterpret_cast<const __bf16*>(s2.ptr)[pix * s2.pitch + s2.off + c]
@@ -141,10 +160,8 @@ __global__ __launch_bounds__(TX* TY) void dna_kernel(const TL* __restrict__ logi
       if (C > 2) o[2] = a2 * inv;
       if (C > 3) o[3] = a3 * inv;
       if (s2.ptr) {
-        second_store(s2, pix, 0, a0 * inv);
-        if (C > 1) second_store(s2, pix, 1, a1 * inv);
-        if (C > 2) second_store(s2, pix, 2, a2 * inv);
-        if (C > 3) second_store(s2, pix, 3, a3 * inv);
+        const float fr[4] = {a0 * inv, a1 * inv, a2 * inv, a3 * inv};
+        second_store_pixel(s2, pix, C, wbase + (P * WW + P) * C, fr);      // window centre = this pixel of the image
       }
     } else {
       const float* dO = dout + pix * C;
@@ -357,16 +374,15 @@ __global__ __launch_bounds__(256) void dna_rows_kernel(const TL* __restrict__ lo
     den = row_sum(den);
     const float inv = 1.f / den;
     if constexpr (!BWD) {
+      float fr[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         if (c < C) {
-          const float v = row_sum(a[c]);
-          if (l16 == c) {
-            out[pix * C + c] = v * inv;
-            if (s2.ptr) second_store(s2, pix, c, v * inv);
-          }
+          fr[c] = row_sum(a[c]) * inv;                                     // a butterfly: every lane of the row holds the sum
+          if (l16 == c) out[pix * C + c] = fr[c];
         }
       }
+      if (s2.ptr && l16 == 4) second_store_pixel(s2, pix, C, win + (P * WW + P + px) * C, fr);
     } else {
       const float dot = row_sum(a[0]) * inv;
       TL* op = dlog + pix * LP;

@@ -11,7 +11,7 @@ Besides the contract line it reports
   roofline      conv_mfma_f32 launches (every conv/deconv fwd, dgrad, wgrad of the step): algorithmic
                 FLOPs (2*B*OH*OW*KH*KW*Cin*Cout per contraction) / their event-timed
                 duration, against the fp32 matrix-core peak (157.3 TFLOP/s);
-  roofline_dna  the DNA stencil forward: algorithmic bytes (k*k+6)*4 per pixel / event-timed duration,
+  roofline_dna  the DNA stencil forward: algorithmic bytes (k*k+6)*4 per pixel (+ the discriminator-input pixel it also writes) / event-timed duration,
                 against 8 TB/s;
   cpu_baseline  the CPU restatement of the reference step (oracle/, torch-CPU fp32; TF-1.0 itself cannot
                 run here) on this host's cores, on a bounded sample of the same workload.
@@ -248,6 +248,10 @@ def main():
                 b, h, w, c = op.inputs[1].shape
                 dna_ms += ms
                 dna_bytes += b * h * w * (op.ksize * op.ksize * (2.0 if args.dtype == 'bf16' else 4.0) + 2 * c * 4.0)
+                if op.second is not None:      # (both training programs read that tensor)
+                    # this launch also writes the discriminator's input pixel (train.py:63-66: concat(frame, generated frame),
+                    # 8 channels of the conv storage type) - the bytes of the concat launch it replaces
+                    dna_bytes += b * h * w * op.second[1].shape[-1] * (2.0 if args.dtype == 'bf16' else 4.0)
         if conv_ms > 0:
             ach = conv_fl / (conv_ms * 1e-3) / 1e12
             peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == 'bf16' else PEAK_F32_MFMA_TFLOPS

@@ -280,7 +280,9 @@ int32_t acg_bias_act_bwd(const void* y, const void* dy, void* dx, float* dbias, 
  * out2 / dout2 (may be NULL): the frame's second home.  train.py:63-66 feeds D concat(current frame, generated frame):
  * forward ALSO writes the frame into channels [out2_offset, out2_offset + c) of out2 - a tensor of out2_dtype (ACG_F32 /
  * ACG_BF16) whose pixels are out2_pitch elements apart, i.e. the discriminator's input - and backward adds the gradient
- * that comes back through those channels of dout2 (same addressing) to dout: no concat, slice or add launch.
+ * that comes back through those channels of dout2 (same addressing) to dout: no concat, slice or add launch.  When out2 is
+ * exactly that concatenation at a pitch of 8 (c == 3, out2_offset == 3, out2_pitch == 8) forward writes the WHOLE pixel -
+ * the image channels and two zero pad channels included - as one vector store; any other layout: the frame channels only.
  * ---------------------------------------------------------------------------------------- */
 size_t acg_dna_workspace_bytes(int32_t batch, int32_t h, int32_t w, int32_t ksize);
 int32_t acg_dna_fwd(const void* logits, const float* bias, const void* image, void* out, void* out2, int32_t out2_pitch,

@@ -523,8 +523,12 @@ int32_t acg_dna_fwd(const void* lv, const float* bias, const void* iv, void* ov,
       double m = exp(l[i * k + j] - mx) / den;
       for (int c = 0; c < C; c++) acc[c] += m * img[(((size_t)b * H + yy) * W + xx) * C + c];
     }
-    for (int c = 0; c < C; c++) { out[(((size_t)b * H + y) * W + x) * C + c] = (float)acc[c];
-      if (out2) out2[(((size_t)b * H + y) * W + x) * o2_pitch + o2_off + c] = (float)acc[c]; }
+    const size_t pix = ((size_t)b * H + y) * W + x;
+    for (int c = 0; c < C; c++) { out[pix * C + c] = (float)acc[c];
+      if (out2) out2[pix * o2_pitch + o2_off + c] = (float)acc[c]; }
+    if (out2 && C == 3 && o2_off == 3 && o2_pitch == 8) {      /* concat(image, frame) at a pitch of 8: the whole pixel */
+      for (int c = 0; c < 3; c++) out2[pix * 8 + c] = img[pix * 3 + c];
+      out2[pix * 8 + 6] = out2[pix * 8 + 7] = 0.f; }
   }
   return ACG_OK;
 }

@@ -206,13 +206,20 @@ def case_dna_second(abi, tol):
         lg, img = randn((b, h, w, k * k), 500 + k).to(dev), uniform((b, h, w, c), 510 + k).to(dev)
         bias = randn((k * k,), 520 + k, 0.3).to(dev)
         for dt in ([torch.float32, torch.bfloat16] if dev.type == 'cuda' else [torch.float32]):
+            ref = abi.dna_fwd(lg, img, k, bias=bias)
+            # (a) the discriminator-input layout, concat(image, frame) at a pitch of 8: the whole pixel is written
             out2 = torch.full((b, h, w, 8), 7.0, dtype=dt, device=dev)
             out = abi.dna_fwd(lg, img, k, bias=bias, out2=out2, out2_off=3)
-            ref = abi.dna_fwd(lg, img, k, bias=bias)
             abi.sync()
             assert torch.equal(out.cpu(), ref.cpu()), 'dna second output changed the frame'
             assert torch.equal(out2[..., 3:6].float().cpu(), ref.to(dt).float().cpu()), 'dna second output %s' % dt
-            assert bool((out2[..., :3] == 7).all()) and bool((out2[..., 6:] == 7).all()), 'dna second output wrote outside its channels'
+            assert torch.equal(out2[..., :3].float().cpu(), img.to(dt).float().cpu()) and bool((out2[..., 6:] == 0).all()), 'dna: concat(image, frame) pixel'
+            # (b) any other layout: the frame channels only
+            out2 = torch.full((b, h, w, 12), 7.0, dtype=dt, device=dev)
+            abi.dna_fwd(lg, img, k, bias=bias, out2=out2, out2_off=5)
+            abi.sync()
+            assert torch.equal(out2[..., 5:8].float().cpu(), ref.to(dt).float().cpu()), 'dna second output %s (pitch 12)' % dt
+            assert bool((out2[..., :5] == 7).all()) and bool((out2[..., 8:] == 7).all()), 'dna second output wrote outside its channels'
             dout = randn((b, h, w, c), 530 + k).to(dev)
             d2 = torch.zeros(b, h, w, 8, dtype=dt, device=dev)
             d2[..., 3:6] = randn((b, h, w, c), 540 + k).to(dev).to(dt)

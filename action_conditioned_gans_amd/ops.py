@@ -932,12 +932,14 @@ class ConcatChannelsOp(G.Op):
         fed_a = isinstance(a, G.Placeholder) and a.dtype == torch.float32
         fed_b = fed_a and isinstance(b, G.Placeholder) and b.dtype == torch.float32
         self.fed_inputs = ([a] if fed_a else []) + ([b] if fed_b else [])
-        if fed_a:
+        # ... and a generated frame that comes out of the DNA kernel is written here by that kernel (acg_dna_fwd out2), which
+        # in the 3 + 3 channels at pitch 8 layout stores the whole pixel - its own image pixel included - as one vector
+        self.by_producer = fed_a and not fed_b and isinstance(b.op, DnaOp) and b is b.op.outputs[0] and b.op.second is None
+        whole_pixel = self.by_producer and a is b.op.inputs[1] and a.shape[-1] == 3 and b.shape[-1] == 3 and shape[-1] == 8
+        if fed_a and not whole_pixel:
             g.add_feed_alias(a, y, 0)
         if fed_b:
             g.add_feed_alias(b, y, a.shape[-1])
-        # ... and a generated frame that comes out of the DNA kernel is written here by that kernel (acg_dna_fwd out2)
-        self.by_producer = fed_a and not fed_b and isinstance(b.op, DnaOp) and b is b.op.outputs[0] and b.op.second is None
         super().__init__(g, name, [a, b], [y])
         if self.by_producer:
             b.op.second = (self, y, a.shape[-1])

@@ -1,9 +1,11 @@
+"""Fixed cost of a bf16 conv launch: forward of 1x1 / 3x3 / 5x5 layers with 1 - 25 K-steps on a 32768 x 128 output (256 tiles of
+128 x 128), 20 launches in a HIP graph.  python tools/fixed_cost_probe.py [alternative library]"""
 import ctypes, os, sys, torch
 ROOT='/root/repo'; sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT,'tests')); sys.path.insert(0, os.path.join(ROOT,'tools'))
 from action_conditioned_gans_amd import _lib as L
 from abi_call import Abi, _p
 from conv16_probe import time_graph
-lib=L.get(); abi=Abi(lib,'cuda:0',conv_dtype=L.ACG_BF16)
+lib=L.Library(sys.argv[1]) if len(sys.argv) > 1 else L.get(); abi=Abi(lib,'cuda:0',conv_dtype=L.ACG_BF16)
 B,S,N=32,32,128
 for k,cin in ((1,8),(1,64),(1,256),(3,64),(5,64)):
     d=abi.desc(B,S,S,cin,k,k,N,1,'SAME')

@@ -410,7 +410,8 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
   // sixteen stores at row strides, no per-element bounds test, branch or 64-bit index multiply.  (The general loop below
   // costs ~1600 instructions and ~190 branches per thread on a 128 x 128 tile: 4.8 us of an 8.7 us one-K-step launch,
   // tools/fixed_cost_probe.py.)
-  const bool full = m0 + BM <= M && n0 + BN <= N && (MODE != MODE_WGRAD || (Cp == p.C && !(p.splits == 1 && p.accumulate != 0.f)));
+  // (rows full; a ragged last column tile - 25 or 121 output channels - only masks lanes, once per 32-column sub-tile)
+  const bool full = m0 + BM <= M && (MODE != MODE_WGRAD || (Cp == p.C && !(p.splits == 1 && p.accumulate != 0.f)));
   if (full) {
     auto store_rows = [&](auto* base, long long pitch, int a, int b) {
       using T = std::remove_pointer_t<decltype(base)>;
@@ -419,26 +420,31 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
     };
     if constexpr (MODE == MODE_DGRAD) {
 #pragma unroll
-      for (int a = 0; a < TA; ++a)
+      for (int b = 0; b < TB; ++b) {
+        if (n0 + wn0 + 32 * b + lrow < N) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const long long off = rows[wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lk].out_off + (n0 + wn0 + lrow);
+          for (int a = 0; a < TA; ++a)
 #pragma unroll
-          for (int b = 0; b < TB; ++b) {
-            if (to_bf16) outh[off + 32 * b] = (__bf16)acc[a][b][r];
-            else outf[off + 32 * b] = acc[a][b][r];
-          }
+            for (int r = 0; r < 16; ++r) {
+              const long long off = rows[wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lk].out_off + (n0 + wn0 + 32 * b + lrow);
+              if (to_bf16) outh[off] = (__bf16)acc[a][b][r];
+              else outf[off] = acc[a][b][r];
+            }
         }
+      }
     } else {
       const long long pitch = MODE == MODE_WGRAD ? N : K8;
 #pragma unroll
-      for (int a = 0; a < TA; ++a)
+      for (int b = 0; b < TB; ++b) {
+        if (n0 + wn0 + 32 * b + lrow < N) {
 #pragma unroll
-        for (int b = 0; b < TB; ++b) {
-          const long long o = (long long)(m0 + wm0 + 32 * a + 4 * lk) * pitch + (n0 + wn0 + 32 * b + lrow);
-          if (to_bf16) store_rows(outh + o, pitch, a, b);
-          else store_rows(outf + o, pitch, a, b);
+          for (int a = 0; a < TA; ++a) {
+            const long long o = (long long)(m0 + wm0 + 32 * a + 4 * lk) * pitch + (n0 + wn0 + 32 * b + lrow);
+            if (to_bf16) store_rows(outh + o, pitch, a, b);
+            else store_rows(outf + o, pitch, a, b);
+          }
         }
+      }
     }
     return;
   }

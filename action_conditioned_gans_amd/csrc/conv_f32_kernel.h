@@ -635,27 +635,28 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
   float* outp = p.out + (p.splits > 1 ? (long long)bz * p.out_numel : 0ll);
   // Full tiles take a straight-line path - one base per 32 x 32 sub-tile, sixteen stores at row strides - instead of a
   // bounds test, a branch and a 64-bit index multiply per element (conv_bf16_kernel.h has the measurement).
-  const bool full = m0 + BM <= M && n0 + BN <= N && (MODE != MODE_WGRAD || (Cp == Cs && !(p.splits == 1 && p.accumulate != 0.f)));
+  // (rows full; a ragged last column tile - 3, 6, 25 or 138 output channels - only masks lanes, once per 32-column sub-tile)
+  const bool full = m0 + BM <= M && (MODE != MODE_WGRAD || (Cp == Cs && !(p.splits == 1 && p.accumulate != 0.f)));
   if (full) {
-    if constexpr (MODE == MODE_DGRAD) {
 #pragma unroll
-      for (int a = 0; a < TA; ++a)
+    for (int b = 0; b < TB; ++b) {
+      if (n0 + wn0 + 32 * b + lrow < N) {
+        if constexpr (MODE == MODE_DGRAD) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const long long off = rows[wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lk].out_off + (n0 + wn0 + lrow);
+          for (int a = 0; a < TA; ++a)
 #pragma unroll
-          for (int b = 0; b < TB; ++b) outp[off + 32 * b] = acc[a][b][r];
+            for (int r = 0; r < 16; ++r)
+              outp[(long long)rows[wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lk].out_off + (n0 + wn0 + 32 * b + lrow)] = acc[a][b][r];
+        } else {
+          const long long pitch = MODE == MODE_WGRAD ? N : p.Ky;
+#pragma unroll
+          for (int a = 0; a < TA; ++a) {
+            float* const o = outp + (long long)(m0 + wm0 + 32 * a + 4 * lk) * pitch + (n0 + wn0 + 32 * b + lrow);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[(long long)((r & 3) + 8 * (r >> 2)) * pitch] = acc[a][b][r];
+          }
         }
-    } else {
-      const long long pitch = MODE == MODE_WGRAD ? N : p.Ky;
-#pragma unroll
-      for (int a = 0; a < TA; ++a)
-#pragma unroll
-        for (int b = 0; b < TB; ++b) {
-          float* const o = outp + (long long)(m0 + wm0 + 32 * a + 4 * lk) * pitch + (n0 + wn0 + 32 * b + lrow);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[(long long)((r & 3) + 8 * (r >> 2)) * pitch] = acc[a][b][r];
-        }
+      }
     }
     return;
   }

@@ -373,17 +373,25 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
   if constexpr (MODE != MODE_WGRAD) {
     if (p.stats != nullptr) {     // BatchNorm statistics of this tile, of the bf16 values as stored (ConvArgs::stats, conv_f32_kernel.h)
       float* const red = reinterpret_cast<float*>(smem);        // the A tiles are dead after the K loop's last barrier
+      const bool rows_full = m0 + BM <= M;                      // block-uniform: full tiles skip the per-element row test
 #pragma unroll
       for (int b = 0; b < TB; ++b) {
         float s1 = 0.f, s2 = 0.f;
+        if (rows_full) {
 #pragma unroll
-        for (int a = 0; a < TA; ++a)
+          for (int a = 0; a < TA; ++a)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            const float v = m0 + row < M ? (float)(__bf16)acc[a][b][r] : 0.f;
-            s1 += v; s2 += v * v;
-          }
+            for (int r = 0; r < 16; ++r) { const float v = (float)(__bf16)acc[a][b][r]; s1 += v; s2 += v * v; }
+        } else {
+#pragma unroll
+          for (int a = 0; a < TA; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lk;
+              const float v = m0 + row < M ? (float)(__bf16)acc[a][b][r] : 0.f;
+              s1 += v; s2 += v * v;
+            }
+        }
         s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
         if (lk == 0) { red[(wr * BN + wn0 + 32 * b + lrow) * 2] = s1; red[(wr * BN + wn0 + 32 * b + lrow) * 2 + 1] = s2; }
       }

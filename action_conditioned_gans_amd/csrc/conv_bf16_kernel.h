@@ -456,39 +456,41 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
     }
     return;
   }
+  // partial row tiles (the last tile of a weight gradient whose taps x channels is no multiple of the tile; tiny layers): per
+  // ROW one validity test and one base index (the weight gradient's division by the padded channel count included), per
+  // element only the column mask
+  const bool acc_out = MODE == MODE_WGRAD && p.splits == 1 && p.accumulate != 0.f;
 #pragma unroll
   for (int a = 0; a < TA; ++a)
 #pragma unroll
-    for (int b = 0; b < TB; ++b)
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      const int m = m0 + row;
+      if (m >= M) continue;
+      long long base;
+      if constexpr (MODE == MODE_DGRAD) {
+        base = rows[row].out_off;
+      } else if constexpr (MODE == MODE_WGRAD) {
+        const int t = div_fast(m, p.mg_cp, p.sh_cp), c = m - t * Cp;
+        if (c >= p.C) continue;
+        base = ((long long)t * p.C + c) * N;
+      } else {
+        base = (long long)m * K8;
+      }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      for (int b = 0; b < TB; ++b) {
         const int n = n0 + wn0 + 32 * b + lrow;
-        const int m = m0 + row;
-        if (m < M && n < N) {
-          long long idx;
-          bool ok = true;
-          if constexpr (MODE == MODE_DGRAD) {
-            idx = (long long)rows[row].out_off + n;
-          } else if constexpr (MODE == MODE_WGRAD) {
-            const int t = m / Cp, c = m - t * Cp;
-            ok = c < p.C;
-            idx = ((long long)t * p.C + c) * N + n;
+        if (n < N) {
+          float v = acc[a][b][r];
+          if (MODE == MODE_WGRAD || !to_bf16) {
+            if (acc_out) v += p.accumulate * outf[base + n];
+            outf[base + n] = v;
           } else {
-            idx = (long long)m * K8 + n;
-          }
-          if (ok) {
-            float v = acc[a][b][r];
-            if constexpr (MODE == MODE_WGRAD) {
-              if (p.splits == 1 && p.accumulate != 0.f) v += p.accumulate * outf[idx];
-              outf[idx] = v;
-            } else {
-              if (to_bf16) outh[idx] = (__bf16)v;
-              else outf[idx] = v;
-            }
+            outh[base + n] = (__bf16)v;
           }
         }
       }
+    }
 }
 
 template <int MODE, int BM, int BN>

@@ -668,40 +668,36 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
     }
     return;
   }
+  // partial row tiles: per ROW one validity test and one base index (the weight gradient's division by the padded channel count
+  // included), per element only the column mask
+  const bool acc_out = MODE == MODE_WGRAD && p.splits == 1 && p.accumulate != 0.f;
 #pragma unroll
   for (int a = 0; a < TA; ++a)
 #pragma unroll
-    for (int b = 0; b < TB; ++b)
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      const int m = m0 + row;
+      if (m >= M) continue;
+      long long base;
+      if constexpr (MODE == MODE_DGRAD) {
+        base = rows[row].out_off;
+      } else if constexpr (MODE == MODE_WGRAD) {
+        const int t = div_fast(m, p.mg_cp, p.sh_cp), c = m - t * Cp;      // (Cp == Cs: c < Cs always)
+        if (c >= Cs) continue;
+        base = ((long long)t * Cs + c) * N;
+      } else {
+        base = (long long)m * p.Ky;
+      }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      for (int b = 0; b < TB; ++b) {
         const int n = n0 + wn0 + 32 * b + lrow;
-        const int m = m0 + row;
-        if (m < M && n < N) {
-          long long idx;
-          bool ok = true;
-          if constexpr (MODE == MODE_DGRAD) {
-            idx = (long long)rows[row].out_off + n;
-          } else if constexpr (MODE == MODE_WGRAD) {
-            if (Cp == Cs) {
-              idx = (long long)m * N + n;
-            } else {  // drop the per-tap padding rows
-              const int t = m / Cp, c = m - t * Cp;
-              ok = c < Cs;
-              idx = ((long long)t * Cs + c) * N + n;
-            }
-          } else {
-            idx = (long long)m * p.Ky + n;
-          }
-          if (ok) {
-            float v = acc[a][b][r];
-            if constexpr (MODE == MODE_WGRAD) {
-              if (p.splits == 1 && p.accumulate != 0.f) v += p.accumulate * outp[idx];
-            }
-            outp[idx] = v;
-          }
+        if (n < N) {
+          float v = acc[a][b][r];
+          if (acc_out) v += p.accumulate * outp[base + n];
+          outp[base + n] = v;
         }
       }
+    }
 }
 
 template <int MODE, int BM, int BN, int WM, int WN, bool RAGGED, bool NVEC>

@@ -14,7 +14,7 @@ lib = L.Library(sys.argv[2]) if len(sys.argv) > 2 else L.get()
 half = dtype == 'bf16'
 code = L.ACG_BF16 if half else L.ACG_F32
 abi = Abi(lib, 'cuda:0', conv_dtype=code)
-B, S, N = 32, 32, 128
+B, S, N = 32, int(os.environ.get("PROBE_S", "32")), 128
 for which in ('fwd', 'dgrad', 'wgrad'):
     for k, cin in ((1, 8), (1, 64), (1, 256), (3, 64), (5, 64)):
         d = abi.desc(B, S, S, cin, k, k, N, 1, 'SAME')

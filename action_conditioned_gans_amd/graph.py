@@ -660,6 +660,11 @@ class Session:
         fused = []
         for ph, val in feed_dict.items():
             src = val if torch.is_tensor(val) else torch.from_numpy(np.ascontiguousarray(val))
+            if self.rt.is_cuda and not src.is_cuda and src.dtype in (torch.float32, torch.float64):
+                # host arrays (the reference's numpy feed_dict): ONE contiguous upload per fed value, then the same fused
+                # device copy as device-resident feeds - a feed may have several destinations (feed aliases), and strided
+                # host -> device copies of each of them cost milliseconds
+                src = src.to(self.rt.device, dtype=torch.float32, non_blocking=True)
             dst = ph.buf if ph.valid_c is None else ph.buf[..., :ph.valid_c]     # pad channels stay zero
             if tuple(src.shape) != tuple(dst.shape):
                 raise ValueError('Cannot feed value of shape %s for %r' % (tuple(src.shape), ph))

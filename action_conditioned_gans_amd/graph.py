@@ -353,7 +353,7 @@ class Runtime:
         # split-K slabs summed by the consuming BatchNorm kernel instead of by a launch of their own: bit-identical, but
         # measured SLOWER (fp32 364 vs 383, bf16 567 vs 600 steps/s, profiles/r2): the one-launch BatchNorm kernels read 16
         # bytes per row and block, and S slabs multiply exactly those poorly coalesced requests; kept as an option
-        self.slab_handoff = False
+        self.slab_handoff = 0
         self.epilogue_stats = True
         self._comm = comm
         self._scratch = {}
@@ -414,7 +414,8 @@ class Session:
                 raise ValueError('Session(dtype=%r): the graph was already built for %s activations' % (dtype, self.graph.act_dtype))
             self.graph.act_dtype = want
         self.rt = Runtime(lib, dev, world_size, rank, process_group, _lib.ACG_BF16 if dtype == 'bf16' else _lib.ACG_F32, comm)
-        self.rt.slab_handoff = bool(slab_handoff)
+        # False / 0: off; True: every split layer; an int N: only layers split into at most N slabs
+        self.rt.slab_handoff = (1 << 30) if slab_handoff is True else int(slab_handoff or 0)
         self.rt.epilogue_stats = bool(epilogue_stats)     # BatchNorm statistics out of the producing conv's epilogue (ops.Conv2dOp.bind)
         if dev.type == 'cuda':
             torch.cuda.set_device(dev)

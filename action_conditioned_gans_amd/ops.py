@@ -273,7 +273,7 @@ class Conv2dOp(_ConvBase):
             # sums them as it loads (acg_bn_act_fwd_slabs) - one launch less
             lib, d = rt.lib, self.desc
             splits = lib.conv2d_splits(ctypes.byref(d), self.which, rt.conv_dtype)
-            if splits > 1:
+            if 1 < splits <= rt.slab_handoff:
                 ws, n = rt.workspace(lib.conv2d_workspace_bytes(ctypes.byref(d), self.which, rt.conv_dtype))
                 self._keep, self._slab = (ws, d), (ws, splits)
                 fn = lib.deconv2d_fwd_slabs if self.transposed else lib.conv2d_fwd_slabs
@@ -319,7 +319,7 @@ class ConvDgradOp(_ConvBase):
         bn = self.bn_bwd_consumer
         hand_off = False
         if bn is not None and id(bn) in rt.program_ops and rt.slab_handoff and lib.bn_bwd_slabs_ok(bn.fwd.rows, bn.fwd.groups):
-            hand_off = lib.conv2d_splits(ctypes.byref(d), self.which, dt) > 1
+            hand_off = 1 < lib.conv2d_splits(ctypes.byref(d), self.which, dt) <= rt.slab_handoff
         if not self.pair_active:
             if hand_off:     # the consuming BatchNorm backward sums the slabs (acg_bn_act_bwd_slabs)
                 ws, n = rt.workspace(lib.conv2d_workspace_bytes(ctypes.byref(d), self.which, dt))

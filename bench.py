@@ -54,7 +54,7 @@ def parse():
     ap.add_argument('--lib', default=None, help='experiment: an alternative build of the library (e.g. the tuning build, whose knobs read the environment)')
     ap.add_argument('--no-epilogue-stats', action='store_true', help='experiment: BatchNorm computes its statistics in a pass of its own instead of taking them from the conv epilogue')
     ap.add_argument('--side-branch', action='store_true', help='experiment: the state head as a parallel branch of the HIP graph (second stream) instead of in line on the main stream; measured slower')
-    ap.add_argument('--slab-handoff', action='store_true', help='experiment: the consuming BatchNorm kernels sum the split-K slabs instead of separate reduction launches (bit-identical; measured slower)')
+    ap.add_argument('--slab-handoff', type=int, default=0, metavar='N', help='experiment: the consuming BatchNorm kernels sum the split-K slabs of layers split into at most N slabs instead of separate reduction launches (measured slower)')
     ap.add_argument('--no-pair', action='store_true', help='experiment: a layer\'s dgrad and wgrad as two launches instead of one')
     ap.add_argument('--dp-collectives', default=None, choices=['stream', 'side'], help='gradient all-reduces (ncclAllReduce captured into the step\'s HIP graph) on the compute stream in program order, or on a side HIP stream overlapping the rest of backward; default: side with more than one rank')
     ap.add_argument('--buckets', type=int, default=0, help='gradient all-reduce buckets per optimizer (data parallel); 0 = 1 for in-order collectives, 2 for side-stream ones')

@@ -28,9 +28,16 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
 __global__ __launch_bounds__(256) void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v, const int* __restrict__ step, long long n, float lr,
                                               float b1, float b2, float eps, float gs, int use_clip, float lo, float hi) {
-  const int t = *step;
-  // lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t)   (SURVEY A.6); fp64 pow keeps the tiny 1-b^t differences exact
-  const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
+  // lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t)   (SURVEY A.6); fp64 pow keeps the tiny 1-b^t differences exact.  ONE thread per
+  // block evaluates it: two double-precision pow calls are several hundred instructions, more than the whole update of
+  // the one or two float4 a thread owns.
+  __shared__ float s_lr_t;
+  if (threadIdx.x == 0) {
+    const int t = *step;
+    s_lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
+  }
+  __syncthreads();
+  const float lr_t = s_lr_t;
   const long long stride = (long long)gridDim.x * 256;
   const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                     reinterpret_cast<uintptr_t>(v)) & 15) == 0;

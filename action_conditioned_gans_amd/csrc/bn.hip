@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd(const TX* __restrict__ x, co
     double var = (double)s2[j] * inv - dm * dm;
     var = var > 0.0 ? var : 0.0;
     mean[j] = (float)((double)pv[j] + dm);
-    rstd[j] = (float)(1.0 / sqrt(var + (double)eps));
+    rstd[j] = rsqrtf((float)var + eps);        // (the float64 square root and division were most of this kernel's instructions)
   }
   if (blockIdx.x == 0 && rl == 0) { stv<V>(save_mean + g * C + c, mean); stv<V>(save_rstd + g * C + c, rstd); }
   // batches of 4 row passes with the loads issued together (a block walks ~4 passes: one memory round trip)
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void bn_resident_fwd(TX* __restrict__ x, const
     double var = (double)s[V + j] * inv - dm * dm;
     var = var > 0.0 ? var : 0.0;
     mean[j] = (float)((double)pv[j] + dm);
-    rstd[j] = (float)(1.0 / sqrt(var + (double)eps));
+    rstd[j] = rsqrtf((float)var + eps);        // (the float64 square root and division were most of this kernel's instructions)
   }
   if (threadIdx.x == 0) { stv<V>(save_mean + g * C + c, mean); stv<V>(save_rstd + g * C + c, rstd); }
 #pragma unroll

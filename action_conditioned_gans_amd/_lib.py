@@ -17,7 +17,7 @@ import torch  # noqa: F401  (import order is the point)
 ACG_F32, ACG_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 3       # include/acgan_hip.h ACG_ABI_VERSION: bumped with every signature / layout / flag-meaning change
 
 LIB_NAME = 'libacgan_hip.so'
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', LIB_NAME)

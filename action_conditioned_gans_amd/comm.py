@@ -24,7 +24,27 @@ class CommError(RuntimeError):
 
 
 class _UniqueId(ctypes.Structure):
-    _fields_ = [('internal', ctypes.c_char * NCCL_UNIQUE_ID_BYTES)]
+    # c_ubyte, not c_char: ctypes reads a c_char array field as a C string and stops at the first NUL, and a real
+    # ncclUniqueId has NULs from byte 9 on (magic, then a sockaddr: AF_INET = 02 00).
+    _fields_ = [('internal', ctypes.c_ubyte * NCCL_UNIQUE_ID_BYTES)]
+
+
+def pack_unique_id(uid):
+    """All 128 bytes of the struct, NULs included."""
+    raw = ctypes.string_at(ctypes.byref(uid), NCCL_UNIQUE_ID_BYTES)
+    assert len(raw) == NCCL_UNIQUE_ID_BYTES
+    return raw
+
+
+def unpack_unique_id(raw, uid=None):
+    """The struct from what pack_unique_id produced on rank 0; anything but exactly 128 bytes is a bootstrap error."""
+    if not isinstance(raw, (bytes, bytearray)) or len(raw) != NCCL_UNIQUE_ID_BYTES:
+        raise CommError('unique-id bootstrap delivered %s, expected %d bytes'
+                        % ('%d bytes' % len(raw) if isinstance(raw, (bytes, bytearray)) else type(raw).__name__,
+                           NCCL_UNIQUE_ID_BYTES))
+    uid = uid if uid is not None else _UniqueId()
+    ctypes.memmove(ctypes.byref(uid), bytes(raw), NCCL_UNIQUE_ID_BYTES)
+    return uid
 
 
 _RCCL = None
@@ -112,8 +132,8 @@ class RcclCommunicator(Communicator):
         if self.rank == 0:
             _check(lib.ncclGetUniqueId(ctypes.byref(uid)), 'ncclGetUniqueId')
         if self.world_size > 1:
-            raw = _share_unique_id(bytes(uid.internal) if self.rank == 0 else None, self.world_size, self.rank, process_group)
-            ctypes.memmove(ctypes.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)
+            raw = _share_unique_id(pack_unique_id(uid) if self.rank == 0 else None, self.world_size, self.rank, process_group)
+            unpack_unique_id(raw, uid)
         self._comm = ctypes.c_void_p()
         with torch.cuda.device(device):
             _check(lib.ncclCommInitRank(ctypes.byref(self._comm), self.world_size, uid, self.rank), 'ncclCommInitRank')

@@ -594,6 +594,12 @@ class Session:
                 r = t.root()
                 if isinstance(r, Placeholder):
                     needed[id(r)] = r
+            # an input that arrives through a feed alias launches nothing and may sit behind an op the walk above pruned
+            # (repeat_batch(placeholder) -> ConcatActionsOp): the placeholder behind it has to be fed all the same
+            for t in getattr(op, 'fed_inputs', ()):
+                src = op._fed_source(t) if hasattr(op, '_fed_source') else t.root()
+                if isinstance(src, Placeholder):
+                    needed[id(src)] = src
         prog.missing_feeds = sorted(r.name for i, r in needed.items() if i not in fed_ids)      # Session.run raises on these
         # feed aliases whose destination this program reads
         prog.alias_copies = {}
@@ -643,21 +649,10 @@ class Session:
                 ops = [o for o in ops if o not in mine]
         return ops
 
-    # ---- run
-    def run(self, fetches, feed_dict=None, device_fetch=False):
-        feed_dict = feed_dict or {}
-        single = not isinstance(fetches, (list, tuple))
-        flat = self._flatten(fetches)
-        if any(isinstance(f, InitOp) for f in flat):
-            self._initialize()
-            return None if single else [None] * len(flat)
-        key = (tuple(id(f) for f in flat), tuple(id(k) for k in feed_dict))
-        prog = self._programs.get(key)
-        if prog is None:
-            prog = self._compile(flat, list(feed_dict.keys()))
-            self._programs[key] = prog
-        if prog.missing_feeds:
-            raise ValueError('You must feed a value for placeholder tensor(s) %s' % ', '.join(prog.missing_feeds))
+    def _feed(self, prog, feed_dict):
+        """Write the fed values where ``prog`` reads them: the placeholder itself when the program uses it, plus every
+        feed alias whose destination the program reads (concatenations written by the feed, tiled action channels).
+        Device-resident float32 feeds go through ONE acg_copy_many launch.  Used by run() and profile_ops()."""
         fused = []
         for ph, val in feed_dict.items():
             src = val if torch.is_tensor(val) else torch.from_numpy(np.ascontiguousarray(val))
@@ -690,6 +685,23 @@ class Session:
                 cl.cols[i], cl.dst_pitch[i], cl.dst_dtype[i] = cols, t.shape[-1], _lib.code(t.dtype)
                 cl.src_div[i], cl.src_mod[i] = (0, 0) if tile is None else tile
             self.rt.lib.copy_many(ctypes.byref(cl), len(fused), _lib.ACG_F32, self.rt.stream_ptr())
+
+    # ---- run
+    def run(self, fetches, feed_dict=None, device_fetch=False):
+        feed_dict = feed_dict or {}
+        single = not isinstance(fetches, (list, tuple))
+        flat = self._flatten(fetches)
+        if any(isinstance(f, InitOp) for f in flat):
+            self._initialize()
+            return None if single else [None] * len(flat)
+        key = (tuple(id(f) for f in flat), tuple(id(k) for k in feed_dict))
+        prog = self._programs.get(key)
+        if prog is None:
+            prog = self._compile(flat, list(feed_dict.keys()))
+            self._programs[key] = prog
+        if prog.missing_feeds:
+            raise ValueError('You must feed a value for placeholder tensor(s) %s' % ', '.join(prog.missing_feeds))
+        self._feed(prog, feed_dict)
         if self._weights_dirty and prog is not None:
             self._refresh_weight_copies()
         self._execute(prog)
@@ -720,9 +732,7 @@ class Session:
         if key not in self._programs:
             self.run(fetches, feed_dict)
         prog = self._programs[key]
-        for ph, val in (feed_dict or {}).items():
-            dst = ph.buf if ph.valid_c is None else ph.buf[..., :ph.valid_c]
-            dst.copy_(val if torch.is_tensor(val) else torch.from_numpy(np.ascontiguousarray(val)), non_blocking=True)
+        self._feed(prog, feed_dict or {})      # exactly what run() writes: used feeds, feed aliases, tiled action channels
         if self._weights_dirty:
             self._refresh_weight_copies()
         stream = torch.cuda.current_stream(self.rt.device)
@@ -833,23 +843,25 @@ class Session:
             return
         if prog.graphs is None:
             graphs = []
-            torch.cuda.synchronize(rt.device)
+            if rt.is_cuda:
+                torch.cuda.synchronize(rt.device)
             try:
                 for kind, seg in prog.segments:
-                    if kind == 'host':
-                        graphs.append(None)
-                        continue
-                    gr = torch.cuda.CUDAGraph()
-                    # thread_local: HIP calls of OTHER threads (none of ours; a host library's helper thread at worst)
-                    # neither see nor invalidate this thread's capture
-                    with torch.cuda.graph(gr, capture_error_mode='thread_local'):
-                        self._launch_segment(seg)     # current stream = the capture stream
-                    graphs.append(gr)
-            except Exception as e:      # a launch that cannot be captured on this stack: say so once, run this program eagerly
+                    graphs.append(None if kind == 'host' else self.capture_segment(seg))
+            except Exception as e:
+                # ONLY "this stack cannot capture that launch" falls back to eager launches (said once, per program).  A bad
+                # kernel argument (AcgError), an unbalanced fork / join ('capture not joined') or any other failure inside
+                # the body is a bug and is raised: with several ranks a silent fallback would leave one rank eager beside
+                # replaying peers and show up as nothing but a line on stderr
+                if not self._capture_unsupported(e):
+                    raise
                 import sys
-                sys.stderr.write('[acgan] HIP-graph capture failed (%s: %s); this program is launched eagerly from now on\n'
-                                 % (type(e).__name__, str(e).splitlines()[0] if str(e) else ''))
-                torch.cuda.synchronize(rt.device)
+                sys.stderr.write('[acgan] HIP-graph capture is not supported for this program (%s: %s); it is launched '
+                                 'eagerly from now on\n' % (type(e).__name__, str(e).splitlines()[0] if str(e) else ''))
+                if rt.is_cuda:
+                    torch.cuda.synchronize(rt.device)
+                    if rt.side_stream is not None and rt.side_stream.is_capturing():
+                        raise RuntimeError('the side stream is still capturing after a failed capture: cannot launch eagerly') from e
                 prog.eager = True
                 for kind, seg in prog.segments:
                     if kind == 'host':
@@ -863,6 +875,32 @@ class Session:
                 seg()
             else:
                 gr.replay()
+
+    def capture_segment(self, seg):
+        """One device segment captured into a HIP graph; returns an object with ``replay()``.  (Tests replace this to
+        exercise the capture-failure path of _execute without a GPU.)"""
+        gr = torch.cuda.CUDAGraph()
+        # thread_local: HIP calls of OTHER threads (none of ours; a host library's helper thread at worst) neither see nor
+        # invalidate this thread's capture
+        with torch.cuda.graph(gr, capture_error_mode='thread_local'):
+            self._launch_segment(seg)     # current stream = the capture stream
+        return gr
+
+    _CAPTURE_UNSUPPORTED = (
+        'StreamCaptureUnsupported', 'operation not permitted when stream is capturing',       # hipError 900
+        'StreamCaptureInvalidated', 'operation failed due to a previous error during capture',  # 901 (follows a 900)
+        'StreamCaptureImplicit', 'disallowed implicit dependency',                             # 906
+    )
+
+    @classmethod
+    def _capture_unsupported(cls, exc):
+        """True only for the HIP runtime's "this call cannot be captured" family.  The sequencing errors of a capture
+        (hipErrorStreamCaptureUnjoined / Unmatched / Merge / Isolation / WrongThread: an unbalanced fork or join in
+        _launch_segment) and errors of our own library (AcgError: a bad kernel argument) are bugs, not stack limits."""
+        if isinstance(exc, _lib.AcgError) or not isinstance(exc, RuntimeError):
+            return False
+        msg = str(exc)
+        return any(k in msg for k in cls._CAPTURE_UNSUPPORTED)
 
 
 @contextlib.contextmanager

@@ -35,7 +35,11 @@
 extern "C" {
 #endif
 
-#define ACG_ABI_VERSION 1
+/* Bumped whenever an exported signature, a struct layout or the meaning of an argument changes; the Python binding
+ * (_lib.Library) refuses a library whose acg_version() differs from the value it was written against.
+ * 1: round 1.  2: round 2 (acg_bn_act_*, acg_bias_act_*, acg_dna_*, acg_copy_list, the flags of acg_*_bwd_pair changed
+ * without a bump - any "version 1" build may be either).  3: round 3. */
+#define ACG_ABI_VERSION 3
 
 typedef void* acg_stream_t; /* hipStream_t */
 

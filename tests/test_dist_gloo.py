@@ -228,7 +228,12 @@ def _uid_worker(rank, world, port, outdir, via):
         if p not in sys.path:
             sys.path.insert(0, p)
     from action_conditioned_gans_amd import comm as C
-    uid = bytes(range(128)) if rank == 0 else None
+    # the same pack -> share -> unpack path RcclCommunicator.__init__ takes, on an id shaped like a real one: an 8-byte
+    # magic, then a sockaddr_in (AF_INET = 02 00 ...) - NUL bytes from byte 9 on (a c_char field would cut it there)
+    mine = C._UniqueId()
+    if rank == 0:
+        C.unpack_unique_id(_UID_PATTERN, mine)
+    uid = C.pack_unique_id(mine) if rank == 0 else None
     if via == 'gloo':
         dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
         got = C._share_unique_id(uid, world, rank, None)
@@ -238,8 +243,26 @@ def _uid_worker(rank, world, port, outdir, via):
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         os.environ.pop('TORCHELASTIC_USE_AGENT_STORE', None)
         got = C._share_unique_id(uid, world, rank, None)
+    C.unpack_unique_id(got, mine)
     with open(os.path.join(outdir, 'uid_%s_%d' % (via, rank)), 'wb') as f:
-        f.write(got)
+        f.write(C.pack_unique_id(mine))
+
+
+_UID_PATTERN = bytes([0x5a, 0x7e, 0x11, 0xc3, 0x9d, 0x02, 0xee, 0x41, 0x02, 0x00, 0x9c, 0x40, 127, 0, 0, 1] + [0] * 8
+                     + [(7 * i) & 0xff if i % 5 else 0 for i in range(104)])
+assert len(_UID_PATTERN) == 128 and _UID_PATTERN.index(0) == 9
+
+
+def test_unique_id_pack_unpack_keeps_all_128_bytes():
+    """`bytes(uid.internal)` on a c_char field stopped at the first NUL.  The struct now round-trips
+    whole, and a short or non-bytes delivery is a CommError instead of a 128-byte read out of a short object."""
+    from action_conditioned_gans_amd import comm as C
+    uid = C.unpack_unique_id(_UID_PATTERN)
+    assert C.pack_unique_id(uid) == _UID_PATTERN
+    assert bytes(bytearray(uid.internal)) == _UID_PATTERN
+    for bad in (_UID_PATTERN[:9], _UID_PATTERN + b'x', None, 'x' * 128):
+        with pytest.raises(C.CommError):
+            C.unpack_unique_id(bad)
 
 
 @pytest.mark.parametrize('via', ['gloo', 'store'])
@@ -249,4 +272,68 @@ def test_rccl_unique_id_bootstrap_over_cpu_channels(via):
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_uid_worker, args=(2, _free_port(), d, via), nprocs=2, join=True)
         for r in (0, 1):
-            assert open(os.path.join(d, 'uid_%s_%d' % (via, r)), 'rb').read() == bytes(range(128)), (via, r)
+            assert open(os.path.join(d, 'uid_%s_%d' % (via, r)), 'rb').read() == _UID_PATTERN, (via, r)
+
+
+# ---- capture failure on ONE rank of two (graph._execute's fallback): no deadlock, identical weights ------------------
+class _FakeGraph:
+    """Stands in for a captured HIP graph on the CPU: replaying it launches the segment."""
+
+    def __init__(self, sess, seg):
+        self.sess, self.seg, self.replays = sess, seg, 0
+
+    def replay(self):
+        self.replays += 1
+        self.sess._launch_segment(self.seg)
+
+
+def _capfail_worker(rank, world, port, outdir, fail_rank):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(2)
+    import train_cases as TC
+    from oracle import cbind
+    from action_conditioned_gans_amd import graph as G
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    sess, tr = TC.build_trainer(lambda **kw: G.Session(device='cpu', lib=cbind.load(), world_size=world, rank=rank, **kw),
+                                CASE, world_size=world, collectives='side')
+    captured = []
+    if fail_rank is not None:
+        sess.use_hip_graphs = True               # the CPU session never captures by itself: route _execute through the hook
+
+        def capture(seg):
+            if rank == fail_rank:
+                raise RuntimeError('HIP error: operation not permitted when stream is capturing')
+            captured.append(_FakeGraph(sess, seg))
+            return captured[-1]
+        sess.capture_segment = capture
+    x, y, a, s = _inputs(rank)
+    for _ in range(3):                            # run 1 eager, run 2 captures (or falls back), run 3 replays (or stays eager)
+        tr.train_d(x, y, a)
+        tr.train_g(x, y, a, s)
+    progs = list(sess._programs.values())
+    out = {'d_param': _flat(tr.d_opt_op.inputs[0]), 'g_param': _flat(tr.g_opt_op.inputs[0]),
+           'eager': np.array([int(p.eager) for p in progs]), 'replays': np.array(sum(g.replays for g in captured))}
+    np.savez(os.path.join(outdir, 'capfail%s_r%d.npz' % ('' if fail_rank is None else '_f%d' % fail_rank, rank)), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_capture_failure_on_one_rank_keeps_the_ranks_in_step():
+    """rank 1's programs cannot be captured (the runtime refuses: hipErrorStreamCaptureUnsupported)
+    while rank 0 captures and replays.  The all-reduces are device ops of the launch list either way, so the eager rank
+    and the replaying rank issue the same collectives in the same order: no deadlock, bit-identical weights on both
+    ranks, equal to a run in which nobody captures."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_capfail_worker, args=(2, _free_port(), d, 1), nprocs=2, join=True)
+        mp.spawn(_capfail_worker, args=(2, _free_port(), d, None), nprocs=2, join=True)
+        got = [dict(np.load(os.path.join(d, 'capfail_f1_r%d.npz' % r))) for r in (0, 1)]
+        ref = [dict(np.load(os.path.join(d, 'capfail_r%d.npz' % r))) for r in (0, 1)]
+    assert got[1]['eager'].all() and not got[0]['eager'].any()       # rank 1 fell back, rank 0 did not
+    assert int(got[0]['replays']) >= 2 and int(got[1]['replays']) == 0
+    for key in ('d_param', 'g_param'):
+        assert np.array_equal(got[0][key], got[1][key]), key
+        assert np.array_equal(got[0][key], ref[0][key]), key
+        assert np.array_equal(ref[0][key], ref[1][key]), key

@@ -341,3 +341,47 @@ def test_cdna_transformation_layer_and_gradients():
     norms = TC.flat_grad_norms(sess, step)
     assert abs(norms['g/cdna_params/weights'] - float(wd.grad.norm())) <= 1e-4 * float(wd.grad.norm())
     assert abs(norms['g/cdna_params/biases'] - float(bd.grad.norm())) <= 1e-4 * float(bd.grad.norm())
+
+
+def test_capture_fallback_only_for_capture_unsupported_errors():
+    """the eager fallback of Session._execute is for "this stack cannot capture that launch" only; a failing
+    kernel argument or an unbalanced fork / join inside the capture body is raised, not swallowed."""
+    from action_conditioned_gans_amd import _lib, graph as G
+    ok = G.Session._capture_unsupported
+    assert ok(RuntimeError('HIP error: operation not permitted when stream is capturing'))
+    assert ok(RuntimeError('hipErrorStreamCaptureUnsupported'))
+    assert ok(RuntimeError('HIP error: operation failed due to a previous error during capture'))
+    assert not ok(RuntimeError('hipErrorStreamCaptureUnjoined: capture was not joined'))
+    assert not ok(RuntimeError('hipErrorStreamCaptureUnmatched'))
+    assert not ok(_lib.AcgError('acg_conv2d_fwd failed (code 1): null pointer while capturing'))
+    assert not ok(ValueError('operation not permitted when stream is capturing'))
+    sess, tr = TC.build_trainer(cpu_session, 'c1_plain_l1')
+    x, y, a, s = TC.MG.inputs(2)
+    tr.pretrain_g(x, y, a, s)
+    sess.use_hip_graphs = True
+
+    def broken(seg):
+        raise _lib.AcgError('acg_conv2d_fwd failed (code 1): bad argument')
+    sess.capture_segment = broken
+    with pytest.raises(_lib.AcgError):
+        tr.pretrain_g(x, y, a, s)
+
+
+def test_every_placeholder_a_program_reads_must_be_fed():
+    """TF: "You must feed a value for placeholder tensor".  Includes placeholders that reach an op only through a feed
+    alias - the action vector tiled into the concatenated maps by the feed copy itself (repeat_batch(placeholder)
+    -> ConcatActionsOp launches nothing, so an un-fed action placeholder used to reuse old data silently)."""
+    sess, tr = TC.build_trainer(cpu_session, 'c2_dna_bce_adam')
+    fd = tr._feed(*TC.MG.inputs(2))
+    programs = {'d': [tr.d_opt_op, tr.clip_d], 'g': [tr.g_opt_op, tr.g_next_frame], 'test': [tr.g_next_frame]}
+    reads = {'d': {'current_frame', 'current_frame_conv', 'next_frame', 'action'},
+             'g': {'current_frame', 'current_frame_conv', 'next_frame', 'action', 'next_state'},
+             'test': {'current_frame', 'current_frame_conv', 'action'}}
+    for ph in list(fd):
+        rest = {k: v for k, v in fd.items() if k is not ph}
+        for key, fetch in programs.items():
+            if ph.name in reads[key]:
+                with pytest.raises(ValueError, match='You must feed a value for placeholder'):
+                    sess.run(fetch, rest)
+            else:
+                sess.run(fetch, rest)      # a placeholder the pruned program never reads may stay un-fed, as in TF

@@ -70,6 +70,7 @@ SIGNATURES = {
     'acg_conv2d_wgrad_slabs': (c_int32, [_P, _P, _D, c_int32, _P, c_size_t, _P]),
     'acg_deconv2d_wgrad_slabs': (c_int32, [_P, _P, _D, c_int32, _P, c_size_t, _P]),
     'acg_conv2d_stats_blocks': (c_int32, [_D, c_int32, c_int32, c_int32]),
+    'acg_conv2d_stats_layout': (c_int32, [_D, c_int32, c_int32, c_int32, ctypes.POINTER(c_int32), ctypes.POINTER(c_int32)]),
     'acg_conv2d_fwd_stats': (c_int32, [_P, _P, _P, _D, c_int32, _P, c_size_t, _P, c_int32, _P]),
     'acg_deconv2d_fwd_stats': (c_int32, [_P, _P, _P, _D, c_int32, _P, c_size_t, _P, c_int32, _P]),
     'acg_conv2d_fwd_slabs': (c_int32, [_P, _P, _D, c_int32, _P, c_size_t, _P]),
@@ -93,7 +94,7 @@ SIGNATURES = {
                                  c_int32, _P, c_size_t, _P]),
     'acg_bn_act_bwd': (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
                                  c_float, c_int32, _P, c_size_t, _P]),
-    'acg_bn_act_fwd_partials': (c_int32, [_P, _P, _P, c_int32, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, c_float,
+    'acg_bn_act_fwd_partials': (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, c_float,
                                           c_int32, _P]),
     'acg_bn_act_fwd_slabs': (c_int32, [_P, c_int32, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, c_float,
                                        c_int32, _P, c_size_t, _P]),
@@ -155,7 +156,7 @@ def code(torch_dtype):
     if torch_dtype == torch.bfloat16:
         return ACG_BF16
     raise TypeError('no storage code for %s' % torch_dtype)
-VALUE_RETURNING = ('acg_version', 'acg_conv2d_splits', 'acg_bn_bwd_slabs_ok', 'acg_conv2d_stats_blocks')     # int32 results that are not status codes
+VALUE_RETURNING = ('acg_version', 'acg_conv2d_splits', 'acg_bn_bwd_slabs_ok', 'acg_conv2d_stats_blocks', 'acg_conv2d_stats_layout')     # int32 results that are not status codes
 
 
 class AcgError(RuntimeError):

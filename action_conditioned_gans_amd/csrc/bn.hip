@@ -205,38 +205,95 @@ __device__ __forceinline__ void sum_partials(const float* __restrict__ part, int
   }
 }
 
+// Forward statistics of one group from the per-tile (sum, M2) partials a convolution's epilogue left (conv_f32_kernel.h
+// tile_stats_epilogue): mean = sum of sums / R, M2 = sum of M2_b + sum_b n_b mean_b^2 - R mean^2 with mean_b = sum_b / n_b.
+// Float64 accumulators: the last two terms cancel to ~(mean / std)^2 digits, which float64 has to spare where float32
+// (round 2's plain sums) lost the variance.  Same thread mapping as sum_partials.  n_b from the tile geometry.
+struct TileGeom { int block_rows, run_rows, blocks_per_run; };
+template <int V>
+__device__ __forceinline__ void merge_tile_partials(const float* __restrict__ part, int g, int nblk, int C, int c, bool cvalid, int rl,
+                                                    const TileGeom tg, long long R, float eps, float (&mean)[V], float (&rstd)[V],
+                                                    double* sh /* 4 * 8 * 3 * V doubles */) {
+  double S[V], Q[V], P[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { S[j] = 0.0; Q[j] = 0.0; P[j] = 0.0; }
+  if (cvalid) {
+    for (int b = rl; b < nblk; b += 32) {
+      const float* o = part + ((long long)g * nblk + b) * 2 * C + c;
+      float a[V], q[V];
+      ldv<V>(o, a); ldv<V>(o + C, q);
+      const int nb = min(tg.block_rows, tg.run_rows - (b % tg.blocks_per_run) * tg.block_rows);
+      const double inv = 1.0 / (double)nb;
+#pragma unroll
+      for (int j = 0; j < V; ++j) { S[j] += (double)a[j]; Q[j] += (double)q[j]; P[j] += (double)a[j] * (double)a[j] * inv; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) { S[j] += __shfl_xor(S[j], off, 64); Q[j] += __shfl_xor(Q[j], off, 64); P[j] += __shfl_xor(P[j], off, 64); }
+  }
+  const int cq = threadIdx.x & 7, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) < 8) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) { double* q = sh + ((wave * 8 + cq) * 3) * V + j; q[0] = S[j]; q[V] = Q[j]; q[2 * V] = P[j]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    double s = 0.0, q = 0.0, pp = 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const double* z = sh + ((w * 8 + cq) * 3) * V + j; s += z[0]; q += z[V]; pp += z[2 * V]; }
+    const double inv = 1.0 / (double)R, dm = s * inv;
+    double var = (q + pp - s * dm) * inv;
+    var = var > 0.0 ? var : 0.0;
+    mean[j] = (float)dm;
+    rstd[j] = rsqrtf((float)var + eps);
+  }
+}
+
+// mode 0: tile (sum, M2) partials of a convolution epilogue; 1: shifted plain sums of bn_stats_partial; 2: mean / rstd are
+// already in save_mean / save_rstd (bn_partials_finalize ran: the convolution left more partial blocks than an apply block
+// should re-read)
+enum { kPartTiles = 0, kPartShifted = 1, kPartDone = 2 };
+
 template <int V, typename TX, typename TY>
 __global__ __launch_bounds__(256) void bn_apply_fwd(const TX* __restrict__ x, const float* __restrict__ beta,
                                                     const float* __restrict__ part, TY* __restrict__ y,
                                                     float* __restrict__ save_mean, float* __restrict__ save_rstd,
                                                     long long R, int C, int nblk, float eps, int act, float leak, int XP, int YP,
-                                                    int shifted) {
-  __shared__ float sh[4 * 8 * 2 * V];
+                                                    int mode, const TileGeom tg) {
+  __shared__ double shd[4 * 8 * 3 * V];
+  float* const sh = reinterpret_cast<float*>(shd);
   const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3, g = blockIdx.z;
   const int c = (blockIdx.y * 8 + cq) * V;
   const bool cvalid = c < C;
-  float s1[V], s2[V];
-  sum_partials<V>(part, g, nblk, C, c, cvalid, rl, s1, s2, sh);
-  if (!cvalid) return;
   const TX* xg = x + (long long)g * R * XP;
   TY* yg = y + (long long)g * R * YP;
-  float pv[V], mean[V], rstd[V], bt[V];
-  if (shifted) {       // partials of bn_stats_partial: sums of (x - first row of the group)
+  float mean[V], rstd[V], bt[V];
+  if (mode == kPartTiles) {
+    merge_tile_partials<V>(part, g, nblk, C, c, cvalid, rl, tg, R, eps, mean, rstd, shd);
+    if (!cvalid) return;
+  } else if (mode == kPartShifted) {       // partials of bn_stats_partial: sums of (x - first row of the group)
+    float s1[V], s2[V], pv[V];
+    sum_partials<V>(part, g, nblk, C, c, cvalid, rl, s1, s2, sh);
+    if (!cvalid) return;
     ldv<V>(xg + c, pv);
-  } else {             // partials out of the producing convolution's epilogue (acg_bn_act_fwd_partials): plain sums
 #pragma unroll
-    for (int j = 0; j < V; ++j) pv[j] = 0.f;
+    for (int j = 0; j < V; ++j) {
+      const double inv = 1.0 / (double)R, dm = (double)s1[j] * inv;
+      double var = (double)s2[j] * inv - dm * dm;
+      var = var > 0.0 ? var : 0.0;
+      mean[j] = (float)((double)pv[j] + dm);
+      rstd[j] = rsqrtf((float)var + eps);        // (the float64 square root and division were most of this kernel's instructions)
+    }
+  } else {
+    if (!cvalid) return;
+    ldv<V>(save_mean + g * C + c, mean); ldv<V>(save_rstd + g * C + c, rstd);
   }
   ldv<V>(beta + c, bt);
-#pragma unroll
-  for (int j = 0; j < V; ++j) {
-    const double inv = 1.0 / (double)R, dm = (double)s1[j] * inv;
-    double var = (double)s2[j] * inv - dm * dm;
-    var = var > 0.0 ? var : 0.0;
-    mean[j] = (float)((double)pv[j] + dm);
-    rstd[j] = rsqrtf((float)var + eps);        // (the float64 square root and division were most of this kernel's instructions)
-  }
-  if (blockIdx.x == 0 && rl == 0) { stv<V>(save_mean + g * C + c, mean); stv<V>(save_rstd + g * C + c, rstd); }
+  if (mode != kPartDone && blockIdx.x == 0 && rl == 0) { stv<V>(save_mean + g * C + c, mean); stv<V>(save_rstd + g * C + c, rstd); }
   // batches of 4 row passes with the loads issued together (a block walks ~4 passes: one memory round trip)
   const long long rstep = (long long)gridDim.x * 32;
   for (long long r = (long long)blockIdx.x * 32 + rl; r < R; r += kU * rstep) {
@@ -252,6 +309,22 @@ __global__ __launch_bounds__(256) void bn_apply_fwd(const TX* __restrict__ x, co
       }
     }
   }
+}
+
+// mean / rstd of every (group, channel) from the tile partials, for tensors whose convolution left so many partial blocks
+// that each apply block re-deriving them costs more than this launch: config 5's d/conv1 leaves 2048 per group, 512 KB
+// per apply block whose own work is 8 KB of the tensor - its BatchNorm ran at 0.8 TB/s (profiles/r2/h_other_ops_bf16_config5.txt)
+template <int V>
+__global__ __launch_bounds__(256) void bn_partials_finalize(const float* __restrict__ part, float* __restrict__ save_mean,
+                                                            float* __restrict__ save_rstd, long long R, int C, int nblk, float eps,
+                                                            const TileGeom tg) {
+  __shared__ double shd[4 * 8 * 3 * V];
+  const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3, g = blockIdx.z;
+  const int c = (blockIdx.y * 8 + cq) * V;
+  const bool cvalid = c < C;
+  float mean[V], rstd[V];
+  merge_tile_partials<V>(part, g, nblk, C, c, cvalid, rl, tg, R, eps, mean, rstd, shd);
+  if (cvalid && rl == 0) { stv<V>(save_mean + g * C + c, mean); stv<V>(save_rstd + g * C + c, rstd); }
 }
 
 // ---- BN backward ----------------------------------------------------------------------------------------
@@ -303,11 +376,11 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const TX* __restrict__ x, 
   }
 }
 
-template <int V, typename TX, typename TY>
+template <int V, typename TX, typename TY, typename TD = TX>
 __global__ __launch_bounds__(256) void bn_apply_bwd(const TX* __restrict__ x, const TY* __restrict__ dy,
                                                     const float* __restrict__ beta, const float* __restrict__ save_mean,
                                                     const float* __restrict__ save_rstd, const float* __restrict__ part,
-                                                    TX* __restrict__ dx, float* __restrict__ dbeta, float dbeta_acc,
+                                                    TD* __restrict__ dx, float* __restrict__ dbeta, float dbeta_acc,
                                                     long long R, int C, int groups, int nblk, int act, float leak, int XP, int YP) {
   __shared__ float sh[4 * 8 * 2 * V];
   const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3, g = blockIdx.z;
@@ -344,7 +417,7 @@ __global__ __launch_bounds__(256) void bn_apply_bwd(const TX* __restrict__ x, co
   if (!cvalid) return;
   const TX* xg = x + (long long)g * R * XP;
   const TY* dyg = dy + (long long)g * R * YP;
-  TX* dxg = dx + (long long)g * R * XP;
+  TD* dxg = dx + (long long)g * R * XP;
   float mean[V], rstd[V], bt[V], m1[V], m2[V];
   ldv<V>(save_mean + g * C + c, mean); ldv<V>(save_rstd + g * C + c, rstd); ldv<V>(beta + c, bt);
   const float invR = 1.f / (float)R;
@@ -443,10 +516,10 @@ __global__ __launch_bounds__(256) void bn_resident_fwd(TX* __restrict__ x, const
 }
 
 // One block per V channels walks the groups in turn (dbeta is the sum over groups of its first reduction).
-template <int V, int NR, typename TX, typename TY, bool SL = false>
+template <int V, int NR, typename TX, typename TY, bool SL = false, typename TD = TX>
 __global__ __launch_bounds__(256) void bn_resident_bwd(const TX* __restrict__ x, const TY* __restrict__ dy,
                                                        const float* __restrict__ beta, const float* __restrict__ save_mean,
-                                                       const float* __restrict__ save_rstd, TX* __restrict__ dx,
+                                                       const float* __restrict__ save_rstd, TD* __restrict__ dx,
                                                        float* __restrict__ dbeta, float dbeta_acc, int R, int C, int groups,
                                                        int act, float leak, int XP, int YP, const Slabs sl) {
   __shared__ float sh[4 * 2 * V];
@@ -753,28 +826,28 @@ int bn_fwd_typed(const void* x, const float* beta, void* y, float* save_mean, fl
   if (int rc = acg::check_launch("bn_stats_partial")) return rc;
   const dim3 ag(tile_row_blocks(R, C, V), (C + 8 * V - 1) / (8 * V), groups);
   if constexpr (same) {
-    if (v4) ACG_LAUNCH((bn_apply_fwd<4, TX, TY>), ag, dim3(256), 0, st, xf, beta, (const float*)part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, 1);
-    else ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, xf, beta, (const float*)part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, 1);
+    if (v4) ACG_LAUNCH((bn_apply_fwd<4, TX, TY>), ag, dim3(256), 0, st, xf, beta, (const float*)part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, (int)kPartShifted, TileGeom{0, 0, 1});
+    else ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, xf, beta, (const float*)part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, (int)kPartShifted, TileGeom{0, 0, 1});
   } else {
-    ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, xf, beta, (const float*)part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, 1);
+    ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, xf, beta, (const float*)part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, (int)kPartShifted, TileGeom{0, 0, 1});
   }
   return acg::check_launch("bn_apply_fwd");
 }
 
-template <typename TX, typename TY>
+template <typename TX, typename TY, typename TD = TX>
 int bn_bwd_typed(const void* x, const void* dy, const float* beta, const float* save_mean, const float* save_rstd, void* dx,
                  float* dbeta, float dbeta_acc, long long R, int C, int groups, int act, float leak, float* part, bool v4, int XP, int YP,
                  hipStream_t st, const Slabs sl = Slabs{nullptr, 0, 0}) {
   constexpr bool same = std::is_same<TX, TY>::value;
   const TX* xf = (const TX*)x;
   const TY* dyf = (const TY*)dy;
-  TX* dxf = (TX*)dx;
+  TD* dxf = (TD*)dx;
   if (!same) v4 = false;
   const int V = v4 ? 4 : 1;
   if (const int nr = resident_nr(R * groups, 16) ? resident_nr(R, 16) : 0) {
     const dim3 rg(C / V);
-#define ACG_BN_RES_BWD(VV, NN) do { if (sl.p) ACG_LAUNCH((bn_resident_bwd<VV, NN, TX, TY, true>), rg, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, (int)R, C, groups, act, leak, XP, YP, sl); \
-    else ACG_LAUNCH((bn_resident_bwd<VV, NN, TX, TY, false>), rg, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, (int)R, C, groups, act, leak, XP, YP, sl); } while (0)
+#define ACG_BN_RES_BWD(VV, NN) do { if (sl.p) ACG_LAUNCH((bn_resident_bwd<VV, NN, TX, TY, true, TD>), rg, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, (int)R, C, groups, act, leak, XP, YP, sl); \
+    else ACG_LAUNCH((bn_resident_bwd<VV, NN, TX, TY, false, TD>), rg, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, (int)R, C, groups, act, leak, XP, YP, sl); } while (0)
 #define ACG_BN_RES_BWD_V(NN) do { if constexpr (same) { if (v4) ACG_BN_RES_BWD(4, NN); else ACG_BN_RES_BWD(1, NN); } else ACG_BN_RES_BWD(1, NN); } while (0)
     switch (nr) {
       case 1: ACG_BN_RES_BWD_V(1); break;
@@ -795,32 +868,46 @@ int bn_bwd_typed(const void* x, const void* dy, const float* beta, const float* 
     if (v4) ACG_LAUNCH((bn_bwd_partial<4, TX, TY>), dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak, XP, YP);
     else ACG_LAUNCH((bn_bwd_partial<1, TX, TY>), dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak, XP, YP);
     if (int rc = acg::check_launch("bn_bwd_partial")) return rc;
-    if (v4) ACG_LAUNCH((bn_apply_bwd<4, TX, TY>), ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)part, dxf, dbeta, dbeta_acc, R, C, groups, nblk, act, leak, XP, YP);
-    else ACG_LAUNCH((bn_apply_bwd<1, TX, TY>), ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)part, dxf, dbeta, dbeta_acc, R, C, groups, nblk, act, leak, XP, YP);
+    if (v4) ACG_LAUNCH((bn_apply_bwd<4, TX, TY, TD>), ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)part, dxf, dbeta, dbeta_acc, R, C, groups, nblk, act, leak, XP, YP);
+    else ACG_LAUNCH((bn_apply_bwd<1, TX, TY, TD>), ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)part, dxf, dbeta, dbeta_acc, R, C, groups, nblk, act, leak, XP, YP);
   } else {
     ACG_LAUNCH((bn_bwd_partial<1, TX, TY>), dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak, XP, YP);
     if (int rc = acg::check_launch("bn_bwd_partial")) return rc;
-    ACG_LAUNCH((bn_apply_bwd<1, TX, TY>), ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)part, dxf, dbeta, dbeta_acc, R, C, groups, nblk, act, leak, XP, YP);
+    ACG_LAUNCH((bn_apply_bwd<1, TX, TY, TD>), ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)part, dxf, dbeta, dbeta_acc, R, C, groups, nblk, act, leak, XP, YP);
   }
   return acg::check_launch("bn_apply_bwd");
 }
 
-// BatchNorm + activation whose statistics arrive as per-tile partial sums out of the producing convolution's epilogue
-// (acg_conv2d_fwd_stats / acg_deconv2d_fwd_stats): the apply pass alone - ONE launch, x is read once.
+// BatchNorm + activation whose statistics arrive as per-tile (sum, M2) partials out of the producing convolution's epilogue
+// (acg_conv2d_fwd_stats / acg_deconv2d_fwd_stats): the apply pass alone - ONE launch, x is read once; above kFinalizeBlocks
+// partial blocks per group a small launch merges them first.
+constexpr int kFinalizeBlocks = 512;
 template <typename TX, typename TY>
-int bn_fwd_partials_typed(const void* x, const float* beta, const float* part, int nblk, void* y, float* save_mean, float* save_rstd,
-                          long long R, int C, int groups, float eps, int act, float leak, bool v4, int XP, int YP, hipStream_t st) {
+int bn_fwd_partials_typed(const void* x, const float* beta, const float* part, int nblk, const TileGeom tg, void* y, float* save_mean,
+                          float* save_rstd, long long R, int C, int groups, float eps, int act, float leak, bool v4, int XP, int YP,
+                          hipStream_t st) {
   constexpr bool same = std::is_same<TX, TY>::value;
   const TX* xf = (const TX*)x;
   TY* yf = (TY*)y;
+  const bool v4p = v4;                     // the partials / statistics side is float32 whatever the tensors are
   if (!same) v4 = false;
   const int V = v4 ? 4 : 1;
+  int mode = kPartTiles;
+  static const int fin = env_int("ACG_BN_FINALIZE_BLOCKS", kFinalizeBlocks);   // tuning hook
+  if (nblk > fin) {
+    const int VF = v4p ? 4 : 1;
+    const dim3 fg(1, (C + 8 * VF - 1) / (8 * VF), groups);
+    if (v4p) ACG_LAUNCH((bn_partials_finalize<4>), fg, dim3(256), 0, st, part, save_mean, save_rstd, R, C, nblk, eps, tg);
+    else ACG_LAUNCH((bn_partials_finalize<1>), fg, dim3(256), 0, st, part, save_mean, save_rstd, R, C, nblk, eps, tg);
+    if (int rc = acg::check_launch("bn_partials_finalize")) return rc;
+    mode = kPartDone;
+  }
   const dim3 ag(tile_row_blocks(R, C, V), (C + 8 * V - 1) / (8 * V), groups);
   if constexpr (same) {
-    if (v4) ACG_LAUNCH((bn_apply_fwd<4, TX, TY>), ag, dim3(256), 0, st, xf, beta, part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, 0);
-    else ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, xf, beta, part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, 0);
+    if (v4) ACG_LAUNCH((bn_apply_fwd<4, TX, TY>), ag, dim3(256), 0, st, xf, beta, part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, mode, tg);
+    else ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, xf, beta, part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, mode, tg);
   } else {
-    ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, xf, beta, part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, 0);
+    ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, xf, beta, part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, mode, tg);
   }
   return acg::check_launch("bn_apply_fwd");
 }
@@ -849,17 +936,23 @@ int32_t acg_bn_act_fwd(const void* x, const float* beta, void* y, float* save_me
   ACG_WITH_TYPES(dtype, "bn_act_fwd", return (bn_fwd_typed<TA, TB>(x, beta, y, save_mean, save_rstd, R, C, groups, eps, act, leak, (float*)ws, v4, XP, YP, acg::to_stream(stream))));
 }
 
-int32_t acg_bn_act_fwd_partials(const void* x, const float* beta, const float* partials, int32_t nblk, void* y, float* save_mean,
-                                float* save_rstd, int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t groups, float eps,
-                                int32_t act, float leak, int32_t dtype, acg_stream_t stream) {
+int32_t acg_bn_act_fwd_partials(const void* x, const float* beta, const float* partials, int32_t nblk, int32_t block_rows, int32_t run_rows,
+                                void* y, float* save_mean, float* save_rstd, int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch,
+                                int32_t groups, float eps, int32_t act, float leak, int32_t dtype, acg_stream_t stream) {
   const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
   ACG_REQUIRE(XP >= C && YP >= C, ACG_ERR_INVALID_ARG, "bn_act_fwd_partials: pitch smaller than the row");
   if (int rc = check_bn("bn_act_fwd_partials", rows, C, groups)) return rc;
   ACG_REQUIRE(x && beta && partials && nblk >= 1 && y && save_mean && save_rstd, ACG_ERR_INVALID_ARG, "bn_act_fwd_partials: null pointer / nblk < 1");
   ACG_REQUIRE(act == ACG_ACT_NONE || act == ACG_ACT_RELU || act == ACG_ACT_LRELU, ACG_ERR_UNSUPPORTED, "bn_act_fwd_partials: activation %d", act);
   const long long R = rows / groups;
+  // the blocks of a group tile `runs` runs of run_rows rows each, block_rows at a time (acg_conv2d_stats_layout)
+  ACG_REQUIRE(block_rows >= 1 && run_rows >= 1, ACG_ERR_INVALID_ARG, "bn_act_fwd_partials: block_rows / run_rows < 1");
+  const int bpr = (int)acg::ceil_div(run_rows, block_rows);
+  ACG_REQUIRE(nblk % bpr == 0 && (long long)(nblk / bpr) * run_rows == R, ACG_ERR_INVALID_ARG,
+              "bn_act_fwd_partials: %d blocks of %d rows in runs of %d do not cover %lld rows per group", nblk, block_rows, run_rows, R);
+  const TileGeom tg{block_rows, run_rows, bpr};
   const bool v4 = vec4_ok(C, x, y, beta) && vec4_ok(C, save_mean, save_rstd, partials) && XP % 4 == 0 && YP % 4 == 0;
-  ACG_WITH_TYPES(dtype, "bn_act_fwd_partials", return (bn_fwd_partials_typed<TA, TB>(x, beta, partials, nblk, y, save_mean, save_rstd, R, C, groups, eps, act, leak, v4, XP, YP, acg::to_stream(stream))));
+  ACG_WITH_TYPES(dtype, "bn_act_fwd_partials", return (bn_fwd_partials_typed<TA, TB>(x, beta, partials, nblk, tg, y, save_mean, save_rstd, R, C, groups, eps, act, leak, v4, XP, YP, acg::to_stream(stream))));
 }
 
 int32_t acg_bn_act_bwd(const void* x, const void* dy, const float* beta, const float* save_mean, const float* save_rstd,
@@ -873,6 +966,9 @@ int32_t acg_bn_act_bwd(const void* x, const void* dy, const float* beta, const f
   ACG_REQUIRE(ws && wsb >= acg_bn_workspace_bytes(rows, C, groups), ACG_ERR_WORKSPACE, "bn_act_bwd: workspace too small");
   const long long R = rows / groups;
   const bool v4 = vec4_ok(C, x, dy, dx) && vec4_ok(C, save_mean, save_rstd, ws) && vec4_ok(C, beta, dbeta, ws) && XP % 4 == 0 && YP % 4 == 0;
+  // ACG_DTYPE2(ACG_F32, ACG_BF16): a head layer of a bf16 network - x and dy float32, dx bf16 (acgan_hip.h)
+  if (dtype == ACG_DTYPE2(ACG_F32, ACG_BF16))
+    return bn_bwd_typed<float, float, __bf16>(x, dy, beta, save_mean, save_rstd, dx, dbeta, dbeta_acc, R, C, groups, act, leak, (float*)ws, v4, XP, YP, acg::to_stream(stream));
   ACG_WITH_TYPES(dtype, "bn_act_bwd", return (bn_bwd_typed<TA, TB>(x, dy, beta, save_mean, save_rstd, dx, dbeta, dbeta_acc, R, C, groups, act, leak, (float*)ws, v4, XP, YP, acg::to_stream(stream))));
 }
 

@@ -369,42 +369,13 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
   // ---- epilogue --------------------------------------------------------------------------------------
   // splits == 1: FWD / DGRAD write the bf16 activation (pitch round8), WGRAD the fp32 gradient; splits > 1: fp32 slabs
   // of out_numel elements laid out like the final tensor, summed (and rounded to bf16) by splitk_reduce.
-  const bool to_bf16 = MODE != MODE_WGRAD && p.splits == 1;
+  const bool to_bf16 = MODE != MODE_WGRAD && p.splits == 1 && !p.out_f32;
   if constexpr (MODE != MODE_WGRAD) {
     if (p.stats != nullptr) {     // BatchNorm statistics of this tile, of the bf16 values as stored (ConvArgs::stats, conv_f32_kernel.h)
-      float* const red = reinterpret_cast<float*>(smem);        // the A tiles are dead after the K loop's last barrier
-      const bool rows_full = m0 + BM <= M;                      // block-uniform: full tiles skip the per-element row test
-#pragma unroll
-      for (int b = 0; b < TB; ++b) {
-        float s1 = 0.f, s2 = 0.f;
-        if (rows_full) {
-#pragma unroll
-          for (int a = 0; a < TA; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { const float v = (float)(__bf16)acc[a][b][r]; s1 += v; s2 += v * v; }
-        } else {
-#pragma unroll
-          for (int a = 0; a < TA; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int row = wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lk;
-              const float v = m0 + row < M ? (float)(__bf16)acc[a][b][r] : 0.f;
-              s1 += v; s2 += v * v;
-            }
-        }
-        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-        if (lk == 0) { red[(wr * BN + wn0 + 32 * b + lrow) * 2] = s1; red[(wr * BN + wn0 + 32 * b + lrow) * 2 + 1] = s2; }
-      }
-      __syncthreads();
-      if (tid < BN && n0 + tid < N) {
-        float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < WM; ++w) { a1 += red[(w * BN + tid) * 2]; a2 += red[(w * BN + tid) * 2 + 1]; }
-        int g = 0, blk;
-        if constexpr (MODE == MODE_DGRAD) { blk = by * p.stats_tpg + tm; } else { g = tm / p.stats_tpg; blk = tm - g * p.stats_tpg; }
-        float* const o = p.stats + ((long long)g * p.stats_nblk + blk) * 2 * N + n0 + tid;
-        o[0] = a1; o[N] = a2;
-      }
+      int g = 0, blk;
+      if constexpr (MODE == MODE_DGRAD) { blk = by * p.stats_tpg + tm; } else { g = tm / p.stats_tpg; blk = tm - g * p.stats_tpg; }
+      tile_stats_epilogue<BM, BN, WM, TA, TB>([&](int a, int b, int r) { return to_bf16 ? (float)(__bf16)acc[a][b][r] : acc[a][b][r]; }, reinterpret_cast<float*>(smem),
+                                              p.stats + ((long long)g * p.stats_nblk + blk) * 2 * N, N, M, m0, n0, wm0, wn0, wr, lrow, lk, tid);
     }
   }
   float* const outf = p.out + (p.splits > 1 ? (long long)bz * p.out_numel : 0ll);

@@ -279,21 +279,22 @@ struct Job {
 // them - a split contraction holds partial sums only; a tile must not straddle two groups; the parity classes of a
 // DGRAD (a transposed layer's forward) must be of one size, or the smaller ones would leave partial blocks unwritten.
 constexpr int kMaxStatsBlocks = 4096;
-int stats_blocks(const Plan& pl, const acg_conv_desc& d, int which, int groups, int* tiles_per_group) {
+int stats_blocks(const Plan& pl, const acg_conv_desc& d, int which, int groups, int* tiles_per_group, int* run_rows = nullptr) {
   if (which == ACG_CONV_WGRAD || pl.splits != 1 || groups < 1) return 0;
   const long long tiles_m = acg::ceil_div(pl.M, pl.bm);
-  long long nblk = 0, tpg = 0;
+  long long nblk = 0, tpg = 0, run = 0;
   if (which == ACG_CONV_DGRAD) {
     if (groups != 1 || d.in_h % d.stride_h || d.in_w % d.stride_w) return 0;
-    tpg = tiles_m; nblk = tiles_m * pl.classes;
+    tpg = tiles_m; nblk = tiles_m * pl.classes; run = pl.M;        // a run of tiles = one stride class
   } else if (groups == 1) {
-    tpg = nblk = tiles_m;
+    tpg = nblk = tiles_m; run = pl.M;
   } else {
     if (pl.M % groups || (pl.M / groups) % pl.bm) return 0;
-    tpg = nblk = pl.M / groups / pl.bm;
+    tpg = nblk = pl.M / groups / pl.bm; run = pl.M / groups;
   }
-  if (nblk < 1 || nblk > kMaxStatsBlocks) return 0;
+  if (nblk < 1 || nblk > kMaxStatsBlocks || run >= (1ll << 31)) return 0;
   if (tiles_per_group) *tiles_per_group = (int)tpg;
+  if (run_rows) *run_rows = (int)run;
   return (int)nblk;
 }
 
@@ -301,7 +302,10 @@ int stats_blocks(const Plan& pl, const acg_conv_desc& d, int which, int groups, 
 // `splits` partial slabs in the workspace and `out` is not touched.
 int prepare(Job& j, int which, const float* gsrc, const float* dense, float* out, float accumulate, const acg_conv_desc* d,
             int dtype, void* ws, size_t ws_bytes, const char* who, bool slabs_only, float* stats = nullptr, int stats_groups = 0) {
-  ACG_REQUIRE(dtype == ACG_F32 || dtype == ACG_BF16, ACG_ERR_UNSUPPORTED, "%s: dtype %d", who, dtype);
+  // ACG_DTYPE2(ACG_BF16, ACG_F32): bf16 operands, the result stored as float32 (a head layer: acgan_hip.h)
+  const bool out_f32 = dtype == ACG_DTYPE2(ACG_BF16, ACG_F32);
+  ACG_REQUIRE(dtype == ACG_F32 || dtype == ACG_BF16 || (out_f32 && which != ACG_CONV_WGRAD), ACG_ERR_UNSUPPORTED, "%s: dtype %d", who, dtype);
+  if (out_f32) dtype = ACG_BF16;
   if (int rc = validate(d, who)) return rc;
   ACG_REQUIRE(gsrc && dense && (out || slabs_only), ACG_ERR_INVALID_ARG, "%s: null tensor pointer", who);
   const Plan pl = make_plan(*d, which, dtype == ACG_BF16);
@@ -311,6 +315,7 @@ int prepare(Job& j, int which, const float* gsrc, const float* dense, float* out
   ConvArgs a{};
   a.gsrc = gsrc; a.dense = dense; a.out = pl.splits > 1 ? (float*)ws : out; a.out_numel = pl.out_numel;
   a.accumulate = accumulate;
+  a.out_f32 = out_f32 ? 1 : 0;
   const bool h = dtype == ACG_BF16;
   const int cin8 = (d->in_c + 7) & ~7, cout8 = (d->out_c + 7) & ~7;
   if (h) {   // bf16 tensors: activations at pitch round8(C); `dense` is a prepared filter copy (acg_weights_prepare_bf16)
@@ -337,7 +342,7 @@ int prepare(Job& j, int which, const float* gsrc, const float* dense, float* out
   if (stats != nullptr) {
     int tpg = 0;
     const int nblk = stats_blocks(pl, *d, which, stats_groups, &tpg);
-    ACG_REQUIRE(nblk > 0, ACG_ERR_UNSUPPORTED, "%s: this shape provides no BatchNorm partials (acg_conv2d_stats_blocks == 0)", who);
+    ACG_REQUIRE(nblk > 0 && !out_f32, ACG_ERR_UNSUPPORTED, "%s: this shape provides no BatchNorm partials (acg_conv2d_stats_blocks == 0)", who);
     a.stats = stats; a.stats_nblk = nblk; a.stats_tpg = tpg;
   }
   j.which = which; j.pl = pl; j.a = a; j.ws = ws; j.out = out; j.accumulate = accumulate; j.slabs_only = slabs_only;
@@ -356,7 +361,7 @@ int launch(const Job& j, hipStream_t st) {
 }
 
 int reduce(const Job& j, hipStream_t st) {
-  if (j.pl.splits > 1 && !j.slabs_only && j.pl.bf16 && j.which != ACG_CONV_WGRAD) {
+  if (j.pl.splits > 1 && !j.slabs_only && j.pl.bf16 && j.which != ACG_CONV_WGRAD && !j.a.out_f32) {
     ACG_LAUNCH(splitk_reduce_bf16, dim3(reduce_blocks(j.pl.out_numel)), dim3(256), 0, st, (const float*)j.ws, (__bf16*)j.out, j.pl.out_numel, j.pl.splits);
     return acg::check_launch("splitk_reduce_bf16");
   }
@@ -433,18 +438,29 @@ int32_t acg_debug_conv_plan(int32_t cfg, int32_t splits) {
 
 size_t acg_conv2d_workspace_bytes(const acg_conv_desc* d, int32_t which, int32_t dtype) {
   if (!d || validate(d, "conv2d_workspace_bytes") != ACG_OK || which < 0 || which > 2) return 0;
-  const Plan pl = make_plan(*d, which, dtype == ACG_BF16);
+  const Plan pl = make_plan(*d, which, acg::dt_valid(dtype) && acg::dt_first(dtype) == ACG_BF16);
   return pl.splits > 1 ? (size_t)pl.splits * (size_t)pl.out_numel * sizeof(float) : 0;
 }
 
 int32_t acg_conv2d_splits(const acg_conv_desc* d, int32_t which, int32_t dtype) {
   if (!d || validate(d, "conv2d_splits") != ACG_OK || which < 0 || which > 2) return 0;
-  return make_plan(*d, which, dtype == ACG_BF16).splits;
+  return make_plan(*d, which, acg::dt_valid(dtype) && acg::dt_first(dtype) == ACG_BF16).splits;
 }
 
 int32_t acg_conv2d_stats_blocks(const acg_conv_desc* d, int32_t which, int32_t dtype, int32_t groups) {
-  if (!d || validate(d, "conv2d_stats_blocks") != ACG_OK || which < 0 || which > 2) return 0;
+  if (!d || validate(d, "conv2d_stats_blocks") != ACG_OK || which < 0 || which > 2 || (dtype != ACG_F32 && dtype != ACG_BF16)) return 0;
   return stats_blocks(make_plan(*d, which, dtype == ACG_BF16), *d, which, groups, nullptr);
+}
+int32_t acg_conv2d_stats_layout(const acg_conv_desc* d, int32_t which, int32_t dtype, int32_t groups, int32_t* block_rows, int32_t* run_rows) {
+  if (!d || validate(d, "conv2d_stats_layout") != ACG_OK || which < 0 || which > 2 || (dtype != ACG_F32 && dtype != ACG_BF16)) return 0;
+  const Plan pl = make_plan(*d, which, dtype == ACG_BF16);
+  int run = 0;
+  const int nblk = stats_blocks(pl, *d, which, groups, nullptr, &run);
+  if (nblk > 0) {
+    if (block_rows) *block_rows = pl.bm;
+    if (run_rows) *run_rows = run;
+  }
+  return nblk;
 }
 int32_t acg_conv2d_fwd_stats(const void* x, const void* w, void* y, const acg_conv_desc* d, int32_t dtype, void* ws, size_t wsb,
                              float* partials, int32_t groups, acg_stream_t s) {

@@ -55,11 +55,12 @@ struct ConvArgs {
   unsigned mg_ow, mg_oh, mg_cp;   // magic multipliers: r / OW = (r * mg_ow) >> sh_ow for 0 <= r < 2^31 (host: fast_div)
   int sh_ow, sh_oh, sh_cp;        // _cp: division by the gathered channel count padded to a multiple of 4
   // FWD / DGRAD with splits == 1, optional: the layer's BatchNorm statistics out of the epilogue.  Each block leaves the
-  // per-channel sum and sum of squares of ITS tile rows (of the values as stored) at
-  // stats[((g * stats_nblk + b) * 2 + {0,1}) * N + n], the partial-block layout bn_apply_fwd sums (bn.hip);
+  // per-channel SUM of ITS tile rows (of the values as stored) and their sum of squared deviations from the tile's own
+  // mean (M2) at stats[((g * stats_nblk + b) * 2 + {0: sum, 1: M2}) * N + n]; bn.hip merges the tiles (tile_stats below);
   // FWD: g = tile_row / stats_tpg, b = tile_row % stats_tpg; DGRAD (one group): b = class * stats_tpg + tile_row.
   float* stats;
   int stats_nblk, stats_tpg;
+  int out_f32;         // bf16 kernels, FWD / DGRAD: the result is stored as float32 (at the bf16 tensor's pitch, round8): a head layer
 };
 
 // Division by a launch-constant through multiply-high (Granlund-Montgomery, N = 31): a runtime integer division is
@@ -139,6 +140,77 @@ __device__ __forceinline__ f4 guarded_ragged(__amdgpu_buffer_rsrc_t rs, int elem
 __device__ __forceinline__ float guarded_scalar(__amdgpu_buffer_rsrc_t rs, int elem_off, bool ok) {
   const unsigned off = ok ? (unsigned)elem_off * 4u : kOob;
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+}
+
+// ---- BatchNorm statistics of a tile, out of the accumulators -----------------------------------------------------------
+// E[x^2] - E[x]^2 from plain float32 sums loses the variance once |mean| >> std (late GAN training: d/conv layers with a
+// drifted mean).  So nothing here ever squares an uncentred value: a thread centres its rows of a column on the first of
+// them, turns the result into (count, sum, M2 about its own mean), and partial results are merged pairwise with the
+// parallel-variance formula (Chan, Golub, LeVeque): M2 = M2a + M2b + (mean_b - mean_a)^2 * na * nb / (na + nb).
+struct TileStat { float n, sum, m2; };
+__device__ __forceinline__ TileStat stat_merge(const TileStat a, const TileStat b) {
+  const float n = a.n + b.n;
+  const float ma = a.sum / fmaxf(a.n, 1.f), mb = b.sum / fmaxf(b.n, 1.f), d = mb - ma;
+  return TileStat{n, a.sum + b.sum, a.m2 + b.m2 + d * d * (a.n * b.n / fmaxf(n, 1.f))};
+}
+// equal, non-zero counts (full tiles): no divisions by the counts
+__device__ __forceinline__ TileStat stat_merge_equal(const TileStat a, const TileStat b) {
+  const float d = (b.sum - a.sum) / a.n;
+  return TileStat{a.n + b.n, a.sum + b.sum, a.m2 + b.m2 + d * d * (0.5f * a.n)};
+}
+// The epilogue step shared by the fp32 and the bf16 kernel.  `value(a, b, r)` = accumulator element as it will be stored;
+// `red`: >= 3 * WM * BN floats of LDS that nothing reads any more (the A tiles after the K loop's last barrier).
+template <int BM, int BN, int WM, int TA, int TB, class V>
+__device__ __forceinline__ void tile_stats_epilogue(V&& value, float* red, float* out_sum, int N, int M, int m0, int n0, int wm0,
+                                                    int wn0, int wr, int lrow, int lk, int tid) {
+  const bool rows_full = m0 + BM <= M;                      // block-uniform: full tiles skip the per-element row test
+#pragma unroll
+  for (int b = 0; b < TB; ++b) {
+    TileStat t;
+    if (rows_full) {
+      const float c = value(0, b, 0);
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float d = value(a, b, r) - c; s1 += d; s2 += d * d; }
+      constexpr float n = 16.f * TA;
+      t = TileStat{n, n * c + s1, fmaxf(s2 - s1 * s1 * (1.f / n), 0.f)};
+      const TileStat o{n, __shfl_xor(t.sum, 32, 64), __shfl_xor(t.m2, 32, 64)};
+      t = stat_merge_equal(t, o);
+    } else {
+      float c = 0.f, n = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          if (m0 + row < M) {
+            const float v = value(a, b, r);
+            if (n == 0.f) c = v;
+            const float d = v - c;
+            n += 1.f; s1 += d; s2 += d * d;
+          }
+        }
+      t = TileStat{n, n * c + s1, fmaxf(s2 - s1 * s1 / fmaxf(n, 1.f), 0.f)};
+      const TileStat o{__shfl_xor(t.n, 32, 64), __shfl_xor(t.sum, 32, 64), __shfl_xor(t.m2, 32, 64)};
+      t = stat_merge(t, o);
+    }
+    if (lk == 0) {
+      float* const q = red + (wr * BN + wn0 + 32 * b + lrow) * 3;
+      q[0] = t.n; q[1] = t.sum; q[2] = t.m2;
+    }
+  }
+  __syncthreads();
+  if (tid < BN && n0 + tid < N) {
+    TileStat t{red[tid * 3], red[tid * 3 + 1], red[tid * 3 + 2]};
+#pragma unroll
+    for (int w = 1; w < WM; ++w) {
+      const float* const q = red + (w * BN + tid) * 3;
+      t = stat_merge(t, TileStat{q[0], q[1], q[2]});
+    }
+    out_sum[n0 + tid] = t.sum; out_sum[N + n0 + tid] = t.m2;
+  }
 }
 
 // RAGGED: gathered channel count not a multiple of 4; NVEC: dense operand rows are float4-loadable (N % 4 == 0).
@@ -604,40 +676,11 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
   }
   // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) --------------
   if constexpr (MODE != MODE_WGRAD) {
-    if (p.stats != nullptr) {     // BatchNorm statistics of this tile (ConvArgs::stats): lane -> half pair -> waves of a column
-      float* const red = reinterpret_cast<float*>(smem);        // the A tiles are dead after the K loop's last barrier
-      const bool rows_full = m0 + BM <= M;                      // block-uniform: full tiles skip the per-element row test
-#pragma unroll
-      for (int b = 0; b < TB; ++b) {
-        float s1 = 0.f, s2 = 0.f;
-        if (rows_full) {
-#pragma unroll
-          for (int a = 0; a < TA; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { const float v = acc[a][b][r]; s1 += v; s2 += v * v; }
-        } else {
-#pragma unroll
-          for (int a = 0; a < TA; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int row = wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lk;
-              const float v = m0 + row < M ? acc[a][b][r] : 0.f;
-              s1 += v; s2 += v * v;
-            }
-        }
-        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-        if (lk == 0) { red[(wr * BN + wn0 + 32 * b + lrow) * 2] = s1; red[(wr * BN + wn0 + 32 * b + lrow) * 2 + 1] = s2; }
-      }
-      __syncthreads();
-      if (tid < BN && n0 + tid < N) {
-        float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < WM; ++w) { a1 += red[(w * BN + tid) * 2]; a2 += red[(w * BN + tid) * 2 + 1]; }
-        int g = 0, blk;
-        if constexpr (MODE == MODE_DGRAD) { blk = by * p.stats_tpg + tm; } else { g = tm / p.stats_tpg; blk = tm - g * p.stats_tpg; }
-        float* const o = p.stats + ((long long)g * p.stats_nblk + blk) * 2 * N + n0 + tid;
-        o[0] = a1; o[N] = a2;
-      }
+    if (p.stats != nullptr) {     // BatchNorm statistics of this tile (ConvArgs::stats): thread -> lane-half pair -> waves of a column
+      int g = 0, blk;
+      if constexpr (MODE == MODE_DGRAD) { blk = by * p.stats_tpg + tm; } else { g = tm / p.stats_tpg; blk = tm - g * p.stats_tpg; }
+      tile_stats_epilogue<BM, BN, WM, TA, TB>([&](int a, int b, int r) { return acc[a][b][r]; }, reinterpret_cast<float*>(smem),
+                                              p.stats + ((long long)g * p.stats_nblk + blk) * 2 * N, N, M, m0, n0, wm0, wn0, wr, lrow, lk, tid);
     }
   }
   float* outp = p.out + (p.splits > 1 ? (long long)bz * p.out_numel : 0ll);

@@ -229,14 +229,16 @@ class _ConvBase(G.Op):
 class Conv2dOp(_ConvBase):
     """y = conv(x, w) (transposed=False) or TF conv2d_transpose(x, w) (transposed=True; desc is the adjoint conv)."""
 
-    def __init__(self, x, w, desc, transposed, name):
+    def __init__(self, x, w, desc, transposed, name, out_f32=False):
         g = G.get_default_graph()
         self.desc, self.transposed = desc, transposed
         self.which = CONV_DGRAD if transposed else CONV_FWD
         c = desc.in_c if transposed else desc.out_c
         shape = (desc.batch, desc.in_h, desc.in_w) if transposed else (desc.batch, desc.out_h, desc.out_w)
         cphys = cpad(c) if half_mode() else c          # bf16 activations live at the channel pitch round8(C)
-        y = _new_act(shape + (cphys,), name + ':0')
+        # out_f32 (bf16 graphs): the result stays float32, at the same pitch - the input of a head BatchNorm (_layer)
+        self.out_f32 = bool(out_f32) and half_mode()
+        y = _new(shape + (cphys,), name + ':0') if self.out_f32 else _new_act(shape + (cphys,), name + ':0')
         if cphys != c:
             y.valid_c = c
         self.wop = _wcopy(w, 'rm' if transposed else 'tr')
@@ -246,25 +248,34 @@ class Conv2dOp(_ConvBase):
 
     bn_consumer = None      # the layer's BnActOp (set by _layer): takes its statistics, or the split-K slabs, from this op
     _slab = None            # (workspace, splits) while this program's BatchNorm sums the slabs itself
-    _stats = None           # (partials, blocks per group) while this program's BatchNorm takes its statistics from the epilogue
+    _stats = None           # (partials, blocks per group, rows per block, rows per run) while this program's BatchNorm takes its statistics from the epilogue
 
     def bind(self, rt):
         x, w = self.inputs
         self._slab = self._stats = None
         bn = self.bn_consumer
+        if self.out_f32:
+            lib, d = rt.lib, self.desc
+            dt = _lib.dtype2(_lib.ACG_BF16, _lib.ACG_F32)
+            ws, n = rt.workspace(lib.conv2d_workspace_bytes(ctypes.byref(d), self.which, dt))
+            self._keep = (ws, d)
+            fn = lib.deconv2d_fwd if self.transposed else lib.conv2d_fwd
+            args = (_p(x.buf), _p(self.wop.buf), _p(self.outputs[0].buf), ctypes.byref(d), dt, _p(ws), n)
+            return lambda s: fn(*args, s)
         if bn is not None and id(bn) in rt.program_ops and rt.epilogue_stats and type(bn) is BnActOp:
             # followed by its BatchNorm in this program and not split: the epilogue leaves per-tile channel sums, the
             # BatchNorm runs its apply pass alone (acg_(de)conv2d_fwd_stats -> acg_bn_act_fwd_partials): one launch and one
             # read of the activation less
             lib, d, dt = rt.lib, self.desc, rt.conv_dtype
-            nblk = lib.conv2d_stats_blocks(ctypes.byref(d), self.which, dt, bn.groups)
+            brows, rrows = ctypes.c_int32(0), ctypes.c_int32(0)
+            nblk = lib.conv2d_stats_layout(ctypes.byref(d), self.which, dt, bn.groups, ctypes.byref(brows), ctypes.byref(rrows))
             if nblk > 0:
                 size = bn.groups * nblk * 2 * bn.c
                 part = self._part.get((rt.device, size))     # one buffer for every program this op is compiled into
                 if part is None:
                     part = self._part[(rt.device, size)] = torch.zeros(size, dtype=torch.float32, device=rt.device)
                 ws, n = rt.workspace(lib.conv2d_workspace_bytes(ctypes.byref(d), self.which, dt))
-                self._keep, self._stats = (ws, d, part), (part, nblk)
+                self._keep, self._stats = (ws, d, part), (part, nblk, brows.value, rrows.value)
                 fn = lib.deconv2d_fwd_stats if self.transposed else lib.conv2d_fwd_stats
                 args = (_p(x.buf), _p(self.wop.buf), _p(self.outputs[0].buf), ctypes.byref(d), dt, _p(ws), n, _p(part), bn.groups)
                 return lambda s: fn(*args, s)
@@ -443,8 +454,8 @@ class BnActOp(G.Op):
         src = self.conv_producer
         stats = src._stats if (src is not None and id(src) in rt.program_ops) else None
         if stats is not None:     # the conv's epilogue left the per-tile channel sums: the apply pass alone
-            part, nblk = stats
-            args = (_p(x.buf), _p(beta.buf), _p(part), nblk, _p(y.buf), _p(mean.buf), _p(rstd.buf), self.rows, self.c, self.xp, self.yp,
+            part, nblk, brows, rrows = stats
+            args = (_p(x.buf), _p(beta.buf), _p(part), nblk, brows, rrows, _p(y.buf), _p(mean.buf), _p(rstd.buf), self.rows, self.c, self.xp, self.yp,
                     self.groups, self.eps, _ACT_CODE[self.act], self.leak, _code2(x, y))
             fn = lib.bn_act_fwd_partials
             return lambda s: fn(*args, s)
@@ -480,7 +491,8 @@ class BnActBwdOp(G.Op):
         x, beta = fwd.inputs
         if dbeta_dst is None:                      # beta frozen in this pass: private scratch slot
             dbeta_dst = _new((fwd.c,), name + '/dbeta_scratch')
-        dx = _new(x.shape, name + ':0', x.dtype)
+        # (a head layer of a bf16 graph reads a float32 conv output, Conv2dOp out_f32: its gradient goes back as bf16)
+        dx = _new(x.shape, name + ':0', act_dtype())
         dx.valid_c = x.valid_c
         super().__init__(g, name, [x, dy, beta, fwd.mean, fwd.rstd], [dx, dbeta_dst])
 
@@ -498,8 +510,9 @@ class BnActBwdOp(G.Op):
                     f.rows, f.c, f.xp, f.yp, f.groups, _ACT_CODE[f.act], f.leak, _code2(x, dy), _p(ws), n)
             fn = lib.bn_act_bwd_slabs
             return lambda s: fn(*args, s)
+        dt = _lib.dtype2(_lib.ACG_F32, _lib.ACG_BF16) if (x.dtype == torch.float32 and dx.dtype == torch.bfloat16) else _code2(x, dy)
         args = (_p(x.buf), _p(dy.buf), _p(beta.buf), _p(mean.buf), _p(rstd.buf), _p(dx.buf), _p(dbeta.buf), self.accumulate,
-                f.rows, f.c, f.xp, f.yp, f.groups, _ACT_CODE[f.act], f.leak, _code2(x, dy), _p(ws), n)
+                f.rows, f.c, f.xp, f.yp, f.groups, _ACT_CODE[f.act], f.leak, dt, _p(ws), n)
         fn = lib.bn_act_bwd
         return lambda s: fn(*args, s)
 
@@ -1120,7 +1133,11 @@ def _layer(inputs, num_outputs, kernel_size, stride, padding, activation_fn, nor
             desc = _desc((b, h, w, cin, kh, kw, num_outputs, stride, padding, pitch))
         weights = g.get_variable(_scope_name('weights'), wshape, winit, share)
         name = _scope_name()
-        out = Conv2dOp(inputs, weights, desc, transposed, name + ('/conv2d_transpose' if transposed else '/conv2d')).outputs[0]
+        # a BatchNorm'd layer without activation is a head (d/conv6, models.py:87-88): in a bf16 graph its conv output stays
+        # float32 - the BatchNorm backward of a 1-channel head cancels to a few per cent of its terms, and one bf16 ulp of its
+        # input moved the whole discriminator gradient by 4-11 %
+        head = normalizer_fn is not None and activation_fn is None
+        out = Conv2dOp(inputs, weights, desc, transposed, name + ('/conv2d_transpose' if transposed else '/conv2d'), out_f32=head).outputs[0]
         act = _act_of(activation_fn)
         if normalizer_fn is not None:
             params = dict(normalizer_params or {})

@@ -101,7 +101,11 @@ int32_t acg_weights_prepare_bf16(const acg_prep_list* list, int32_t count, acg_s
 int32_t acg_debug_conv_plan(int32_t cfg, int32_t splits);
 #endif
 
-/* slim.conv2d's tf.nn.conv2d: models.py:12-15,34-37,42-51,82-88. */
+/* slim.conv2d's tf.nn.conv2d: models.py:12-15,34-37,42-51,82-88.
+ * dtype ACG_DTYPE2(ACG_BF16, ACG_F32) (acg_conv2d_fwd / acg_deconv2d_fwd): bf16 operands, y stored as float32 at the
+ * bf16 tensor's channel pitch round8(out_c) - a head layer whose BatchNorm has no activation (d/conv6, models.py:87-88):
+ * its BatchNorm backward is a difference of nearly equal terms, and bf16 rounding of its 1-channel input moved the
+ * whole discriminator gradient by 4-11 % (round 2's test_epilogue_statistics tolerance). */
 int32_t acg_conv2d_fwd(const void* x, const void* w, void* y, const acg_conv_desc* d, int32_t dtype,
                        void* workspace, size_t workspace_bytes, acg_stream_t stream);
 /* its gradient w.r.t. x (what tf.gradients emits for train.py:100-102). */
@@ -148,14 +152,20 @@ int32_t acg_splitk_reduce_many(const acg_reduce_list* list, int32_t count, acg_s
 
 /* BatchNorm statistics out of the producing convolution (models.py:10-15,31-44,80-87: every conv / conv2d_transpose but
  * three feeds slim.batch_norm, whose first pass re-reads the whole activation for its per-channel mean and variance).
- * acg_(de)conv2d_fwd_stats are acg_(de)conv2d_fwd that also leave, per row tile of the output, the per-channel sum and
- * sum of squares of the values as stored:
- *   partials[((g * nblk + b) * 2 + {0: sum, 1: sum of squares}) * out_channels + c],  g < groups, b < nblk
- * with nblk = acg_conv2d_stats_blocks(desc, which, dtype, groups) (which = ACG_CONV_FWD for a conv layer, ACG_CONV_DGRAD on
- * the adjoint descriptor for a transposed layer; 0 = this shape cannot: it is split over K, a tile would straddle two
- * groups, or the stride classes of a transposed layer differ in size - use the plain entry and acg_bn_act_fwd).
+ * acg_(de)conv2d_fwd_stats are acg_(de)conv2d_fwd that also leave, per row tile ("block") of the output, the per-channel
+ * SUM of the values as stored and their sum of squared deviations from the block's own mean (M2):
+ *   partials[((g * nblk + b) * 2 + {0: sum, 1: M2}) * out_channels + c],  g < groups, b < nblk
+ * (never a plain sum of squares: E[x^2] - E[x]^2 in float32 loses the variance once |mean| >> std).  Blocks are merged
+ * with the parallel-variance formula, which needs their row counts: nblk = acg_conv2d_stats_layout(desc, which, dtype,
+ * groups, &block_rows, &run_rows) - block b of a group covers min(block_rows, run_rows - (b % ceil(run_rows / block_rows))
+ * * block_rows) rows (a "run" = the rows of one group, or of one stride class of a transposed layer).
+ * which = ACG_CONV_FWD for a conv layer, ACG_CONV_DGRAD on the adjoint descriptor for a transposed layer; nblk = 0: this
+ * shape cannot - it is split over K, a tile would straddle two groups, or the stride classes of a transposed layer differ
+ * in size: use the plain entry and acg_bn_act_fwd.  acg_conv2d_stats_blocks returns nblk alone.
  * acg_bn_act_fwd_partials (below) consumes them: BatchNorm + activation in ONE launch. */
 int32_t acg_conv2d_stats_blocks(const acg_conv_desc* d, int32_t which, int32_t dtype, int32_t groups);
+int32_t acg_conv2d_stats_layout(const acg_conv_desc* d, int32_t which, int32_t dtype, int32_t groups, int32_t* block_rows,
+                                int32_t* run_rows);
 int32_t acg_conv2d_fwd_stats(const void* x, const void* w, void* y, const acg_conv_desc* d, int32_t dtype, void* workspace,
                              size_t workspace_bytes, float* partials, int32_t groups, acg_stream_t stream);
 int32_t acg_deconv2d_fwd_stats(const void* x, const void* w, void* y, const acg_conv_desc* adj, int32_t dtype, void* workspace,
@@ -224,8 +234,10 @@ int32_t acg_bn_act_bwd_sums(const void* x, const void* dy, const float* beta, co
  * launch while keeping separate batch statistics).  save_mean/save_rstd: [groups*channels].
  *   y = act((x - mean) * rsqrt(var + eps) + beta),  var biased.
  * bwd:  dbeta = dbeta_accumulate * dbeta + sum(dpre),  dx through mean and variance.
- * dtype: storage of x / dx, or ACG_DTYPE2(x, y) with y / dy the second type (ACG_DTYPE2(ACG_BF16, ACG_F32): the
- * loss-facing d/conv6 of a bf16 network keeps float32 logits).  Statistics, beta and dbeta are float32.
+ * dtype: storage of x / dx, or ACG_DTYPE2(x, y) with y / dy the second type (ACG_DTYPE2(ACG_BF16, ACG_F32): a
+ * loss-facing layer of a bf16 network keeps float32 logits).  acg_bn_act_bwd only: ACG_DTYPE2(ACG_F32, ACG_BF16) = x and
+ * dy float32, dx bf16 - the head layer whose conv output is kept in float32 (acg_conv2d_fwd) hands its gradient back
+ * into the bf16 network.  Statistics, beta and dbeta are float32.
  * x / dx rows are x_pitch elements apart, y / dy rows y_pitch (0 = dense = channels): the one-channel bf16 output of
  * d/conv6 sits at a pitch of 8; pad channels are neither read nor written.
  * ---------------------------------------------------------------------------------------- */
@@ -244,12 +256,14 @@ int32_t acg_bn_act_bwd_slabs(const void* x, const float* dy_slabs, int32_t split
                              const float* save_rstd, void* dx, float* dbeta, float dbeta_accumulate, int64_t rows,
                              int32_t channels, int32_t x_pitch, int32_t y_pitch, int32_t groups, int32_t act, float leak,
                              int32_t dtype, void* workspace, size_t workspace_bytes, acg_stream_t stream);
-/* BatchNorm + activation from the partial sums of acg_(de)conv2d_fwd_stats (plain sums over each block's rows; `nblk`
- * blocks per group): mean = sum / rows_per_group, var = sumsq / rows_per_group - mean^2 (float64 combine), then the
- * same apply pass as acg_bn_act_fwd.  No workspace. */
-int32_t acg_bn_act_fwd_partials(const void* x, const float* beta, const float* partials, int32_t nblk, void* y, float* save_mean,
-                                float* save_rstd, int64_t rows, int32_t channels, int32_t x_pitch, int32_t y_pitch,
-                                int32_t groups, float eps, int32_t act, float leak, int32_t dtype, acg_stream_t stream);
+/* BatchNorm + activation from the per-block (sum, M2) partials of acg_(de)conv2d_fwd_stats (`nblk` blocks per group, with
+ * the block_rows / run_rows of acg_conv2d_stats_layout): mean = sum of sums / rows_per_group, variance = (sum of M2 +
+ * sum_b n_b * (mean_b - mean)^2) / rows_per_group (float64 merge), then the same apply pass as acg_bn_act_fwd.  More
+ * than 512 blocks per group are merged by a small launch of their own first.  No workspace. */
+int32_t acg_bn_act_fwd_partials(const void* x, const float* beta, const float* partials, int32_t nblk, int32_t block_rows,
+                                int32_t run_rows, void* y, float* save_mean, float* save_rstd, int64_t rows, int32_t channels,
+                                int32_t x_pitch, int32_t y_pitch, int32_t groups, float eps, int32_t act, float leak, int32_t dtype,
+                                acg_stream_t stream);
 int32_t acg_bn_act_fwd(const void* x, const float* beta, void* y, float* save_mean, float* save_rstd,
                        int64_t rows, int32_t channels, int32_t x_pitch, int32_t y_pitch, int32_t groups, float eps,
                        int32_t act, float leak, int32_t dtype, void* workspace, size_t workspace_bytes,

@@ -168,16 +168,29 @@ int32_t acg_conv2d_stats_blocks(const acg_conv_desc* d, int32_t which, int32_t d
   if (rows % groups) return 0;
   return (rows / groups) % 2 == 0 ? 2 : 1;
 }
+int32_t acg_conv2d_stats_layout(const acg_conv_desc* d, int32_t which, int32_t dtype, int32_t groups, int32_t* block_rows, int32_t* run_rows) {
+  const int nblk = acg_conv2d_stats_blocks(d, which, dtype, groups);
+  if (nblk > 0) {
+    int64_t rows; int C, pitch;
+    stats_rows(d, which, &rows, &C, &pitch);
+    if (block_rows) *block_rows = (int32_t)(rows / groups / nblk);
+    if (run_rows) *run_rows = (int32_t)(rows / groups);
+  }
+  return nblk;
+}
+/* per block: the sum and M2 = the sum of squared deviations from the block's own mean (include/acgan_hip.h) */
 static void stats_of(const float* y, const acg_conv_desc* d, int32_t which, int32_t groups, float* part) {
   int64_t rows; int C, pitch;
   stats_rows(d, which, &rows, &C, &pitch);
   const int nblk = acg_conv2d_stats_blocks(d, which, ACG_F32, groups);
   const int64_t R = rows / groups, per = R / nblk;
   for (int g = 0; g < groups; g++) for (int b = 0; b < nblk; b++) for (int c = 0; c < C; c++) {
-    double s1 = 0, s2 = 0;
-    for (int64_t r = g * R + b * per; r < g * R + (b + 1) * per; r++) { double v = y[r * pitch + c]; s1 += v; s2 += v * v; }
+    double s1 = 0, m2 = 0;
+    for (int64_t r = g * R + b * per; r < g * R + (b + 1) * per; r++) s1 += y[r * pitch + c];
+    const double mb = s1 / (double)per;
+    for (int64_t r = g * R + b * per; r < g * R + (b + 1) * per; r++) { double dv = y[r * pitch + c] - mb; m2 += dv * dv; }
     part[((size_t)(g * nblk + b) * 2) * C + c] = (float)s1;
-    part[((size_t)(g * nblk + b) * 2 + 1) * C + c] = (float)s2;
+    part[((size_t)(g * nblk + b) * 2 + 1) * C + c] = (float)m2;
   }
 }
 int32_t acg_conv2d_fwd_stats(const void* x, const void* w, void* y, const acg_conv_desc* d, int32_t dtype, void* ws, size_t wsb,
@@ -287,18 +300,27 @@ int32_t acg_bn_act_fwd(const void* xv, const float* beta, void* yv, float* save_
   return ACG_OK;
 }
 
-int32_t acg_bn_act_fwd_partials(const void* xv, const float* beta, const float* partials, int32_t nblk, void* yv, float* save_mean,
-                                float* save_rstd, int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t groups, float eps,
-                                int32_t act, float leak, int32_t dtype, acg_stream_t s) {
+int32_t acg_bn_act_fwd_partials(const void* xv, const float* beta, const float* partials, int32_t nblk, int32_t block_rows, int32_t run_rows,
+                                void* yv, float* save_mean, float* save_rstd, int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch,
+                                int32_t groups, float eps, int32_t act, float leak, int32_t dtype, acg_stream_t s) {
   (void)s; REQUIRE_F32(dtype);
-  if (groups <= 0 || rows % groups || nblk < 1) return fail(ACG_ERR_INVALID_ARG, "bn partials: rows not divisible by groups / nblk < 1");
+  if (groups <= 0 || rows % groups || nblk < 1 || block_rows < 1 || run_rows < 1) return fail(ACG_ERR_INVALID_ARG, "bn partials: rows not divisible by groups / nblk < 1");
   const float* x = xv; float* y = yv; int64_t R = rows / groups;
   const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
+  const int bpr = (run_rows + block_rows - 1) / block_rows;
+  if (nblk % bpr || (int64_t)(nblk / bpr) * run_rows != R) return fail(ACG_ERR_INVALID_ARG, "bn partials: blocks do not cover the group");
   for (int g = 0; g < groups; g++) for (int c = 0; c < C; c++) {
     const float* xg = x + (size_t)g * R * XP; float* yg = y + (size_t)g * R * YP;
-    double s1 = 0, s2 = 0;
-    for (int b = 0; b < nblk; b++) { s1 += partials[((size_t)(g * nblk + b) * 2) * C + c]; s2 += partials[((size_t)(g * nblk + b) * 2 + 1) * C + c]; }
-    double m = s1 / (double)R, v = s2 / (double)R - m * m;
+    double s1 = 0;
+    for (int b = 0; b < nblk; b++) s1 += partials[((size_t)(g * nblk + b) * 2) * C + c];
+    const double m = s1 / (double)R;
+    double m2 = 0;     /* merge of the blocks: sum of M2_b + n_b (mean_b - mean)^2 */
+    for (int b = 0; b < nblk; b++) {
+      int nb = run_rows - (b % bpr) * block_rows; if (nb > block_rows) nb = block_rows;
+      const double mb = partials[((size_t)(g * nblk + b) * 2) * C + c] / (double)nb;
+      m2 += partials[((size_t)(g * nblk + b) * 2 + 1) * C + c] + (double)nb * (mb - m) * (mb - m);
+    }
+    double v = m2 / (double)R;
     if (v < 0) v = 0;
     double rstd = 1.0 / sqrt(v + (double)eps);
     save_mean[g * C + c] = (float)m; save_rstd[g * C + c] = (float)rstd;

@@ -83,7 +83,9 @@ def _layer(params, net, spec, x, create=None):
     # (bias layers, d/conv6 without activation) hand float32 to the losses
     w = T.q_weight(params[wname])
     x = T.q_act(x)
-    y = T.q_act(T.conv2d(x, w, s, pad) if kind == 'c' else T.conv2d_transpose(x, w, s, pad))
+    y = T.conv2d(x, w, s, pad) if kind == 'c' else T.conv2d_transpose(x, w, s, pad)
+    # a BatchNorm'd layer without activation (d/conv6) keeps its conv output in float32, only its gradient is bf16
+    y = T.q_grad(y) if (norm and act is None) else T.q_act(y)
     if norm:
         y = T.batch_norm_train(y, params['%s/%s/BatchNorm/beta' % (net, scope)])
     else:

@@ -47,8 +47,25 @@ class _RoundFwd(torch.autograd.Function):
         return g
 
 
+class _RoundBwd(torch.autograd.Function):
+    """forward: identity (the tensor is kept in float32); backward: g -> bf16(g) (its gradient is stored as bf16)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
 def q_act(x):
     return _RoundBoth.apply(x) if _BF16[0] else x
+
+
+def q_grad(x):
+    """A float32 tensor inside a bf16 network whose gradient goes back as bf16 (the conv output of a head layer)."""
+    return _RoundBwd.apply(x) if _BF16[0] else x
 
 
 def q_weight(w):

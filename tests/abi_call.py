@@ -69,11 +69,19 @@ class Abi:
         return rm, tr
 
     # ---- conv family (x NHWC, w HWIO)
-    def conv2d_fwd(self, x, w, stride, padding):
+    def conv2d_fwd(self, x, w, stride, padding, out_f32=False):
+        """``out_f32`` (bf16 only): ACG_DTYPE2(ACG_BF16, ACG_F32) - bf16 operands, float32 result at the pitch round8."""
         b, h, wd, c = x.shape
         pitch = c if c != w.shape[2] else 0            # x carries pad channels beyond the filter's Cin
         d = self.desc(b, h, wd, w.shape[2], w.shape[0], w.shape[1], w.shape[3], stride, padding, pitch)
         ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_FWD, self.conv_dtype))
+        if self.half and out_f32:
+            d.in_pitch = 0
+            x16, (rm, tr) = self.to16(x[..., :d.in_c]), self.prep_weights(w)
+            cp = (d.out_c + 7) // 8 * 8
+            y = torch.full((b, d.out_h, d.out_w, cp), 7.0, dtype=torch.float32, device=self.device)
+            self.lib.conv2d_fwd(_p(x16), _p(tr), _p(y), ctypes.byref(d), L.dtype2(L.ACG_BF16, L.ACG_F32), _p(ws), n, self.stream())
+            return y[..., :d.out_c].contiguous()
         if self.half:
             d.in_pitch = 0
             x16, (rm, tr) = self.to16(x[..., :d.in_c]), self.prep_weights(w)
@@ -225,15 +233,20 @@ class Abi:
                             L.dtype2(L.code(x.dtype), L.code(y.dtype)), _p(ws), n, self.stream())
         return y, mean, rstd
 
-    def bn_act_bwd(self, x, dy, beta, mean, rstd, act, groups=1, leak=0.2, dbeta=None, accumulate=0.0):
+    def bn_act_bwd(self, x, dy, beta, mean, rstd, act, groups=1, leak=0.2, dbeta=None, accumulate=0.0, dx_dtype=None):
+        """``dx_dtype`` bfloat16 with float32 x / dy: ACG_DTYPE2(ACG_F32, ACG_BF16), the float32 head of a bf16 network."""
         xp, c = x.shape[-1], dy.shape[-1]
         rows = x.numel() // xp
-        dx = torch.zeros_like(x)
+        dx = torch.zeros_like(x, dtype=dx_dtype or x.dtype)
         if dbeta is None:
             dbeta = self.empty(c)
         ws, n = self.ws(self.lib.bn_workspace_bytes(rows, c, groups))
+        dt = L.dtype2(L.code(x.dtype), L.code(dy.dtype))
+        if dx.dtype != x.dtype:
+            assert x.dtype == torch.float32 and dy.dtype == torch.float32 and dx.dtype == torch.bfloat16
+            dt = L.dtype2(L.ACG_F32, L.ACG_BF16)
         self.lib.bn_act_bwd(_p(x), _p(dy), _p(beta), _p(mean), _p(rstd), _p(dx), _p(dbeta), accumulate, rows, c, xp, c,
-                            groups, ACT[act], leak, L.dtype2(L.code(x.dtype), L.code(dy.dtype)), _p(ws), n, self.stream())
+                            groups, ACT[act], leak, dt, _p(ws), n, self.stream())
         return dx, dbeta
 
     # ---- BatchNorm statistics out of the producing convolution's epilogue
@@ -247,9 +260,12 @@ class Abi:
             b, h, wd, cin = x.shape
             d = self.desc(b, h, wd, w.shape[2], w.shape[0], w.shape[1], w.shape[3], stride, padding)
             which, c, oshape = L.CONV_FWD, d.out_c, (b, d.out_h, d.out_w)
-        nblk = self.lib.conv2d_stats_blocks(ctypes.byref(d), which, self.conv_dtype, groups)
+        brows, rrows = ctypes.c_int32(0), ctypes.c_int32(0)
+        nblk = self.lib.conv2d_stats_layout(ctypes.byref(d), which, self.conv_dtype, groups, ctypes.byref(brows), ctypes.byref(rrows))
+        assert nblk == self.lib.conv2d_stats_blocks(ctypes.byref(d), which, self.conv_dtype, groups)
         if nblk <= 0:
             return None
+        brows, rrows = brows.value, rrows.value
         part = torch.full((groups * nblk * 2 * c,), float('nan'), device=self.device)
         ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), which, self.conv_dtype))
         fn = self.lib.deconv2d_fwd_stats if transposed else self.lib.conv2d_fwd_stats
@@ -261,13 +277,13 @@ class Abi:
             conv = torch.zeros(*oshape, cp, dtype=torch.bfloat16, device=self.device)
             fn(_p(x16), _p(rm if transposed else tr), _p(conv), ctypes.byref(d), self.conv_dtype, _p(ws), n, _p(part), groups, self.stream())
             y = torch.zeros(*oshape, cp, dtype=torch.bfloat16, device=self.device)
-            self.lib.bn_act_fwd_partials(_p(conv), _p(beta), _p(part), nblk, _p(y), _p(mean), _p(rstd), rows, c, cp, cp, groups, eps,
+            self.lib.bn_act_fwd_partials(_p(conv), _p(beta), _p(part), nblk, brows, rrows, _p(y), _p(mean), _p(rstd), rows, c, cp, cp, groups, eps,
                                          ACT[act], leak, L.dtype2(L.ACG_BF16, L.ACG_BF16), self.stream())
             return self.from16(conv, c), self.from16(y, c), mean, rstd
         conv = self.empty(*oshape, c)
         fn(_p(x), _p(w), _p(conv), ctypes.byref(d), self.conv_dtype, _p(ws), n, _p(part), groups, self.stream())
         y = self.empty(*oshape, c)
-        self.lib.bn_act_fwd_partials(_p(conv), _p(beta), _p(part), nblk, _p(y), _p(mean), _p(rstd), rows, c, c, c, groups, eps, ACT[act],
+        self.lib.bn_act_fwd_partials(_p(conv), _p(beta), _p(part), nblk, brows, rrows, _p(y), _p(mean), _p(rstd), rows, c, c, c, groups, eps, ACT[act],
                                      leak, L.dtype2(L.ACG_F32, L.ACG_F32), self.stream())
         return conv, y, mean, rstd
 

@@ -197,6 +197,29 @@ def case_conv_bn_stats(abi, tol, tol_stat, min_fused=1):
     assert fused >= min_fused, 'only %d of %d layers took the fused path' % (fused, len(STATS_LAYERS))
 
 
+def case_conv_bn_stats_large_mean(abi, tol_stat):
+    """the statistics out of the conv epilogue must survive |mean| >> std (a drifted d/conv layer late
+    in GAN training).  1x1 convolutions with positive weights over inputs offset by 300: per-channel mean / std of the
+    output ~ 1e3, where E[x^2] - E[x]^2 from float32 sums (round 2) has no digits left.  Checked: the saved mean and rstd
+    against float64 statistics of the tensor as stored."""
+    r = (lambda t: t.bfloat16().float()) if abi.half else (lambda t: t)
+    for i, (b, h, w, cin, cout, groups) in enumerate([(8, 32, 32, 8, 64, 1), (16, 16, 16, 16, 32, 2), (4, 24, 20, 8, 40, 1)]):
+        x = uniform((b, h, w, cin), 700 + i) + 300.0
+        wt = randn((1, 1, cin, cout), 710 + i, 0.1).abs() + 0.02
+        beta = randn((cout,), 720 + i, 0.5)
+        got = abi.conv_bn_fused(x.to(abi.device), wt.to(abi.device), beta.to(abi.device), 1, 'SAME', 'relu', groups, False)
+        assert got is not None, 'large-mean layer %d did not take the fused path' % i
+        conv, y, mean, rstd = got
+        abi.sync()
+        rows = conv.detach().double().cpu().reshape(groups, -1, cout)          # the tensor as the kernel stored it
+        m, v = rows.mean(1), rows.var(1, unbiased=False)
+        ratio = (m.abs() / v.sqrt()).min().item()
+        assert ratio > 100, 'test premise: mean / std = %.1f' % ratio
+        close(mean, m.reshape(-1), 1e-6, 'large-mean layer %d mean' % i)
+        close(rstd, (1.0 / torch.sqrt(v + 1e-3)).reshape(-1), tol_stat, 'large-mean layer %d rstd' % i)
+        assert torch.isfinite(y.double()).all()
+
+
 def case_dna_second(abi, tol):
     """acg_dna_fwd out2 / acg_dna_bwd dout2 (the frame's second home, train.py:63-66): forward writes the frame also into channels
     [3, 6) of an 8-pitched tensor (float32 and bfloat16), leaving the other channels alone; backward with a gradient window equals
@@ -616,6 +639,34 @@ def case_bn_head_bf16(abi, tol, seed=0):
         assert dx.dtype == torch.bfloat16 and (dx[..., c:] == 0).all()
         close(dx[..., :c].float(), dx_ref, tol, 'bn head dx')
         close(dbeta, db_ref, 2e-4, 'bn head dbeta')
+
+
+def case_head_f32_in_bf16_network(abi, tol_w, tol_dx, seed=0):
+    """The head layer of a bf16 network kept in float32 (d/conv6, models.py:87-88): acg_conv2d_fwd with
+    ACG_DTYPE2(ACG_BF16, ACG_F32) - bf16 operands, float32 result at the pitch round8, split over K or not - and
+    acg_bn_act_bwd with ACG_DTYPE2(ACG_F32, ACG_BF16): float32 x / dy at a pitch of 8, bf16 dx."""
+    dev = abi.device
+    for i, (b, h, w, cin, cout, k, s_, pad) in enumerate([(8, 2, 2, 512, 1, 2, 1, 'SAME'), (2, 16, 16, 16, 5, 3, 1, 'SAME'), (4, 32, 32, 8, 40, 1, 1, 'SAME')]):
+        x, wt = uniform((b, h, w, cin), seed + i), randn((k, k, cin, cout), seed + 10 + i, 0.1)
+        y = abi.conv2d_fwd(x.to(dev), wt.to(dev), s_, pad, out_f32=True)
+        abi.sync()
+        y_ref = T.conv2d(r16(x).double(), r16(wt).double(), s_, pad)
+        close(y, y_ref, tol_w, 'head conv (bf16 operands, f32 result) %d' % i)       # no rounding of the result: accumulation level
+    for lead, c, groups in [((8, 2, 2), 1, 2), ((6, 3, 3), 5, 1)]:
+        x = randn(lead + (c,), seed, 1.5) + 0.3
+        beta = randn((c,), seed + 1, 0.3)
+        xd, bd = x.double().requires_grad_(True), beta.double().requires_grad_(True)
+        y_ref = _bn_ref(xd, bd, None, groups)
+        dy = randn(tuple(y_ref.shape), seed + 2)
+        dx_ref, db_ref = torch.autograd.grad(y_ref, [xd, bd], dy.double())
+        xp = torch.zeros(*lead, 8, dtype=torch.float32, device=dev)
+        xp[..., :c] = x.to(dev)
+        y, mean, rstd = abi.bn_act_fwd(xp, beta.to(dev), None, groups, y_dtype=torch.float32, c=c)
+        close(y, y_ref, 2e-5, 'f32 head bn fwd')
+        dx, dbeta = abi.bn_act_bwd(xp, dy.to(dev), beta.to(dev), mean, rstd, None, groups, dx_dtype=torch.bfloat16)
+        assert dx.dtype == torch.bfloat16 and dx.shape[-1] == 8 and (dx[..., c:] == 0).all()
+        close(dx[..., :c].float(), dx_ref, tol_dx, 'f32 head bn dx (bf16)')
+        close(dbeta, db_ref, 2e-4, 'f32 head bn dbeta')
 
 
 def case_bias_bf16(abi, tol, seed=0):

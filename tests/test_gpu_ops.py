@@ -46,6 +46,15 @@ def test_conv_bn_stats_bf16(hip_abi_bf16):
     C.case_conv_bn_stats(hip_abi_bf16, TOL_BF16, 2e-3, min_fused=4)
 
 
+def test_conv_bn_stats_large_mean(hip_abi):
+    """Tile statistics are centred before they are squared and merged Chan-style (mean / std ~ 1e3)."""
+    C.case_conv_bn_stats_large_mean(hip_abi, 2e-3)
+
+
+def test_conv_bn_stats_large_mean_bf16(hip_abi_bf16):
+    C.case_conv_bn_stats_large_mean(hip_abi_bf16, 2e-3)
+
+
 def test_dna_second(hip_abi):
     """The frame's second home: acg_dna_fwd out2 / acg_dna_bwd dout2, float32 and bf16 tensors, both kernel families."""
     C.case_dna_second(hip_abi, 1e-5)
@@ -72,6 +81,11 @@ def test_bn_bf16(hip_abi, shape):
 
 def test_bn_head_bf16(hip_abi):
     C.case_bn_head_bf16(hip_abi, 6e-3)
+
+
+def test_head_f32_in_bf16_network(hip_abi_bf16):
+    """d/conv6 of a bf16 network stays float32: conv result and BatchNorm input float32, gradient back as bf16."""
+    C.case_head_f32_in_bf16_network(hip_abi_bf16, TOL_CONV, 6e-3)
 
 
 def test_bias_bf16(hip_abi):

@@ -1,6 +1,8 @@
 """GPU parity of the whole training step (host runtime over libacgan_hip.so) against the fp64-oracle
 golden vectors, plus HIP-graph replay equivalence.  Tolerance: 1e-3 rel (north_star) on frames and
 losses; gradients are compared per variable by L2 norm at 10x that."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -265,11 +267,15 @@ def test_training_loop_runs_wass_rmsprop_n_critic():
 # concatenated maps and the gradients of all of them; float32 master weights, weight gradients, statistics and
 # losses).  What is left between the two is summation order (fp32 vs fp64 accumulation) and the one-ulp bf16 rounding
 # flips it causes (2^-8 relative each), compounding through ~10 layers:
-BF16_TOL = {'frame': 1.5e-2,      # max abs error of the predicted frame / frame scale
-            'state': 3e-2,        # predicted state (a 5-vector behind three strided convs on 4x4 maps)
-            'loss': 5e-3,         # D and G loss values, relative
-            'grad_norm': 5e-2,    # per-variable gradient L2 norm, relative
-            'grad_cos': 0.97}     # per-variable gradient direction: cosine with the oracle's gradient
+# Round 3 (profiles/r3/bf16_vs_oracle_*.txt, the per-variable table this test prints): every weight gradient's norm is
+# within 0.5 % (betas, 100x smaller vectors, within 2.5 %) and every cosine >= 0.992 at batch 32 / >= 0.983 at batch 2,
+# after the head layer d/conv6 stopped rounding its conv output to bf16 (round 2: 3.6 % / 0.984).  The cosine floor is
+# the chaos of storage rounding amplified by the BatchNorm'd head (test_epilogue_statistics_match_the_statistics_pass).
+BF16_TOL = {'frame': 1.0e-2,      # max abs error of the predicted frame / frame scale        (measured 0.71e-2 / 0.37e-2)
+            'state': 1.5e-2,      # predicted state (a 5-vector behind three strided convs)    (0.83e-2 / 1.0e-2)
+            'loss': 5e-3,         # D and G loss values, relative                              (<= 4e-5)
+            'grad_norm': 3e-2,    # per-variable gradient L2 norm, relative                    (2.5e-2 / 1.8e-2, betas)
+            'grad_cos': 0.98}     # per-variable gradient direction: cosine with the oracle's  (0.9923 / 0.9837)
 
 
 def _bf16_step_vs_oracle(B, S, K, loss, opt, seed):
@@ -301,19 +307,24 @@ def _bf16_step_vs_oracle(B, S, K, loss, opt, seed):
         flat = step_op.inputs[1].buf.detach().double().cpu()
         return {n: flat[o:o + g.variables[n].numel].reshape(g.variables[n].shape) for n, o in offs.items()}
 
+    lines = []
+
     def check_grads(got, want, what):
         scale = max(float(v.norm()) for v in want.values())
         worst_n, worst_c = 0.0, 1.0
+        failures = []
         for n, w in want.items():
             wn, gn = float(w.norm()), float(got[n].norm())
             if wn < 1e-6 * scale:
                 assert gn <= 1e-3 * scale, (what, n, gn)
                 continue
             cos = float((w * got[n]).sum() / (wn * gn))
+            lines.append('%-8s %-36s |g| %.4e  norm err %+.4f  cos %.5f' % (what, n, wn, (gn - wn) / wn, cos))
             worst_n, worst_c = max(worst_n, abs(gn - wn) / wn), min(worst_c, cos)
-            assert abs(gn - wn) <= BF16_TOL['grad_norm'] * wn + 1e-5 * scale, (what, n, gn, wn)
-            assert cos >= BF16_TOL['grad_cos'], (what, n, cos)
+            if abs(gn - wn) > BF16_TOL['grad_norm'] * wn + 1e-5 * scale or cos < BF16_TOL['grad_cos']:
+                failures.append((what, n, gn, wn, cos))
         report[what] = (worst_n, worst_c)
+        return failures
 
     with OT.bf16_storage():
         frame, state, _ = tr.test(x, y, a)
@@ -325,13 +336,21 @@ def _bf16_step_vs_oracle(B, S, K, loss, opt, seed):
         od = ot.train_d(td(x), td(y), td(a), return_all=True)
         report['d_loss'] = abs(dsumm['discriminator_loss'] - float(od['d_loss'])) / max(abs(float(od['d_loss'])), 1.0)
         assert report['d_loss'] <= BF16_TOL['loss'], report
-        check_grads(got_d, ot.last_grads, 'D grad')
+        bad = check_grads(got_d, ot.last_grads, 'D grad')
         res = sess.run([tr.g_opt_op, tr.g_loss], tr._feed(x, y, a, s))
         got_g = grads_of(tr.g_opt_op)
         og = ot.train_g(td(x), td(y), td(a), td(s), return_all=True)
         report['g_loss'] = abs(res[1][0] - float(og['g_loss'])) / abs(float(og['g_loss']))
         assert report['g_loss'] <= BF16_TOL['loss'], report
-        check_grads(got_g, ot.last_grads, 'G grad')
+        bad += check_grads(got_g, ot.last_grads, 'G grad')
+    # the per-variable table: printed always, kept when ACG_BF16_REPORT names a directory
+    table = '\n'.join(lines)
+    print(table)
+    if os.environ.get('ACG_BF16_REPORT'):
+        with open(os.path.join(os.environ['ACG_BF16_REPORT'], 'bf16_vs_oracle_b%d_s%d_k%d.txt' % (B, S, K)), 'w') as f:
+            f.write('# bf16 pipeline vs fp64 oracle with the same tensors rounded to bf16: per-variable gradient norm error and cosine\n')
+            f.write(table + '\n' + repr(report) + '\n')
+    assert not bad, bad
     print('bf16 vs oracle (B=%d, %dx%d, k=%d):' % (B, S, S, K), {k: (tuple(round(float(t), 5) for t in v) if isinstance(v, tuple) else round(float(v), 5)) for k, v in report.items()})
 
 
@@ -414,9 +433,9 @@ def test_epilogue_statistics_match_the_statistics_pass(dtype):
     different order (per row tile, then float64), so the gradients and frames of the first D + G step must agree with the
     statistics-pass run to rounding level, and the fused path must actually have been taken."""
     from action_conditioned_gans_amd import ops as O
-    x, y, a, s = TC.MG.inputs(2)
-    xs, ys = np.tile(x, (4, 1, 1, 1)), np.tile(y, (4, 1, 1, 1))
-    as_, ss = np.tile(a, (4, 1)), np.tile(s, (4, 1))
+    # eight DISTINCT samples (round 2 tiled two samples four times: BatchNorm over 8 distinct values per channel in the
+    # 2x2 layers - an ill-conditioned normalisation that amplified one bf16 ulp into 4-11 % of the discriminator gradient)
+    xs, ys, as_, ss = TC.MG.inputs(8)
     finals = []
     for fused in (False, True):
         sess, tr = TC.build_trainer(gpu_session, 'c2_dna_bce_adam', batch=8, dtype=dtype, epilogue_stats=fused)
@@ -430,11 +449,21 @@ def test_epilogue_statistics_match_the_statistics_pass(dtype):
         finals.append((grads, frames))
     (g0, f0), (g1, f1) = finals
     # the gradients of the first D and G step (the weights behind them are an Adam step apart whatever the gradient's size, so
-    # they are the wrong thing to compare): whole-buffer relative error at accumulation-order level
-    # (bf16: a last-bit change of a statistic re-rounds every activation behind it, and rounding noise is the bf16 gradient's
-    # error floor - the bf16-vs-oracle tests of this file sit at cosine 0.984 - so the bound there is that floor)
-    tol = 2e-5 if dtype == 'f32' else 0.1          # measured: 2.7e-6 / 1.1e-6 (float32), 4.4e-2 / 2.4e-3 (bf16: D, G)
-    for a0, a1, who in zip(g0, g1, ('d', 'g')):
+    # they are the wrong thing to compare), whole-buffer relative error.
+    # float32: the discriminator's loss is smooth -> accumulation-order level.  The generator's loss is not: |G - y| and the
+    # GDL (ops.py:100-120) have kinks, and ONE element of the 8 x 64 x 64 x 3 frame gradient changing sign moves the whole
+    # gradient by 2 / sqrt(1.5e6) = 1.6e-3 - which a rounding-level change of the frame does to the odd element that sits
+    # within 1e-7 of a kink (measured with eight distinct samples: D 3.7e-6, G 1.7e-3 = one flip); allow three.
+    # bf16: storage rounding is chaotic - a last-bit change of one statistic re-rounds 3e-5 of that layer's elements by a
+    # whole bf16 ulp, the next layer's inputs then differ by 2e-5 everywhere, which re-rounds 0.5 % of ITS outputs, and after
+    # three or four layers two runs differ by the full bf16 rounding noise (~3e-3 per element) everywhere.  The discriminator
+    # then amplifies it: its last layer is BatchNorm'd without activation (models.py:87-88), dy of the bce loss is nearly
+    # linear in the normalised logit, and BatchNorm backward removes exactly the constant and linear parts - what is left is
+    # ~1/30 of dy, so a 2e-3 relative perturbation of the normalised logits is 5-10 % of the gradient.  That is the floor of
+    # ANY two bf16 runs of this model (the bf16-vs-oracle tests above sit at cosine 0.9967 = 8 %); measured here with eight
+    # distinct samples: D 6.3e-2, G 4.6e-2 (G: ~200 of the frame-loss kinks flip under a 1e-4 change of the frame).
+    tols = {'f32': (2e-5, 5e-3), 'bf16': (0.1, 0.1)}[dtype]
+    for a0, a1, who, tol in zip(g0, g1, ('d', 'g'), tols):
         err = float((a0 - a1).norm() / a0.norm())
         print('epilogue statistics vs pass, %s, %s gradient: relative difference %.3g' % (dtype, who, err))
         assert err <= tol, (who, err)

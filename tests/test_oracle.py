@@ -58,6 +58,10 @@ def test_conv_bn_stats(oracle_abi):
     C.case_conv_bn_stats(oracle_abi, TOL, TOL, min_fused=6)
 
 
+def test_conv_bn_stats_large_mean(oracle_abi):
+    C.case_conv_bn_stats_large_mean(oracle_abi, 1e-4)
+
+
 def test_dna_second(oracle_abi):
     C.case_dna_second(oracle_abi, TOL)
 

@@ -206,26 +206,45 @@ __device__ __forceinline__ void sum_partials(const float* __restrict__ part, int
 }
 
 // Forward statistics of one group from the per-tile (sum, M2) partials a convolution's epilogue left (conv_f32_kernel.h
-// tile_stats_epilogue): mean = sum of sums / R, M2 = sum of M2_b + sum_b n_b mean_b^2 - R mean^2 with mean_b = sum_b / n_b.
-// Float64 accumulators: the last two terms cancel to ~(mean / std)^2 digits, which float64 has to spare where float32
-// (round 2's plain sums) lost the variance.  Same thread mapping as sum_partials.  n_b from the tile geometry.
+// tile_stats_epilogue), merged with the parallel-variance formula about a REFERENCE mean - the first tile's - so that
+// float32 is enough: with d_b = sum_b - n_b * ref (small: a tile mean deviates from the reference by ~std / sqrt(n_b))
+//   mean = ref + sum(d_b) / R,   M2 = sum(M2_b) + sum(d_b^2 / n_b) - sum(d_b)^2 / R
+// every term is centred, nothing of size mean^2 is ever formed (round 2 summed plain squares: the variance was gone once
+// |mean| >> std; a float64 merge of uncentred terms is robust too, but cost this prologue 4 us per layer).
+// Same thread mapping as sum_partials.  n_b from the tile geometry (all tiles full unless run_rows % block_rows).
 struct TileGeom { int block_rows, run_rows, blocks_per_run; };
 template <int V>
 __device__ __forceinline__ void merge_tile_partials(const float* __restrict__ part, int g, int nblk, int C, int c, bool cvalid, int rl,
                                                     const TileGeom tg, long long R, float eps, float (&mean)[V], float (&rstd)[V],
-                                                    double* sh /* 4 * 8 * 3 * V doubles */) {
-  double S[V], Q[V], P[V];
+                                                    float* sh /* 4 * 8 * 3 * V floats */) {
+  float S[V], Q[V], P[V], ref[V];
 #pragma unroll
-  for (int j = 0; j < V; ++j) { S[j] = 0.0; Q[j] = 0.0; P[j] = 0.0; }
+  for (int j = 0; j < V; ++j) { S[j] = 0.f; Q[j] = 0.f; P[j] = 0.f; ref[j] = 0.f; }
+  const bool uniform = tg.run_rows % tg.block_rows == 0;      // block-uniform
   if (cvalid) {
-    for (int b = rl; b < nblk; b += 32) {
-      const float* o = part + ((long long)g * nblk + b) * 2 * C + c;
-      float a[V], q[V];
-      ldv<V>(o, a); ldv<V>(o + C, q);
-      const int nb = min(tg.block_rows, tg.run_rows - (b % tg.blocks_per_run) * tg.block_rows);
-      const double inv = 1.0 / (double)nb;
+    const float* p0 = part + (long long)g * nblk * 2 * C + c;
+    ldv<V>(p0, ref);
+    const float inv0 = 1.f / (float)min(tg.block_rows, tg.run_rows);
 #pragma unroll
-      for (int j = 0; j < V; ++j) { S[j] += (double)a[j]; Q[j] += (double)q[j]; P[j] += (double)a[j] * (double)a[j] * inv; }
+    for (int j = 0; j < V; ++j) ref[j] *= inv0;
+    if (uniform) {
+      const float nb = (float)tg.block_rows, inv = 1.f / nb;
+      for (int b = rl; b < nblk; b += 32) {
+        const float* o = p0 + (long long)b * 2 * C;
+        float a[V], q[V];
+        ldv<V>(o, a); ldv<V>(o + C, q);
+#pragma unroll
+        for (int j = 0; j < V; ++j) { const float d = fmaf(-nb, ref[j], a[j]); S[j] += d; P[j] = fmaf(d * inv, d, P[j]); Q[j] += q[j]; }
+      }
+    } else {
+      for (int b = rl; b < nblk; b += 32) {
+        const float* o = p0 + (long long)b * 2 * C;
+        float a[V], q[V];
+        ldv<V>(o, a); ldv<V>(o + C, q);
+        const float nb = (float)min(tg.block_rows, tg.run_rows - (b % tg.blocks_per_run) * tg.block_rows), inv = 1.f / nb;
+#pragma unroll
+        for (int j = 0; j < V; ++j) { const float d = fmaf(-nb, ref[j], a[j]); S[j] += d; P[j] = fmaf(d * inv, d, P[j]); Q[j] += q[j]; }
+      }
     }
   }
 #pragma unroll
@@ -237,19 +256,18 @@ __device__ __forceinline__ void merge_tile_partials(const float* __restrict__ pa
   __syncthreads();
   if ((threadIdx.x & 63) < 8) {
 #pragma unroll
-    for (int j = 0; j < V; ++j) { double* q = sh + ((wave * 8 + cq) * 3) * V + j; q[0] = S[j]; q[V] = Q[j]; q[2 * V] = P[j]; }
+    for (int j = 0; j < V; ++j) { float* q = sh + ((wave * 8 + cq) * 3) * V + j; q[0] = S[j]; q[V] = Q[j]; q[2 * V] = P[j]; }
   }
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < V; ++j) {
-    double s = 0.0, q = 0.0, pp = 0.0;
+    float s = 0.f, q = 0.f, pp = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { const double* z = sh + ((w * 8 + cq) * 3) * V + j; s += z[0]; q += z[V]; pp += z[2 * V]; }
-    const double inv = 1.0 / (double)R, dm = s * inv;
-    double var = (q + pp - s * dm) * inv;
-    var = var > 0.0 ? var : 0.0;
-    mean[j] = (float)dm;
-    rstd[j] = rsqrtf((float)var + eps);
+    for (int w = 0; w < 4; ++w) { const float* z = sh + ((w * 8 + cq) * 3) * V + j; s += z[0]; q += z[V]; pp += z[2 * V]; }
+    const float inv = 1.f / (float)R, dm = s * inv;
+    const float var = fmaxf((q + (pp - s * dm)) * inv, 0.f);
+    mean[j] = ref[j] + dm;
+    rstd[j] = rsqrtf(var + eps);
   }
 }
 
@@ -264,8 +282,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd(const TX* __restrict__ x, co
                                                     float* __restrict__ save_mean, float* __restrict__ save_rstd,
                                                     long long R, int C, int nblk, float eps, int act, float leak, int XP, int YP,
                                                     int mode, const TileGeom tg) {
-  __shared__ double shd[4 * 8 * 3 * V];
-  float* const sh = reinterpret_cast<float*>(shd);
+  __shared__ float sh[4 * 8 * 3 * V];
   const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3, g = blockIdx.z;
   const int c = (blockIdx.y * 8 + cq) * V;
   const bool cvalid = c < C;
@@ -273,7 +290,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd(const TX* __restrict__ x, co
   TY* yg = y + (long long)g * R * YP;
   float mean[V], rstd[V], bt[V];
   if (mode == kPartTiles) {
-    merge_tile_partials<V>(part, g, nblk, C, c, cvalid, rl, tg, R, eps, mean, rstd, shd);
+    merge_tile_partials<V>(part, g, nblk, C, c, cvalid, rl, tg, R, eps, mean, rstd, sh);
     if (!cvalid) return;
   } else if (mode == kPartShifted) {       // partials of bn_stats_partial: sums of (x - first row of the group)
     float s1[V], s2[V], pv[V];
@@ -318,12 +335,12 @@ template <int V>
 __global__ __launch_bounds__(256) void bn_partials_finalize(const float* __restrict__ part, float* __restrict__ save_mean,
                                                             float* __restrict__ save_rstd, long long R, int C, int nblk, float eps,
                                                             const TileGeom tg) {
-  __shared__ double shd[4 * 8 * 3 * V];
+  __shared__ float sh[4 * 8 * 3 * V];
   const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3, g = blockIdx.z;
   const int c = (blockIdx.y * 8 + cq) * V;
   const bool cvalid = c < C;
   float mean[V], rstd[V];
-  merge_tile_partials<V>(part, g, nblk, C, c, cvalid, rl, tg, R, eps, mean, rstd, shd);
+  merge_tile_partials<V>(part, g, nblk, C, c, cvalid, rl, tg, R, eps, mean, rstd, sh);
   if (cvalid && rl == 0) { stv<V>(save_mean + g * C + c, mean); stv<V>(save_rstd + g * C + c, rstd); }
 }
 

@@ -9,7 +9,9 @@
 //  * WGRAD contracts over pixels, the slow axis of both of its operands: the tiles go to LDS as they lie in memory,
 //    [pixel][channel] in 8-row x 32-column subtiles, and the MFMA fragments are read with ds_read_b64_tr_b16 (hardware
 //    transpose, two reads per fragment) - no register transpose.
-// Tiles: 64x64 and 128x128 per 256-thread block (wave tile 32x32 / 64x64).
+// Tiles: 64x64 and 128x128 per 256-thread block (wave tile 32x32 / 64x64), and 128x32 (four waves stacked along M, wave
+// tile 32x32) for FWD / DGRAD contractions with at most 32 output columns: g/tconv4's 25 DNA logits, d/conv1's 6-channel
+// input gradient, g/conv1 - on a 64-wide tile half or more of every MFMA was padding (profiles/r2: 174 and 34 TFLOP/s).
 #pragma once
 #include "conv_f32_kernel.h"
 
@@ -39,7 +41,7 @@ __device__ __forceinline__ int tr_off(int row, int ch) {
 
 template <int MODE, int BM, int BN>
 __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, const int by, const int bz, const int gx, char* smem) {
-  constexpr int WM = 2, WN = 2;
+  constexpr int WN = BN >= 64 ? 2 : 1, WM = 4 / WN;
   constexpr int TA = BM / (32 * WM), TB = BN / (32 * WN);
   constexpr int QA = BM / 32, QB = BN / 32;          // octs per thread per K-step and operand
   constexpr int NROW = (MODE == MODE_WGRAD) ? 2 * 256 : BM;
@@ -503,7 +505,10 @@ int launch_mode16(const Plan& pl, const ConvArgs& a, hipStream_t st);
   int launch_mode16<MODE>(const Plan& pl, const ConvArgs& a, hipStream_t st) {                                \
     const dim3 grid((unsigned)(acg::ceil_div(pl.M, pl.bm) * acg::ceil_div(pl.N, pl.bn)), (unsigned)pl.classes, \
                     (unsigned)pl.splits);                                                                     \
-    if (pl.bm == 128) ACG_LAUNCH((conv_mfma_bf16<MODE, 128, 128>), grid, dim3(256), 0, st, a);                \
+    if (pl.bn == 32) {                                                                                        \
+      if constexpr (MODE != MODE_WGRAD) ACG_LAUNCH((conv_mfma_bf16<MODE, 128, 32>), grid, dim3(256), 0, st, a); \
+      else return acg::fail(ACG_ERR_UNSUPPORTED, "conv_mfma_bf16: no 128x32 weight-gradient tile");           \
+    } else if (pl.bm == 128) ACG_LAUNCH((conv_mfma_bf16<MODE, 128, 128>), grid, dim3(256), 0, st, a);         \
     else ACG_LAUNCH((conv_mfma_bf16<MODE, 64, 64>), grid, dim3(256), 0, st, a);                               \
     return acg::check_launch("conv_mfma_bf16");                                                               \
   }

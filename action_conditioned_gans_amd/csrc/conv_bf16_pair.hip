@@ -4,15 +4,16 @@
 namespace acgconv {
 
 namespace {
-template <int MODE_A, int BMA>
+template <int MODE_A, int BMA, int BNA>
 void launch_b(const Plan& pb, const ConvArgs& a, const ConvArgs& b, const PairGeom& g, unsigned blocks, hipStream_t st) {
-  if (pb.bm == 128) ACG_LAUNCH((conv_pair_bf16<MODE_A, BMA, BMA, 128, 128>), dim3(blocks), dim3(256), 0, st, a, b, g);
-  else ACG_LAUNCH((conv_pair_bf16<MODE_A, BMA, BMA, 64, 64>), dim3(blocks), dim3(256), 0, st, a, b, g);
+  if (pb.bm == 128) ACG_LAUNCH((conv_pair_bf16<MODE_A, BMA, BNA, 128, 128>), dim3(blocks), dim3(256), 0, st, a, b, g);
+  else ACG_LAUNCH((conv_pair_bf16<MODE_A, BMA, BNA, 64, 64>), dim3(blocks), dim3(256), 0, st, a, b, g);
 }
 template <int MODE_A>
 void launch_a(const Plan& pa, const Plan& pb, const ConvArgs& a, const ConvArgs& b, const PairGeom& g, unsigned blocks, hipStream_t st) {
-  if (pa.bm == 128) launch_b<MODE_A, 128>(pb, a, b, g, blocks, st);
-  else launch_b<MODE_A, 64>(pb, a, b, g, blocks, st);
+  if (pa.bn == 32) launch_b<MODE_A, 128, 32>(pb, a, b, g, blocks, st);          // narrow input gradient (g/conv2: 32 channels)
+  else if (pa.bm == 128) launch_b<MODE_A, 128, 128>(pb, a, b, g, blocks, st);
+  else launch_b<MODE_A, 64, 64>(pb, a, b, g, blocks, st);
 }
 }  // namespace
 

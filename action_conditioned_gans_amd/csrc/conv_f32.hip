@@ -233,7 +233,12 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
     static const int big_min = env_int("ACG_PLAN16_BIG_TILES", 256);
     const bool big = pl.N > 64 && pl.M >= 128 && (which == ACG_CONV_WGRAD ? pl.nk >= 256 : tiles_for(128, 128) >= big_min);
     pl.cfg = big ? 1 : 3; pl.bm = pl.bn = big ? 128 : 64;
+    // at most 32 output columns (g/tconv4's 25 logits, d/conv1's 6-channel input gradient, g/conv1, the state head): the
+    // 128x32 tile - no MFMA columns of padding beyond the first 32 (forward / input gradient only)
+    static const int narrow = env_int("ACG_PLAN16_NARROW", 1);
+    if (narrow && which != ACG_CONV_WGRAD && pl.N <= 32 && pl.M >= 128) { pl.cfg = 2; pl.bm = 128; pl.bn = 32; }
     if (g_force_cfg == 1 || g_force_cfg == 3) { pl.cfg = g_force_cfg; pl.bm = pl.bn = g_force_cfg == 1 ? 128 : 64; }
+    if (g_force_cfg == 2 && which != ACG_CONV_WGRAD) { pl.cfg = 2; pl.bm = 128; pl.bn = 32; }
     pl.ragged = false; pl.nvec = true;
   }
   pl.tiles = tiles_for(pl.bm, pl.bn);

@@ -258,7 +258,7 @@ int32_t acg_bn_act_bwd_slabs(const void* x, const float* dy_slabs, int32_t split
                              int32_t dtype, void* workspace, size_t workspace_bytes, acg_stream_t stream);
 /* BatchNorm + activation from the per-block (sum, M2) partials of acg_(de)conv2d_fwd_stats (`nblk` blocks per group, with
  * the block_rows / run_rows of acg_conv2d_stats_layout): mean = sum of sums / rows_per_group, variance = (sum of M2 +
- * sum_b n_b * (mean_b - mean)^2) / rows_per_group (float64 merge), then the same apply pass as acg_bn_act_fwd.  More
+ * sum_b n_b * (mean_b - mean)^2) / rows_per_group (merged about the first block's mean), then the apply pass of acg_bn_act_fwd.  More
  * than 512 blocks per group are merged by a small launch of their own first.  No workspace. */
 int32_t acg_bn_act_fwd_partials(const void* x, const float* beta, const float* partials, int32_t nblk, int32_t block_rows,
                                 int32_t run_rows, void* y, float* save_mean, float* save_rstd, int64_t rows, int32_t channels,

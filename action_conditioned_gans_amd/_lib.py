@@ -85,11 +85,13 @@ SIGNATURES = {
     'acg_deconv2d_dgrad': (c_int32, _conv),
     'acg_deconv2d_wgrad': (c_int32, _wgrad),
     'acg_bn_workspace_bytes': (c_size_t, [c_int64, c_int32, c_int32]),
-    'acg_bn_moments': (c_int32, [_P, _P, c_int64, c_int32, c_int32, c_int32, _P, c_size_t, _P]),
-    'acg_bn_act_fwd_moments': (c_int32, [_P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_float, c_int32, c_float, c_int32, _P]),
-    'acg_bn_bwd_sums': (c_int32, [_P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_float, c_int32, _P, c_size_t, _P]),
-    'acg_bn_act_bwd_sums': (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, c_float, c_int64, c_int32, c_int32, c_int32,
-                                      c_float, c_int32, _P]),
+    'acg_bn_moments': (c_int32, [_P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, c_size_t, _P]),
+    'acg_bn_act_fwd_moments': (c_int32, [_P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, c_float,
+                                         c_int32, _P]),
+    'acg_bn_bwd_sums': (c_int32, [_P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, _P,
+                                  c_size_t, _P]),
+    'acg_bn_act_bwd_sums': (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, c_float, c_int64, c_int32, c_int32, c_int32, c_int32,
+                                      c_int32, c_float, c_int32, _P]),
     'acg_bn_act_fwd': (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, c_float,
                                  c_int32, _P, c_size_t, _P]),
     'acg_bn_act_bwd': (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,

@@ -398,13 +398,18 @@ __global__ __launch_bounds__(256) void bn_apply_bwd(const TX* __restrict__ x, co
                                                     const float* __restrict__ beta, const float* __restrict__ save_mean,
                                                     const float* __restrict__ save_rstd, const float* __restrict__ part,
                                                     TD* __restrict__ dx, float* __restrict__ dbeta, float dbeta_acc,
-                                                    long long R, int C, int groups, int nblk, int act, float leak, int XP, int YP) {
+                                                    long long R, int C, int groups, int nblk, int act, float leak, int XP, int YP,
+                                                    const float* __restrict__ gsums = nullptr, float inv_total = 0.f) {
   __shared__ float sh[4 * 8 * 2 * V];
   const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3, g = blockIdx.z;
   const int c = (blockIdx.y * 8 + cq) * V;
   const bool cvalid = c < C;
   float s1[V], s2[V];
-  if (blockIdx.x == 0 && g == 0) {   // this block also owns dbeta of its channels: sum over every group
+  if (gsums != nullptr) {            // synchronised BatchNorm: the sums of the GLOBAL batch are given, dbeta is formed elsewhere
+#pragma unroll
+    for (int j = 0; j < V; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    if (cvalid) { ldv<V>(gsums + (g * 2 + 0) * C + c, s1); ldv<V>(gsums + (g * 2 + 1) * C + c, s2); }
+  } else if (blockIdx.x == 0 && g == 0) {   // this block also owns dbeta of its channels: sum over every group
     float tot[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) tot[j] = 0.f;
@@ -437,7 +442,7 @@ __global__ __launch_bounds__(256) void bn_apply_bwd(const TX* __restrict__ x, co
   TD* dxg = dx + (long long)g * R * XP;
   float mean[V], rstd[V], bt[V], m1[V], m2[V];
   ldv<V>(save_mean + g * C + c, mean); ldv<V>(save_rstd + g * C + c, rstd); ldv<V>(beta + c, bt);
-  const float invR = 1.f / (float)R;
+  const float invR = gsums != nullptr ? inv_total : 1.f / (float)R;
 #pragma unroll
   for (int j = 0; j < V; ++j) { m1[j] = s1[j] * invR; m2[j] = s2[j] * invR; }
   const long long rstep = (long long)gridDim.x * 32;
@@ -728,8 +733,9 @@ int tile_row_blocks(long long R, int C, int V) {
 
 // ---- synchronised BatchNorm (optional data-parallel mode; plain elementwise kernels, nothing tuned) -----------
 // moments / sums from the per-block partials: one thread per (group, channel), fp64 combine
-__global__ __launch_bounds__(256) void bn_moments_finalize(const float* __restrict__ part, const float* __restrict__ x,
-                                                           float* __restrict__ moments, long long R, int C, int groups, int nblk) {
+template <typename TX>
+__global__ __launch_bounds__(256) void bn_moments_finalize(const float* __restrict__ part, const TX* __restrict__ x,
+                                                           float* __restrict__ moments, long long R, int C, int XP, int groups, int nblk) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= groups * C) return;
   const int g = i / C, c = i - g * C;
@@ -738,10 +744,19 @@ __global__ __launch_bounds__(256) void bn_moments_finalize(const float* __restri
     s1 += part[((long long)g * nblk + b) * 2 * C + c];
     s2 += part[((long long)g * nblk + b) * 2 * C + C + c];
   }
-  const double shift = x[(long long)g * R * C + c], dm = s1 / (double)R;
+  const double shift = (double)acg::ldf(x + (long long)g * R * XP + c), dm = s1 / (double)R;
   double var = s2 / (double)R - dm * dm;
   moments[(g * 2 + 0) * C + c] = (float)(shift + dm);
   moments[(g * 2 + 1) * C + c] = (float)(var > 0.0 ? var : 0.0);
+}
+// (mean, var) of the global batch -> the saved mean / rstd the apply kernels read (bn_apply_fwd mode kPartDone)
+__global__ __launch_bounds__(256) void bn_moments_to_stats(const float* __restrict__ moments, float* __restrict__ save_mean,
+                                                           float* __restrict__ save_rstd, int C, int groups, float eps) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= groups * C) return;
+  const int g = i / C, c = i - g * C;
+  save_mean[i] = moments[(g * 2 + 0) * C + c];
+  save_rstd[i] = 1.0f / sqrtf(moments[(g * 2 + 1) * C + c] + eps);
 }
 __global__ __launch_bounds__(256) void bn_sums_finalize(const float* __restrict__ part, float* __restrict__ sums, int C,
                                                         int groups, int nblk) {
@@ -755,33 +770,6 @@ __global__ __launch_bounds__(256) void bn_sums_finalize(const float* __restrict_
   }
   sums[(g * 2 + 0) * C + c] = (float)s1;
   sums[(g * 2 + 1) * C + c] = (float)s2;
-}
-__global__ __launch_bounds__(256) void bn_fwd_moments_k(const float* __restrict__ x, const float* __restrict__ beta,
-                                                        const float* __restrict__ moments, float* __restrict__ y,
-                                                        float* __restrict__ save_mean, float* __restrict__ save_rstd,
-                                                        long long R, int C, int groups, float eps, int act, float leak) {
-  const long long n = (long long)groups * R * C, stride = (long long)gridDim.x * 256;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    const long long row = i / C;
-    const int c = (int)(i - row * C), g = (int)(row / R);
-    const float mean = moments[(g * 2 + 0) * C + c], rstd = 1.0f / sqrtf(moments[(g * 2 + 1) * C + c] + eps);
-    y[i] = acg::act_apply(act, (x[i] - mean) * rstd + beta[c], leak);
-    if (row == (long long)g * R) { save_mean[g * C + c] = mean; save_rstd[g * C + c] = rstd; }
-  }
-}
-__global__ __launch_bounds__(256) void bn_bwd_sums_k(const float* __restrict__ x, const float* __restrict__ dy,
-                                                     const float* __restrict__ beta, const float* __restrict__ save_mean,
-                                                     const float* __restrict__ save_rstd, const float* __restrict__ sums,
-                                                     float* __restrict__ dx, long long R, int C, int groups, float inv_total,
-                                                     int act, float leak) {
-  const long long n = (long long)groups * R * C, stride = (long long)gridDim.x * 256;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    const long long row = i / C;
-    const int c = (int)(i - row * C), g = (int)(row / R);
-    const float rstd = save_rstd[g * C + c], xh = (x[i] - save_mean[g * C + c]) * rstd;
-    const float dp = dy[i] * acg::act_deriv_pre(act, xh + beta[c], leak);
-    dx[i] = rstd * (dp - sums[(g * 2 + 0) * C + c] * inv_total - xh * sums[(g * 2 + 1) * C + c] * inv_total);
-  }
 }
 __global__ __launch_bounds__(256) void bn_dbeta_local_k(const float* __restrict__ local_sums, float* __restrict__ dbeta,
                                                         float acc, int C, int groups) {
@@ -1024,67 +1012,139 @@ int32_t acg_bn_act_bwd_slabs(const void* x, const float* dy_slabs, int32_t split
   ACG_WITH_TYPES(dtype, "bn_act_bwd_slabs", return (bn_bwd_typed<TA, TB>(x, nullptr, beta, save_mean, save_rstd, dx, dbeta, dbeta_acc, R, C, groups, act, leak, (float*)ws, v4, XP, YP, acg::to_stream(stream), sl)));
 }
 
-int32_t acg_bn_moments(const void* x, float* moments, int64_t rows, int32_t C, int32_t groups, int32_t dtype, void* ws,
+}  // extern "C"
+
+// ---- synchronised BatchNorm entries: any storage-type pair the plain entries take, pitched rows ---------------------------
+namespace {
+template <typename TX>
+int bn_moments_typed(const void* x, float* moments, long long R, int C, int XP, int groups, float* part, bool v4, hipStream_t st) {
+  TX* xf = (TX*)const_cast<void*>(x);
+  const int V = v4 ? 4 : 1, nblk = vpartial_blocks(R, C, V, 8);
+  if (v4) ACG_LAUNCH((bn_stats_partial<4, TX>), dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk, XP, Slabs{nullptr, 0, 0});
+  else ACG_LAUNCH((bn_stats_partial<1, TX>), dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk, XP, Slabs{nullptr, 0, 0});
+  if (int rc = acg::check_launch("bn_stats_partial")) return rc;
+  ACG_LAUNCH((bn_moments_finalize<TX>), dim3((groups * C + 255) / 256), dim3(256), 0, st, (const float*)part, (const TX*)x, moments, R, C, XP, groups, nblk);
+  return acg::check_launch("bn_moments_finalize");
+}
+template <typename TX, typename TY>
+int bn_fwd_moments_typed(const void* x, const float* beta, void* y, float* save_mean, float* save_rstd, long long R, int C, int groups,
+                         float eps, int act, float leak, bool v4, int XP, int YP, hipStream_t st) {
+  constexpr bool same = std::is_same<TX, TY>::value;
+  if (!same) v4 = false;
+  const int V = v4 ? 4 : 1;
+  const dim3 ag(tile_row_blocks(R, C, V), (C + 8 * V - 1) / (8 * V), groups);
+  const TileGeom tg{0, 0, 1};
+  if constexpr (same) {
+    if (v4) ACG_LAUNCH((bn_apply_fwd<4, TX, TY>), ag, dim3(256), 0, st, (const TX*)x, beta, (const float*)nullptr, (TY*)y, save_mean, save_rstd, R, C, 0, eps, act, leak, XP, YP, (int)kPartDone, tg);
+    else ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, (const TX*)x, beta, (const float*)nullptr, (TY*)y, save_mean, save_rstd, R, C, 0, eps, act, leak, XP, YP, (int)kPartDone, tg);
+  } else {
+    ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, (const TX*)x, beta, (const float*)nullptr, (TY*)y, save_mean, save_rstd, R, C, 0, eps, act, leak, XP, YP, (int)kPartDone, tg);
+  }
+  return acg::check_launch("bn_apply_fwd");
+}
+template <typename TX, typename TY>
+int bn_bwd_sums_typed(const void* x, const void* dy, const float* beta, const float* save_mean, const float* save_rstd, float* sums,
+                      long long R, int C, int groups, int act, float leak, float* part, bool v4, int XP, int YP, hipStream_t st) {
+  constexpr bool same = std::is_same<TX, TY>::value;
+  if (!same) v4 = false;
+  const int V = v4 ? 4 : 1, nblk = vpartial_blocks(R, C, V, 4);
+  if constexpr (same) {
+    if (v4) ACG_LAUNCH((bn_bwd_partial<4, TX, TY>), dim3(nblk, groups), dim3(256), 0, st, (const TX*)x, (const TY*)dy, beta, save_mean, save_rstd, part, R, C, nblk, act, leak, XP, YP);
+    else ACG_LAUNCH((bn_bwd_partial<1, TX, TY>), dim3(nblk, groups), dim3(256), 0, st, (const TX*)x, (const TY*)dy, beta, save_mean, save_rstd, part, R, C, nblk, act, leak, XP, YP);
+  } else {
+    ACG_LAUNCH((bn_bwd_partial<1, TX, TY>), dim3(nblk, groups), dim3(256), 0, st, (const TX*)x, (const TY*)dy, beta, save_mean, save_rstd, part, R, C, nblk, act, leak, XP, YP);
+  }
+  if (int rc = acg::check_launch("bn_bwd_partial")) return rc;
+  ACG_LAUNCH(bn_sums_finalize, dim3((groups * C + 255) / 256), dim3(256), 0, st, (const float*)part, sums, C, groups, nblk);
+  return acg::check_launch("bn_sums_finalize");
+}
+template <typename TX, typename TY, typename TD = TX>
+int bn_bwd_apply_sums_typed(const void* x, const void* dy, const float* beta, const float* save_mean, const float* save_rstd,
+                            const float* gsums, float inv_total, void* dx, long long R, int C, int groups, int act, float leak, bool v4,
+                            int XP, int YP, hipStream_t st) {
+  constexpr bool same = std::is_same<TX, TY>::value;
+  if (!same) v4 = false;
+  const int V = v4 ? 4 : 1;
+  const dim3 ag(tile_row_blocks(R, C, V), (C + 8 * V - 1) / (8 * V), groups);
+  if constexpr (same) {
+    if (v4) ACG_LAUNCH((bn_apply_bwd<4, TX, TY, TD>), ag, dim3(256), 0, st, (const TX*)x, (const TY*)dy, beta, save_mean, save_rstd, (const float*)nullptr, (TD*)dx, (float*)nullptr, 0.f, R, C, groups, 0, act, leak, XP, YP, gsums, inv_total);
+    else ACG_LAUNCH((bn_apply_bwd<1, TX, TY, TD>), ag, dim3(256), 0, st, (const TX*)x, (const TY*)dy, beta, save_mean, save_rstd, (const float*)nullptr, (TD*)dx, (float*)nullptr, 0.f, R, C, groups, 0, act, leak, XP, YP, gsums, inv_total);
+  } else {
+    ACG_LAUNCH((bn_apply_bwd<1, TX, TY, TD>), ag, dim3(256), 0, st, (const TX*)x, (const TY*)dy, beta, save_mean, save_rstd, (const float*)nullptr, (TD*)dx, (float*)nullptr, 0.f, R, C, groups, 0, act, leak, XP, YP, gsums, inv_total);
+  }
+  return acg::check_launch("bn_apply_bwd");
+}
+}  // namespace
+
+extern "C" {
+
+int32_t acg_bn_moments(const void* x, float* moments, int64_t rows, int32_t C, int32_t x_pitch, int32_t groups, int32_t dtype, void* ws,
                        size_t wsb, acg_stream_t stream) {
-  ACG_REQUIRE_F32(dtype);
+  const int XP = x_pitch > 0 ? x_pitch : C;
+  ACG_REQUIRE(XP >= C, ACG_ERR_INVALID_ARG, "bn_moments: pitch smaller than the row");
   if (int rc = check_bn("bn_moments", rows, C, groups)) return rc;
   ACG_REQUIRE(x && moments, ACG_ERR_INVALID_ARG, "bn_moments: null pointer");
   ACG_REQUIRE(ws && wsb >= acg_bn_workspace_bytes(rows, C, groups), ACG_ERR_WORKSPACE, "bn_moments: workspace too small");
+  ACG_REQUIRE(dtype == ACG_F32 || dtype == ACG_BF16, ACG_ERR_UNSUPPORTED, "bn_moments: dtype %d (the storage type of x)", dtype);
   const long long R = rows / groups;
-  hipStream_t st = acg::to_stream(stream);
-  const bool v4 = vec4_ok(C, x, x, ws);
-  const int V = v4 ? 4 : 1, nblk = vpartial_blocks(R, C, V, 8);
-  if (v4) ACG_LAUNCH((bn_stats_partial<4, float>), dim3(nblk, groups), dim3(256), 0, st, (float*)const_cast<void*>(x), (float*)ws, R, C, nblk, C, Slabs{nullptr, 0, 0});
-  else ACG_LAUNCH((bn_stats_partial<1, float>), dim3(nblk, groups), dim3(256), 0, st, (float*)const_cast<void*>(x), (float*)ws, R, C, nblk, C, Slabs{nullptr, 0, 0});
-  if (int rc = acg::check_launch("bn_stats_partial")) return rc;
-  ACG_LAUNCH(bn_moments_finalize, dim3((groups * C + 255) / 256), dim3(256), 0, st, (const float*)ws, (const float*)x, moments, R, C, groups, nblk);
-  return acg::check_launch("bn_moments_finalize");
+  const bool v4 = vec4_ok(C, x, x, ws) && XP % 4 == 0;
+  if (dtype == ACG_BF16) return bn_moments_typed<__bf16>(x, moments, R, C, XP, groups, (float*)ws, v4, acg::to_stream(stream));
+  return bn_moments_typed<float>(x, moments, R, C, XP, groups, (float*)ws, v4, acg::to_stream(stream));
 }
 
 int32_t acg_bn_act_fwd_moments(const void* x, const float* beta, const float* moments, void* y, float* save_mean,
-                               float* save_rstd, int64_t rows, int32_t C, int32_t groups, float eps, int32_t act, float leak,
-                               int32_t dtype, acg_stream_t stream) {
-  ACG_REQUIRE_F32(dtype);
+                               float* save_rstd, int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t groups, float eps,
+                               int32_t act, float leak, int32_t dtype, acg_stream_t stream) {
+  const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
+  ACG_REQUIRE(XP >= C && YP >= C, ACG_ERR_INVALID_ARG, "bn_act_fwd_moments: pitch smaller than the row");
   if (int rc = check_bn("bn_act_fwd_moments", rows, C, groups)) return rc;
   ACG_REQUIRE(x && beta && moments && y && save_mean && save_rstd, ACG_ERR_INVALID_ARG, "bn_act_fwd_moments: null pointer");
   ACG_REQUIRE(act == ACG_ACT_NONE || act == ACG_ACT_RELU || act == ACG_ACT_LRELU, ACG_ERR_UNSUPPORTED, "bn_act_fwd_moments: activation %d", act);
-  const long long n = rows * (long long)C;
-  ACG_LAUNCH(bn_fwd_moments_k, dim3((int)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, acg::to_stream(stream),
-             (const float*)x, beta, moments, (float*)y, save_mean, save_rstd, rows / groups, C, groups, eps, act, leak);
-  return acg::check_launch("bn_act_fwd_moments");
+  hipStream_t st = acg::to_stream(stream);
+  ACG_LAUNCH(bn_moments_to_stats, dim3((groups * C + 255) / 256), dim3(256), 0, st, moments, save_mean, save_rstd, C, groups, eps);
+  if (int rc = acg::check_launch("bn_moments_to_stats")) return rc;
+  const long long R = rows / groups;
+  const bool v4 = vec4_ok(C, x, y, beta) && vec4_ok(C, save_mean, save_rstd, beta) && XP % 4 == 0 && YP % 4 == 0;
+  ACG_WITH_TYPES(dtype, "bn_act_fwd_moments", return (bn_fwd_moments_typed<TA, TB>(x, beta, y, save_mean, save_rstd, R, C, groups, eps, act, leak, v4, XP, YP, st)));
 }
 
 int32_t acg_bn_bwd_sums(const void* x, const void* dy, const float* beta, const float* save_mean, const float* save_rstd,
-                        float* sums, int64_t rows, int32_t C, int32_t groups, int32_t act, float leak, int32_t dtype, void* ws,
-                        size_t wsb, acg_stream_t stream) {
-  ACG_REQUIRE_F32(dtype);
+                        float* sums, int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t groups, int32_t act, float leak,
+                        int32_t dtype, void* ws, size_t wsb, acg_stream_t stream) {
+  const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
+  ACG_REQUIRE(XP >= C && YP >= C, ACG_ERR_INVALID_ARG, "bn_bwd_sums: pitch smaller than the row");
   if (int rc = check_bn("bn_bwd_sums", rows, C, groups)) return rc;
   ACG_REQUIRE(x && dy && beta && save_mean && save_rstd && sums, ACG_ERR_INVALID_ARG, "bn_bwd_sums: null pointer");
   ACG_REQUIRE(ws && wsb >= acg_bn_workspace_bytes(rows, C, groups), ACG_ERR_WORKSPACE, "bn_bwd_sums: workspace too small");
   const long long R = rows / groups;
   hipStream_t st = acg::to_stream(stream);
-  const bool v4 = vec4_ok(C, x, dy, ws) && vec4_ok(C, save_mean, save_rstd, beta);
-  const int V = v4 ? 4 : 1, nblk = vpartial_blocks(R, C, V, 4);
-  if (v4) ACG_LAUNCH((bn_bwd_partial<4, float, float>), dim3(nblk, groups), dim3(256), 0, st, (const float*)x, (const float*)dy, beta, save_mean, save_rstd, (float*)ws, R, C, nblk, act, leak, C, C);
-  else ACG_LAUNCH((bn_bwd_partial<1, float, float>), dim3(nblk, groups), dim3(256), 0, st, (const float*)x, (const float*)dy, beta, save_mean, save_rstd, (float*)ws, R, C, nblk, act, leak, C, C);
-  if (int rc = acg::check_launch("bn_bwd_partial")) return rc;
-  ACG_LAUNCH(bn_sums_finalize, dim3((groups * C + 255) / 256), dim3(256), 0, st, (const float*)ws, sums, C, groups, nblk);
-  return acg::check_launch("bn_sums_finalize");
+  const bool v4 = vec4_ok(C, x, dy, ws) && vec4_ok(C, save_mean, save_rstd, beta) && XP % 4 == 0 && YP % 4 == 0;
+  if (dtype == ACG_DTYPE2(ACG_F32, ACG_BF16))      // the float32 head of a bf16 network: x and dy float32 (dx, bf16, is not touched here)
+    return bn_bwd_sums_typed<float, float>(x, dy, beta, save_mean, save_rstd, sums, R, C, groups, act, leak, (float*)ws, v4, XP, YP, st);
+  ACG_WITH_TYPES(dtype, "bn_bwd_sums", return (bn_bwd_sums_typed<TA, TB>(x, dy, beta, save_mean, save_rstd, sums, R, C, groups, act, leak, (float*)ws, v4, XP, YP, st)));
 }
 
 int32_t acg_bn_act_bwd_sums(const void* x, const void* dy, const float* beta, const float* save_mean, const float* save_rstd,
                             const float* sums, const float* local_sums, int64_t total_rows, void* dx, float* dbeta,
-                            float dbeta_acc, int64_t rows, int32_t C, int32_t groups, int32_t act, float leak, int32_t dtype,
-                            acg_stream_t stream) {
-  ACG_REQUIRE_F32(dtype);
+                            float dbeta_acc, int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t groups, int32_t act,
+                            float leak, int32_t dtype, acg_stream_t stream) {
+  const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
+  ACG_REQUIRE(XP >= C && YP >= C, ACG_ERR_INVALID_ARG, "bn_act_bwd_sums: pitch smaller than the row");
   if (int rc = check_bn("bn_act_bwd_sums", rows, C, groups)) return rc;
   ACG_REQUIRE(x && dy && beta && save_mean && save_rstd && sums && local_sums && dx && dbeta, ACG_ERR_INVALID_ARG, "bn_act_bwd_sums: null pointer");
   ACG_REQUIRE(total_rows >= rows / groups, ACG_ERR_INVALID_ARG, "bn_act_bwd_sums: total_rows smaller than this rank's rows");
   hipStream_t st = acg::to_stream(stream);
-  const long long n = rows * (long long)C;
-  ACG_LAUNCH(bn_bwd_sums_k, dim3((int)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, st, (const float*)x, (const float*)dy,
-             beta, save_mean, save_rstd, sums, (float*)dx, rows / groups, C, groups, 1.0f / (float)total_rows, act, leak);
-  if (int rc = acg::check_launch("bn_bwd_sums_k")) return rc;
+  const long long R = rows / groups;
+  const float inv_total = 1.0f / (float)total_rows;
+  const bool v4 = vec4_ok(C, x, dy, dx) && vec4_ok(C, save_mean, save_rstd, beta) && vec4_ok(C, sums, sums, sums) && XP % 4 == 0 && YP % 4 == 0;
+  int rc;
+  if (dtype == ACG_DTYPE2(ACG_F32, ACG_BF16)) {
+    rc = bn_bwd_apply_sums_typed<float, float, __bf16>(x, dy, beta, save_mean, save_rstd, sums, inv_total, dx, R, C, groups, act, leak, v4, XP, YP, st);
+  } else {
+    rc = ACG_OK;
+    ACG_WITH_TYPES(dtype, "bn_act_bwd_sums", rc = (bn_bwd_apply_sums_typed<TA, TB>(x, dy, beta, save_mean, save_rstd, sums, inv_total, dx, R, C, groups, act, leak, v4, XP, YP, st)));
+  }
+  if (rc) return rc;
   ACG_LAUNCH(bn_dbeta_local_k, dim3((C + 255) / 256), dim3(256), 0, st, local_sums, dbeta, dbeta_acc, C, groups);
   return acg::check_launch("bn_dbeta_local_k");
 }

@@ -510,9 +510,8 @@ class BnActBwdOp(G.Op):
                     f.rows, f.c, f.xp, f.yp, f.groups, _ACT_CODE[f.act], f.leak, _code2(x, dy), _p(ws), n)
             fn = lib.bn_act_bwd_slabs
             return lambda s: fn(*args, s)
-        dt = _lib.dtype2(_lib.ACG_F32, _lib.ACG_BF16) if (x.dtype == torch.float32 and dx.dtype == torch.bfloat16) else _code2(x, dy)
         args = (_p(x.buf), _p(dy.buf), _p(beta.buf), _p(mean.buf), _p(rstd.buf), _p(dx.buf), _p(dbeta.buf), self.accumulate,
-                f.rows, f.c, f.xp, f.yp, f.groups, _ACT_CODE[f.act], f.leak, dt, _p(ws), n)
+                f.rows, f.c, f.xp, f.yp, f.groups, _ACT_CODE[f.act], f.leak, _bn_bwd_code(x, dy, dx), _p(ws), n)
         fn = lib.bn_act_bwd
         return lambda s: fn(*args, s)
 
@@ -522,15 +521,17 @@ class BnMomentsOp(G.Op):
     """This rank's per-group mean / biased variance (acg_bn_moments)."""
 
     def __init__(self, x, groups, name):
-        c = x.shape[-1]
-        self.rows, self.c, self.groups = x.numel // c, c, int(groups)
+        self.xp = x.shape[-1]
+        c = x.valid_c or self.xp
+        self.rows, self.c, self.groups = x.numel // self.xp, c, int(groups)
         super().__init__(G.get_default_graph(), name, [x], [_new((groups * 2 * c,), name + ':0')])
 
     def bind(self, rt):
         lib = rt.lib
         ws, n = rt.workspace(lib.bn_workspace_bytes(self.rows, self.c, self.groups))
         self._keep = ws
-        args = (_p(self.inputs[0].buf), _p(self.outputs[0].buf), self.rows, self.c, self.groups, ACG_F32, _p(ws), n)
+        x = self.inputs[0]
+        args = (_p(x.buf), _p(self.outputs[0].buf), self.rows, self.c, self.xp, self.groups, _code(x), _p(ws), n)
         fn = lib.bn_moments
         return lambda s: fn(*args, s)
 
@@ -559,20 +560,28 @@ class BnMomentsAllReduceOp(G.Op):
 
 
 class BnApplyMomentsOp(G.Op):
-    """y = act((x - mean) * rstd + beta) with GIVEN (global) moments; saves mean / rstd for backward."""
+    """y = act((x - mean) * rstd + beta) with GIVEN (global) moments; saves mean / rstd for backward.  Storage types and
+    pitches as BnActOp: bf16 activations at the pitch round8(C), a head layer's float32 input and dense float32 output."""
 
     def __init__(self, x, beta, gmoments, act, leak, eps, groups, name):
-        c = x.shape[-1]
+        self.xp = x.shape[-1]
+        c = x.valid_c or self.xp
         self.act, self.leak, self.eps, self.groups = act, float(leak), float(eps), int(groups)
-        self.rows, self.c = x.numel // c, c
+        self.rows, self.c = x.numel // self.xp, c
         self.mean, self.rstd = _new((groups * c,), name + '/mean'), _new((groups * c,), name + '/rstd')
-        super().__init__(G.get_default_graph(), name, [x, beta, gmoments], [_new(x.shape, name + ':0'), self.mean, self.rstd])
+        if act is None and half_mode():
+            y = _new(x.shape[:-1] + (c,), name + ':0')
+        else:
+            y = _new(x.shape, name + ':0', x.dtype)
+            y.valid_c = x.valid_c
+        self.yp = y.shape[-1]
+        super().__init__(G.get_default_graph(), name, [x, beta, gmoments], [y, self.mean, self.rstd])
 
     def bind(self, rt):
         x, beta, gm = self.inputs
         y, mean, rstd = self.outputs
-        args = (_p(x.buf), _p(beta.buf), _p(gm.buf), _p(y.buf), _p(mean.buf), _p(rstd.buf), self.rows, self.c, self.groups,
-                self.eps, _ACT_CODE[self.act], self.leak, ACG_F32)
+        args = (_p(x.buf), _p(beta.buf), _p(gm.buf), _p(y.buf), _p(mean.buf), _p(rstd.buf), self.rows, self.c, self.xp, self.yp,
+                self.groups, self.eps, _ACT_CODE[self.act], self.leak, _code2(x, y))
         fn = rt.lib.bn_act_fwd_moments
         return lambda s: fn(*args, s)
 
@@ -588,6 +597,13 @@ class BnApplyMomentsOp(G.Op):
         return [op.outputs[0] if needs[0] else None, None, None]     # the moments' dependence on x is inside dx
 
 
+def _bn_bwd_code(x, dy, dx):
+    """dtype of a BatchNorm backward call: ACG_DTYPE2(x, dy), or the float32-head code (x, dy float32; dx bf16)."""
+    if x.dtype == torch.float32 and dx.dtype == torch.bfloat16:
+        return _lib.dtype2(_lib.ACG_F32, _lib.ACG_BF16)
+    return _code2(x, dy)
+
+
 class BnBwdSumsOp(G.Op):
     def __init__(self, fwd, dy, name):
         self.fwd = fwd
@@ -599,8 +615,8 @@ class BnBwdSumsOp(G.Op):
         ws, n = rt.workspace(lib.bn_workspace_bytes(f.rows, f.c, f.groups))
         self._keep = ws
         x, dy, beta, mean, rstd = self.inputs
-        args = (_p(x.buf), _p(dy.buf), _p(beta.buf), _p(mean.buf), _p(rstd.buf), _p(self.outputs[0].buf), f.rows, f.c, f.groups,
-                _ACT_CODE[f.act], f.leak, ACG_F32, _p(ws), n)
+        args = (_p(x.buf), _p(dy.buf), _p(beta.buf), _p(mean.buf), _p(rstd.buf), _p(self.outputs[0].buf), f.rows, f.c, f.xp, f.yp,
+                f.groups, _ACT_CODE[f.act], f.leak, _code2(x, dy), _p(ws), n)
         fn = lib.bn_bwd_sums
         return lambda s: fn(*args, s)
 
@@ -628,7 +644,9 @@ class BnBwdApplySumsOp(G.Op):
         x, beta, _ = fwd.inputs
         if dbeta_dst is None:
             dbeta_dst = _new((fwd.c,), name + '/dbeta_scratch')
-        super().__init__(G.get_default_graph(), name, [x, dy, beta, fwd.mean, fwd.rstd, gsums, lsums], [_new(x.shape, name + ':0'), dbeta_dst])
+        dx = _new(x.shape, name + ':0', act_dtype())
+        dx.valid_c = x.valid_c
+        super().__init__(G.get_default_graph(), name, [x, dy, beta, fwd.mean, fwd.rstd, gsums, lsums], [dx, dbeta_dst])
 
     def bind(self, rt):
         f = self.fwd
@@ -636,7 +654,7 @@ class BnBwdApplySumsOp(G.Op):
         dx, dbeta = self.outputs
         total = (f.rows // f.groups) * rt.world_size
         args = (_p(x.buf), _p(dy.buf), _p(beta.buf), _p(mean.buf), _p(rstd.buf), _p(gs.buf), _p(ls.buf), total, _p(dx.buf),
-                _p(dbeta.buf), self.accumulate, f.rows, f.c, f.groups, _ACT_CODE[f.act], f.leak, ACG_F32)
+                _p(dbeta.buf), self.accumulate, f.rows, f.c, f.xp, f.yp, f.groups, _ACT_CODE[f.act], f.leak, _bn_bwd_code(x, dy, dx))
         fn = rt.lib.bn_act_bwd_sums
         return lambda s: fn(*args, s)
 
@@ -1096,8 +1114,6 @@ def batch_norm(inputs, decay=0.999, center=True, scale=False, epsilon=0.001, act
     fused = act if act is not None else (None, 0.0)
     dp = G.get_default_graph().collections.get('data_parallel')
     if dp is not None and getattr(dp, 'sync_bn', False) and dp.active:
-        if half_mode():
-            raise NotImplementedError('synchronised BatchNorm (exact-global-batch validation mode) is float32 only')
         # statistics of the global batch: moments -> all-reduce (host) -> apply (SURVEY 8(e) caveat 1)
         mom = BnMomentsOp(inputs, groups, name + '/moments').outputs[0]
         gmom = BnMomentsAllReduceOp(mom, groups, c, name + '/moments_allreduce').outputs[0]
@@ -1342,7 +1358,10 @@ class FrameLossOp(LossHead):
         ws, n = rt.workspace(rt.lib.frame_loss_workspace_bytes(gen.numel))
         self._keep = ws
         w1, w2 = self.grad_weights or (0.0, 0.0)
-        args = (_p(gen.buf), _p(gt.buf), _p(self.outputs[0].buf), _p(self.dgen.buf) if self.dgen is not None else None,
+        # the gradient op's own value outputs are read by nobody (loss values come from the forward head, when a program
+        # fetches them at all): gradient only - no reductions, no finalize launch
+        pout = None if self.dgen is not None else _p(self.outputs[0].buf)
+        args = (_p(gen.buf), _p(gt.buf), pout, _p(self.dgen.buf) if self.dgen is not None else None,
                 b, h, w, c, float(w1), float(w2), ACG_F32, _p(ws), n)
         fn = rt.lib.frame_loss
         return lambda s: fn(*args, s)

@@ -212,19 +212,22 @@ int32_t acg_deconv2d_bwd_pair(const void* dy, const void* w, const void* x, void
  *         acg_bn_act_bwd_sums       dx with the global sums and total_rows (global rows per group);
  *                                   dbeta = dbeta_acc * dbeta + sum_g local_sums[g][0][c]  (this rank's share; the
  *                                   gradient all-reduce averages it like every other parameter gradient)
+ * Storage types and pitches as in acg_bn_act_fwd / acg_bn_act_bwd (round 3: bf16 networks - BASELINE config 3 - can run
+ * the N-rank == 1-rank validation mode): acg_bn_moments takes the plain storage type of x; the other three the dtype of
+ * the plain entry they stand in for, ACG_DTYPE2(ACG_F32, ACG_BF16) for the float32 head of a bf16 network included.
  * ---------------------------------------------------------------------------------------- */
-int32_t acg_bn_moments(const void* x, float* moments, int64_t rows, int32_t channels, int32_t groups, int32_t dtype,
+int32_t acg_bn_moments(const void* x, float* moments, int64_t rows, int32_t channels, int32_t x_pitch, int32_t groups, int32_t dtype,
                        void* workspace, size_t workspace_bytes, acg_stream_t stream);
 int32_t acg_bn_act_fwd_moments(const void* x, const float* beta, const float* moments, void* y, float* save_mean,
-                               float* save_rstd, int64_t rows, int32_t channels, int32_t groups, float eps, int32_t act,
-                               float leak, int32_t dtype, acg_stream_t stream);
+                               float* save_rstd, int64_t rows, int32_t channels, int32_t x_pitch, int32_t y_pitch, int32_t groups,
+                               float eps, int32_t act, float leak, int32_t dtype, acg_stream_t stream);
 int32_t acg_bn_bwd_sums(const void* x, const void* dy, const float* beta, const float* save_mean, const float* save_rstd,
-                        float* sums, int64_t rows, int32_t channels, int32_t groups, int32_t act, float leak, int32_t dtype,
-                        void* workspace, size_t workspace_bytes, acg_stream_t stream);
+                        float* sums, int64_t rows, int32_t channels, int32_t x_pitch, int32_t y_pitch, int32_t groups, int32_t act,
+                        float leak, int32_t dtype, void* workspace, size_t workspace_bytes, acg_stream_t stream);
 int32_t acg_bn_act_bwd_sums(const void* x, const void* dy, const float* beta, const float* save_mean,
                             const float* save_rstd, const float* sums, const float* local_sums, int64_t total_rows,
-                            void* dx, float* dbeta, float dbeta_acc, int64_t rows, int32_t channels, int32_t groups,
-                            int32_t act, float leak, int32_t dtype, acg_stream_t stream);
+                            void* dx, float* dbeta, float dbeta_acc, int64_t rows, int32_t channels, int32_t x_pitch,
+                            int32_t y_pitch, int32_t groups, int32_t act, float leak, int32_t dtype, acg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * slim.batch_norm (training mode, scale=False, center=True) fused with the layer activation:
@@ -385,7 +388,9 @@ int32_t acg_add(const void* a, const void* b, void* y, int64_t n, int32_t dtype,
  * gradient pointer is non-NULL, d(scale * loss)/d(input) in the same pass.
  * ---------------------------------------------------------------------------------------- */
 /* out[0] = sum|gen-gt|  (tf.norm ord=1, train.py:73);  out[1] = GDL(gen,gt) (ops.py:100-120);
- * dgen = w_l1 * d out[0] + w_gdl * d out[1]   (tf.abs gradient: sign, 0 at 0). */
+ * dgen = w_l1 * d out[0] + w_gdl * d out[1]   (tf.abs gradient: sign, 0 at 0).  out2 == NULL (with dgen): the gradient
+ * alone, ONE launch and no reductions - the training step of train.py:122-129 fetches the frame, not the loss value.
+ * At most 4 channels. */
 size_t acg_frame_loss_workspace_bytes(int64_t n);
 int32_t acg_frame_loss(const void* gen, const void* gt, float* out2, void* dgen, int32_t batch, int32_t h,
                        int32_t w, int32_t c, float w_l1, float w_gdl, int32_t dtype, void* workspace,

@@ -355,63 +355,66 @@ int32_t acg_bn_act_bwd(const void* xv, const void* dyv, const float* beta, const
 }
 
 /* ---- synchronised BatchNorm (SURVEY 8(e) caveat 1): statistics of the global batch, collectives by the caller */
-int32_t acg_bn_moments(const void* xv, float* moments, int64_t rows, int32_t C, int32_t groups, int32_t dtype, void* ws,
+int32_t acg_bn_moments(const void* xv, float* moments, int64_t rows, int32_t C, int32_t x_pitch, int32_t groups, int32_t dtype, void* ws,
                        size_t wsb, acg_stream_t s) {
   (void)ws; (void)wsb; (void)s; REQUIRE_F32(dtype);
   if (groups <= 0 || rows % groups) return fail(ACG_ERR_INVALID_ARG, "bn: rows not divisible by groups");
-  const float* x = xv; int64_t R = rows / groups;
+  const float* x = xv; int64_t R = rows / groups; const int XP = x_pitch > 0 ? x_pitch : C;
   for (int g = 0; g < groups; g++) for (int c = 0; c < C; c++) {
-    const float* xg = x + (size_t)g * R * C; double m = 0, v = 0;
-    for (int64_t r = 0; r < R; r++) m += xg[r * C + c];
+    const float* xg = x + (size_t)g * R * XP; double m = 0, v = 0;
+    for (int64_t r = 0; r < R; r++) m += xg[r * XP + c];
     m /= (double)R;
-    for (int64_t r = 0; r < R; r++) { double t = xg[r * C + c] - m; v += t * t; }
+    for (int64_t r = 0; r < R; r++) { double t = xg[r * XP + c] - m; v += t * t; }
     moments[(g * 2 + 0) * C + c] = (float)m; moments[(g * 2 + 1) * C + c] = (float)(v / (double)R);
   }
   return ACG_OK;
 }
 int32_t acg_bn_act_fwd_moments(const void* xv, const float* beta, const float* moments, void* yv, float* save_mean,
-                               float* save_rstd, int64_t rows, int32_t C, int32_t groups, float eps, int32_t act, float leak,
-                               int32_t dtype, acg_stream_t s) {
+                               float* save_rstd, int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t groups, float eps,
+                               int32_t act, float leak, int32_t dtype, acg_stream_t s) {
   (void)s; REQUIRE_F32(dtype);
   if (groups <= 0 || rows % groups) return fail(ACG_ERR_INVALID_ARG, "bn: rows not divisible by groups");
   const float* x = xv; float* y = yv; int64_t R = rows / groups;
+  const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
   for (int g = 0; g < groups; g++) for (int c = 0; c < C; c++) {
     double m = moments[(g * 2 + 0) * C + c], rstd = 1.0 / sqrt((double)moments[(g * 2 + 1) * C + c] + (double)eps);
     save_mean[g * C + c] = (float)m; save_rstd[g * C + c] = (float)rstd;
-    for (int64_t r = 0; r < R; r++) { size_t i = ((size_t)g * R + r) * C + c; y[i] = (float)act_f(act, (x[i] - m) * rstd + beta[c], leak); }
+    for (int64_t r = 0; r < R; r++) { size_t row = (size_t)g * R + r; y[row * YP + c] = (float)act_f(act, (x[row * XP + c] - m) * rstd + beta[c], leak); }
   }
   return ACG_OK;
 }
 int32_t acg_bn_bwd_sums(const void* xv, const void* dyv, const float* beta, const float* save_mean, const float* save_rstd,
-                        float* sums, int64_t rows, int32_t C, int32_t groups, int32_t act, float leak, int32_t dtype, void* ws,
-                        size_t wsb, acg_stream_t s) {
+                        float* sums, int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t groups, int32_t act, float leak,
+                        int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
   (void)ws; (void)wsb; (void)s; REQUIRE_F32(dtype);
   if (groups <= 0 || rows % groups) return fail(ACG_ERR_INVALID_ARG, "bn: rows not divisible by groups");
   const float* x = xv; const float* dy = dyv; int64_t R = rows / groups;
+  const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
   for (int g = 0; g < groups; g++) for (int c = 0; c < C; c++) {
     double m = save_mean[g * C + c], rstd = save_rstd[g * C + c], s1 = 0, s2 = 0;
-    for (int64_t r = 0; r < R; r++) { size_t i = ((size_t)g * R + r) * C + c; double xh = (x[i] - m) * rstd;
-      double dp = dy[i] * act_df(act, xh + beta[c], leak); s1 += dp; s2 += dp * xh; }
+    for (int64_t r = 0; r < R; r++) { size_t row = (size_t)g * R + r; double xh = (x[row * XP + c] - m) * rstd;
+      double dp = dy[row * YP + c] * act_df(act, xh + beta[c], leak); s1 += dp; s2 += dp * xh; }
     sums[(g * 2 + 0) * C + c] = (float)s1; sums[(g * 2 + 1) * C + c] = (float)s2;
   }
   return ACG_OK;
 }
 int32_t acg_bn_act_bwd_sums(const void* xv, const void* dyv, const float* beta, const float* save_mean, const float* save_rstd,
                             const float* sums, const float* local_sums, int64_t total_rows, void* dxv, float* dbeta,
-                            float dbeta_acc, int64_t rows, int32_t C, int32_t groups, int32_t act, float leak, int32_t dtype,
-                            acg_stream_t s) {
+                            float dbeta_acc, int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t groups, int32_t act,
+                            float leak, int32_t dtype, acg_stream_t s) {
   (void)s; REQUIRE_F32(dtype);
   if (groups <= 0 || rows % groups) return fail(ACG_ERR_INVALID_ARG, "bn: rows not divisible by groups");
   const float* x = xv; const float* dy = dyv; float* dx = dxv; int64_t R = rows / groups;
+  const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
   if (total_rows < R) return fail(ACG_ERR_INVALID_ARG, "bn_act_bwd_sums: total_rows smaller than this rank's rows");
   for (int c = 0; c < C; c++) {
     double db = 0;
     for (int g = 0; g < groups; g++) {
       double m = save_mean[g * C + c], rstd = save_rstd[g * C + c];
       double m1 = sums[(g * 2 + 0) * C + c] / (double)total_rows, m2 = sums[(g * 2 + 1) * C + c] / (double)total_rows;
-      for (int64_t r = 0; r < R; r++) { size_t i = ((size_t)g * R + r) * C + c; double xh = (x[i] - m) * rstd;
-        double dp = dy[i] * act_df(act, xh + beta[c], leak);
-        dx[i] = (float)(rstd * (dp - m1 - xh * m2)); }
+      for (int64_t r = 0; r < R; r++) { size_t row = (size_t)g * R + r; double xh = (x[row * XP + c] - m) * rstd;
+        double dp = dy[row * YP + c] * act_df(act, xh + beta[c], leak);
+        dx[row * XP + c] = (float)(rstd * (dp - m1 - xh * m2)); }
       db += local_sums[(g * 2 + 0) * C + c];
     }
     dbeta[c] = (float)((dbeta_acc != 0.f ? (double)dbeta_acc * dbeta[c] : 0.0) + db);
@@ -671,7 +674,7 @@ int32_t acg_frame_loss(const void* gv, const void* tv, float* out2, void* dgv, i
     }
   }
 #undef AT
-  out2[0] = (float)l1; out2[1] = (float)gdl;
+  if (out2) { out2[0] = (float)l1; out2[1] = (float)gdl; }      /* out2 == NULL: the gradient alone */
   return ACG_OK;
 }
 int32_t acg_l2norm_loss(const float* p, const float* g, float* out, float* dp, int64_t n, float scale, acg_stream_t s) {

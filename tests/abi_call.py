@@ -288,38 +288,47 @@ class Abi:
         return conv, y, mean, rstd
 
     # ---- synchronised BatchNorm entries (statistics supplied by the caller)
-    def bn_moments(self, x, groups=1):
-        c = x.shape[-1]
-        rows = x.numel() // c
+    def bn_moments(self, x, groups=1, c=None):
+        """``c`` < x.shape[-1]: rows carry pad channels (pitch x.shape[-1]); x float32 or bfloat16."""
+        xp = x.shape[-1]
+        c = c or xp
+        rows = x.numel() // xp
         mom = self.empty(groups * 2 * c)
         ws, n = self.ws(self.lib.bn_workspace_bytes(rows, c, groups))
-        self.lib.bn_moments(_p(x), _p(mom), rows, c, groups, L.ACG_F32, _p(ws), n, self.stream())
+        self.lib.bn_moments(_p(x), _p(mom), rows, c, xp, groups, L.code(x.dtype), _p(ws), n, self.stream())
         return mom
 
-    def bn_act_fwd_moments(self, x, beta, moments, act, groups=1, eps=1e-3, leak=0.2):
-        c = x.shape[-1]
-        rows = x.numel() // c
-        y = torch.empty_like(x)
+    def bn_act_fwd_moments(self, x, beta, moments, act, groups=1, eps=1e-3, leak=0.2, c=None, y_dtype=None):
+        xp = x.shape[-1]
+        c = c or xp
+        rows = x.numel() // xp
+        dense = y_dtype is not None and y_dtype != x.dtype
+        y = torch.zeros(*x.shape[:-1], c if dense else xp, dtype=y_dtype or x.dtype, device=self.device)
         mean, rstd = self.empty(groups * c), self.empty(groups * c)
-        self.lib.bn_act_fwd_moments(_p(x), _p(beta), _p(moments), _p(y), _p(mean), _p(rstd), rows, c, groups, eps, ACT[act], leak,
-                                    L.ACG_F32, self.stream())
+        self.lib.bn_act_fwd_moments(_p(x), _p(beta), _p(moments), _p(y), _p(mean), _p(rstd), rows, c, xp, y.shape[-1], groups, eps,
+                                    ACT[act], leak, L.dtype2(L.code(x.dtype), L.code(y.dtype)), self.stream())
         return y, mean, rstd
 
-    def bn_bwd_sums(self, x, dy, beta, mean, rstd, act, groups=1, leak=0.2):
-        c = x.shape[-1]
-        rows = x.numel() // c
+    def bn_bwd_sums(self, x, dy, beta, mean, rstd, act, groups=1, leak=0.2, c=None):
+        xp = x.shape[-1]
+        c = c or xp
+        rows = x.numel() // xp
         sums = self.empty(groups * 2 * c)
         ws, n = self.ws(self.lib.bn_workspace_bytes(rows, c, groups))
-        self.lib.bn_bwd_sums(_p(x), _p(dy), _p(beta), _p(mean), _p(rstd), _p(sums), rows, c, groups, ACT[act], leak, L.ACG_F32,
-                             _p(ws), n, self.stream())
+        self.lib.bn_bwd_sums(_p(x), _p(dy), _p(beta), _p(mean), _p(rstd), _p(sums), rows, c, xp, dy.shape[-1], groups, ACT[act], leak,
+                             L.dtype2(L.code(x.dtype), L.code(dy.dtype)), _p(ws), n, self.stream())
         return sums
 
-    def bn_act_bwd_sums(self, x, dy, beta, mean, rstd, sums, local_sums, total_rows, act, groups=1, leak=0.2):
-        c = x.shape[-1]
-        rows = x.numel() // c
-        dx, dbeta = torch.empty_like(x), self.empty(c)
+    def bn_act_bwd_sums(self, x, dy, beta, mean, rstd, sums, local_sums, total_rows, act, groups=1, leak=0.2, c=None, dx_dtype=None):
+        xp = x.shape[-1]
+        c = c or xp
+        rows = x.numel() // xp
+        dx, dbeta = torch.zeros_like(x, dtype=dx_dtype or x.dtype), self.empty(c)
+        dt = L.dtype2(L.code(x.dtype), L.code(dy.dtype))
+        if dx.dtype != x.dtype:
+            dt = L.dtype2(L.ACG_F32, L.ACG_BF16)
         self.lib.bn_act_bwd_sums(_p(x), _p(dy), _p(beta), _p(mean), _p(rstd), _p(sums), _p(local_sums), total_rows, _p(dx),
-                                 _p(dbeta), 0.0, rows, c, groups, ACT[act], leak, L.ACG_F32, self.stream())
+                                 _p(dbeta), 0.0, rows, c, xp, dy.shape[-1], groups, ACT[act], leak, dt, self.stream())
         return dx, dbeta
 
     def bias_act_fwd(self, x, bias, act, leak=0.2, c=None, y_dtype=None):
@@ -418,9 +427,9 @@ class Abi:
         return y
 
     # ---- losses
-    def frame_loss(self, gen, gt, w_l1, w_gdl, want_grad=True):
+    def frame_loss(self, gen, gt, w_l1, w_gdl, want_grad=True, want_values=True):
         b, h, w, c = gen.shape
-        out = self.empty(2)
+        out = self.empty(2) if want_values else None
         dgen = torch.empty_like(gen) if want_grad else None
         ws, n = self.ws(self.lib.frame_loss_workspace_bytes(gen.numel()))
         self.lib.frame_loss(_p(gen), _p(gt), _p(out), _p(dgen), b, h, w, c, w_l1, w_gdl, L.ACG_F32, _p(ws), n,

@@ -402,6 +402,54 @@ def case_sync_bn_entries(abi, shape, act, groups, tol):
     close(dx2, dx_ref, tol * 8, tag + ' dx (two identical ranks)'); close(dbeta2, dbeta_ref, tol * 8, tag + ' dbeta (two identical ranks)')
 
 
+def case_sync_bn_entries_bf16(abi, tol):
+    """The same four entries in the storage types of a bf16 network (round 3: BASELINE config 3 can run the N-rank ==
+    1-rank validation mode): bf16 x / y / dy / dx at the pitch round8(C), and the float32 head (x, dy float32 at a pitch
+    of 8, dense float32 y, bf16 dx).  One rank (global = local): they must reproduce acg_bn_act_fwd / _bwd on the same
+    tensors - bit for bit where the arithmetic is the same kernel, to rounding level otherwise."""
+    dev = abi.device
+    g = torch.Generator().manual_seed(19)
+    for lead, c, groups, act in [((4, 16, 16), 32, 2, 'lrelu'), ((2, 8, 8), 138, 1, 'relu'), ((6, 5, 5), 12, 1, 'relu')]:
+        cp = (c + 7) // 8 * 8
+        x = torch.zeros(*lead, cp, dtype=torch.bfloat16, device=dev)
+        x[..., :c] = (torch.randn(*lead, c, generator=g) * 2 + 0.5).to(dev).to(torch.bfloat16)
+        dy = torch.zeros(*lead, cp, dtype=torch.bfloat16, device=dev)
+        dy[..., :c] = torch.randn(*lead, c, generator=g).to(dev).to(torch.bfloat16)
+        beta = torch.randn(c, generator=g).to(dev)
+        y_ref, mean_ref, rstd_ref = abi.bn_act_fwd(x, beta, act, groups=groups, c=c)
+        mom = abi.bn_moments(x, groups=groups, c=c)
+        y, mean, rstd = abi.bn_act_fwd_moments(x, beta, mom, act, groups=groups, c=c)
+        tag = 'sync_bn bf16 %s c=%d %s g%d' % (lead, c, act, groups)
+        close(mean, mean_ref, tol, tag + ' mean'); close(rstd, rstd_ref, tol * 4, tag + ' rstd')
+        close(y[..., :c].float(), y_ref[..., :c].float(), 8e-3, tag + ' y')      # one bf16 ulp where mean / rstd differ in the last bit
+        assert (y[..., c:] == 0).all()
+        rows_per_group = x.numel() // cp // groups
+        # backward against the fp64 BatchNorm gradient of the same stored tensors
+        xd, bd = x[..., :c].double().cpu().requires_grad_(True), beta.double().cpu().requires_grad_(True)
+        dx64, db64 = torch.autograd.grad(_bn_ref(xd, bd, act, groups), [xd, bd], dy[..., :c].double().cpu())
+        sums = abi.bn_bwd_sums(x, dy, beta, mean_ref, rstd_ref, act, groups=groups, c=c)
+        dx, dbeta = abi.bn_act_bwd_sums(x, dy, beta, mean_ref, rstd_ref, sums, sums, rows_per_group, act, groups=groups, c=c)
+        assert dx.dtype == torch.bfloat16 and (dx[..., c:] == 0).all()
+        close(dx[..., :c].float(), dx64, 8e-3, tag + ' dx'); close(dbeta, db64, 2e-4, tag + ' dbeta')
+    # the float32 head (d/conv6): x float32 at a pitch of 8, y / dy dense float32, dx bf16
+    for lead, c, groups in [((8, 2, 2), 1, 2), ((6, 3, 3), 5, 1)]:
+        x32 = torch.zeros(*lead, 8, device=dev)
+        x32[..., :c] = (torch.randn(*lead, c, generator=g) * 1.5 + 0.3).to(dev)
+        beta = torch.randn(c, generator=g).to(dev)
+        dy = torch.randn(*lead, c, generator=g).to(dev)
+        y_ref, mean_ref, rstd_ref = abi.bn_act_fwd(x32, beta, None, groups, y_dtype=torch.float32, c=c)
+        dx_ref, dbeta_ref = abi.bn_act_bwd(x32, dy, beta, mean_ref, rstd_ref, None, groups, dx_dtype=torch.bfloat16)
+        mom = abi.bn_moments(x32, groups=groups, c=c)
+        y, mean, rstd = abi.bn_act_fwd_moments(x32, beta, mom, None, groups=groups, c=c, y_dtype=torch.float32)
+        y = y[..., :c] if y.shape[-1] != c else y
+        close(mean, mean_ref, tol, 'sync_bn head mean'); close(rstd, rstd_ref, tol * 4, 'sync_bn head rstd'); close(y, y_ref, tol * 4, 'sync_bn head y')
+        sums = abi.bn_bwd_sums(x32, dy, beta, mean_ref, rstd_ref, None, groups=groups, c=c)
+        rows_per_group = x32.numel() // 8 // groups
+        dx, dbeta = abi.bn_act_bwd_sums(x32, dy, beta, mean_ref, rstd_ref, sums, sums, rows_per_group, None, groups=groups, c=c, dx_dtype=torch.bfloat16)
+        assert dx.dtype == torch.bfloat16
+        close(dx[..., :c].float(), dx_ref[..., :c].float(), 8e-3, 'sync_bn head dx'); close(dbeta, dbeta_ref, tol * 8, 'sync_bn head dbeta')
+
+
 PAIR_LAYERS = [   # (x shape, w shape, stride, padding, transposed)
     ((4, 16, 16, 8), (5, 5, 8, 16), 2, 'SAME', False),        # both contractions on the 128x32 tile, weight gradient split
     ((4, 16, 16, 64), (5, 5, 64, 128), 2, 'SAME', False),     # 64x64 tiles (g/conv3-like), both split
@@ -755,7 +803,7 @@ def case_plumbing(abi, tol):
 
 def case_losses(abi, tol, seed=0):
     dev = abi.device
-    for shp in [(2, 64, 64, 3), (1, 5, 7, 3), (3, 2, 2, 1)]:
+    for shp in [(2, 64, 64, 3), (1, 5, 7, 3), (3, 2, 2, 1), (2, 16, 32, 4), (1, 12, 16, 2)]:
         gen, gt = uniform(shp, seed), uniform(shp, seed + 1)
         gd = gen.double().requires_grad_(True)
         l1 = (gd - gt.double()).abs().sum()
@@ -770,6 +818,9 @@ def case_losses(abi, tol, seed=0):
         # symmetric in its arguments (reference passes them swapped, train.py:81 vs ops.py:100; defect D10)
         out_sw, _ = abi.frame_loss(gt.to(dev), gen.to(dev), w1, w2, want_grad=False)
         close(out_sw, out, 1e-6, 'frame_loss symmetry')
+        # the gradient alone (what the training step launches: no values, no finalize): the very same gradient
+        _, dgen2 = abi.frame_loss(gen.to(dev), gt.to(dev), w1, w2, want_values=False)
+        assert torch.equal(dgen2.cpu(), dgen.cpu()), 'frame_loss gradient-only mode %s' % (shp,)
     pred, tgt = randn((32, 5), seed + 2), randn((32, 5), seed + 3)
     pd = pred.double().requires_grad_(True)
     n2 = torch.sqrt(((pd - tgt.double()) ** 2).sum())

@@ -168,6 +168,10 @@ def test_sync_bn_entries(hip_abi, shape, act, groups):
     C.case_sync_bn_entries(hip_abi, shape, act, groups, TOL)
 
 
+def test_sync_bn_entries_bf16(hip_abi):
+    C.case_sync_bn_entries_bf16(hip_abi, TOL)
+
+
 def test_bwd_pair(hip_abi):
     C.case_bwd_pair(hip_abi, TOL_CONV, exact=True)
 

@@ -508,3 +508,111 @@ def test_data_parallel_machinery_on_one_rank():
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, os.path.join(here, 'dp_one_rank.py')], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'DP_ONE_RANK_OK' in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[:3000], r.stderr[-2000:])
+
+
+def _push_like_stream(batch, steps, seed=3):
+    """A learnable synthetic stream (the bench's white noise has nothing to learn): smooth random images (8x8 noise
+    upsampled to 64x64) that move horizontally by -2..2 pixels, the shift encoded in the first action component; the state
+    is a fixed linear function of the action.  -> list of (x, y, action||state, next_state)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(steps):
+        low = rng.uniform(-1, 1, (batch, 8, 8, 3)).astype(np.float32)
+        x = np.clip(np.kron(low, np.ones((1, 8, 8, 1), np.float32)) + 0.05 * rng.standard_normal((batch, 64, 64, 3)).astype(np.float32), -1, 1)
+        shift = rng.integers(-2, 3, batch)
+        y = np.stack([np.roll(x[i], int(shift[i]), axis=1) for i in range(batch)])
+        a = rng.standard_normal((batch, 10)).astype(np.float32) * 0.1
+        a[:, 0] = shift / 2.0
+        s = (a[:, :5] * 0.5 + 0.1).astype(np.float32)
+        out.append((x, y, a, s))
+    return out
+
+
+@pytest.mark.timeout(900)
+def test_bf16_training_tracks_fp32_over_200_steps():
+    """the bf16 pipeline (BASELINE configs 3 / 5) against the float32 one over a whole trajectory, not
+    one step.  200 generator pre-training iterations (train.py:114-121, the deterministic part of the reference loop:
+    0.05 L1 / B + state loss, Adam) on the same learnable stream from the same initial weights, then 40 adversarial
+    D + G iterations.  Declared band: the pre-training loss averaged over the last 20 iterations within 5 % of the
+    float32 run and the PSNR on held-out batches within 0.5 dB, both runs having actually learned (loss down by > 25 %,
+    PSNR up by > 1 dB); every weight finite after the adversarial phase and D's weights inside the clip."""
+    from action_conditioned_gans_amd import optim, train as T
+    B, n_pre, n_adv = 16, 200, 40
+    stream = _push_like_stream(B, n_pre + n_adv)
+    held = _push_like_stream(B, 4, seed=11)
+    curves = {}
+    for dtype in ('f32', 'bf16'):
+        sess, tr = TC.build_trainer(gpu_session, 'c2_dna_bce_adam', batch=B, dtype=dtype)
+
+        def psnr():
+            vals = []
+            for x, y, a, s in held:
+                frame = tr.test(x, y, a)[0]
+                vals.append(10.0 * np.log10(1.0 / np.mean((frame - y) ** 2)))
+            return float(np.mean(vals))
+        p0 = psnr()
+        # (Trainer.pretrain_g returns g_loss, which carries the adversarial and GDL terms; what it MINIMISES is g_l2_loss)
+        losses = [float(np.asarray(sess.run([tr.g_pretrain_opt_op, tr.g_l2_loss], tr._feed(*stream[i]))[1]).reshape(-1)[0]) for i in range(n_pre)]
+        p1 = psnr()
+        for i in range(n_pre, n_pre + n_adv):
+            x, y, a, s = stream[i]
+            tr.train_d(x, y, a)
+            tr.train_g(x, y, a, s)
+        torch.cuda.synchronize()
+        for v in tr.g_vars + tr.d_vars:
+            assert torch.isfinite(sess.get_value(v)).all(), (dtype, v.name)
+        for v in tr.d_vars:
+            assert sess.get_value(v).abs().max().item() <= 0.01 + 1e-7, (dtype, v.name)
+        curves[dtype] = (np.array(losses), p0, p1, psnr())
+        print('%s: pre-training loss %.4f -> %.4f (mean of first / last 20), held-out PSNR %.2f -> %.2f dB, %.2f dB after %d adversarial iterations'
+              % (dtype, np.mean(losses[:20]), np.mean(losses[-20:]), p0, p1, curves[dtype][3], n_adv))
+    (l32, a0, a1, _), (l16, b0, b1, _) = curves['f32'], curves['bf16']
+    for l, q0, q1, who in ((l32, a0, a1, 'f32'), (l16, b0, b1, 'bf16')):
+        assert np.mean(l[-20:]) < 0.75 * np.mean(l[:20]), (who, 'did not learn', np.mean(l[:20]), np.mean(l[-20:]))
+        assert q1 > q0 + 1.0, (who, 'PSNR did not improve', q0, q1)
+    assert abs(np.mean(l16[-20:]) - np.mean(l32[-20:])) <= 0.05 * np.mean(l32[-20:]), (np.mean(l16[-20:]), np.mean(l32[-20:]))
+    assert abs(b1 - a1) <= 0.5, (b1, a1)
+    # the two trajectories stay together all along, not just at the end: windowed means within 8 %
+    for lo in range(0, n_pre, 20):
+        m32, m16 = np.mean(l32[lo:lo + 20]), np.mean(l16[lo:lo + 20])
+        assert abs(m16 - m32) <= 0.08 * m32, (lo, m16, m32)
+
+
+@pytest.mark.timeout(900)
+def test_config5_full_per_gpu_size_replay_equals_eager():
+    """BASELINE config 5 at its full per-GPU size - batch 32, 128x128x3, 11x11 DNA kernel, bf16 - which the oracle cannot
+    reach (its fp64 step is checked at batch 2): the size-independent properties instead.  Every conv takes the plan it
+    has in the bench (128x128 and 128x32 bf16 tiles, unsplit layers with epilogue statistics, the BatchNorm finalize
+    launch behind more than 512 partial blocks); three D + G steps launched eagerly and three replayed from captured
+    HIP graphs must leave bit-identical weights and frames, all finite, D inside its clip."""
+    from action_conditioned_gans_amd import optim, train as T
+    rng = np.random.default_rng(31)
+    B, S = 32, 128
+    x = rng.uniform(-1, 1, (B, S, S, 3)).astype(np.float32)
+    y = np.clip(np.roll(x, 3, axis=2) + 0.05 * rng.standard_normal(x.shape).astype(np.float32), -1, 1)
+    a = rng.standard_normal((B, 10)).astype(np.float32)
+    s = rng.standard_normal((B, 5)).astype(np.float32)
+    finals = []
+    for use_graphs in (False, True):
+        G.reset_default_graph()
+        optim.set_data_parallel(1)
+        sess = gpu_session(dtype='bf16', use_hip_graphs=use_graphs)
+        tr = T.Trainer(sess, True, 'bce', 'adam', True, batch_size=B, img_size=S, ksize=11)
+        sess.run(G.global_variables_initializer())
+        for _ in range(3):
+            tr.train_d(x, y, a)
+            frames = tr.train_g(x, y, a, s)
+        torch.cuda.synchronize()
+        g = G.get_default_graph()
+        progs = list(sess._programs.values())
+        assert all((p.graphs is not None) == use_graphs for p in progs if p is not None and p.runs >= 2)
+        finals.append(({n: sess.get_value(v) for n, v in g.variables.items()}, frames))
+        del sess, tr
+        torch.cuda.empty_cache()
+    (pe, fe), (pg, fg) = finals
+    assert np.isfinite(fe).all() and np.array_equal(fe, fg)
+    for n in pe:
+        assert torch.isfinite(pe[n]).all(), n
+        assert torch.equal(pe[n], pg[n]), n
+        if n.startswith('d/'):
+            assert pe[n].abs().max().item() <= 0.01 + 1e-7, n

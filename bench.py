@@ -228,7 +228,7 @@ def main():
         recs += sess.profile_ops([tr.g_opt_op, tr.g_next_frame], tr._feed(x, y, a, s), repeats=args.profile_repeats, relaunch=relaunch)
         conv_ms = conv_fl = conv_by = 0.0
         n_conv = n_launch = 0
-        dna_ms = dna_bytes = 0.0
+        dna_ms = dna_bytes = dna_bytes_survey = 0.0
         for op, ms in recs:
             kind = type(op).__name__
             kernel_ms[kind] = kernel_ms.get(kind, 0.0) + ms
@@ -248,6 +248,7 @@ def main():
                 b, h, w, c = op.inputs[1].shape
                 dna_ms += ms
                 dna_bytes += b * h * w * (op.ksize * op.ksize * (2.0 if args.dtype == 'bf16' else 4.0) + 2 * c * 4.0)
+                dna_bytes_survey += b * h * w * (op.ksize * op.ksize + 2 * c) * (2.0 if args.dtype == 'bf16' else 4.0)      # (k*k + 6) * sizeof
                 if op.second is not None:      # (both training programs read that tensor)
                     # this launch also writes the discriminator's input pixel (train.py:63-66: concat(frame, generated frame),
                     # 8 channels of the conv storage type) - the bytes of the concat launch it replaces
@@ -260,15 +261,16 @@ def main():
             # passes, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md); null when no summary matches the workload
             traffic, traffic_note, pmc_dna = None, None, None
             tag = '%s_b%d_s%d_k%d%s' % (args.dtype, B, S, args.ksize, '' if dna else '_plain')
-            pmc = os.path.join(ROOT, 'profiles', 'r2', 'pmc_traffic_%s.json' % tag)
+            pmc_round = 'r3' if os.path.exists(os.path.join(ROOT, 'profiles', 'r3', 'pmc_traffic_%s.json' % tag)) else 'r2'
+            pmc = os.path.join(ROOT, 'profiles', pmc_round, 'pmc_traffic_%s.json' % tag)
             if adv and args.loss == 'bce' and os.path.exists(pmc):
                 with open(pmc) as f:
                     pj = json.load(f)
                 c = pj.get('conv')
                 if c:
                     traffic = round(c['fetch_bytes_per_launch'] + c['write_bytes_per_launch'])     # bytes per launch
-                    traffic_note = ('HBM-side bytes per conv launch (FETCH_SIZE x2 + WRITE_SIZE) from profiles/r2/pmc_traffic_%s.txt, separate '
-                                    '--pmc passes of this command; algorithmic (operands + result once) %d bytes per launch' % (tag, round(conv_by / max(n_launch, 1))))
+                    traffic_note = ('HBM-side bytes per conv launch (FETCH_SIZE x2 + WRITE_SIZE) from profiles/%s/pmc_traffic_%s.txt, separate '
+                                    '--pmc passes of this command; algorithmic (operands + result once) %d bytes per launch' % (pmc_round, tag, round(conv_by / max(n_launch, 1))))
                 pmc_dna = pj.get('dna_fwd')
             roof = {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': peak, 'unit': 'TFLOP/s',
                     'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_note': traffic_note,
@@ -283,7 +285,12 @@ def main():
                         'frac': round(gbs / PEAK_HBM_GBS, 4),
                         'traffic': round(pmc_dna['fetch_bytes_per_launch'] + pmc_dna['write_bytes_per_launch']) if (conv_ms > 0 and pmc_dna) else None,
                         'kernel': 'dna_rows_kernel<K,fwd>' if args.ksize >= 6 else 'dna_kernel<K,4,fwd>',
-                        'algorithmic_mb_per_step': round(dna_bytes / 1e6, 2), 'ms_per_step_in_kernel': round(dna_ms, 4)}
+                        'algorithmic_mb_per_step': round(dna_bytes / 1e6, 2), 'ms_per_step_in_kernel': round(dna_ms, 4),
+                        # the same launches by SURVEY 8(d)'s byte count alone ((k*k + 6) * sizeof per pixel: 16.25 MB at config 2),
+                        # without the discriminator-input pixel this kernel also writes
+                        'survey_definition': {'algorithmic_mb_per_step': round(dna_bytes_survey / 1e6, 2),
+                                              'achieved': round(dna_bytes_survey / (dna_ms * 1e-3) / 1e9, 1),
+                                              'frac': round(dna_bytes_survey / (dna_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}}
 
     if rank != 0:
         _leave_distributed(sess)
@@ -291,16 +298,26 @@ def main():
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, n_critic)
-    is_config2 = (B == 32 and S == 64 and args.seq_len == 8 and adv and args.loss == 'bce' and dna and args.ksize == 5
-                  and args.opt == 'adam' and args.dtype == 'f32')
+    # which BASELINE.json configuration this run is: config 2 itself (the headline), or the per-GPU shard of configs 3 / 4
+    # (global batch 256 / 128 over 8 / 4 GPUs = 32 per GPU) or config 5's geometry at 32 per GPU (its per-GPU batch is not stated)
+    std = B == 32 and adv and dna
+    if std and S == 64 and args.seq_len == 8 and args.ksize == 5 and args.loss == 'bce' and args.opt == 'adam' and args.dtype == 'f32':
+        which = 'BASELINE config 2'
+    elif std and S == 64 and args.seq_len == 8 and args.ksize == 5 and args.loss == 'bce' and args.opt == 'adam' and args.dtype == 'bf16':
+        which = 'BASELINE config 3, per-GPU shard (global batch 256 over 8 GPUs)'
+    elif std and S == 64 and args.seq_len == 8 and args.ksize == 5 and args.loss == 'wass' and args.opt == 'rmsprop':
+        which = 'BASELINE config 4, per-GPU shard (global batch 128 over 4 GPUs; n_critic = 5, D weight clip)'
+    elif std and S == 128 and args.seq_len == 16 and args.ksize == 11 and args.dtype == 'bf16' and args.loss == 'bce':
+        which = 'BASELINE config 5 geometry (128x128x3 T=16, 11x11 DNA kernel, bf16), 32 per GPU'
+    else:
+        which = 'variant of BASELINE config 2'
     line = {
         'metric': 'GAN train steps/sec (G+D) on 64x64x3xT=8 push seq', 'value': round(world * args.steps / elapsed, 3),
         'unit': 'steps/s (batch-%d G+D steps, all ranks)' % B, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': '%s per GPU: batch=%d %dx%dx3 T=%d %s--loss %s %s(k=%d) --opt %s %s'
-                               % ('BASELINE config 2' if is_config2 else 'variant of BASELINE config 2',
-                                  B, S, S, args.seq_len, '--adv ' if adv else '', args.loss, '--dna ' if dna else 'plain-G ',
+                               % (which, B, S, S, args.seq_len, '--adv ' if adv else '', args.loss, '--dna ' if dna else 'plain-G ',
                                   args.ksize, args.opt, 'fp32' if args.dtype == 'f32' else 'bf16-MFMA/fp32-accumulate'),
                    'global_batch': B * world, 'n_critic': n_critic, 'parallelism': 'dp%d' % world,
                    'hip_graphs': not args.no_graphs, 'timed_blocks': len(blocks), 'timed_seconds': round(float(np.sum(blocks)), 3),

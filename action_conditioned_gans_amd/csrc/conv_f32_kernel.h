@@ -419,6 +419,24 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
 #pragma unroll
     for (int u = 0; u < QB; ++u) { const int n = n0 + (tid >> 3) + 32 * u; nK[u] = n * p.K; nOk[u] = n < N; }
   }
+#ifdef ACG_NORM_PROBE
+  // COST PROBE (tools only, `make probe`; never in the shipped library): what normalise-on-load would add to the loaders -
+  // act((x - mean) * rstd + beta) on every GATHERED element on its way into LDS, zero padding applied after the activation.
+  // Parameters that leave the values unchanged (scale 1, shift 0, floor -inf) come from LDS so that nothing folds away;
+  // the in-bounds flag of every gathered quad is carried from its load to its store, as the real thing would have to.
+  __shared__ f4 probe_par[3][16];
+  if (tid < 16) { probe_par[0][tid] = f4{1.f, 1.f, 1.f, 1.f}; probe_par[1][tid] = f4{0.f, 0.f, 0.f, 0.f}; probe_par[2][tid] = f4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f}; }
+  bool probe_ok[NST][RA];
+  f4 probe_s = {1.f, 1.f, 1.f, 1.f}, probe_t = {0.f, 0.f, 0.f, 0.f}, probe_lo = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+  __syncthreads();
+  if constexpr (MODE == MODE_WGRAD) { probe_s = probe_par[0][tid & 15]; probe_t = probe_par[1][tid & 15]; probe_lo = probe_par[2][tid & 15]; }   // a thread's channel quad is fixed
+  auto probe_apply = [&](f4 q, const f4& ps, const f4& pt, const f4& pl, bool ok) {
+    f4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float z = fmaf(q[e], ps[e], pt[e]); r[e] = ok ? fmaxf(z, pl[e]) : 0.f; }
+    return r;
+  };
+#endif
   struct Prep {
     int t, kc, aoff, tb, bt, bc, boff, brow;
     bool kv;
@@ -459,11 +477,17 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
       if constexpr (MODE == MODE_WGRAD) {   // raw rows now; the transpose happens at store time
         const RowInfo ri = q.wri[I];
         const bool ok = live && wg_nvalid > 0 && tap_ok(ri, wg_t);
+#ifdef ACG_NORM_PROBE
+        probe_ok[ST][I] = ok;
+#endif
         if constexpr (!ragged) ra[ST][I] = guarded_quad(rs_g, ri.base + wg_off, ok);
         else ra[ST][I] = guarded_ragged(rs_g, ri.base + wg_off, ok, wg_nvalid);
       } else {
         // k-fast gather: 8 consecutive lanes walk 8 quads (128 contiguous bytes) of one gathered row
         const RowInfo ri = myrow[I];
+#ifdef ACG_NORM_PROBE
+        probe_ok[ST][I] = q.kv && tap_ok(ri, q.t);
+#endif
         if constexpr (!ragged) ra[ST][I] = guarded_quad(rs_g, ri.base + q.aoff, q.kv && tap_ok(ri, q.t));
         else ra[ST][I] = guarded_ragged(rs_g, ri.base + q.aoff, q.kv && tap_ok(ri, q.t), Cs - q.kc);
       }
@@ -527,6 +551,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
     f4* const As = As_all + buf * ASZ;
     f4* const Bs = Bs_all + buf * BSZ;
     if constexpr (MODE == MODE_WGRAD) {
+#ifdef ACG_NORM_PROBE
+#pragma unroll
+      for (int e = 0; e < LPA; ++e) ra[ST][e] = probe_apply(ra[ST][e], probe_s, probe_t, probe_lo, probe_ok[ST][e]);
+#endif
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float v[LPA];
@@ -536,6 +564,14 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
       }
     } else {
       const int kq = tid & 7, rg = tid >> 3;
+#ifdef ACG_NORM_PROBE
+      {   // the channel quad of this K-step's gathers: one parameter lookup per K-step (all QA quads of a thread share it)
+        const int c4 = (kq + ST) & 15;
+        const f4 ps = probe_par[0][c4], pt = probe_par[1][c4], pl = probe_par[2][c4];
+#pragma unroll
+        for (int u = 0; u < QA; ++u) ra[ST][u] = probe_apply(ra[ST][u], ps, pt, pl, probe_ok[ST][u]);
+      }
+#endif
 #pragma unroll
       for (int u = 0; u < QA; ++u) put(As, BM, kq, rg + 32 * u, ra[ST][u]);
       if constexpr (MODE == MODE_DGRAD) {

@@ -218,6 +218,18 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
   const int bk = bf16 ? BKH : BK;
   pl.nk = (int)((K + bk - 1) / bk);
   if (pl.nk < 1) pl.nk = 1;
+  // The few-MFLOP layers (d/conv6, g/sconv4, g/sconv5): one launch of the direct kernels instead of 2-16 K-splits of 1-8
+  // tiles plus a slab reduction (conv_direct.hip).  All three contractions of a layer take the same decision.
+  static const int direct_on = env_int("ACG_PLAN_DIRECT", 1);
+  const double flops = 2.0 * d.batch * d.out_h * d.out_w * d.kh * d.kw * (double)d.in_c * d.out_c;
+  // float32, at most 8 output channels (d/conv6, g/sconv5): measured wins of 4-7 us per contraction.  Sixteen channels
+  // (g/sconv4) lose - every lane then walks 16 strided dword loads per pixel and the launch is latency-bound at 10-19 us
+  // against 9 us tiled - and the bf16 tiled path, which does not split these layers, is already at 5 us
+  // (profiles/r3/d_direct_small_convs.txt).
+  if (direct_on && !bf16 && g_force_cfg < 0 && g_force_splits < 0 && d.out_c <= 8 && flops <= 8.0e6) {
+    pl.direct = true; pl.cfg = 9; pl.bm = pl.bn = 64; pl.tiles = 1; pl.splits = 1; pl.ragged = false; pl.nvec = true;
+    return pl;
+  }
   auto tiles_for = [&](int bm, int bn) { return acg::ceil_div(pl.M, bm) * acg::ceil_div(pl.N, bn) * pl.classes; };
   // Planner (evidence: profiles/r1 tuning sweeps, tools/fit_planner.py).  Split K until ~1 block per CU for
   // FWD/DGRAD and ~2 per CU for WGRAD (long K = B*OH*OW, heavier loaders: a second resident block hides its
@@ -285,7 +297,7 @@ struct Job {
 // DGRAD (a transposed layer's forward) must be of one size, or the smaller ones would leave partial blocks unwritten.
 constexpr int kMaxStatsBlocks = 4096;
 int stats_blocks(const Plan& pl, const acg_conv_desc& d, int which, int groups, int* tiles_per_group, int* run_rows = nullptr) {
-  if (which == ACG_CONV_WGRAD || pl.splits != 1 || groups < 1) return 0;
+  if (which == ACG_CONV_WGRAD || pl.splits != 1 || groups < 1 || pl.direct) return 0;
   const long long tiles_m = acg::ceil_div(pl.M, pl.bm);
   long long nblk = 0, tpg = 0, run = 0;
   if (which == ACG_CONV_DGRAD) {
@@ -355,6 +367,7 @@ int prepare(Job& j, int which, const float* gsrc, const float* dense, float* out
 }
 
 int launch(const Job& j, hipStream_t st) {
+  if (j.pl.direct) return launch_direct(j.which, j.pl.bf16, j.a, st);
   if (j.pl.bf16) {
     if (j.which == ACG_CONV_FWD) return launch_mode16<MODE_FWD>(j.pl, j.a, st);
     if (j.which == ACG_CONV_DGRAD) return launch_mode16<MODE_DGRAD>(j.pl, j.a, st);
@@ -399,7 +412,14 @@ int run_pair(int whichA, const float* gsrcA, const float* denseA, float* outA, c
   if (int rc = prepare(jb, ACG_CONV_WGRAD, gsrcB, denseB, outB, accumulateB, d, dtype, wsB, wsbB, who, slabs_only_B)) return rc;
   hipStream_t st = acg::to_stream(stream);
   static const int enabled = env_int("ACG_CONV_PAIR", 1);       // 0: always two launches (A/B comparison)
-  if (enabled && g_force_cfg < 0 && ja.pl.bf16 && jb.pl.bf16 && (whichA == ACG_CONV_FWD || whichA == ACG_CONV_DGRAD) &&
+  if (ja.pl.direct || jb.pl.direct) {
+    if (enabled && ja.pl.direct && jb.pl.direct && whichA == ACG_CONV_DGRAD) {
+      if (int rc = launch_direct_pair(ja.pl.bf16, ja.a, jb.a, st)) return rc;
+    } else {
+      if (int rc = launch(ja, st)) return rc;
+      if (int rc = launch(jb, st)) return rc;
+    }
+  } else if (enabled && g_force_cfg < 0 && ja.pl.bf16 && jb.pl.bf16 && (whichA == ACG_CONV_FWD || whichA == ACG_CONV_DGRAD) &&
       (long long)ja.pl.tiles * ja.pl.splits + (long long)jb.pl.tiles * jb.pl.splits < (1ll << 30)) {
     if (int rc = launch_pair16(whichA == ACG_CONV_FWD ? MODE_FWD : MODE_DGRAD, ja.pl, ja.a, jb.pl, jb.a, st)) return rc;
   } else if (enabled && g_force_cfg < 0 && pair_supported(whichA, ja.pl, jb.pl)) {

@@ -822,8 +822,13 @@ struct Plan {
   long long M, N;  // per class (class 0 = largest) GEMM extents (M padded per tap for WGRAD)
   int classes, nk, splits;
   bool ragged, nvec, bf16;
+  bool direct;     // a few-MFLOP contraction with at most 16 output channels: the direct kernels of conv_direct.hip, one launch, no slabs
   long long tiles, out_numel;
 };
+
+// conv_direct.hip
+int launch_direct(int which, bool bf16, const ConvArgs& a, hipStream_t st);
+int launch_direct_pair(bool bf16, const ConvArgs& a, const ConvArgs& b, hipStream_t st);
 
 template <int MODE>
 int launch_mode(const Plan& pl, const ConvArgs& a, hipStream_t st);

@@ -157,7 +157,7 @@ def case_bwd_pair_bf16(abi, tol, tol_w):
 
 
 STATS_LAYERS = [   # (x shape, w shape, stride, padding, transposed, groups, act)
-    ((4, 16, 16, 8), (5, 5, 8, 16), 2, 'SAME', False, 1, 'relu'),
+    ((4, 16, 16, 8), (5, 5, 8, 32), 2, 'SAME', False, 1, 'relu'),            # (16 output channels would take the direct kernels: no statistics)
     ((8, 32, 32, 3), (5, 5, 3, 32), 2, 'SAME', False, 1, 'relu'),        # g/conv1-like: N = 32 (the 128 x 32 tile in fp32)
     ((8, 32, 32, 6), (5, 5, 6, 64), 2, 'SAME', False, 2, 'lrelu'),       # d/conv1-like: two groups (fake | real)
     ((6, 18, 14, 12), (3, 3, 12, 40), 1, 'SAME', False, 1, None),        # ragged rows and columns
@@ -451,7 +451,7 @@ def case_sync_bn_entries_bf16(abi, tol):
 
 
 PAIR_LAYERS = [   # (x shape, w shape, stride, padding, transposed)
-    ((4, 16, 16, 8), (5, 5, 8, 16), 2, 'SAME', False),        # both contractions on the 128x32 tile, weight gradient split
+    ((4, 16, 16, 8), (5, 5, 8, 24), 2, 'SAME', False),        # both contractions on the 128x32 tile, weight gradient split
     ((4, 16, 16, 64), (5, 5, 64, 128), 2, 'SAME', False),     # 64x64 tiles (g/conv3-like), both split
     ((2, 9, 7, 4), (5, 5, 4, 36), 2, 'SAME', False),          # ragged extents, mixed tiles
     ((4, 12, 12, 12), (3, 3, 12, 8), 1, 'VALID', False),
@@ -509,8 +509,9 @@ def case_wgrad_deferred(abi, tol, exact):
     """acg_(de)conv2d_wgrad_slabs + ONE acg_splitk_reduce_many over several layers == the per-layer acg_(de)conv2d_wgrad
     (bit for bit on the HIP side: same slabs, same summation order), including an accumulating entry and a ragged size."""
     dev = abi.device
-    layers = [((4, 16, 16, 8), (5, 5, 8, 16), 2, 'SAME', False), ((4, 18, 14, 3), (5, 5, 3, 5), 1, 'SAME', False),
-              ((4, 12, 12, 12), (3, 3, 12, 8), 1, 'VALID', False), ((4, 8, 8, 16), (5, 5, 8, 16), 2, None, True)]
+    # (more than 16 output channels each: smaller layers take the direct kernels, which never split)
+    layers = [((4, 16, 16, 8), (5, 5, 8, 32), 2, 'SAME', False), ((4, 18, 14, 3), (5, 5, 3, 40), 1, 'SAME', False),
+              ((4, 12, 12, 12), (3, 3, 12, 24), 1, 'VALID', False), ((4, 8, 8, 32), (5, 5, 8, 32), 2, None, True)]
     entries, want, got = [], [], []
     for i, (xs, ws_, stride, padding, transposed) in enumerate(layers):
         x = randn(xs, 20 + i).to(dev)

@@ -216,11 +216,12 @@ struct TileGeom { int block_rows, run_rows, blocks_per_run; };
 template <int V>
 __device__ __forceinline__ void merge_tile_partials(const float* __restrict__ part, int g, int nblk, int C, int c, bool cvalid, int rl,
                                                     const TileGeom tg, long long R, float eps, float (&mean)[V], float (&rstd)[V],
-                                                    float* sh /* 4 * 8 * 3 * V floats */) {
+                                                    float* sh /* (blockDim.x / 64) * 8 * 3 * V floats */) {
   float S[V], Q[V], P[V], ref[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) { S[j] = 0.f; Q[j] = 0.f; P[j] = 0.f; ref[j] = 0.f; }
   const bool uniform = tg.run_rows % tg.block_rows == 0;      // block-uniform
+  const int nrl = (int)blockDim.x >> 3, nwaves = (int)blockDim.x >> 6;     // row lanes (32 in the apply kernels, 128 in the finalize launch)
   if (cvalid) {
     const float* p0 = part + (long long)g * nblk * 2 * C + c;
     ldv<V>(p0, ref);
@@ -229,7 +230,8 @@ __device__ __forceinline__ void merge_tile_partials(const float* __restrict__ pa
     for (int j = 0; j < V; ++j) ref[j] *= inv0;
     if (uniform) {
       const float nb = (float)tg.block_rows, inv = 1.f / nb;
-      for (int b = rl; b < nblk; b += 32) {
+#pragma unroll 8
+      for (int b = rl; b < nblk; b += nrl) {      // (unrolled: the loads of eight partial blocks in flight - this loop is pure latency)
         const float* o = p0 + (long long)b * 2 * C;
         float a[V], q[V];
         ldv<V>(o, a); ldv<V>(o + C, q);
@@ -237,7 +239,7 @@ __device__ __forceinline__ void merge_tile_partials(const float* __restrict__ pa
         for (int j = 0; j < V; ++j) { const float d = fmaf(-nb, ref[j], a[j]); S[j] += d; P[j] = fmaf(d * inv, d, P[j]); Q[j] += q[j]; }
       }
     } else {
-      for (int b = rl; b < nblk; b += 32) {
+      for (int b = rl; b < nblk; b += nrl) {
         const float* o = p0 + (long long)b * 2 * C;
         float a[V], q[V];
         ldv<V>(o, a); ldv<V>(o + C, q);
@@ -263,7 +265,7 @@ __device__ __forceinline__ void merge_tile_partials(const float* __restrict__ pa
   for (int j = 0; j < V; ++j) {
     float s = 0.f, q = 0.f, pp = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { const float* z = sh + ((w * 8 + cq) * 3) * V + j; s += z[0]; q += z[V]; pp += z[2 * V]; }
+    for (int w = 0; w < nwaves; ++w) { const float* z = sh + ((w * 8 + cq) * 3) * V + j; s += z[0]; q += z[V]; pp += z[2 * V]; }
     const float inv = 1.f / (float)R, dm = s * inv;
     const float var = fmaxf((q + (pp - s * dm)) * inv, 0.f);
     mean[j] = ref[j] + dm;
@@ -758,18 +760,28 @@ __global__ __launch_bounds__(256) void bn_moments_to_stats(const float* __restri
   save_mean[i] = moments[(g * 2 + 0) * C + c];
   save_rstd[i] = 1.0f / sqrtf(moments[(g * 2 + 1) * C + c] + eps);
 }
+// sums[g][{0,1}][c] = sum over the partial blocks; block (x = 32 channels, y = group) of 256 threads = 8 block lanes x 32
+// channels, eight loads in flight per thread (one thread per channel walking 512 partials serially cost 100+ us)
 __global__ __launch_bounds__(256) void bn_sums_finalize(const float* __restrict__ part, float* __restrict__ sums, int C,
                                                         int groups, int nblk) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= groups * C) return;
-  const int g = i / C, c = i - g * C;
+  __shared__ double sh[2][256];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl, g = blockIdx.y;
   double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s1 += part[((long long)g * nblk + b) * 2 * C + c];
-    s2 += part[((long long)g * nblk + b) * 2 * C + C + c];
+  if (c < C) {
+#pragma unroll 8
+    for (int b = rl; b < nblk; b += 8) {
+      const float* o = part + ((long long)g * nblk + b) * 2 * C + c;
+      s1 += (double)o[0]; s2 += (double)o[C];
+    }
   }
-  sums[(g * 2 + 0) * C + c] = (float)s1;
-  sums[(g * 2 + 1) * C + c] = (float)s2;
+  sh[0][threadIdx.x] = s1; sh[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+#pragma unroll
+    for (int r = 1; r < 8; ++r) { s1 += sh[0][r * 32 + cl]; s2 += sh[1][r * 32 + cl]; }
+    sums[(g * 2 + 0) * C + c] = (float)s1;
+    sums[(g * 2 + 1) * C + c] = (float)s2;
+  }
 }
 __global__ __launch_bounds__(256) void bn_dbeta_local_k(const float* __restrict__ local_sums, float* __restrict__ dbeta,
                                                         float acc, int C, int groups) {
@@ -1055,7 +1067,7 @@ int bn_bwd_sums_typed(const void* x, const void* dy, const float* beta, const fl
     ACG_LAUNCH((bn_bwd_partial<1, TX, TY>), dim3(nblk, groups), dim3(256), 0, st, (const TX*)x, (const TY*)dy, beta, save_mean, save_rstd, part, R, C, nblk, act, leak, XP, YP);
   }
   if (int rc = acg::check_launch("bn_bwd_partial")) return rc;
-  ACG_LAUNCH(bn_sums_finalize, dim3((groups * C + 255) / 256), dim3(256), 0, st, (const float*)part, sums, C, groups, nblk);
+  ACG_LAUNCH(bn_sums_finalize, dim3((C + 31) / 32, groups), dim3(256), 0, st, (const float*)part, sums, C, groups, nblk);
   return acg::check_launch("bn_sums_finalize");
 }
 template <typename TX, typename TY, typename TD = TX>

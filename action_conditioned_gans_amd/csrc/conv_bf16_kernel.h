@@ -39,7 +39,7 @@ __device__ __forceinline__ int tr_off(int row, int ch) {
   return (W16 / 4) * 512 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
 }
 
-template <int MODE, int BM, int BN>
+template <int MODE, int BM, int BN, bool EPI = false>
 __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, const int by, const int bz, const int gx, char* smem) {
   constexpr int WN = BN >= 64 ? 2 : 1, WM = 4 / WN;
   constexpr int TA = BM / (32 * WM), TB = BN / (32 * WN);
@@ -131,7 +131,7 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
         const int w2 = m % Wc; const int t2 = m / Wc; const int h2 = t2 % Hc; const int b = t2 / Hc;
         const int y0 = h2 + dp0, x0 = w2 + dq0;
         ri.base = ((b * p.OH + y0) * p.OW + x0) * K8;
-        ri.out_off = ((b * p.H + h2 * p.sh + ph) * p.W + (w2 * p.sw + pw)) * Cin8;
+        ri.out_off = ((b * p.H + h2 * p.sh + ph) * p.W + (w2 * p.sw + pw)) * (EPI ? p.Cx : Cin8);      // EPI: dense float32 rows
         const unsigned long long mk = tap_mask(max(0, y0 - p.OH + 1), min(nti, y0 + 1), max(0, x0 - p.OW + 1), min(ntj, x0 + 1), ntj);
         ri.mask_lo = (unsigned)mk; ri.mask_hi = (unsigned)(mk >> 32);
       }
@@ -371,7 +371,18 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
   // ---- epilogue --------------------------------------------------------------------------------------
   // splits == 1: FWD / DGRAD write the bf16 activation (pitch round8), WGRAD the fp32 gradient; splits > 1: fp32 slabs
   // of out_numel elements laid out like the final tensor, summed (and rounded to bf16) by splitk_reduce.
-  const bool to_bf16 = MODE != MODE_WGRAD && p.splits == 1 && !p.out_f32;
+  const bool to_bf16 = MODE != MODE_WGRAD && p.splits == 1 && !p.out_f32 && !EPI;
+  if constexpr (EPI) {          // bias + activation of a layer built with normalizer_fn = None (models.py:20-21): float32 out
+#pragma unroll
+    for (int b = 0; b < TB; ++b) {
+      const int n = n0 + wn0 + 32 * b + lrow;
+      const float bv = n < N ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = acg::act_apply(p.act, acc[a][b][r] + bv, p.leak);
+    }
+  }
   if constexpr (MODE != MODE_WGRAD) {
     if (p.stats != nullptr) {     // BatchNorm statistics of this tile, of the bf16 values as stored (ConvArgs::stats, conv_f32_kernel.h)
       int g = 0, blk;
@@ -466,7 +477,7 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
     }
 }
 
-template <int MODE, int BM, int BN>
+template <int MODE, int BM, int BN, bool EPI = false>
 __global__ __launch_bounds__(256) void conv_mfma_bf16(const ConvArgs p) {
   __shared__ __align__(16) char smem[conv16_lds_bytes<MODE, BM, BN>()];
   if constexpr (MODE == MODE_WGRAD) {      // grid (tiles, 1, splits)
@@ -474,7 +485,7 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16(const ConvArgs p) {
     wgrad_xcd_map((int)(blockIdx.x + gridDim.x * blockIdx.z), (int)gridDim.x, (int)gridDim.z, tile, split);
     conv16_body<MODE, BM, BN>(p, tile, 0, split, (int)gridDim.x, smem);
   } else {
-    conv16_body<MODE, BM, BN>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
+    conv16_body<MODE, BM, BN, EPI>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
   }
 }
 

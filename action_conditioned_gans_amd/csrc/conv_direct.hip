@@ -11,9 +11,8 @@
 // (First cut, measured: lanes over channels inside a serial tap loop and 32 filter rows x 8 pixel groups per block left
 // g/sconv4's weight gradient on 9 blocks walking 64 dependent-latency iterations each: 72 us.  Parallelism first.)
 // Round 1's direct kernel (one output per 8-lane group, a serial chain of dependent loads: 73-129 us) was the wrong shape,
-// not the wrong idea.  Storage: float32 tensors and the float32 filter, or bf16 tensors at the pitch round8(C) with the
-// prepared bf16 filter copies (acg_weights_prepare_bf16: 'tr' [tap][n][c8] for FWD, 'rm' [tap][c][n8] for DGRAD); weight
-// gradients are float32 either way.
+// not the wrong idea.  float32 only: the bf16 tiled path does not split these layers and already runs them in ~5 us, and
+// with 16 output channels (g/sconv4) a lane's strided loads make the launch latency-bound (profiles/r3/d_direct_small_convs.txt).
 #include "conv_bf16_kernel.h"
 
 namespace acgconv {
@@ -21,35 +20,25 @@ namespace acgconv {
 namespace {
 
 
-// W[tap][c][n] in the layout the contraction's dense operand has
-enum { WL_F32 = 0, WL_TR16 = 1, WL_RM16 = 2 };
-template <int WL>
-__device__ __forceinline__ float wload(const void* w, int tap, int c, int n, int C, int N, int C8, int N8) {
-  if constexpr (WL == WL_F32) return reinterpret_cast<const float*>(w)[((long long)tap * C + c) * N + n];
-  else if constexpr (WL == WL_TR16) return (float)reinterpret_cast<const __bf16*>(w)[((long long)tap * N + n) * C8 + c];
-  else return (float)reinterpret_cast<const __bf16*>(w)[((long long)tap * C + c) * N8 + n];
-}
-
 // y[b,p,q,n] = sum_{tap in bounds, c} x[b, p*s - pt + i, q*s - pl + j, c] * W[tap][c][n]
 // A BLOCK per output pixel: its 256 threads split the flattened (tap, channel) reduction, U steps at a time with all
 // loads of the U steps issued before the first multiply - these layers leave one or two waves per CU, so nothing but the
 // wave's own independent loads hides a memory round trip (a wave per pixel walking 32 dependent passes: 9 us for d/conv6).
-template <typename T, int WL, int NB>
-__global__ __launch_bounds__(256) void direct_fwd(const T* __restrict__ x, const void* __restrict__ w, void* __restrict__ yv,
-                                                  const ConvArgs p, int out_f32) {
+template <int NB>
+__global__ __launch_bounds__(256) void direct_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                  const ConvArgs p) {
   constexpr int U = NB == 1 ? 8 : (NB == 8 ? 4 : 2);
   __shared__ float red[4 * NB];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int m = blockIdx.x;
-  const int C8 = (p.C + 7) & ~7, N8 = (p.K + 7) & ~7;
-  const int xp = sizeof(T) == 2 ? C8 : p.Cx, yp = sizeof(T) == 2 ? N8 : p.Ky;
+  const int xp = p.Cx, yp = p.Ky;
   const int q = m % p.OW, t2 = m / p.OW, pp = t2 % p.OH, b = t2 / p.OH;
   const int y0 = pp * p.sh - p.pt, x0 = q * p.sw - p.pl;
   float acc[NB];
 #pragma unroll
   for (int n = 0; n < NB; ++n) acc[n] = 0.f;
   const int Ktot = p.KH * p.KW * p.C;
-  const T* const xb = x + (long long)b * p.H * p.W * xp;
+  const float* const xb = x + (long long)b * p.H * p.W * xp;
   for (int k0 = tid; k0 < Ktot; k0 += 256 * U) {
     float xv[U], wv[U][NB];
 #pragma unroll
@@ -60,11 +49,10 @@ __global__ __launch_bounds__(256) void direct_fwd(const T* __restrict__ x, const
       const int tap = kk / p.C, c = kk - tap * p.C, i = tap / p.KW, j = tap - i * p.KW;
       const int yy = y0 + i, xx = x0 + j;
       const bool in = live && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-      xv[u] = in ? (float)xb[(yy * p.W + xx) * xp + c] : 0.f;
+      xv[u] = in ? xb[(yy * p.W + xx) * xp + c] : 0.f;
 #pragma unroll
       for (int n = 0; n < NB; ++n) {
-        if constexpr (WL == WL_F32) wv[u][n] = (n < p.K) ? reinterpret_cast<const float*>(w)[(long long)kk * p.K + n] : 0.f;
-        else wv[u][n] = (n < p.K) ? wload<WL>(w, tap, c, n, p.C, p.K, C8, N8) : 0.f;
+        wv[u][n] = (n < p.K) ? w[(long long)kk * p.K + n] : 0.f;          // W[tap][c][n] with (tap * C + c) = k
       }
     }
 #pragma unroll
@@ -84,17 +72,15 @@ __global__ __launch_bounds__(256) void direct_fwd(const T* __restrict__ x, const
   __syncthreads();
   if (tid < NB && tid < p.K) {
     const float v = red[tid] + red[NB + tid] + red[2 * NB + tid] + red[3 * NB + tid];
-    if (sizeof(T) == 2 && !out_f32) reinterpret_cast<__bf16*>(yv)[(long long)m * yp + tid] = (__bf16)v;
-    else reinterpret_cast<float*>(yv)[(long long)m * yp + tid] = v;
+    y[(long long)m * yp + tid] = v;
   }
 }
 
 // dx[b,y,x,c] = sum_{taps (i,j) with y + pt - i = p*s, x + pl - j = q*s, (p,q) in range} sum_n dy[b,p,q,n] * W[tap][c][n]
-template <typename T, int WL, int NB>
-__device__ __forceinline__ void direct_dgrad_body(const T* __restrict__ dy, const void* __restrict__ w, T* __restrict__ dx, const ConvArgs& p,
+template <int NB>
+__device__ __forceinline__ void direct_dgrad_body(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, const ConvArgs& p,
                                                   int block, int nblocks) {
-  const int C8 = (p.C + 7) & ~7, N8 = (p.K + 7) & ~7;
-  const int xp = sizeof(T) == 2 ? C8 : p.Cx, yp = sizeof(T) == 2 ? N8 : p.Ky;
+  const int xp = p.Cx, yp = p.Ky;
   const long long total = (long long)p.batch * p.H * p.W * p.C;
   for (long long e = (long long)block * 256 + threadIdx.x; e < total; e += (long long)nblocks * 256) {
     const int c = (int)(e % p.C);
@@ -108,30 +94,28 @@ __device__ __forceinline__ void direct_dgrad_body(const T* __restrict__ dy, cons
       if (pp >= p.OH) continue;
       for (int j = j0, q = q0; j < p.KW && q >= 0; j += p.sw, --q) {
         if (q >= p.OW) continue;
-        const T* dr = dy + ((long long)(b * p.OH + pp) * p.OW + q) * yp;
+        const float* dr = dy + ((long long)(b * p.OH + pp) * p.OW + q) * yp;
         const int tap = i * p.KW + j;
         float dv[NB], wv[NB];                       // both rows requested before the first multiply
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
-          dv[n] = n < p.K ? (float)dr[n] : 0.f;
-          if constexpr (WL == WL_F32) wv[n] = n < p.K ? reinterpret_cast<const float*>(w)[((long long)tap * p.C + c) * p.K + n] : 0.f;
-          else wv[n] = n < p.K ? wload<WL>(w, tap, c, n, p.C, p.K, C8, N8) : 0.f;
+          dv[n] = n < p.K ? dr[n] : 0.f;
+          wv[n] = n < p.K ? w[((long long)tap * p.C + c) * p.K + n] : 0.f;
         }
 #pragma unroll
         for (int n = 0; n < NB; ++n) acc = fmaf(dv[n], wv[n], acc);
       }
     }
-    dx[pix * xp + c] = (T)acc;
+    dx[pix * xp + c] = acc;
   }
 }
 
 // dw[tap][c][n] = accumulate * dw + sum_{b,p,q in bounds} x[b, p*s - pt + i, q*s - pl + j, c] * dy[b,p,q,n]
 // a wave per filter row (tap, c); `block` = 4 rows
-template <typename T, int NB>
-__device__ __forceinline__ void direct_wgrad_body(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw, const ConvArgs& p,
+template <int NB>
+__device__ __forceinline__ void direct_wgrad_body(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, const ConvArgs& p,
                                                   int block) {
-  const int C8 = (p.C + 7) & ~7, N8 = (p.K + 7) & ~7;
-  const int xp = sizeof(T) == 2 ? C8 : p.Cx, yp = sizeof(T) == 2 ? N8 : p.Ky;
+  const int xp = p.Cx, yp = p.Ky;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = block * 4 + wave, nrows = p.KH * p.KW * p.C;
   if (row >= nrows) return;
@@ -151,10 +135,10 @@ __device__ __forceinline__ void direct_wgrad_body(const T* __restrict__ x, const
       const int q = mm % p.OW, t2 = mm / p.OW, pp = t2 % p.OH, b = t2 / p.OH;
       const int yy = pp * p.sh - p.pt + i, xx = q * p.sw - p.pl + j;
       const bool in = live && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-      xv[u] = in ? (float)x[((long long)(b * p.H + yy) * p.W + xx) * xp + c] : 0.f;
-      const T* dr = dy + (long long)mm * yp;
+      xv[u] = in ? x[((long long)(b * p.H + yy) * p.W + xx) * xp + c] : 0.f;
+      const float* dr = dy + (long long)mm * yp;
 #pragma unroll
-      for (int n = 0; n < NB; ++n) dv[u][n] = n < p.K ? (float)dr[n] : 0.f;
+      for (int n = 0; n < NB; ++n) dv[u][n] = n < p.K ? dr[n] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -177,20 +161,20 @@ __device__ __forceinline__ void direct_wgrad_body(const T* __restrict__ x, const
   }
 }
 
-template <typename T, int WL, int NB>
-__global__ __launch_bounds__(256) void direct_dgrad(const T* __restrict__ dy, const void* __restrict__ w, T* __restrict__ dx, const ConvArgs p) {
-  direct_dgrad_body<T, WL, NB>(dy, w, dx, p, (int)blockIdx.x, (int)gridDim.x);
+template <int NB>
+__global__ __launch_bounds__(256) void direct_dgrad(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, const ConvArgs p) {
+  direct_dgrad_body<NB>(dy, w, dx, p, (int)blockIdx.x, (int)gridDim.x);
 }
-template <typename T, int NB>
-__global__ __launch_bounds__(256) void direct_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw, const ConvArgs p) {
-  direct_wgrad_body<T, NB>(x, dy, dw, p, (int)blockIdx.x);
+template <int NB>
+__global__ __launch_bounds__(256) void direct_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, const ConvArgs p) {
+  direct_wgrad_body<NB>(x, dy, dw, p, (int)blockIdx.x);
 }
 // a layer's input gradient and weight gradient out of one grid: blocks [0, nA) run the input gradient
-template <typename T, int WL, int NB>
-__global__ __launch_bounds__(256) void direct_pair(const T* __restrict__ dy, const void* __restrict__ w, T* __restrict__ dx, const ConvArgs a,
-                                                   const T* __restrict__ x, float* __restrict__ dw, const ConvArgs b, int nA) {
-  if ((int)blockIdx.x < nA) direct_dgrad_body<T, WL, NB>(dy, w, dx, a, (int)blockIdx.x, nA);
-  else direct_wgrad_body<T, NB>(x, dy, dw, b, (int)blockIdx.x - nA);
+template <int NB>
+__global__ __launch_bounds__(256) void direct_pair(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, const ConvArgs a,
+                                                   const float* __restrict__ x, float* __restrict__ dw, const ConvArgs b, int nA) {
+  if ((int)blockIdx.x < nA) direct_dgrad_body<NB>(dy, w, dx, a, (int)blockIdx.x, nA);
+  else direct_wgrad_body<NB>(x, dy, dw, b, (int)blockIdx.x - nA);
 }
 
 int dgrad_blocks(const ConvArgs& a) {
@@ -202,45 +186,32 @@ int wgrad_blocks(const ConvArgs& a) { return (int)acg::ceil_div((long long)a.KH 
 }  // namespace
 
 // One contraction on the direct kernels.  `a` as prepared for the tiled path (gsrc / dense / out as that mode defines them).
-int launch_direct(int which, bool bf16, const ConvArgs& a, hipStream_t st) {
-  const int nb = a.K <= 1 ? 1 : (a.K <= 8 ? 8 : 16);
+int launch_direct(int which, const ConvArgs& a, hipStream_t st) {
+  const bool one = a.K <= 1;
   if (which == ACG_CONV_FWD) {
     const dim3 grid((unsigned)((long long)a.batch * a.OH * a.OW));
-#define ACG_DF(T, WL) do { if (nb == 1) ACG_LAUNCH((direct_fwd<T, WL, 1>), grid, dim3(256), 0, st, (const T*)a.gsrc, (const void*)a.dense, (void*)a.out, a, a.out_f32); \
-      else if (nb == 8) ACG_LAUNCH((direct_fwd<T, WL, 8>), grid, dim3(256), 0, st, (const T*)a.gsrc, (const void*)a.dense, (void*)a.out, a, a.out_f32); \
-      else ACG_LAUNCH((direct_fwd<T, WL, 16>), grid, dim3(256), 0, st, (const T*)a.gsrc, (const void*)a.dense, (void*)a.out, a, a.out_f32); } while (0)
-    if (bf16) ACG_DF(__bf16, WL_TR16); else ACG_DF(float, WL_F32);
-#undef ACG_DF
+    if (one) ACG_LAUNCH((direct_fwd<1>), grid, dim3(256), 0, st, a.gsrc, a.dense, a.out, a);
+    else ACG_LAUNCH((direct_fwd<8>), grid, dim3(256), 0, st, a.gsrc, a.dense, a.out, a);
     return acg::check_launch("direct_fwd");
   }
   if (which == ACG_CONV_DGRAD) {
     const dim3 grid((unsigned)dgrad_blocks(a));
-#define ACG_DD(T, WL) do { if (nb == 1) ACG_LAUNCH((direct_dgrad<T, WL, 1>), grid, dim3(256), 0, st, (const T*)a.gsrc, (const void*)a.dense, (T*)a.out, a); \
-      else if (nb == 8) ACG_LAUNCH((direct_dgrad<T, WL, 8>), grid, dim3(256), 0, st, (const T*)a.gsrc, (const void*)a.dense, (T*)a.out, a); \
-      else ACG_LAUNCH((direct_dgrad<T, WL, 16>), grid, dim3(256), 0, st, (const T*)a.gsrc, (const void*)a.dense, (T*)a.out, a); } while (0)
-    if (bf16) ACG_DD(__bf16, WL_RM16); else ACG_DD(float, WL_F32);
-#undef ACG_DD
+    if (one) ACG_LAUNCH((direct_dgrad<1>), grid, dim3(256), 0, st, a.gsrc, a.dense, a.out, a);
+    else ACG_LAUNCH((direct_dgrad<8>), grid, dim3(256), 0, st, a.gsrc, a.dense, a.out, a);
     return acg::check_launch("direct_dgrad");
   }
   const dim3 grid((unsigned)wgrad_blocks(a));
-#define ACG_DW(T) do { if (nb == 1) ACG_LAUNCH((direct_wgrad<T, 1>), grid, dim3(256), 0, st, (const T*)a.gsrc, (const T*)a.dense, a.out, a); \
-    else if (nb == 8) ACG_LAUNCH((direct_wgrad<T, 8>), grid, dim3(256), 0, st, (const T*)a.gsrc, (const T*)a.dense, a.out, a); \
-    else ACG_LAUNCH((direct_wgrad<T, 16>), grid, dim3(256), 0, st, (const T*)a.gsrc, (const T*)a.dense, a.out, a); } while (0)
-  if (bf16) ACG_DW(__bf16); else ACG_DW(float);
-#undef ACG_DW
+  if (one) ACG_LAUNCH((direct_wgrad<1>), grid, dim3(256), 0, st, a.gsrc, a.dense, a.out, a);
+  else ACG_LAUNCH((direct_wgrad<8>), grid, dim3(256), 0, st, a.gsrc, a.dense, a.out, a);
   return acg::check_launch("direct_wgrad");
 }
 
 // input gradient (a: DGRAD) + weight gradient (b: WGRAD) of one conv layer in one launch
-int launch_direct_pair(bool bf16, const ConvArgs& a, const ConvArgs& b, hipStream_t st) {
-  const int nb = a.K <= 1 ? 1 : (a.K <= 8 ? 8 : 16);
+int launch_direct_pair(const ConvArgs& a, const ConvArgs& b, hipStream_t st) {
   const int nA = dgrad_blocks(a);
   const dim3 grid((unsigned)(nA + wgrad_blocks(b)));
-#define ACG_DP(T, WL) do { if (nb == 1) ACG_LAUNCH((direct_pair<T, WL, 1>), grid, dim3(256), 0, st, (const T*)a.gsrc, (const void*)a.dense, (T*)a.out, a, (const T*)b.gsrc, b.out, b, nA); \
-    else if (nb == 8) ACG_LAUNCH((direct_pair<T, WL, 8>), grid, dim3(256), 0, st, (const T*)a.gsrc, (const void*)a.dense, (T*)a.out, a, (const T*)b.gsrc, b.out, b, nA); \
-    else ACG_LAUNCH((direct_pair<T, WL, 16>), grid, dim3(256), 0, st, (const T*)a.gsrc, (const void*)a.dense, (T*)a.out, a, (const T*)b.gsrc, b.out, b, nA); } while (0)
-  if (bf16) ACG_DP(__bf16, WL_RM16); else ACG_DP(float, WL_F32);
-#undef ACG_DP
+  if (a.K <= 1) ACG_LAUNCH((direct_pair<1>), grid, dim3(256), 0, st, a.gsrc, a.dense, a.out, a, b.gsrc, b.out, b, nA);
+  else ACG_LAUNCH((direct_pair<8>), grid, dim3(256), 0, st, a.gsrc, a.dense, a.out, a, b.gsrc, b.out, b, nA);
   return acg::check_launch("direct_pair");
 }
 

@@ -367,7 +367,7 @@ int prepare(Job& j, int which, const float* gsrc, const float* dense, float* out
 }
 
 int launch(const Job& j, hipStream_t st) {
-  if (j.pl.direct) return launch_direct(j.which, j.pl.bf16, j.a, st);
+  if (j.pl.direct) return launch_direct(j.which, j.a, st);
   if (j.pl.bf16) {
     if (j.which == ACG_CONV_FWD) return launch_mode16<MODE_FWD>(j.pl, j.a, st);
     if (j.which == ACG_CONV_DGRAD) return launch_mode16<MODE_DGRAD>(j.pl, j.a, st);
@@ -414,7 +414,7 @@ int run_pair(int whichA, const float* gsrcA, const float* denseA, float* outA, c
   static const int enabled = env_int("ACG_CONV_PAIR", 1);       // 0: always two launches (A/B comparison)
   if (ja.pl.direct || jb.pl.direct) {
     if (enabled && ja.pl.direct && jb.pl.direct && whichA == ACG_CONV_DGRAD) {
-      if (int rc = launch_direct_pair(ja.pl.bf16, ja.a, jb.a, st)) return rc;
+      if (int rc = launch_direct_pair(ja.a, jb.a, st)) return rc;
     } else {
       if (int rc = launch(ja, st)) return rc;
       if (int rc = launch(jb, st)) return rc;
@@ -496,6 +496,30 @@ int32_t acg_deconv2d_fwd_stats(const void* x, const void* w, void* y, const acg_
                                float* partials, int32_t groups, acg_stream_t s) {
   ACG_REQUIRE(partials != nullptr, ACG_ERR_INVALID_ARG, "deconv2d_fwd_stats: null partials");
   return run(ACG_CONV_DGRAD, (const float*)x, (const float*)w, (float*)y, 0.f, adj, dtype, ws, wsb, s, "deconv2d_fwd_stats", false, partials, groups);
+}
+
+// Bias + activation in the epilogue of a transposed layer's forward (models.py:20-21: tanh(conv2d_transpose(x) + b), the plain
+// generator's frame): available where the plan is the unsplit 128x32 tile with 16-byte gathers.
+static bool deconv_bias_act_plan(const acg_conv_desc* adj, int dtype, Plan* out) {
+  if (!adj || validate(adj, "deconv2d_fwd_bias_act") != ACG_OK || (dtype != ACG_F32 && dtype != ACG_BF16)) return false;
+  const Plan pl = make_plan(*adj, ACG_CONV_DGRAD, dtype == ACG_BF16);
+  if (out) *out = pl;
+  return !pl.direct && pl.splits == 1 && pl.bm == 128 && pl.bn == 32 && !pl.ragged && g_force_cfg < 0;
+}
+int32_t acg_deconv2d_fwd_bias_act_ok(const acg_conv_desc* adj, int32_t dtype) { return deconv_bias_act_plan(adj, dtype, nullptr) ? 1 : 0; }
+int32_t acg_deconv2d_fwd_bias_act(const void* x, const void* w, const float* bias, float* y, const acg_conv_desc* adj, int32_t act,
+                                  float leak, int32_t dtype, acg_stream_t s) {
+  ACG_REQUIRE(bias && y, ACG_ERR_INVALID_ARG, "deconv2d_fwd_bias_act: null pointer");
+  ACG_REQUIRE(act >= ACG_ACT_NONE && act <= ACG_ACT_TANH, ACG_ERR_INVALID_ARG, "deconv2d_fwd_bias_act: activation %d", act);
+  ACG_REQUIRE(deconv_bias_act_plan(adj, dtype, nullptr), ACG_ERR_UNSUPPORTED, "deconv2d_fwd_bias_act: this shape does not take the fused epilogue (acg_deconv2d_fwd_bias_act_ok == 0)");
+  acg_conv_desc d = *adj;
+  if (dtype == ACG_BF16) d.in_pitch = 0;      // (checked against round8 by prepare; the OUTPUT pitch is set below)
+  Job j;
+  if (int rc = prepare(j, ACG_CONV_DGRAD, (const float*)x, (const float*)w, y, 0.f, &d, dtype, nullptr, 0, "deconv2d_fwd_bias_act", false)) return rc;
+  j.a.bias = bias; j.a.act = act; j.a.leak = leak;
+  j.a.Cx = adj->in_pitch > 0 ? adj->in_pitch : adj->in_c;      // y: dense float32 rows (in_pitch of the adjoint = y's pitch)
+  hipStream_t st = acg::to_stream(s);
+  return dtype == ACG_BF16 ? launch_deconv_fwd_epi16(j.pl, j.a, st) : launch_deconv_fwd_epi(j.pl, j.a, st);
 }
 
 int32_t acg_conv2d_wgrad_slabs(const void* x, const void* dy, const acg_conv_desc* d, int32_t dtype, void* ws, size_t wsb,

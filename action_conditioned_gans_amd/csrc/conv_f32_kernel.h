@@ -61,6 +61,10 @@ struct ConvArgs {
   float* stats;
   int stats_nblk, stats_tpg;
   int out_f32;         // bf16 kernels, FWD / DGRAD: the result is stored as float32 (at the bf16 tensor's pitch, round8): a head layer
+  // EPI kernel variants only (acg_deconv2d_fwd_bias_act): out = act(acc + bias[n]), stored as float32 at the pitch Cx
+  const float* bias;
+  int act;
+  float leak;
 };
 
 // Division by a launch-constant through multiply-high (Granlund-Montgomery, N = 31): a runtime integer division is
@@ -240,7 +244,7 @@ constexpr int conv_lds_bytes() {
          2 * kMaxTaps * (int)sizeof(int);
 }
 
-template <int MODE, int BM, int BN, int WM, int WN, bool RAGGED, bool NVEC>
+template <int MODE, int BM, int BN, int WM, int WN, bool RAGGED, bool NVEC, bool EPI = false>
 __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const int by, const int bz, const int gx, char* smem) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int TA = BM / (32 * WM), TB = BN / (32 * WN);
@@ -719,6 +723,17 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
                                               p.stats + ((long long)g * p.stats_nblk + blk) * 2 * N, N, M, m0, n0, wm0, wn0, wr, lrow, lk, tid);
     }
   }
+  if constexpr (EPI) {          // bias + activation of a layer built with normalizer_fn = None (models.py:20-21: tanh(deconv + b))
+#pragma unroll
+    for (int b = 0; b < TB; ++b) {
+      const int n = n0 + wn0 + 32 * b + lrow;
+      const float bv = n < N ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = acg::act_apply(p.act, acc[a][b][r] + bv, p.leak);
+    }
+  }
   float* outp = p.out + (p.splits > 1 ? (long long)bz * p.out_numel : 0ll);
   // Full tiles take a straight-line path - one base per 32 x 32 sub-tile, sixteen stores at row strides - instead of a
   // bounds test, a branch and a 64-bit index multiply per element (conv_bf16_kernel.h has the measurement).
@@ -779,7 +794,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
     }
 }
 
-template <int MODE, int BM, int BN, int WM, int WN, bool RAGGED, bool NVEC>
+template <int MODE, int BM, int BN, int WM, int WN, bool RAGGED, bool NVEC, bool EPI = false>
 __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
   __shared__ __align__(16) char smem[conv_lds_bytes<MODE, BM, BN>()];
   if constexpr (MODE == MODE_WGRAD) {      // grid (tiles, 1, splits)
@@ -787,7 +802,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
     wgrad_xcd_map((int)(blockIdx.x + gridDim.x * blockIdx.z), (int)gridDim.x, (int)gridDim.z, tile, split);
     conv_body<MODE, BM, BN, WM, WN, RAGGED, NVEC>(p, tile, 0, split, (int)gridDim.x, smem);
   } else {
-    conv_body<MODE, BM, BN, WM, WN, RAGGED, NVEC>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
+    conv_body<MODE, BM, BN, WM, WN, RAGGED, NVEC, EPI>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
   }
 }
 
@@ -822,13 +837,13 @@ struct Plan {
   long long M, N;  // per class (class 0 = largest) GEMM extents (M padded per tap for WGRAD)
   int classes, nk, splits;
   bool ragged, nvec, bf16;
-  bool direct;     // a few-MFLOP contraction with at most 16 output channels: the direct kernels of conv_direct.hip, one launch, no slabs
+  bool direct;     // a few-MFLOP float32 contraction with at most 8 output channels: the direct kernels of conv_direct.hip, one launch, no slabs
   long long tiles, out_numel;
 };
 
 // conv_direct.hip
-int launch_direct(int which, bool bf16, const ConvArgs& a, hipStream_t st);
-int launch_direct_pair(bool bf16, const ConvArgs& a, const ConvArgs& b, hipStream_t st);
+int launch_direct(int which, const ConvArgs& a, hipStream_t st);
+int launch_direct_pair(const ConvArgs& a, const ConvArgs& b, hipStream_t st);
 
 template <int MODE>
 int launch_mode(const Plan& pl, const ConvArgs& a, hipStream_t st);
@@ -836,6 +851,9 @@ int launch_mode(const Plan& pl, const ConvArgs& a, hipStream_t st);
 // conv_f32_pair.hip: A (modeA = MODE_FWD or MODE_DGRAD) and a weight gradient B in one launch; fp32, float4-able dense
 // operands, both gathers ragged or neither (pair_supported) - the caller launches the two separately otherwise.
 bool pair_supported(int modeA, const Plan& pa, const Plan& pb);
+// conv_f32_dgrad.hip / conv_bf16_dgrad.hip: the one EPI instantiation each (a transposed layer's forward on the 128x32 tile)
+int launch_deconv_fwd_epi(const Plan& pl, const ConvArgs& a, hipStream_t st);
+int launch_deconv_fwd_epi16(const Plan& pl, const ConvArgs& a, hipStream_t st);
 int launch_pair(int modeA, const Plan& pa, const ConvArgs& a, const Plan& pb, const ConvArgs& b, hipStream_t st);
 
 template <int MODE, bool RAGGED, bool NVEC>

@@ -355,6 +355,7 @@ class Runtime:
         # bytes per row and block, and S slabs multiply exactly those poorly coalesced requests; kept as an option
         self.slab_handoff = 0
         self.epilogue_stats = True
+        self.epilogue_bias = True
         self._comm = comm
         self._scratch = {}
 
@@ -396,7 +397,8 @@ class Session:
     """``tf.Session`` stand-in bound to one GPU (one process per GPU)."""
 
     def __init__(self, device='cuda:0', graph=None, use_hip_graphs=True, lib=None,
-                 world_size=1, rank=0, process_group=None, dtype='f32', pair_bwd=True, comm=None, slab_handoff=False, epilogue_stats=True, side_branches=False):
+                 world_size=1, rank=0, process_group=None, dtype='f32', pair_bwd=True, comm=None, slab_handoff=False, epilogue_stats=True, side_branches=False,
+                 epilogue_bias=True):
         self.graph = graph or get_default_graph()
         dev = torch.device(device)
         if lib is None:
@@ -417,6 +419,7 @@ class Session:
         # False / 0: off; True: every split layer; an int N: only layers split into at most N slabs
         self.rt.slab_handoff = (1 << 30) if slab_handoff is True else int(slab_handoff or 0)
         self.rt.epilogue_stats = bool(epilogue_stats)     # BatchNorm statistics out of the producing conv's epilogue (ops.Conv2dOp.bind)
+        self.rt.epilogue_bias = bool(epilogue_bias)       # bias + activation of a transposed head layer in its epilogue (models.py:20-21)
         if dev.type == 'cuda':
             torch.cuda.set_device(dev)
         self.use_hip_graphs = use_hip_graphs and dev.type == 'cuda'

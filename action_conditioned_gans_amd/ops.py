@@ -247,12 +247,32 @@ class Conv2dOp(_ConvBase):
         super().__init__(g, name, [x, w], [y])
 
     bn_consumer = None      # the layer's BnActOp (set by _layer): takes its statistics, or the split-K slabs, from this op
+    bias_consumer = None    # the layer's BiasActOp (set by _layer): bias + activation move into this op's epilogue where they can
+    _fused_bias = False     # this program: the epilogue wrote the BiasActOp's output, that op launches nothing
     _slab = None            # (workspace, splits) while this program's BatchNorm sums the slabs itself
     _stats = None           # (partials, blocks per group, rows per block, rows per run) while this program's BatchNorm takes its statistics from the epilogue
 
     def bind(self, rt):
         x, w = self.inputs
         self._slab = self._stats = None
+        self._fused_bias = False
+        bc = self.bias_consumer
+        if (bc is not None and rt.epilogue_bias and id(bc) in rt.program_ops and self.transposed and not self.out_f32 and bc.has_bias
+                and bc.outputs[0].dtype == torch.float32):
+            # models.py:20-21: tanh(conv2d_transpose(x) + b) - bias and activation in the deconv's epilogue, straight into the
+            # BiasActOp's output tensor (acg_deconv2d_fwd_bias_act), where the planner runs the layer unsplit on its 128x32 tile
+            lib, dt = rt.lib, rt.conv_dtype
+            d = ConvDesc()
+            ctypes.memmove(ctypes.byref(d), ctypes.byref(self.desc), ctypes.sizeof(ConvDesc))
+            d.in_pitch = bc.yp if bc.yp != d.in_c else 0
+            if dt == _lib.ACG_BF16:
+                d.in_pitch = 0
+            if lib.deconv2d_fwd_bias_act_ok(ctypes.byref(d), dt):
+                d.in_pitch = bc.yp if bc.yp != d.in_c else 0
+                self._keep, self._fused_bias = (d,), True
+                args = (_p(x.buf), _p(self.wop.buf), _p(bc.inputs[1].buf), _p(bc.outputs[0].buf), ctypes.byref(d), _ACT_CODE[bc.act], bc.leak, dt)
+                fn = lib.deconv2d_fwd_bias_act
+                return lambda s: fn(*args, s)
         bn = self.bn_consumer
         if self.out_f32:
             lib, d = rt.lib, self.desc
@@ -677,7 +697,12 @@ class BiasActOp(G.Op):
         super().__init__(g, name, [x] + ([bias] if bias is not None else []), [y])
         self.has_bias = bias is not None
 
+    conv_producer = None    # the layer's Conv2dOp (set by _layer)
+
     def bind(self, rt):
+        src = self.conv_producer
+        if src is not None and id(src) in rt.program_ops and src._fused_bias:
+            return None                               # the deconv's epilogue wrote y (Conv2dOp.bind): nothing to launch
         x, y = self.inputs[0], self.outputs[0]
         pb = _p(self.inputs[1].buf) if self.has_bias else None
         args = (_p(x.buf), pb, _p(y.buf), self.rows, self.c, self.xp, self.yp, _ACT_CODE[self.act], self.leak, _code2(x, y))
@@ -1170,8 +1195,11 @@ def _layer(inputs, num_outputs, kernel_size, stride, padding, activation_fn, nor
         else:
             bias = g.get_variable(_scope_name('biases'), (num_outputs,), biases_initializer or zeros_initializer(), share)
             # a layer without BatchNorm is a head in the reference nets (frame, state, DNA logits): float32 result
+            conv_op = out.op
             if act is not None:
-                return BiasActOp(out, bias, act[0], act[1], name + '/bias_act', head=True).outputs[0]
+                op = BiasActOp(out, bias, act[0], act[1], name + '/bias_act', head=True)
+                conv_op.bias_consumer, op.conv_producer = op, conv_op      # bias + activation may move into the deconv's epilogue
+                return op.outputs[0]
             out = BiasActOp(out, bias, None, 0.0, name + '/bias', head=True).outputs[0]
         if activation_fn is not None:
             out = BiasActOp(out, None, act[0], act[1], name + '/act').outputs[0] if act is not None else activation_fn(out)

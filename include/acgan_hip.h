@@ -171,6 +171,15 @@ int32_t acg_conv2d_fwd_stats(const void* x, const void* w, void* y, const acg_co
 int32_t acg_deconv2d_fwd_stats(const void* x, const void* w, void* y, const acg_conv_desc* adj, int32_t dtype, void* workspace,
                                size_t workspace_bytes, float* partials, int32_t groups, acg_stream_t stream);
 
+/* Bias + activation in the epilogue of a transposed layer's forward: y = act(conv2d_transpose(x, w) + bias), y float32 at
+ * the pitch adj->in_pitch (0 = dense) whatever dtype the operands have - slim.conv2d_transpose(..., normalizer_fn=None,
+ * activation_fn=tf.tanh) of models.py:20-21, the plain generator's frame, without the separate bias pass over the frame.
+ * acg_deconv2d_fwd_bias_act_ok: 1 when the planner runs this shape unsplit on its 128x32 tile (at most 32 output channels,
+ * 16-byte gathers), else use acg_deconv2d_fwd + acg_bias_act_fwd.  Backward is acg_bias_act_bwd on y as before. */
+int32_t acg_deconv2d_fwd_bias_act_ok(const acg_conv_desc* adj, int32_t dtype);
+int32_t acg_deconv2d_fwd_bias_act(const void* x, const void* w, const float* bias, float* y, const acg_conv_desc* adj, int32_t act,
+                                  float leak, int32_t dtype, acg_stream_t stream);
+
 /* Split-K hand-off to the consuming BatchNorm.  A small layer is split over K to fill the chip and would need a
  * launch of its own to sum the partial slabs; its output (forward) or input gradient (backward) is read next by the
  * layer's BatchNorm kernel (models.py:10-15: every conv but three is followed by batch_norm), which can sum the slabs as it

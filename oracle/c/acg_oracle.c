@@ -210,6 +210,21 @@ int32_t acg_deconv2d_fwd_stats(const void* x, const void* w, void* y, const acg_
   return ACG_OK;
 }
 
+static double act_f(int act, double u, double leak);
+/* bias + activation in the deconv epilogue: the restatement never fuses (ok == 0); the entry itself is the plain composition */
+int32_t acg_deconv2d_fwd_bias_act_ok(const acg_conv_desc* adj, int32_t dtype) { (void)adj; (void)dtype; return 0; }
+int32_t acg_deconv2d_fwd_bias_act(const void* x, const void* w, const float* bias, float* y, const acg_conv_desc* adj, int32_t act,
+                                  float leak, int32_t dtype, acg_stream_t s) {
+  REQUIRE_F32(dtype);
+  if (!bias || !y || !adj) return fail(ACG_ERR_INVALID_ARG, "deconv2d_fwd_bias_act: null pointer");
+  int rc = acg_deconv2d_fwd(x, w, y, adj, dtype, NULL, 0, s);
+  if (rc) return rc;
+  const int C = adj->in_c, P = adj->in_pitch > 0 ? adj->in_pitch : C;
+  const int64_t rows = (int64_t)adj->batch * adj->in_h * adj->in_w;
+  for (int64_t r = 0; r < rows; r++) for (int c = 0; c < C; c++) y[r * P + c] = (float)act_f(act, (double)y[r * P + c] + bias[c], leak);
+  return ACG_OK;
+}
+
 /* split-K hand-off entries: the restatement never splits forward / input-gradient contractions (acg_conv2d_splits) */
 int32_t acg_conv2d_fwd_slabs(const void* x, const void* w, const acg_conv_desc* d, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
   (void)x; (void)w; (void)d; (void)dtype; (void)ws; (void)wsb; (void)s; return fail(ACG_ERR_UNSUPPORTED, "cpu oracle: contraction is not split"); }

@@ -92,6 +92,21 @@ class Abi:
         self.lib.conv2d_fwd(_p(x), _p(w), _p(y), ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
         return y
 
+    def deconv2d_fwd_bias_act(self, x, w, bias, stride, act, leak=0.2):
+        """acg_deconv2d_fwd_bias_act: y = act(conv2d_transpose(x, w) + bias), dense float32; None where the shape is not fused."""
+        d = self._adj(x.shape, tuple(w.shape), stride)
+        if self.half:
+            d.in_pitch = d.out_pitch = 0
+        if not self.lib.deconv2d_fwd_bias_act_ok(ctypes.byref(d), self.conv_dtype):
+            return None
+        y = torch.full((d.batch, d.in_h, d.in_w, d.in_c), 7.0, dtype=torch.float32, device=self.device)
+        if self.half:
+            x16, (rm, tr) = self.to16(x), self.prep_weights(w)
+            self.lib.deconv2d_fwd_bias_act(_p(x16), _p(rm), _p(bias), _p(y), ctypes.byref(d), ACT[act], leak, self.conv_dtype, self.stream())
+        else:
+            self.lib.deconv2d_fwd_bias_act(_p(x), _p(w), _p(bias), _p(y), ctypes.byref(d), ACT[act], leak, self.conv_dtype, self.stream())
+        return y
+
     def conv2d_dgrad(self, dy, w, x_shape, stride, padding):
         b, h, wd, c = x_shape
         pitch = c if c != w.shape[2] else 0

@@ -220,6 +220,44 @@ def case_conv_bn_stats_large_mean(abi, tol_stat):
         assert torch.isfinite(y.double()).all()
 
 
+def case_bn_large_tensor(abi, tol_stat):
+    """BatchNorm at config 5's tensor sizes (4-8 M elements, more than 512 partial blocks per group): forward behind a conv
+    epilogue's statistics (acg_conv2d_fwd_stats -> bn_partials_finalize -> apply) and the two-launch backward, against float64
+    BatchNorm of the tensor as stored."""
+    dev = abi.device
+    half = abi.half
+    r = (lambda t: t.bfloat16().float()) if half else (lambda t: t)
+    cout, groups, act = (32, 2, 'lrelu') if half else (64, 1, 'relu')
+    b, h, w, cin = 8, 128, 128, 8
+    x, wt = uniform((b, h, w, cin), 800), randn((1, 1, cin, cout), 801, 0.3)
+    beta = randn((cout,), 802, 0.5)
+    got = abi.conv_bn_fused(x.to(dev), wt.to(dev), beta.to(dev), 1, 'SAME', act, groups, False)
+    assert got is not None
+    conv, y, mean, rstd = got
+    abi.sync()
+    rows = conv.detach().double().cpu().reshape(groups, -1, cout)
+    m, v = rows.mean(1), rows.var(1, unbiased=False)
+    close(mean, m.reshape(-1), tol_stat, 'large bn mean'); close(rstd, (1.0 / torch.sqrt(v + 1e-3)).reshape(-1), tol_stat, 'large bn rstd')
+    pre = (rows - m[:, None, :]) / torch.sqrt(v[:, None, :] + 1e-3) + beta.double()
+    want = {'relu': torch.relu, 'lrelu': lambda t: torch.where(t > 0, t, 0.2 * t)}[act](pre).reshape(conv.shape)
+    close(y, want, 8e-3 if half else 2e-5, 'large bn y')
+    # backward on the same stored tensor
+    cp = (cout + 7) // 8 * 8 if half else cout
+    store = torch.bfloat16 if half else torch.float32
+    xs = torch.zeros(b, h, w, cp, dtype=store, device=dev)
+    xs[..., :cout] = conv.to(dev).to(store)
+    dy = torch.zeros(b, h, w, cp, dtype=store, device=dev)
+    dy[..., :cout] = randn((b, h, w, cout), 803).to(dev).to(store)
+    dx, dbeta = abi.bn_act_bwd(xs, dy, beta.to(dev), mean, rstd, act, groups)
+    abi.sync()
+    xd = xs[..., :cout].double().cpu().requires_grad_(True)
+    bd = beta.double().requires_grad_(True)
+    dx64, db64 = torch.autograd.grad(_bn_ref(xd, bd, act, groups), [xd, bd], dy[..., :cout].double().cpu())
+    close(dx[..., :cout].float(), dx64, 8e-3 if half else 2e-5, 'large bn dx'); close(dbeta, db64, 3e-4, 'large bn dbeta')
+    if half:
+        assert (dx[..., cout:] == 0).all() and (y.shape[-1] == cout or (y[..., cout:] == 0).all())
+
+
 def case_dna_second(abi, tol):
     """acg_dna_fwd out2 / acg_dna_bwd dout2 (the frame's second home, train.py:63-66): forward writes the frame also into channels
     [3, 6) of an 8-pitched tensor (float32 and bfloat16), leaving the other channels alone; backward with a gradient window equals
@@ -716,6 +754,27 @@ def case_head_f32_in_bf16_network(abi, tol_w, tol_dx, seed=0):
         assert dx.dtype == torch.bfloat16 and dx.shape[-1] == 8 and (dx[..., c:] == 0).all()
         close(dx[..., :c].float(), dx_ref, tol_dx, 'f32 head bn dx (bf16)')
         close(dbeta, db_ref, 2e-4, 'f32 head bn dbeta')
+
+
+def case_deconv_bias_act(abi, tol):
+    """acg_deconv2d_fwd_bias_act: tanh(conv2d_transpose(x, w) + b) in one launch (models.py:20-21, the plain generator's frame),
+    against the float64 composition; shapes the planner runs unsplit on its 128x32 tile, float32 and bf16 operands."""
+    dev = abi.device
+    r = (lambda t: t.bfloat16().float()) if abi.half else (lambda t: t)
+    fused = 0
+    for i, (b, ih, iw, cin, cout, k, s_, act) in enumerate([(16, 32, 32, 64, 3, 5, 2, 'tanh'), (8, 32, 32, 32, 25, 5, 2, None), (32, 16, 16, 16, 8, 3, 2, 'relu')]):
+        x, wt = uniform((b, ih, iw, cin), 900 + i), randn((k, k, cout, cin), 910 + i, 0.1)
+        bias = randn((cout,), 920 + i, 0.5)
+        y = abi.deconv2d_fwd_bias_act(x.to(dev), wt.to(dev), bias.to(dev), s_, act)
+        if y is None:
+            continue
+        fused += 1
+        abi.sync()
+        pre = T.conv2d_transpose(r(x).double(), r(wt).double(), s_, 'SAME') + bias.double()
+        want = {'tanh': torch.tanh, 'relu': torch.relu, None: lambda t: t}[act](pre)
+        assert y.dtype == torch.float32 and y.shape == want.shape
+        close(y, want, tol, 'deconv + bias + %s in the epilogue, layer %d' % (act, i))
+    assert fused >= 2, 'only %d layers took the fused epilogue' % fused
 
 
 def case_bias_bf16(abi, tol, seed=0):

@@ -46,6 +46,15 @@ def test_conv_bn_stats_bf16(hip_abi_bf16):
     C.case_conv_bn_stats(hip_abi_bf16, TOL_BF16, 2e-3, min_fused=4)
 
 
+def test_bn_large_tensor(hip_abi):
+    """Config-5-sized BatchNorm (8.4 M float32 elements, 2048+ partial blocks): the finalize launch in front of the apply."""
+    C.case_bn_large_tensor(hip_abi, 1e-4)
+
+
+def test_bn_large_tensor_bf16(hip_abi_bf16):
+    C.case_bn_large_tensor(hip_abi_bf16, 2e-3)
+
+
 def test_conv_bn_stats_large_mean(hip_abi):
     """Tile statistics are centred before they are squared and merged Chan-style (mean / std ~ 1e3)."""
     C.case_conv_bn_stats_large_mean(hip_abi, 2e-3)
@@ -86,6 +95,14 @@ def test_bn_head_bf16(hip_abi):
 def test_head_f32_in_bf16_network(hip_abi_bf16):
     """d/conv6 of a bf16 network stays float32: conv result and BatchNorm input float32, gradient back as bf16."""
     C.case_head_f32_in_bf16_network(hip_abi_bf16, TOL_CONV, 6e-3)
+
+
+def test_deconv_bias_act_epilogue(hip_abi):
+    C.case_deconv_bias_act(hip_abi, TOL_CONV)
+
+
+def test_deconv_bias_act_epilogue_bf16(hip_abi_bf16):
+    C.case_deconv_bias_act(hip_abi_bf16, TOL_CONV)          # float32 result of bf16 operands: accumulation level
 
 
 def test_bias_bf16(hip_abi):

@@ -620,3 +620,34 @@ def test_config5_full_per_gpu_size_replay_equals_eager():
         assert torch.equal(pe[n], pg[n]), n
         if n.startswith('d/'):
             assert pe[n].abs().max().item() <= 0.01 + 1e-7, n
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_plain_generator_bias_tanh_in_the_deconv_epilogue(dtype):
+    """models.py:20-21: the plain generator's frame is tanh(conv2d_transpose + b).  At batch 16 the last deconv runs unsplit, so its
+    bias and tanh move into its epilogue (Conv2dOp._fused_bias; one launch and one pass over the frame less): frames and the
+    weights after one pre-training step must match the run that keeps the separate bias_act launch."""
+    from action_conditioned_gans_amd import ops as O, optim, train as T
+    rng = np.random.default_rng(5)
+    B = 16
+    x, y = rng.uniform(-1, 1, (B, 64, 64, 3)).astype(np.float32), rng.uniform(-1, 1, (B, 64, 64, 3)).astype(np.float32)
+    a, s = rng.standard_normal((B, 10)).astype(np.float32), rng.standard_normal((B, 5)).astype(np.float32)
+    outs = []
+    for fuse in (False, True):
+        G.reset_default_graph()
+        optim.set_data_parallel(1)
+        sess = gpu_session(dtype=dtype, epilogue_bias=fuse)
+        tr = T.Trainer(sess, False, 'bce', 'adam', False, batch_size=B)
+        sess.run(G.global_variables_initializer())
+        frame = tr.test(x, y, a)[0]
+        tr.pretrain_g(x, y, a, s)
+        torch.cuda.synchronize()
+        g = G.get_default_graph()
+        n = sum(1 for o in g.ops if isinstance(o, O.Conv2dOp) and o._fused_bias)
+        assert n == (1 if fuse else 0), (fuse, n)
+        outs.append((frame, {k: sess.get_value(v) for k, v in g.variables.items()}))
+    (f0, w0), (f1, w1) = outs
+    tol = 2e-6 if dtype == 'f32' else 1e-2      # bf16: the separate op reads the deconv output ROUNDED to bf16, the epilogue its float32 accumulator
+    assert float(np.abs(f1 - f0).max()) <= tol, float(np.abs(f1 - f0).max())
+    for k in w0:
+        assert torch.isfinite(w1[k]).all(), k

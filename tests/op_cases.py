@@ -258,6 +258,111 @@ def case_bn_large_tensor(abi, tol_stat):
         assert (dx[..., cout:] == 0).all() and (y.shape[-1] == cout or (y[..., cout:] == 0).all())
 
 
+# Every conv / deconv layer of the DNA generator and the discriminator at BASELINE config 2's per-GPU size (batch 32, 64x64;
+# Appendix B of SURVEY.md) plus config 5's two largest (128x128): (kind, B, H, W, Cin, Cout, k, stride, padding)
+BASELINE_LAYERS = [
+    ('c', 32, 64, 64, 3, 32, 5, 2, 'SAME'), ('c', 32, 32, 32, 32, 64, 5, 2, 'SAME'), ('c', 32, 16, 16, 64, 128, 5, 2, 'SAME'),
+    ('c', 32, 8, 8, 128, 256, 5, 2, 'SAME'), ('d', 32, 4, 4, 266, 128, 5, 2, 'SAME'), ('d', 32, 8, 8, 128, 128, 5, 2, 'SAME'),
+    ('c', 32, 16, 16, 128, 32, 3, 2, 'SAME'), ('c', 32, 8, 8, 32, 16, 3, 2, 'SAME'), ('c', 32, 4, 4, 16, 5, 4, 1, 'VALID'),
+    ('d', 32, 16, 16, 128, 128, 5, 2, 'SAME'), ('d', 32, 32, 32, 128, 25, 5, 2, 'SAME'),
+    ('c', 64, 64, 64, 6, 64, 5, 2, 'SAME'), ('c', 64, 32, 32, 64, 128, 5, 2, 'SAME'), ('c', 64, 16, 16, 138, 128, 5, 2, 'SAME'),
+    ('c', 64, 8, 8, 128, 256, 5, 2, 'SAME'), ('c', 64, 4, 4, 256, 512, 5, 2, 'SAME'), ('c', 64, 2, 2, 512, 1, 2, 1, 'SAME'),
+    ('d', 32, 64, 64, 128, 121, 5, 2, 'SAME'), ('c', 32, 128, 128, 6, 64, 5, 2, 'SAME'),
+]
+
+
+def case_conv_adjoint_identities(abi, tol):
+    """Size-independent properties at BASELINE's full per-GPU sizes, where no float64 oracle run fits a test: a conv layer is
+    linear in x and in w, so for random x, w, dy
+        <fwd(x, w), dy>  =  <x, dgrad(dy, w)>  =  <w, wgrad(x, dy)>
+    - one identity ties the three contractions of a layer (and the split-K, tile and pairing choices the planner makes at
+    these sizes) together.  Inner products in float64 on the device.  bf16: outputs are rounded once (2^-9 per element,
+    unbiased), which the sums average out; the bar there is 3e-3."""
+    dev = abi.device
+    dot = lambda a, b: float((a.double() * b.double()).sum().item())      # noqa: E731
+    for i, (kind, b, h, w, cin, cout, k, s_, pad) in enumerate(BASELINE_LAYERS):
+        x = uniform((b, h, w, cin), 1000 + i).to(dev)
+        if kind == 'c':
+            wt = randn((k, k, cin, cout), 1100 + i, 0.1).to(dev)
+            y = abi.conv2d_fwd(x, wt, s_, pad)
+            dy = randn(tuple(y.shape), 1200 + i).to(dev)
+            dx = abi.conv2d_dgrad(dy, wt, tuple(x.shape), s_, pad)
+            dw = abi.conv2d_wgrad(x, dy, tuple(wt.shape), s_, pad)
+        else:
+            wt = randn((k, k, cout, cin), 1100 + i, 0.1).to(dev)
+            y = abi.deconv2d_fwd(x, wt, s_)
+            dy = randn(tuple(y.shape), 1200 + i).to(dev)
+            dx = abi.deconv2d_dgrad(dy, wt, tuple(x.shape), s_)
+            dw = abi.deconv2d_wgrad(x, dy, tuple(wt.shape), s_)
+        abi.sync()
+        if abi.half:      # the kernels saw the operands rounded to bf16
+            x, wt, dy = x.bfloat16().float(), wt.bfloat16().float(), dy.bfloat16().float()
+        a, bq, c = dot(y, dy), dot(x, dx), dot(wt, dw)
+        scale = float(y.double().norm().item() * dy.double().norm().item())
+        tag = 'layer %d %s' % (i, (kind, b, h, w, cin, cout, k, s_))
+        assert abs(a - bq) <= tol * scale, '%s: <y,dy> %.6e vs <x,dx> %.6e (scale %.3e)' % (tag, a, bq, scale)
+        assert abs(a - c) <= tol * scale, '%s: <y,dy> %.6e vs <w,dw> %.6e (scale %.3e)' % (tag, a, c, scale)
+        del x, wt, y, dy, dx, dw
+
+
+def case_full_size_properties(abi):
+    """DNA stencil and BatchNorm at BASELINE's full per-GPU sizes through properties that need no oracle:
+      DNA   softmax weights sum to one: a constant image comes back unchanged wherever the k x k window lies inside the
+            frame (no border renormalisation, models.py:60-72); the frame is linear in the image; the logits' gradient
+            sums to zero over the taps of every pixel (softmax), and dbias is its sum over pixels;
+      BN    (no activation) every output channel has mean beta and variance var / (var + eps); the input gradient sums to
+            zero over the batch and is orthogonal to the normalised input, per channel."""
+    dev = abi.device
+    for (b, hw, k, dt) in [(32, 64, 5, torch.float32), (32, 64, 5, torch.bfloat16), (32, 128, 11, torch.bfloat16), (8, 128, 11, torch.float32)]:
+        kk = k * k
+        lp = (kk + 7) // 8 * 8 if dt == torch.bfloat16 else kk
+        lg = torch.zeros(b, hw, hw, lp, dtype=dt, device=dev)
+        lg[..., :kk] = (randn((b, hw, hw, kk), 1300 + k).to(dev) * 2).to(dt)
+        bias = randn((kk,), 1301, 0.3).to(dev)
+        const = torch.tensor([0.7, -0.2, 0.4], device=dev).expand(b, hw, hw, 3).contiguous()
+        out = abi.dna_fwd(lg, const, k, bias=bias)
+        p = (k - 1) // 2
+        inner = out[:, p:hw - (k - 1 - p), p:hw - (k - 1 - p)]
+        assert float((inner - const[:, p:hw - (k - 1 - p), p:hw - (k - 1 - p)]).abs().max()) <= 2e-6, ('dna constant image', k, dt)
+        i1, i2 = uniform((b, hw, hw, 3), 1302).to(dev), uniform((b, hw, hw, 3), 1303).to(dev)
+        lin = abi.dna_fwd(lg, 0.3 * i1 - 1.7 * i2, k, bias=bias)
+        ref = 0.3 * abi.dna_fwd(lg, i1, k, bias=bias) - 1.7 * abi.dna_fwd(lg, i2, k, bias=bias)
+        assert float((lin - ref).abs().max()) <= 1e-5, ('dna linearity', k, dt)
+        dout = randn((b, hw, hw, 3), 1304).to(dev)
+        dl, dbias = abi.dna_bwd(lg, i1, dout, k, bias=bias, want_dbias=True)
+        abi.sync()
+        dlf = dl[..., :kk].float()
+        tap_sum = dlf.sum(-1).abs().max().item()
+        assert tap_sum <= (2e-2 if dt == torch.bfloat16 else 1e-5) * max(dlf.abs().max().item(), 1e-6) * kk ** 0.5, ('dna sum_t dlogits', k, dt, tap_sum)
+        if dt == torch.float32:        # (bf16: dbias sums the float32 values before they are rounded into dlogits)
+            assert float((dbias - dlf.double().sum((0, 1, 2)).float()).abs().max()) <= 1e-4 * max(float(dbias.abs().max()), 1e-6) + 1e-5, ('dna dbias', k)
+        if dt == torch.bfloat16:
+            assert (dl[..., kk:] == 0).all()
+        del lg, out, lin, ref, dl
+    for lead, c, groups, dt in [((64, 32, 32), 64, 2, torch.float32), ((32, 64, 64), 128, 1, torch.bfloat16), ((64, 64, 64), 64, 2, torch.bfloat16)]:
+        x = (randn(lead + (c,), 1400, 1.5) + 0.7).to(dev).to(dt)
+        beta = randn((c,), 1401, 0.3).to(dev)
+        y, mean, rstd = abi.bn_act_fwd(x, beta, None, groups, y_dtype=None)
+        yg = y.float().reshape(groups, -1, c).double()
+        xg = x.float().reshape(groups, -1, c).double()
+        var = xg.var(1, unbiased=False)
+        tolm = 2e-3 if dt == torch.bfloat16 else 1e-5
+        assert float((yg.mean(1) - beta.double()).abs().max()) <= tolm, ('bn mean', lead, dt)
+        assert float((yg.var(1, unbiased=False) - var / (var + 1e-3)).abs().max()) <= 4 * tolm, ('bn var', lead, dt)
+        dy = randn(lead + (c,), 1402).to(dev).to(dt)
+        dx, dbeta = abi.bn_act_bwd(x, dy, beta, mean, rstd, None, groups)
+        abi.sync()
+        dxg = dx.float().reshape(groups, -1, c).double()
+        xh = (xg - xg.mean(1, keepdim=True)) / torch.sqrt(var + 1e-3)[:, None, :]
+        n = dxg.shape[1]
+        scale = float(dxg.abs().mean()) * n
+        tolb = 2e-3 if dt == torch.bfloat16 else 1e-5
+        assert float(dxg.sum(1).abs().max()) <= tolb * scale, ('bn sum dx', lead, dt, float(dxg.sum(1).abs().max()) / scale)
+        assert float((dxg * xh).sum(1).abs().max()) <= tolb * scale, ('bn sum dx xhat', lead, dt)
+        assert float((dbeta.double() - dy.float().double().reshape(-1, c).sum(0)).abs().max()) <= 1e-4 * n ** 0.5 * groups, ('bn dbeta', lead, dt)
+        del x, y, dy, dx
+
+
 def case_dna_second(abi, tol):
     """acg_dna_fwd out2 / acg_dna_bwd dout2 (the frame's second home, train.py:63-66): forward writes the frame also into channels
     [3, 6) of an 8-pitched tensor (float32 and bfloat16), leaving the other channels alone; backward with a gradient window equals

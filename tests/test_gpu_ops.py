@@ -42,6 +42,21 @@ def test_conv_bn_stats(hip_abi):
     C.case_conv_bn_stats(hip_abi, TOL_CONV, 1e-4, min_fused=4)
 
 
+def test_conv_adjoint_identities_at_baseline_sizes(hip_abi):
+    """<fwd(x,w),dy> = <x,dgrad(dy,w)> = <w,wgrad(x,dy)> for every layer of config 2 at batch 32 (+ config 5's largest two)."""
+    C.case_conv_adjoint_identities(hip_abi, 2e-5)
+
+
+def test_conv_adjoint_identities_at_baseline_sizes_bf16(hip_abi_bf16):
+    C.case_conv_adjoint_identities(hip_abi_bf16, 3e-3)
+
+
+def test_full_size_properties_of_dna_and_batchnorm(hip_abi):
+    """Constant-image, linearity and sum-to-zero properties of the DNA stencil; moment and orthogonality properties of BatchNorm -
+    at config 2 / 3 / 5's per-GPU tensor sizes."""
+    C.case_full_size_properties(hip_abi)
+
+
 def test_conv_bn_stats_bf16(hip_abi_bf16):
     C.case_conv_bn_stats(hip_abi_bf16, TOL_BF16, 2e-3, min_fused=4)
 

@@ -33,10 +33,14 @@ __device__ __forceinline__ f4 guarded_oct(__amdgpu_buffer_rsrc_t rs, int elem_of
 }
 
 // byte offset of 16-byte chunk `ch` of row `row` in a [rows][W16 chunks] bf16 tile stored as 8-row x 32-column
-// subtiles (cdna guide T10, image (a)): row reads and transposed reads are both conflict-free
+// subtiles (cdna guide T10, image (a)): transposed reads are conflict-free.  Round 3: the row pair inside a subtile is
+// swapped in every odd 32-column block ((row & 7) ^ ((ch >> 2) & 1)).  A ds_write_b128 group is 8 lanes = chunks 0..7 of ONE
+// row, i.e. two subtiles 512 bytes apart - the same 64 bytes of the 128-byte store banking, a 2-way conflict on every
+// store of the weight-gradient loader (PMC: 28 % of that kernel's LDS cycles, profiles/r3/b_conv16_pmc_wgrad_vs_fwd.txt);
+// with the swap the two halves land in different 64-byte bank halves.  Reads pick the same rows, permuted.
 template <int W16>
 __device__ __forceinline__ int tr_off(int row, int ch) {
-  return (W16 / 4) * 512 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
+  return (W16 / 4) * 512 * (row >> 3) + 512 * (ch >> 2) + 64 * ((row & 7) ^ ((ch >> 2) & 1)) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
 }
 
 template <int MODE, int BM, int BN, bool EPI = false>
@@ -267,17 +271,16 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
     const int g1 = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const int x = (2 * lk + s) & 3, rowpart = (OA / 4) * 512 * lk + 64 * (q + 4 * s);
+      const int x = (2 * lk + s) & 3, r8 = q + 4 * s;      // row & 7 of the fragment row this lane addresses
 #pragma unroll
       for (int a = 0; a < TA; ++a) {
         const int col = wm0 + 32 * a + 16 * g1 + 4 * pp, ch = col >> 3;
-        tra[a][s] = rowpart + 512 * (ch >> 2) + 16 * ((ch & 3) ^ x) + 8 * ((col >> 2) & 1);
+        tra[a][s] = (OA / 4) * 512 * lk + 64 * (r8 ^ ((ch >> 2) & 1)) + 512 * (ch >> 2) + 16 * ((ch & 3) ^ x) + 8 * ((col >> 2) & 1);
       }
-      const int rowpartb = (OB / 4) * 512 * lk + 64 * (q + 4 * s);
 #pragma unroll
       for (int b = 0; b < TB; ++b) {
         const int col = wn0 + 32 * b + 16 * g1 + 4 * pp, ch = col >> 3;
-        trb[b][s] = rowpartb + 512 * (ch >> 2) + 16 * ((ch & 3) ^ x) + 8 * ((col >> 2) & 1);
+        trb[b][s] = (OB / 4) * 512 * lk + 64 * (r8 ^ ((ch >> 2) & 1)) + 512 * (ch >> 2) + 16 * ((ch & 3) ^ x) + 8 * ((col >> 2) & 1);
       }
     }
   }

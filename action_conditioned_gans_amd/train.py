@@ -219,9 +219,10 @@ def _log_jsonl(path, record):
 def train(input_path, output_path, test_output_path, log_dir, model_dir, arg_adv, arg_loss, arg_opt, arg_transform,
           batch_size=64, img_size=64, seq_len=8, ksize=5, train_iter=TRAIN_ITER, pretrain_iter=PRETRAIN_ITER,
           n_critic=None, device='cuda:0', world_size=1, rank=0, process_group=None, log_every=100, quiet=False,
-          eval_every=500, resume=None):
+          eval_every=500, resume=None, dtype='f32'):
     """Training loop of train.py:179-309.  ``input_path``: 'synthetic' (seeded random sequences) or a directory of
-    push-dataset TFRecords, read by push_data.PushDataset (the reference's build_tfrecord_input, ops.py:140-223)."""
+    push-dataset TFRecords, read by push_data.PushDataset (the reference's build_tfrecord_input, ops.py:140-223).
+    ``dtype``: 'f32', or 'bf16' for the bf16 pipeline of BASELINE configs 3 and 5 (bf16 activations, float32 master weights)."""
     np.random.seed(7)                                           # train.py:14
     synthetic = input_path in (None, '', 'synthetic')
     if synthetic:
@@ -233,7 +234,7 @@ def train(input_path, output_path, test_output_path, log_dir, model_dir, arg_adv
     boolean_mask = build_all_mask(seq_len)
     G.reset_default_graph()
     optim.set_data_parallel(world_size)
-    with G.Session(device=device, world_size=world_size, rank=rank, process_group=process_group) as sess:
+    with G.Session(device=device, world_size=world_size, rank=rank, process_group=process_group, dtype=dtype) as sess:
         trainer = Trainer(sess, arg_adv, arg_loss, arg_opt, arg_transform, batch_size, img_size, ksize)
         sess.run(G.global_variables_initializer())
         saver = Saver()                                                           # train.py:215
@@ -307,6 +308,7 @@ def main(argv=None):
     parser.add_argument('--n_critic', type=int, default=None)
     parser.add_argument('--train_iter', type=int, default=TRAIN_ITER)
     parser.add_argument('--pretrain_iter', type=int, default=PRETRAIN_ITER)
+    parser.add_argument('--dtype', type=str, default='f32', choices=['f32', 'bf16'])
     args = parser.parse_args(argv)
     model_dir = os.path.join(args.output_path, 'models')
     log_dir = os.path.join(args.output_path, 'logs')
@@ -322,7 +324,7 @@ def main(argv=None):
     train(args.input_path, os.path.join(args.output_path, 'train_output'), os.path.join(args.output_path, 'test_output'),
           log_dir, model_dir, args.adv, args.loss, args.opt, args.dna, batch_size=args.batch_size, img_size=args.img_size,
           seq_len=args.seq_len, ksize=args.ksize, train_iter=args.train_iter, pretrain_iter=args.pretrain_iter,
-          n_critic=args.n_critic, device='cuda:%d' % local_rank, world_size=world_size, rank=rank)
+          n_critic=args.n_critic, device='cuda:%d' % local_rank, world_size=world_size, rank=rank, dtype=args.dtype)
 
 
 if __name__ == '__main__':

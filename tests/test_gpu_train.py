@@ -249,12 +249,13 @@ def test_device_resident_feeds_equal_host_feeds():
     assert np.array_equal(host[0], devr[0]) and np.array_equal(host[1], devr[1])
 
 
-def test_training_loop_runs_wass_rmsprop_n_critic():
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_training_loop_runs_wass_rmsprop_n_critic(dtype):
     """train() end to end on synthetic sequences: pretrain iterations, then n_critic=5 D steps per G step
-    (train.py:217-263) with weight clip; weights stay finite and inside the clip range."""
+    (train.py:217-263) with weight clip; weights stay finite and inside the clip range.  Both pipelines (`--dtype`)."""
     from action_conditioned_gans_amd import train as T
     tr = T.train('synthetic', None, None, None, None, True, 'wass', 'rmsprop', True, batch_size=4, seq_len=8,
-                 train_iter=6, pretrain_iter=2, device='cuda:0', quiet=True)
+                 train_iter=6, pretrain_iter=2, device='cuda:0', quiet=True, dtype=dtype)
     for v in tr.d_vars:
         val = tr.sess.get_value(v)
         assert torch.isfinite(val).all() and val.abs().max().item() <= 0.01 + 1e-7, v.name

@@ -34,8 +34,9 @@ def main():
     ap.add_argument('--cout', type=int, default=128)
     ap.add_argument('--cins', default='64,128,256')
     ap.add_argument('--which', default='fwd,dgrad,wgrad')
+    ap.add_argument('--lib', default=None, help='an alternative build of the library (kernel A/B experiments)')
     args = ap.parse_args()
-    lib = L.get()
+    lib = L.Library(args.lib) if args.lib else L.get()
     abi = Abi(lib, 'cuda:0', conv_dtype=L.ACG_BF16)
     B, S, N = args.batch, args.hw, args.cout
     for which in args.which.split(','):

@@ -17,7 +17,8 @@ import torch  # noqa: F401  (import order is the point)
 ACG_F32, ACG_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 0, 1, 2
-ABI_VERSION = 3       # include/acgan_hip.h ACG_ABI_VERSION: bumped with every signature / layout / flag-meaning change
+SLABS_ROWS, SLABS_QUADS = 0, 1       # acgan_hip.h ACG_SLABS_*
+ABI_VERSION = 4       # include/acgan_hip.h ACG_ABI_VERSION: bumped with every signature / layout / flag-meaning change
 
 LIB_NAME = 'libacgan_hip.so'
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', LIB_NAME)
@@ -75,10 +76,10 @@ SIGNATURES = {
     'acg_deconv2d_fwd_stats': (c_int32, [_P, _P, _P, _D, c_int32, _P, c_size_t, _P, c_int32, _P]),
     'acg_deconv2d_fwd_bias_act_ok': (c_int32, [_D, c_int32]),
     'acg_deconv2d_fwd_bias_act': (c_int32, [_P, _P, _P, _P, _D, c_int32, c_float, c_int32, _P]),
-    'acg_conv2d_fwd_slabs': (c_int32, [_P, _P, _D, c_int32, _P, c_size_t, _P]),
-    'acg_conv2d_dgrad_slabs': (c_int32, [_P, _P, _D, c_int32, _P, c_size_t, _P]),
-    'acg_deconv2d_fwd_slabs': (c_int32, [_P, _P, _D, c_int32, _P, c_size_t, _P]),
-    'acg_deconv2d_dgrad_slabs': (c_int32, [_P, _P, _D, c_int32, _P, c_size_t, _P]),
+    'acg_conv2d_fwd_slabs': (c_int32, [_P, _P, _D, c_int32, c_int32, _P, c_size_t, _P]),
+    'acg_conv2d_dgrad_slabs': (c_int32, [_P, _P, _D, c_int32, c_int32, _P, c_size_t, _P]),
+    'acg_deconv2d_fwd_slabs': (c_int32, [_P, _P, _D, c_int32, c_int32, _P, c_size_t, _P]),
+    'acg_deconv2d_dgrad_slabs': (c_int32, [_P, _P, _D, c_int32, c_int32, _P, c_size_t, _P]),
     'acg_conv2d_bwd_pair': (c_int32, [_P, _P, _P, _P, _P, c_float, _D, c_int32, _P, c_size_t, _P, c_size_t, c_int32, _P]),
     'acg_deconv2d_bwd_pair': (c_int32, [_P, _P, _P, _P, _P, c_float, _D, c_int32, _P, c_size_t, _P, c_size_t, c_int32, _P]),
     'acg_splitk_reduce_many': (c_int32, [ctypes.POINTER(ReduceList), c_int32, _P]),
@@ -100,11 +101,12 @@ SIGNATURES = {
                                  c_float, c_int32, _P, c_size_t, _P]),
     'acg_bn_act_fwd_partials': (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, c_float,
                                           c_int32, _P]),
+    'acg_bn_slabs_layout': (c_int32, [c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
     'acg_bn_act_fwd_slabs': (c_int32, [_P, c_int32, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, c_float,
-                                       c_int32, _P, c_size_t, _P]),
+                                       c_int32, c_int32, _P, c_size_t, _P]),
     'acg_bn_bwd_slabs_ok': (c_int32, [c_int64, c_int32]),
     'acg_bn_act_bwd_slabs': (c_int32, [_P, _P, c_int32, _P, _P, _P, _P, _P, c_float, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
-                                       c_float, c_int32, _P, c_size_t, _P]),
+                                       c_float, c_int32, c_int32, _P, c_size_t, _P]),
     'acg_bias_workspace_bytes': (c_size_t, [c_int64, c_int32]),
     'acg_bias_act_fwd': (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, _P]),
     'acg_bias_act_bwd': (c_int32, [_P, _P, _P, _P, c_float, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_int32,
@@ -160,7 +162,7 @@ def code(torch_dtype):
     if torch_dtype == torch.bfloat16:
         return ACG_BF16
     raise TypeError('no storage code for %s' % torch_dtype)
-VALUE_RETURNING = ('acg_version', 'acg_conv2d_splits', 'acg_bn_bwd_slabs_ok', 'acg_conv2d_stats_blocks', 'acg_conv2d_stats_layout', 'acg_deconv2d_fwd_bias_act_ok')     # int32 results that are not status codes
+VALUE_RETURNING = ('acg_version', 'acg_conv2d_splits', 'acg_bn_bwd_slabs_ok', 'acg_bn_slabs_layout', 'acg_conv2d_stats_blocks', 'acg_conv2d_stats_layout', 'acg_deconv2d_fwd_bias_act_ok')     # int32 results that are not status codes
 
 
 class AcgError(RuntimeError):

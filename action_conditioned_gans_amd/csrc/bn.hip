@@ -105,19 +105,23 @@ __device__ __forceinline__ void reduce_rsub_v(const VMap<V>& m, float (&a)[V], f
 }
 
 // Split-K hand-off (acg_bn_act_fwd_slabs / acg_bn_act_bwd_slabs): the producing convolution left `splits` fp32 partial
-// slabs, each laid out like the tensor; the BatchNorm kernel that would read the tensor sums them itself - in slab
-// order, rounded to the tensor's storage type: the very values splitk_reduce would have written - and, where the tensor
-// is needed later (x: BatchNorm backward re-reads it), writes it back.  `slabs` == nullptr: the tensor is read as is.
-struct Slabs { const float* p; int splits; long long stride; };
+// slabs; the BatchNorm kernel that would read the tensor sums them itself - in slab order, rounded to the tensor's
+// storage type: the very values splitk_reduce would have written - and, where the tensor is needed later (x: BatchNorm
+// backward re-reads it), writes it back.  `slabs` == nullptr: the tensor is read as is.
+// Two slab layouts (ACG_SLABS_ROWS / ACG_SLABS_QUADS): `qrows` == 0, each slab is laid out like the tensor ([rows][pitch]);
+// `qrows` = all rows of the tensor, a slab is [channels / 4][rows][4] - the 16 bytes a register-resident block (4 channels,
+// every row) reads per row are then consecutive in memory, where the row layout costs it one cache line per row and slab.
+struct Slabs { const float* p; int splits; long long stride; long long qrows; };
 template <bool SL, int V, typename T>
-__device__ __forceinline__ void ld_or_sum(T* base, long long off, const Slabs& sl, bool write, float (&v)[V]) {
+__device__ __forceinline__ void ld_or_sum(T* base, long long off, const Slabs& sl, bool write, float (&v)[V], long long qoff = 0) {
   if constexpr (!SL) { ldv<V>(base + off, v); return; }
+  const long long so = sl.qrows ? qoff : off;
 #pragma unroll
   for (int j = 0; j < V; ++j) v[j] = 0.f;
 #pragma unroll 4
   for (int z = 0; z < sl.splits; ++z) {
     float t[V];
-    ldv<V>(sl.p + (long long)z * sl.stride + off, t);
+    ldv<V>(sl.p + (long long)z * sl.stride + so, t);
 #pragma unroll
     for (int j = 0; j < V; ++j) v[j] += t[j];
   }
@@ -504,9 +508,13 @@ __global__ __launch_bounds__(256) void bn_resident_fwd(TX* __restrict__ x, const
   const long long gb = (long long)g * R * XP + c;
   TY* yg = y + (long long)g * R * YP + c;
   float v[NR][V], pv[V], bt[V];
+  const long long qb = ((long long)blockIdx.x * sl.qrows + (long long)g * R) * 4;       // quad layout (V == 4): this block's run of rows
 #pragma unroll
-  for (int u = 0; u < NR; ++u) ld_or_sum<SL, V>(x, gb + (long long)min((int)threadIdx.x + u * 256, R - 1) * XP, sl, (int)threadIdx.x + u * 256 < R, v[u]);
-  ld_or_sum<SL, V>(x, gb, sl, false, pv);      // shift by the group's first row, as in bn_stats_partial
+  for (int u = 0; u < NR; ++u) {
+    const int rq = min((int)threadIdx.x + u * 256, R - 1);
+    ld_or_sum<SL, V>(x, gb + (long long)rq * XP, sl, (int)threadIdx.x + u * 256 < R, v[u], qb + 4ll * rq);
+  }
+  ld_or_sum<SL, V>(x, gb, sl, false, pv, qb);      // shift by the group's first row, as in bn_stats_partial
   ldv<V>(beta + c, bt);
   float s[2 * V];
 #pragma unroll
@@ -559,7 +567,7 @@ __global__ __launch_bounds__(256) void bn_resident_bwd(const TX* __restrict__ x,
     for (int u = 0; u < NR; ++u) {
       const int rq = min((int)threadIdx.x + u * 256, R - 1);
       ldv<V>(x + base + rq * XP, xv[u]);
-      ld_or_sum<SL, V>(const_cast<TY*>(dy), ybase + (long long)rq * YP, sl, false, dv[u]);
+      ld_or_sum<SL, V>(const_cast<TY*>(dy), ybase + (long long)rq * YP, sl, false, dv[u], (((long long)blockIdx.x * sl.qrows + (long long)g * R) + rq) * 4);
     }
     ldv<V>(save_mean + g * C + c, mean); ldv<V>(save_rstd + g * C + c, rstd);
     float s[2 * V];
@@ -808,7 +816,7 @@ bool vec4_ok(int C, const void* a, const void* b, const void* c) {
 // layer of a bf16 network) exists for the scalar (V = 1) variants only.
 template <typename TX, typename TY>
 int bn_fwd_typed(const void* x, const float* beta, void* y, float* save_mean, float* save_rstd, long long R, int C, int groups,
-                 float eps, int act, float leak, float* part, bool v4, int XP, int YP, hipStream_t st, const Slabs sl = Slabs{nullptr, 0, 0}) {
+                 float eps, int act, float leak, float* part, bool v4, int XP, int YP, hipStream_t st, const Slabs sl = Slabs{nullptr, 0, 0, 0}) {
   constexpr bool same = std::is_same<TX, TY>::value;
   TX* xf = (TX*)const_cast<void*>(x);
   TY* yf = (TY*)y;
@@ -854,7 +862,7 @@ int bn_fwd_typed(const void* x, const float* beta, void* y, float* save_mean, fl
 template <typename TX, typename TY, typename TD = TX>
 int bn_bwd_typed(const void* x, const void* dy, const float* beta, const float* save_mean, const float* save_rstd, void* dx,
                  float* dbeta, float dbeta_acc, long long R, int C, int groups, int act, float leak, float* part, bool v4, int XP, int YP,
-                 hipStream_t st, const Slabs sl = Slabs{nullptr, 0, 0}) {
+                 hipStream_t st, const Slabs sl = Slabs{nullptr, 0, 0, 0}) {
   constexpr bool same = std::is_same<TX, TY>::value;
   const TX* xf = (const TX*)x;
   const TY* dyf = (const TY*)dy;
@@ -991,16 +999,19 @@ int32_t acg_bn_act_bwd(const void* x, const void* dy, const float* beta, const f
 
 int32_t acg_bn_act_fwd_slabs(const float* slabs, int32_t splits, void* x, const float* beta, void* y, float* save_mean, float* save_rstd,
                              int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t groups, float eps, int32_t act, float leak,
-                             int32_t dtype, void* ws, size_t wsb, acg_stream_t stream) {
+                             int32_t dtype, int32_t layout, void* ws, size_t wsb, acg_stream_t stream) {
   const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
   ACG_REQUIRE(XP >= C && YP >= C, ACG_ERR_INVALID_ARG, "bn_act_fwd_slabs: pitch smaller than the row");
+  ACG_REQUIRE(layout == ACG_SLABS_ROWS || (layout == ACG_SLABS_QUADS && acg_bn_slabs_layout(rows, C, x_pitch, y_pitch, groups, dtype, 0) == ACG_SLABS_QUADS),
+              ACG_ERR_UNSUPPORTED, "bn_act_fwd_slabs: slab layout %d for this tensor (acg_bn_slabs_layout)", layout);
   if (int rc = check_bn("bn_act_fwd_slabs", rows, C, groups)) return rc;
   ACG_REQUIRE(slabs && splits >= 1 && x && beta && y && save_mean && save_rstd, ACG_ERR_INVALID_ARG, "bn_act_fwd_slabs: null pointer / splits < 1");
   ACG_REQUIRE(act == ACG_ACT_NONE || act == ACG_ACT_RELU || act == ACG_ACT_LRELU, ACG_ERR_UNSUPPORTED, "bn_act_fwd_slabs: activation %d", act);
   ACG_REQUIRE(ws && wsb >= acg_bn_workspace_bytes(rows, C, groups), ACG_ERR_WORKSPACE, "bn_act_fwd_slabs: workspace too small");
   const long long R = rows / groups;
   const bool v4 = vec4_ok(C, x, y, beta) && vec4_ok(C, save_mean, save_rstd, ws) && vec4_ok(C, slabs, slabs, slabs) && XP % 4 == 0 && YP % 4 == 0;
-  const Slabs sl{slabs, splits, (long long)rows * XP};
+  ACG_REQUIRE(layout == ACG_SLABS_ROWS || v4, ACG_ERR_INVALID_ARG, "bn_act_fwd_slabs: the quad layout needs 16-byte aligned pointers");
+  const Slabs sl{slabs, splits, (long long)rows * XP, layout == ACG_SLABS_QUADS ? (long long)rows : 0ll};
   ACG_WITH_TYPES(dtype, "bn_act_fwd_slabs", return (bn_fwd_typed<TA, TB>(x, beta, y, save_mean, save_rstd, R, C, groups, eps, act, leak, (float*)ws, v4, XP, YP, acg::to_stream(stream), sl)));
 }
 
@@ -1009,18 +1020,31 @@ int32_t acg_bn_bwd_slabs_ok(int64_t rows, int32_t groups) {
   return (resident_nr(rows, 16) && resident_nr(rows / groups, 16)) ? 1 : 0;
 }
 
+int32_t acg_bn_slabs_layout(int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t groups, int32_t dtype, int32_t backward) {
+  if (rows <= 0 || C <= 0 || groups <= 0 || rows % groups) return -1;
+  const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
+  const bool resident = backward ? acg_bn_bwd_slabs_ok(rows, groups) != 0 : resident_nr(rows / groups, 32) != 0;
+  if (backward && !resident) return -1;
+  // the register-resident kernels with four channels per block read [channels / 4][rows][4] slabs as consecutive 16-byte rows
+  const bool quads = resident && C % 4 == 0 && XP % 4 == 0 && YP % 4 == 0 && acg::dt_valid(dtype) && acg::dt_first(dtype) == acg::dt_second(dtype);
+  return quads ? ACG_SLABS_QUADS : ACG_SLABS_ROWS;
+}
+
 int32_t acg_bn_act_bwd_slabs(const void* x, const float* dy_slabs, int32_t splits, const float* beta, const float* save_mean,
                              const float* save_rstd, void* dx, float* dbeta, float dbeta_acc, int64_t rows, int32_t C, int32_t x_pitch,
-                             int32_t y_pitch, int32_t groups, int32_t act, float leak, int32_t dtype, void* ws, size_t wsb, acg_stream_t stream) {
+                             int32_t y_pitch, int32_t groups, int32_t act, float leak, int32_t dtype, int32_t layout, void* ws, size_t wsb, acg_stream_t stream) {
   const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
   ACG_REQUIRE(XP >= C && YP >= C, ACG_ERR_INVALID_ARG, "bn_act_bwd_slabs: pitch smaller than the row");
+  ACG_REQUIRE(layout == ACG_SLABS_ROWS || (layout == ACG_SLABS_QUADS && acg_bn_slabs_layout(rows, C, x_pitch, y_pitch, groups, dtype, 1) == ACG_SLABS_QUADS),
+              ACG_ERR_UNSUPPORTED, "bn_act_bwd_slabs: slab layout %d for this tensor (acg_bn_slabs_layout)", layout);
   if (int rc = check_bn("bn_act_bwd_slabs", rows, C, groups)) return rc;
   ACG_REQUIRE(x && dy_slabs && splits >= 1 && beta && save_mean && save_rstd && dx && dbeta, ACG_ERR_INVALID_ARG, "bn_act_bwd_slabs: null pointer / splits < 1");
   ACG_REQUIRE(act == ACG_ACT_NONE || act == ACG_ACT_RELU || act == ACG_ACT_LRELU, ACG_ERR_UNSUPPORTED, "bn_act_bwd_slabs: activation %d", act);
   ACG_REQUIRE(acg_bn_bwd_slabs_ok(rows, groups), ACG_ERR_UNSUPPORTED, "bn_act_bwd_slabs: tensor too large for the one-launch kernels (acg_bn_bwd_slabs_ok)");
   const long long R = rows / groups;
   const bool v4 = vec4_ok(C, x, dy_slabs, dx) && vec4_ok(C, save_mean, save_rstd, beta) && vec4_ok(C, beta, dbeta, dbeta) && XP % 4 == 0 && YP % 4 == 0;
-  const Slabs sl{dy_slabs, splits, (long long)rows * YP};
+  ACG_REQUIRE(layout == ACG_SLABS_ROWS || v4, ACG_ERR_INVALID_ARG, "bn_act_bwd_slabs: the quad layout needs 16-byte aligned pointers");
+  const Slabs sl{dy_slabs, splits, (long long)rows * YP, layout == ACG_SLABS_QUADS ? (long long)rows : 0ll};
   ACG_WITH_TYPES(dtype, "bn_act_bwd_slabs", return (bn_bwd_typed<TA, TB>(x, nullptr, beta, save_mean, save_rstd, dx, dbeta, dbeta_acc, R, C, groups, act, leak, (float*)ws, v4, XP, YP, acg::to_stream(stream), sl)));
 }
 

@@ -135,7 +135,7 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
         const int w2 = m % Wc; const int t2 = m / Wc; const int h2 = t2 % Hc; const int b = t2 / Hc;
         const int y0 = h2 + dp0, x0 = w2 + dq0;
         ri.base = ((b * p.OH + y0) * p.OW + x0) * K8;
-        ri.out_off = ((b * p.H + h2 * p.sh + ph) * p.W + (w2 * p.sw + pw)) * (EPI ? p.Cx : Cin8);      // EPI: dense float32 rows
+        ri.out_off = ((b * p.H + h2 * p.sh + ph) * p.W + (w2 * p.sw + pw)) * (EPI ? p.Cx : (p.slab_rows ? 4 : Cin8));      // EPI: dense float32 rows
         const unsigned long long mk = tap_mask(max(0, y0 - p.OH + 1), min(nti, y0 + 1), max(0, x0 - p.OW + 1), min(ntj, x0 + 1), ntj);
         ri.mask_lo = (unsigned)mk; ri.mask_hi = (unsigned)(mk >> 32);
       }
@@ -407,6 +407,10 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
   // tools/fixed_cost_probe.py.)
   // (rows full; a ragged last column tile - 25 or 121 output channels - only masks lanes, once per 32-column sub-tile)
   const bool full = m0 + BM <= M && (MODE != MODE_WGRAD || (Cp == p.C && !(p.splits == 1 && p.accumulate != 0.f)));
+  // column term of an element's offset: n, or in the quad slab layout (ConvArgs::slab_rows; float32 slabs only) the quad's
+  // run of rows + n & 3
+  const bool quads = MODE != MODE_WGRAD && p.slab_rows > 0;
+  auto col_off = [&](int n) -> long long { return quads ? (long long)(n >> 2) * p.slab_rows * 4 + (n & 3) : (long long)n; };
   if (full) {
     auto store_rows = [&](auto* base, long long pitch, int a, int b) {
       using T = std::remove_pointer_t<decltype(base)>;
@@ -417,24 +421,25 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
 #pragma unroll
       for (int b = 0; b < TB; ++b) {
         if (n0 + wn0 + 32 * b + lrow < N) {
+          const long long co = col_off(n0 + wn0 + 32 * b + lrow);
 #pragma unroll
           for (int a = 0; a < TA; ++a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const long long off = rows[wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lk].out_off + (n0 + wn0 + 32 * b + lrow);
+              const long long off = rows[wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lk].out_off + co;
               if (to_bf16) outh[off] = (__bf16)acc[a][b][r];
               else outf[off] = acc[a][b][r];
             }
         }
       }
     } else {
-      const long long pitch = MODE == MODE_WGRAD ? N : K8;
+      const long long pitch = MODE == MODE_WGRAD ? N : (quads ? 4 : K8);
 #pragma unroll
       for (int b = 0; b < TB; ++b) {
         if (n0 + wn0 + 32 * b + lrow < N) {
 #pragma unroll
           for (int a = 0; a < TA; ++a) {
-            const long long o = (long long)(m0 + wm0 + 32 * a + 4 * lk) * pitch + (n0 + wn0 + 32 * b + lrow);
+            const long long o = (long long)(m0 + wm0 + 32 * a + 4 * lk) * pitch + col_off(n0 + wn0 + 32 * b + lrow);
             if (to_bf16) store_rows(outh + o, pitch, a, b);
             else store_rows(outf + o, pitch, a, b);
           }
@@ -462,18 +467,19 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
         if (c >= p.C) continue;
         base = ((long long)t * p.C + c) * N;
       } else {
-        base = (long long)m * K8;
+        base = (long long)m * (quads ? 4 : K8);
       }
 #pragma unroll
       for (int b = 0; b < TB; ++b) {
         const int n = n0 + wn0 + 32 * b + lrow;
         if (n < N) {
+          const long long o = base + col_off(n);
           float v = acc[a][b][r];
           if (MODE == MODE_WGRAD || !to_bf16) {
-            if (acc_out) v += p.accumulate * outf[base + n];
-            outf[base + n] = v;
+            if (acc_out) v += p.accumulate * outf[o];
+            outf[o] = v;
           } else {
-            outh[base + n] = (__bf16)v;
+            outh[o] = (__bf16)v;
           }
         }
       }

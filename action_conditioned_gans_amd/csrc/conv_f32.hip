@@ -318,7 +318,8 @@ int stats_blocks(const Plan& pl, const acg_conv_desc& d, int which, int groups, 
 // slabs_only (weight gradients whose reduction is deferred to acg_splitk_reduce_many): the contraction leaves its
 // `splits` partial slabs in the workspace and `out` is not touched.
 int prepare(Job& j, int which, const float* gsrc, const float* dense, float* out, float accumulate, const acg_conv_desc* d,
-            int dtype, void* ws, size_t ws_bytes, const char* who, bool slabs_only, float* stats = nullptr, int stats_groups = 0) {
+            int dtype, void* ws, size_t ws_bytes, const char* who, bool slabs_only, float* stats = nullptr, int stats_groups = 0,
+            int slab_layout = ACG_SLABS_ROWS) {
   // ACG_DTYPE2(ACG_BF16, ACG_F32): bf16 operands, the result stored as float32 (a head layer: acgan_hip.h)
   const bool out_f32 = dtype == ACG_DTYPE2(ACG_BF16, ACG_F32);
   ACG_REQUIRE(dtype == ACG_F32 || dtype == ACG_BF16 || (out_f32 && which != ACG_CONV_WGRAD), ACG_ERR_UNSUPPORTED, "%s: dtype %d", who, dtype);
@@ -354,6 +355,13 @@ int prepare(Job& j, int which, const float* gsrc, const float* dense, float* out
   a.batch = d->batch; a.H = d->in_h; a.W = d->in_w; a.C = d->in_c; a.OH = d->out_h; a.OW = d->out_w; a.K = d->out_c;
   a.KH = d->kh; a.KW = d->kw; a.sh = d->stride_h; a.sw = d->stride_w; a.pt = d->pad_top; a.pl = d->pad_left;
   a.splits = pl.splits;
+  if (slab_layout != ACG_SLABS_ROWS) {      // slabs for the layer's BatchNorm in the layout its one-launch kernels read (acgan_hip.h)
+    const long long orows = which == ACG_CONV_DGRAD ? (long long)d->batch * d->in_h * d->in_w : (long long)d->batch * d->out_h * d->out_w;
+    const int oc = which == ACG_CONV_DGRAD ? d->in_c : d->out_c, opitch = which == ACG_CONV_DGRAD ? (h ? cin8 : a.Cx) : (h ? cout8 : a.Ky);
+    ACG_REQUIRE(slab_layout == ACG_SLABS_QUADS && slabs_only && which != ACG_CONV_WGRAD, ACG_ERR_INVALID_ARG, "%s: slab layout %d", who, slab_layout);
+    ACG_REQUIRE(((oc + 3) & ~3) <= opitch && orows * 4 < (1ll << 31), ACG_ERR_UNSUPPORTED, "%s: the quad slab layout needs round4(channels) <= pitch", who);
+    a.slab_rows = (int)orows;
+  }
   { const FastDiv fw = fast_div(d->out_w), fh = fast_div(d->out_h); a.mg_ow = fw.magic; a.sh_ow = fw.shift; a.mg_oh = fh.magic; a.sh_oh = fh.shift;
     const FastDiv fc = fast_div(which == ACG_CONV_DGRAD ? (h ? cout8 : (d->out_c + 3) & ~3) : (h ? cin8 : (d->in_c + 3) & ~3)); a.mg_cp = fc.magic; a.sh_cp = fc.shift; }
   if (stats != nullptr) {
@@ -393,9 +401,9 @@ int reduce(const Job& j, hipStream_t st) {
 
 int run(int which, const float* gsrc, const float* dense, float* out, float accumulate, const acg_conv_desc* d, int dtype,
         void* ws, size_t ws_bytes, acg_stream_t stream, const char* who, bool slabs_only = false, float* stats = nullptr,
-        int stats_groups = 0) {
+        int stats_groups = 0, int slab_layout = ACG_SLABS_ROWS) {
   Job j;
-  if (int rc = prepare(j, which, gsrc, dense, out, accumulate, d, dtype, ws, ws_bytes, who, slabs_only, stats, stats_groups)) return rc;
+  if (int rc = prepare(j, which, gsrc, dense, out, accumulate, d, dtype, ws, ws_bytes, who, slabs_only, stats, stats_groups, slab_layout)) return rc;
   hipStream_t st = acg::to_stream(stream);
   if (int rc = launch(j, st)) return rc;
   return reduce(j, st);
@@ -408,7 +416,8 @@ int run_pair(int whichA, const float* gsrcA, const float* denseA, float* outA, c
              acg_stream_t stream, const char* who) {
   Job ja, jb;
   const bool slabs_only_B = (slab_flags & 1) != 0, slabs_only_A = (slab_flags & 2) != 0;
-  if (int rc = prepare(ja, whichA, gsrcA, denseA, outA, 0.f, d, dtype, wsA, wsbA, who, slabs_only_A)) return rc;
+  ACG_REQUIRE(!(slab_flags & 4) || slabs_only_A, ACG_ERR_INVALID_ARG, "%s: flag 4 (quad slab layout) without flag 2", who);
+  if (int rc = prepare(ja, whichA, gsrcA, denseA, outA, 0.f, d, dtype, wsA, wsbA, who, slabs_only_A, nullptr, 0, (slab_flags & 4) ? ACG_SLABS_QUADS : ACG_SLABS_ROWS)) return rc;
   if (int rc = prepare(jb, ACG_CONV_WGRAD, gsrcB, denseB, outB, accumulateB, d, dtype, wsB, wsbB, who, slabs_only_B)) return rc;
   hipStream_t st = acg::to_stream(stream);
   static const int enabled = env_int("ACG_CONV_PAIR", 1);       // 0: always two launches (A/B comparison)
@@ -532,17 +541,17 @@ int32_t acg_deconv2d_wgrad_slabs(const void* x, const void* dy, const acg_conv_d
 }
 
 // split-K hand-off to the consuming BatchNorm (acg_bn_act_fwd_slabs / acg_bn_act_bwd_slabs): the contraction only
-int32_t acg_conv2d_fwd_slabs(const void* x, const void* w, const acg_conv_desc* d, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
-  return run(ACG_CONV_FWD, (const float*)x, (const float*)w, nullptr, 0.f, d, dtype, ws, wsb, s, "conv2d_fwd_slabs", true);
+int32_t acg_conv2d_fwd_slabs(const void* x, const void* w, const acg_conv_desc* d, int32_t dtype, int32_t layout, void* ws, size_t wsb, acg_stream_t s) {
+  return run(ACG_CONV_FWD, (const float*)x, (const float*)w, nullptr, 0.f, d, dtype, ws, wsb, s, "conv2d_fwd_slabs", true, nullptr, 0, layout);
 }
-int32_t acg_conv2d_dgrad_slabs(const void* dy, const void* w, const acg_conv_desc* d, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
-  return run(ACG_CONV_DGRAD, (const float*)dy, (const float*)w, nullptr, 0.f, d, dtype, ws, wsb, s, "conv2d_dgrad_slabs", true);
+int32_t acg_conv2d_dgrad_slabs(const void* dy, const void* w, const acg_conv_desc* d, int32_t dtype, int32_t layout, void* ws, size_t wsb, acg_stream_t s) {
+  return run(ACG_CONV_DGRAD, (const float*)dy, (const float*)w, nullptr, 0.f, d, dtype, ws, wsb, s, "conv2d_dgrad_slabs", true, nullptr, 0, layout);
 }
-int32_t acg_deconv2d_fwd_slabs(const void* x, const void* w, const acg_conv_desc* adj, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
-  return run(ACG_CONV_DGRAD, (const float*)x, (const float*)w, nullptr, 0.f, adj, dtype, ws, wsb, s, "deconv2d_fwd_slabs", true);
+int32_t acg_deconv2d_fwd_slabs(const void* x, const void* w, const acg_conv_desc* adj, int32_t dtype, int32_t layout, void* ws, size_t wsb, acg_stream_t s) {
+  return run(ACG_CONV_DGRAD, (const float*)x, (const float*)w, nullptr, 0.f, adj, dtype, ws, wsb, s, "deconv2d_fwd_slabs", true, nullptr, 0, layout);
 }
-int32_t acg_deconv2d_dgrad_slabs(const void* dy, const void* w, const acg_conv_desc* adj, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
-  return run(ACG_CONV_FWD, (const float*)dy, (const float*)w, nullptr, 0.f, adj, dtype, ws, wsb, s, "deconv2d_dgrad_slabs", true);
+int32_t acg_deconv2d_dgrad_slabs(const void* dy, const void* w, const acg_conv_desc* adj, int32_t dtype, int32_t layout, void* ws, size_t wsb, acg_stream_t s) {
+  return run(ACG_CONV_FWD, (const float*)dy, (const float*)w, nullptr, 0.f, adj, dtype, ws, wsb, s, "deconv2d_dgrad_slabs", true, nullptr, 0, layout);
 }
 
 int32_t acg_conv2d_bwd_pair(const void* dy, const void* w, const void* x, void* dx, float* dw, float dw_accumulate,

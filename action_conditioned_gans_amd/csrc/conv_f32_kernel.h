@@ -60,6 +60,10 @@ struct ConvArgs {
   // FWD: g = tile_row / stats_tpg, b = tile_row % stats_tpg; DGRAD (one group): b = class * stats_tpg + tile_row.
   float* stats;
   int stats_nblk, stats_tpg;
+  // FWD / DGRAD slabs (splits > 1) handed to the layer's BatchNorm: 0 = each slab [rows][pitch] like the tensor; > 0 = the
+  // ACG_SLABS_QUADS layout [channels / 4][slab_rows][4] (slab_rows = all rows of the tensor), element (m, n) at
+  // ((n >> 2) * slab_rows + m) * 4 + (n & 3)
+  int slab_rows;
   int out_f32;         // bf16 kernels, FWD / DGRAD: the result is stored as float32 (at the bf16 tensor's pitch, round8): a head layer
   // EPI kernel variants only (acg_deconv2d_fwd_bias_act): out = act(acc + bias[n]), stored as float32 at the pitch Cx
   const float* bias;
@@ -346,7 +350,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
         const int w2 = m % Wc; const int t2 = m / Wc; const int h2 = t2 % Hc; const int b = t2 / Hc;
         const int y0 = h2 + dp0, x0 = w2 + dq0;  // dY coordinates of tap (0,0)
         ri.base = ((b * p.OH + y0) * p.OW + x0) * p.Ky;
-        ri.out_off = ((b * p.H + h2 * p.sh + ph) * p.W + (w2 * p.sw + pw)) * p.Cx;
+        ri.out_off = ((b * p.H + h2 * p.sh + ph) * p.W + (w2 * p.sw + pw)) * (p.slab_rows ? 4 : p.Cx);
         // tap (ti,tj) reads dY[y0 - ti][x0 - tj]
         const unsigned long long mk = tap_mask(max(0, y0 - p.OH + 1), min(nti, y0 + 1), max(0, x0 - p.OW + 1), min(ntj, x0 + 1), ntj);
         ri.mask_lo = (unsigned)mk; ri.mask_hi = (unsigned)(mk >> 32);
@@ -739,23 +743,27 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
   // bounds test, a branch and a 64-bit index multiply per element (conv_bf16_kernel.h has the measurement).
   // (rows full; a ragged last column tile - 3, 6, 25 or 138 output channels - only masks lanes, once per 32-column sub-tile)
   const bool full = m0 + BM <= M && (MODE != MODE_WGRAD || (Cp == Cs && !(p.splits == 1 && p.accumulate != 0.f)));
+  // column term of an element's offset: n, or in the quad slab layout (ConvArgs::slab_rows) the quad's run of rows + n & 3
+  const bool quads = MODE != MODE_WGRAD && p.slab_rows > 0;
+  auto col_off = [&](int n) -> long long { return quads ? (long long)(n >> 2) * p.slab_rows * 4 + (n & 3) : (long long)n; };
+  const long long row_pitch = MODE == MODE_WGRAD ? N : (quads ? 4 : p.Ky);
   if (full) {
 #pragma unroll
     for (int b = 0; b < TB; ++b) {
       if (n0 + wn0 + 32 * b + lrow < N) {
+        const long long co = col_off(n0 + wn0 + 32 * b + lrow);
         if constexpr (MODE == MODE_DGRAD) {
 #pragma unroll
           for (int a = 0; a < TA; ++a)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-              outp[(long long)rows[wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lk].out_off + (n0 + wn0 + 32 * b + lrow)] = acc[a][b][r];
+              outp[(long long)rows[wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lk].out_off + co] = acc[a][b][r];
         } else {
-          const long long pitch = MODE == MODE_WGRAD ? N : p.Ky;
 #pragma unroll
           for (int a = 0; a < TA; ++a) {
-            float* const o = outp + (long long)(m0 + wm0 + 32 * a + 4 * lk) * pitch + (n0 + wn0 + 32 * b + lrow);
+            float* const o = outp + (long long)(m0 + wm0 + 32 * a + 4 * lk) * row_pitch + co;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[(long long)((r & 3) + 8 * (r >> 2)) * pitch] = acc[a][b][r];
+            for (int r = 0; r < 16; ++r) o[(long long)((r & 3) + 8 * (r >> 2)) * row_pitch] = acc[a][b][r];
           }
         }
       }
@@ -780,15 +788,16 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
         if (c >= Cs) continue;
         base = ((long long)t * Cs + c) * N;
       } else {
-        base = (long long)m * p.Ky;
+        base = (long long)m * row_pitch;
       }
 #pragma unroll
       for (int b = 0; b < TB; ++b) {
         const int n = n0 + wn0 + 32 * b + lrow;
         if (n < N) {
+          const long long o = base + col_off(n);
           float v = acc[a][b][r];
-          if (acc_out) v += p.accumulate * outp[base + n];
-          outp[base + n] = v;
+          if (acc_out) v += p.accumulate * outp[o];
+          outp[o] = v;
         }
       }
     }

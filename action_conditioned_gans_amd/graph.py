@@ -354,6 +354,7 @@ class Runtime:
         # measured SLOWER (fp32 364 vs 383, bf16 567 vs 600 steps/s, profiles/r2): the one-launch BatchNorm kernels read 16
         # bytes per row and block, and S slabs multiply exactly those poorly coalesced requests; kept as an option
         self.slab_handoff = 0
+        self.slab_rows = False                 # hand-offs in the ACG_SLABS_ROWS layout too (Session(slab_handoff=True / N))
         self.epilogue_stats = True
         self.epilogue_bias = True
         self._comm = comm
@@ -416,8 +417,10 @@ class Session:
                 raise ValueError('Session(dtype=%r): the graph was already built for %s activations' % (dtype, self.graph.act_dtype))
             self.graph.act_dtype = want
         self.rt = Runtime(lib, dev, world_size, rank, process_group, _lib.ACG_BF16 if dtype == 'bf16' else _lib.ACG_F32, comm)
-        # False / 0: off; True: every split layer; an int N: only layers split into at most N slabs
-        self.rt.slab_handoff = (1 << 30) if slab_handoff is True else int(slab_handoff or 0)
+        # False / 0: off; 'quads': every split layer whose BatchNorm reads the quad slab layout (the one-launch kernels);
+        # True: every split layer, either layout; an int N: either layout, only layers split into at most N slabs
+        self.rt.slab_handoff = (1 << 30) if slab_handoff in (True, 'quads') else int(slab_handoff or 0)
+        self.rt.slab_rows = slab_handoff != 'quads' 
         self.rt.epilogue_stats = bool(epilogue_stats)     # BatchNorm statistics out of the producing conv's epilogue (ops.Conv2dOp.bind)
         self.rt.epilogue_bias = bool(epilogue_bias)       # bias + activation of a transposed head layer in its epilogue (models.py:20-21)
         if dev.type == 'cuda':

@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from . import graph as G
-from ._lib import ACG_F32, CONV_DGRAD, CONV_FWD, CONV_WGRAD, ConvDesc
+from ._lib import ACG_F32, CONV_DGRAD, CONV_FWD, CONV_WGRAD, SLABS_QUADS, ConvDesc
 
 DNA_KERN_SIZE = 5          # ops.py:12
 _ACT_CODE = {None: _lib.ACT_NONE, 'relu': _lib.ACT_RELU, 'lrelu': _lib.ACT_LRELU, 'tanh': _lib.ACT_TANH}
@@ -304,12 +304,13 @@ class Conv2dOp(_ConvBase):
             # sums them as it loads (acg_bn_act_fwd_slabs) - one launch less
             lib, d = rt.lib, self.desc
             splits = lib.conv2d_splits(ctypes.byref(d), self.which, rt.conv_dtype)
-            if 1 < splits <= rt.slab_handoff:
+            layout = bn.slab_layout(rt, splits, False)
+            if layout >= 0:
                 ws, n = rt.workspace(lib.conv2d_workspace_bytes(ctypes.byref(d), self.which, rt.conv_dtype))
-                self._keep, self._slab = (ws, d), (ws, splits)
+                self._keep, self._slab = (ws, d), (ws, splits, layout)
                 fn = lib.deconv2d_fwd_slabs if self.transposed else lib.conv2d_fwd_slabs
                 pa, pb, dref, pws, dt = _p(x.buf), _p(self.wop.buf), ctypes.byref(d), _p(ws), rt.conv_dtype
-                return lambda s: fn(pa, pb, dref, dt, pws, n, s)
+                return lambda s: fn(pa, pb, dref, dt, layout, pws, n, s)
         return self._bind(rt, 'deconv2d_fwd' if self.transposed else 'conv2d_fwd', x, self.wop, self.outputs[0])
 
     def grad(self, gouts, needs, ctx):
@@ -348,16 +349,17 @@ class ConvDgradOp(_ConvBase):
         lib, d, dt = rt.lib, self.desc, rt.conv_dtype
         self._slab = None
         bn = self.bn_bwd_consumer
-        hand_off = False
-        if bn is not None and id(bn) in rt.program_ops and rt.slab_handoff and lib.bn_bwd_slabs_ok(bn.fwd.rows, bn.fwd.groups):
-            hand_off = 1 < lib.conv2d_splits(ctypes.byref(d), self.which, dt) <= rt.slab_handoff
+        layout = -1
+        if bn is not None and id(bn) in rt.program_ops and rt.slab_handoff:
+            layout = bn.fwd.slab_layout(rt, lib.conv2d_splits(ctypes.byref(d), self.which, dt), True, dy=self.outputs[0])
+        hand_off = layout >= 0
         if not self.pair_active:
             if hand_off:     # the consuming BatchNorm backward sums the slabs (acg_bn_act_bwd_slabs)
                 ws, n = rt.workspace(lib.conv2d_workspace_bytes(ctypes.byref(d), self.which, dt))
-                self._keep, self._slab = (ws, d), (ws, lib.conv2d_splits(ctypes.byref(d), self.which, dt))
+                self._keep, self._slab = (ws, d), (ws, lib.conv2d_splits(ctypes.byref(d), self.which, dt), layout)
                 fn = lib.deconv2d_dgrad_slabs if self.transposed else lib.conv2d_dgrad_slabs
                 pa, pb, dref, pws = _p(dy.buf), _p(w.buf), ctypes.byref(d), _p(ws)
-                return lambda s: fn(pa, pb, dref, dt, pws, n, s)
+                return lambda s: fn(pa, pb, dref, dt, layout, pws, n, s)
             return self._bind(rt, 'deconv2d_dgrad' if self.transposed else 'conv2d_dgrad', dy, w, self.outputs[0])
         # ONE launch for dx and dw: the two contractions share the CUs instead of running one grid after the other
         wg = self.pair_w
@@ -365,7 +367,7 @@ class ConvDgradOp(_ConvBase):
         wsd, nd = rt.workspace(lib.conv2d_workspace_bytes(ctypes.byref(d), self.which, dt))
         wsw, nw = rt.workspace(lib.conv2d_workspace_bytes(ctypes.byref(d), CONV_WGRAD, dt))
         if hand_off:
-            self._slab = (wsd, lib.conv2d_splits(ctypes.byref(d), self.which, dt))
+            self._slab = (wsd, lib.conv2d_splits(ctypes.byref(d), self.which, dt), layout)
         slabs = 0
         if wg.deferred_to is not None:
             splits = lib.conv2d_splits(ctypes.byref(d), CONV_WGRAD, dt)
@@ -375,7 +377,7 @@ class ConvDgradOp(_ConvBase):
         self._keep = (wsd, wsw, d)
         fn = lib.deconv2d_bwd_pair if self.transposed else lib.conv2d_bwd_pair
         args = (_p(dy.buf), _p(w.buf), _p(x.buf), _p(self.outputs[0].buf), None if slabs else _p(wg.outputs[0].buf), wg.accumulate,
-                ctypes.byref(d), dt, _p(wsd), nd, _p(wsw), nw, slabs | (2 if hand_off else 0))
+                ctypes.byref(d), dt, _p(wsd), nd, _p(wsw), nw, slabs | (2 if hand_off else 0) | (4 if layout == SLABS_QUADS else 0))
         return lambda s: fn(*args, s)
 
 
@@ -465,6 +467,15 @@ class BnActOp(G.Op):
         self.yp = y.shape[-1]
         super().__init__(g, name, [x, beta], [y, self.mean, self.rstd])
 
+    def slab_layout(self, rt, splits, backward, dy=None):
+        """The slab layout this BatchNorm (forward, or its backward reading `dy`) takes from a producer split `splits` ways
+        in the program being compiled; -1: none, the producer runs its own reduction (acg_bn_slabs_layout)."""
+        if not 1 < splits <= rt.slab_handoff:
+            return -1
+        code = _code2(self.inputs[0], dy if backward else self.outputs[0])
+        layout = rt.lib.bn_slabs_layout(self.rows, self.c, self.xp, self.yp, self.groups, code, 1 if backward else 0)
+        return layout if (layout == SLABS_QUADS or rt.slab_rows) else -1
+
     def bind(self, rt):
         lib = rt.lib
         ws, n = rt.workspace(lib.bn_workspace_bytes(self.rows, self.c, self.groups))
@@ -481,9 +492,9 @@ class BnActOp(G.Op):
             return lambda s: fn(*args, s)
         slab = src._slab if (src is not None and id(src) in rt.program_ops) else None
         if slab is not None:      # the conv left its split-K slabs: sum them here and write x for the backward pass
-            sws, splits = slab
+            sws, splits, layout = slab
             args = (_p(sws), splits, _p(x.buf), _p(beta.buf), _p(y.buf), _p(mean.buf), _p(rstd.buf), self.rows, self.c, self.xp, self.yp,
-                    self.groups, self.eps, _ACT_CODE[self.act], self.leak, _code2(x, y), _p(ws), n)
+                    self.groups, self.eps, _ACT_CODE[self.act], self.leak, _code2(x, y), layout, _p(ws), n)
             fn = lib.bn_act_fwd_slabs
             return lambda s: fn(*args, s)
         args = (_p(x.buf), _p(beta.buf), _p(y.buf), _p(mean.buf), _p(rstd.buf), self.rows, self.c, self.xp, self.yp, self.groups,
@@ -525,9 +536,9 @@ class BnActBwdOp(G.Op):
         src = self.dy_producer
         slab = src._slab if (src is not None and id(src) in rt.program_ops) else None
         if slab is not None:      # dy arrives as the producing dgrad's split-K slabs
-            sws, splits = slab
+            sws, splits, layout = slab
             args = (_p(x.buf), _p(sws), splits, _p(beta.buf), _p(mean.buf), _p(rstd.buf), _p(dx.buf), _p(dbeta.buf), self.accumulate,
-                    f.rows, f.c, f.xp, f.yp, f.groups, _ACT_CODE[f.act], f.leak, _code2(x, dy), _p(ws), n)
+                    f.rows, f.c, f.xp, f.yp, f.groups, _ACT_CODE[f.act], f.leak, _code2(x, dy), layout, _p(ws), n)
             fn = lib.bn_act_bwd_slabs
             return lambda s: fn(*args, s)
         args = (_p(x.buf), _p(dy.buf), _p(beta.buf), _p(mean.buf), _p(rstd.buf), _p(dx.buf), _p(dbeta.buf), self.accumulate,

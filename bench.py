@@ -54,7 +54,7 @@ def parse():
     ap.add_argument('--lib', default=None, help='experiment: an alternative build of the library (e.g. the tuning build, whose knobs read the environment)')
     ap.add_argument('--no-epilogue-stats', action='store_true', help='experiment: BatchNorm computes its statistics in a pass of its own instead of taking them from the conv epilogue')
     ap.add_argument('--side-branch', action='store_true', help='experiment: the state head as a parallel branch of the HIP graph (second stream) instead of in line on the main stream; measured slower')
-    ap.add_argument('--slab-handoff', type=int, default=0, metavar='N', help='experiment: the consuming BatchNorm kernels sum the split-K slabs of layers split into at most N slabs instead of separate reduction launches (measured slower)')
+    ap.add_argument('--slab-handoff', default=None, metavar='MODE', help="split-K hand-off to the consuming BatchNorm: 'off', 'quads' (layers whose BatchNorm reads the quad slab layout), 'all', or N = either layout for layers split into at most N slabs; default: the Session's")
     ap.add_argument('--no-pair', action='store_true', help='experiment: a layer\'s dgrad and wgrad as two launches instead of one')
     ap.add_argument('--dp-collectives', default=None, choices=['stream', 'side'], help='gradient all-reduces (ncclAllReduce captured into the step\'s HIP graph) on the compute stream in program order, or on a side HIP stream overlapping the rest of backward; default: side with more than one rank')
     ap.add_argument('--buckets', type=int, default=0, help='gradient all-reduce buckets per optimizer (data parallel); 0 = 1 for in-order collectives, 2 for side-stream ones')
@@ -136,7 +136,7 @@ def main():
     G.reset_default_graph()
     optim.set_data_parallel(world, n_buckets=args.buckets, force=args.force_dp, sync_bn=args.sync_bn, exact_global_batch=args.exact_global_batch,
                             collectives=args.dp_collectives)
-    sess = G.Session(device=device, side_branches=args.side_branch, slab_handoff=args.slab_handoff, epilogue_stats=not args.no_epilogue_stats, pair_bwd=not args.no_pair, use_hip_graphs=not args.no_graphs, world_size=world, rank=rank, dtype=args.dtype)
+    sess = G.Session(device=device, side_branches=args.side_branch, **({} if args.slab_handoff is None else {'slab_handoff': {'off': False, 'quads': 'quads', 'all': True}.get(args.slab_handoff, args.slab_handoff if not str(args.slab_handoff).isdigit() else int(args.slab_handoff))}), epilogue_stats=not args.no_epilogue_stats, pair_bwd=not args.no_pair, use_hip_graphs=not args.no_graphs, world_size=world, rank=rank, dtype=args.dtype)
     tr = T.Trainer(sess, adv, args.loss, args.opt, dna, batch_size=B, img_size=S, ksize=args.ksize, seed=0)
     sess.run(G.global_variables_initializer())
 

@@ -38,8 +38,9 @@ extern "C" {
 /* Bumped whenever an exported signature, a struct layout or the meaning of an argument changes; the Python binding
  * (_lib.Library) refuses a library whose acg_version() differs from the value it was written against.
  * 1: round 1.  2: round 2 (acg_bn_act_*, acg_bias_act_*, acg_dna_*, acg_copy_list, the flags of acg_*_bwd_pair changed
- * without a bump - any "version 1" build may be either).  3: round 3. */
-#define ACG_ABI_VERSION 3
+ * without a bump - any "version 1" build may be either).  3: round 3.  4: the `layout` argument of the slab hand-off
+ * entries (acg_*_slabs, acg_bn_act_*_slabs), acg_bn_slabs_layout. */
+#define ACG_ABI_VERSION 4
 
 typedef void* acg_stream_t; /* hipStream_t */
 
@@ -183,16 +184,22 @@ int32_t acg_deconv2d_fwd_bias_act(const void* x, const void* w, const float* bia
 /* Split-K hand-off to the consuming BatchNorm.  A small layer is split over K to fill the chip and would need a
  * launch of its own to sum the partial slabs; its output (forward) or input gradient (backward) is read next by the
  * layer's BatchNorm kernel (models.py:10-15: every conv but three is followed by batch_norm), which can sum the slabs as it
- * loads them: acg_(de)conv2d_fwd_slabs / _dgrad_slabs run the contraction only - `splits` float32 slabs, each laid out like
- * the tensor, stay in the workspace (an error when acg_conv2d_splits == 1) - and acg_bn_act_fwd_slabs /
- * acg_bn_act_bwd_slabs (below) take them.  Same values as the separate reduction, one launch less per layer and pass. */
-int32_t acg_conv2d_fwd_slabs(const void* x, const void* w, const acg_conv_desc* d, int32_t dtype, void* workspace,
+ * loads them: acg_(de)conv2d_fwd_slabs / _dgrad_slabs run the contraction only - `splits` float32 slabs stay in the
+ * workspace (an error when acg_conv2d_splits == 1) - and acg_bn_act_fwd_slabs / acg_bn_act_bwd_slabs (below) take them.
+ * Same values as the separate reduction, one launch less per layer and pass.
+ * `layout` of a slab (rows = all pixels of the tensor, pitch = its channel pitch; a slab is rows * pitch floats either way):
+ *   ACG_SLABS_ROWS   [rows][pitch], like the tensor
+ *   ACG_SLABS_QUADS  [ceil(channels / 4)][rows][4]: the layout the one-launch BatchNorm kernels (four channels per block,
+ *                    every row) read as consecutive 16-byte rows - ask acg_bn_slabs_layout which one the consumer takes. */
+#define ACG_SLABS_ROWS 0
+#define ACG_SLABS_QUADS 1
+int32_t acg_conv2d_fwd_slabs(const void* x, const void* w, const acg_conv_desc* d, int32_t dtype, int32_t layout, void* workspace,
                              size_t workspace_bytes, acg_stream_t stream);
-int32_t acg_conv2d_dgrad_slabs(const void* dy, const void* w, const acg_conv_desc* d, int32_t dtype, void* workspace,
+int32_t acg_conv2d_dgrad_slabs(const void* dy, const void* w, const acg_conv_desc* d, int32_t dtype, int32_t layout, void* workspace,
                                size_t workspace_bytes, acg_stream_t stream);
-int32_t acg_deconv2d_fwd_slabs(const void* x, const void* w, const acg_conv_desc* adj, int32_t dtype, void* workspace,
+int32_t acg_deconv2d_fwd_slabs(const void* x, const void* w, const acg_conv_desc* adj, int32_t dtype, int32_t layout, void* workspace,
                                size_t workspace_bytes, acg_stream_t stream);
-int32_t acg_deconv2d_dgrad_slabs(const void* dy, const void* w, const acg_conv_desc* adj, int32_t dtype, void* workspace,
+int32_t acg_deconv2d_dgrad_slabs(const void* dy, const void* w, const acg_conv_desc* adj, int32_t dtype, int32_t layout, void* workspace,
                                  size_t workspace_bytes, acg_stream_t stream);
 
 /* A layer's input gradient and weight gradient in ONE launch (both consume dy, neither reads the other's result):
@@ -201,7 +208,8 @@ int32_t acg_deconv2d_dgrad_slabs(const void* dy, const void* w, const acg_conv_d
  * instead of running one grid after the other.  Workspaces as for the separate entries (acg_conv2d_workspace_bytes
  * with ACG_CONV_DGRAD / ACG_CONV_WGRAD; for the transposed layer ACG_CONV_FWD / ACG_CONV_WGRAD on the adjoint).
  * wgrad_slabs_only is a bit set: 1 = leave the weight-gradient slabs (dw may be NULL), 2 = leave the input-gradient
- * slabs for acg_bn_act_bwd_slabs (dx may be NULL; an error when that contraction is not split). */
+ * slabs for acg_bn_act_bwd_slabs (dx may be NULL; an error when that contraction is not split), 4 = those input-gradient
+ * slabs in the ACG_SLABS_QUADS layout. */
 int32_t acg_conv2d_bwd_pair(const void* dy, const void* w, const void* x, void* dx, float* dw, float dw_accumulate,
                             const acg_conv_desc* d, int32_t dtype, void* ws_dgrad, size_t ws_dgrad_bytes, void* ws_wgrad,
                             size_t ws_wgrad_bytes, int32_t wgrad_slabs_only, acg_stream_t stream);
@@ -255,19 +263,24 @@ int32_t acg_bn_act_bwd_sums(const void* x, const void* dy, const float* beta, co
  * ---------------------------------------------------------------------------------------- */
 size_t acg_bn_workspace_bytes(int64_t rows, int32_t channels, int32_t groups);
 /* The same with the split-K hand-off described at acg_conv2d_fwd_slabs: forward reads x as the sum of `splits` float32
- * slabs (each rows * x_pitch elements, summed in slab order and rounded to x's storage type - what the separate
+ * slabs (each rows * x_pitch floats in `layout`, summed in slab order and rounded to x's storage type - what the separate
  * reduction would have stored) and WRITES x, which backward re-reads; backward reads dy as the sum of `splits` slabs
- * (each rows * y_pitch elements) and stores it nowhere.  acg_bn_bwd_slabs_ok: 1 when backward can take slabs (tensors
- * small enough for the one-launch kernels - the split layers are), else run the plain reduction + acg_bn_act_bwd. */
+ * (each rows * y_pitch floats) and stores it nowhere.
+ * acg_bn_slabs_layout: the slab layout this BatchNorm wants from its producer - ACG_SLABS_QUADS when the one-launch
+ * kernels with four channels per block run (rows per group <= 2048, channels and pitches multiples of 4, dtype a plain
+ * ACG_F32 / ACG_BF16), else ACG_SLABS_ROWS; -1 when it cannot take slabs at all (backward of a tensor too large for the
+ * one-launch kernels: run the plain reduction + acg_bn_act_bwd).  acg_bn_bwd_slabs_ok: the backward half of that test. */
+int32_t acg_bn_slabs_layout(int64_t rows, int32_t channels, int32_t x_pitch, int32_t y_pitch, int32_t groups, int32_t dtype,
+                            int32_t backward);
 int32_t acg_bn_act_fwd_slabs(const float* slabs, int32_t splits, void* x, const float* beta, void* y, float* save_mean,
                              float* save_rstd, int64_t rows, int32_t channels, int32_t x_pitch, int32_t y_pitch, int32_t groups,
-                             float eps, int32_t act, float leak, int32_t dtype, void* workspace, size_t workspace_bytes,
+                             float eps, int32_t act, float leak, int32_t dtype, int32_t layout, void* workspace, size_t workspace_bytes,
                              acg_stream_t stream);
 int32_t acg_bn_bwd_slabs_ok(int64_t rows, int32_t groups);
 int32_t acg_bn_act_bwd_slabs(const void* x, const float* dy_slabs, int32_t splits, const float* beta, const float* save_mean,
                              const float* save_rstd, void* dx, float* dbeta, float dbeta_accumulate, int64_t rows,
                              int32_t channels, int32_t x_pitch, int32_t y_pitch, int32_t groups, int32_t act, float leak,
-                             int32_t dtype, void* workspace, size_t workspace_bytes, acg_stream_t stream);
+                             int32_t dtype, int32_t layout, void* workspace, size_t workspace_bytes, acg_stream_t stream);
 /* BatchNorm + activation from the per-block (sum, M2) partials of acg_(de)conv2d_fwd_stats (`nblk` blocks per group, with
  * the block_rows / run_rows of acg_conv2d_stats_layout): mean = sum of sums / rows_per_group, variance = (sum of M2 +
  * sum_b n_b * (mean_b - mean)^2) / rows_per_group (merged about the first block's mean), then the apply pass of acg_bn_act_fwd.  More

@@ -226,24 +226,26 @@ int32_t acg_deconv2d_fwd_bias_act(const void* x, const void* w, const float* bia
 }
 
 /* split-K hand-off entries: the restatement never splits forward / input-gradient contractions (acg_conv2d_splits) */
-int32_t acg_conv2d_fwd_slabs(const void* x, const void* w, const acg_conv_desc* d, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
-  (void)x; (void)w; (void)d; (void)dtype; (void)ws; (void)wsb; (void)s; return fail(ACG_ERR_UNSUPPORTED, "cpu oracle: contraction is not split"); }
-int32_t acg_conv2d_dgrad_slabs(const void* x, const void* w, const acg_conv_desc* d, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
-  (void)x; (void)w; (void)d; (void)dtype; (void)ws; (void)wsb; (void)s; return fail(ACG_ERR_UNSUPPORTED, "cpu oracle: contraction is not split"); }
-int32_t acg_deconv2d_fwd_slabs(const void* x, const void* w, const acg_conv_desc* d, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
-  (void)x; (void)w; (void)d; (void)dtype; (void)ws; (void)wsb; (void)s; return fail(ACG_ERR_UNSUPPORTED, "cpu oracle: contraction is not split"); }
-int32_t acg_deconv2d_dgrad_slabs(const void* x, const void* w, const acg_conv_desc* d, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
-  (void)x; (void)w; (void)d; (void)dtype; (void)ws; (void)wsb; (void)s; return fail(ACG_ERR_UNSUPPORTED, "cpu oracle: contraction is not split"); }
+int32_t acg_conv2d_fwd_slabs(const void* x, const void* w, const acg_conv_desc* d, int32_t dtype, int32_t layout, void* ws, size_t wsb, acg_stream_t s) {
+  (void)x; (void)w; (void)d; (void)dtype; (void)layout; (void)ws; (void)wsb; (void)s; return fail(ACG_ERR_UNSUPPORTED, "cpu oracle: contraction is not split"); }
+int32_t acg_conv2d_dgrad_slabs(const void* x, const void* w, const acg_conv_desc* d, int32_t dtype, int32_t layout, void* ws, size_t wsb, acg_stream_t s) {
+  (void)x; (void)w; (void)d; (void)dtype; (void)layout; (void)ws; (void)wsb; (void)s; return fail(ACG_ERR_UNSUPPORTED, "cpu oracle: contraction is not split"); }
+int32_t acg_deconv2d_fwd_slabs(const void* x, const void* w, const acg_conv_desc* d, int32_t dtype, int32_t layout, void* ws, size_t wsb, acg_stream_t s) {
+  (void)x; (void)w; (void)d; (void)dtype; (void)layout; (void)ws; (void)wsb; (void)s; return fail(ACG_ERR_UNSUPPORTED, "cpu oracle: contraction is not split"); }
+int32_t acg_deconv2d_dgrad_slabs(const void* x, const void* w, const acg_conv_desc* d, int32_t dtype, int32_t layout, void* ws, size_t wsb, acg_stream_t s) {
+  (void)x; (void)w; (void)d; (void)dtype; (void)layout; (void)ws; (void)wsb; (void)s; return fail(ACG_ERR_UNSUPPORTED, "cpu oracle: contraction is not split"); }
 int32_t acg_bn_bwd_slabs_ok(int64_t rows, int32_t groups) { (void)rows; (void)groups; return 0; }
+int32_t acg_bn_slabs_layout(int64_t rows, int32_t C, int32_t xp, int32_t yp, int32_t groups, int32_t dtype, int32_t backward) {
+  (void)rows; (void)C; (void)xp; (void)yp; (void)groups; (void)dtype; (void)backward; return -1; }
 int32_t acg_bn_act_fwd_slabs(const float* slabs, int32_t splits, void* x, const float* beta, void* y, float* save_mean, float* save_rstd,
                              int64_t rows, int32_t C, int32_t xp, int32_t yp, int32_t groups, float eps, int32_t act, float leak, int32_t dtype,
-                             void* ws, size_t wsb, acg_stream_t s) {
-  (void)slabs; (void)splits; (void)x; (void)beta; (void)y; (void)save_mean; (void)save_rstd; (void)rows; (void)C; (void)xp; (void)yp; (void)groups;
+                             int32_t layout, void* ws, size_t wsb, acg_stream_t s) {
+  (void)layout; (void)slabs; (void)splits; (void)x; (void)beta; (void)y; (void)save_mean; (void)save_rstd; (void)rows; (void)C; (void)xp; (void)yp; (void)groups;
   (void)eps; (void)act; (void)leak; (void)dtype; (void)ws; (void)wsb; (void)s; return fail(ACG_ERR_UNSUPPORTED, "cpu oracle: no split-K hand-off"); }
 int32_t acg_bn_act_bwd_slabs(const void* x, const float* dy_slabs, int32_t splits, const float* beta, const float* save_mean,
                              const float* save_rstd, void* dx, float* dbeta, float acc, int64_t rows, int32_t C, int32_t xp, int32_t yp,
-                             int32_t groups, int32_t act, float leak, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
-  (void)x; (void)dy_slabs; (void)splits; (void)beta; (void)save_mean; (void)save_rstd; (void)dx; (void)dbeta; (void)acc; (void)rows; (void)C; (void)xp;
+                             int32_t groups, int32_t act, float leak, int32_t dtype, int32_t layout, void* ws, size_t wsb, acg_stream_t s) {
+  (void)layout; (void)x; (void)dy_slabs; (void)splits; (void)beta; (void)save_mean; (void)save_rstd; (void)dx; (void)dbeta; (void)acc; (void)rows; (void)C; (void)xp;
   (void)yp; (void)groups; (void)act; (void)leak; (void)dtype; (void)ws; (void)wsb; (void)s; return fail(ACG_ERR_UNSUPPORTED, "cpu oracle: no split-K hand-off"); }
 int32_t acg_weights_prepare_bf16(const acg_prep_list* l, int32_t count, acg_stream_t s) {
   (void)l; (void)count; (void)s;

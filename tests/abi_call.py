@@ -302,6 +302,97 @@ class Abi:
                                      leak, L.dtype2(L.ACG_F32, L.ACG_F32), self.stream())
         return conv, y, mean, rstd
 
+    # ---- split-K hand-off: the contraction leaves its slabs, the layer's BatchNorm kernel sums them
+    def _layer_desc(self, x_shape, w_shape, stride, padding, transposed):
+        if transposed:
+            d = self._adj(x_shape, tuple(w_shape), stride)
+            which, c, oshape = L.CONV_DGRAD, d.in_c, (d.batch, d.in_h, d.in_w)
+        else:
+            b, h, wd, cin = x_shape
+            d = self.desc(b, h, wd, w_shape[2], w_shape[0], w_shape[1], w_shape[3], stride, padding)
+            which, c, oshape = L.CONV_FWD, d.out_c, (b, d.out_h, d.out_w)
+        if self.half:
+            d.in_pitch = d.out_pitch = 0
+        return d, which, c, oshape
+
+    def conv_bn_handoff(self, x, w, beta, stride, padding, act, groups=1, transposed=False, layout=None, eps=1e-3, leak=0.2):
+        """acg_(de)conv2d_fwd_slabs + acg_bn_act_fwd_slabs -> (conv output as written back, y, mean, rstd, layout), float32;
+        None when the planner does not split this layer.  ``layout`` None: what acg_bn_slabs_layout asks for."""
+        d, which, c, oshape = self._layer_desc(x.shape, w.shape, stride, padding, transposed)
+        splits = self.lib.conv2d_splits(ctypes.byref(d), which, self.conv_dtype)
+        if splits < 2:
+            return None
+        cp = (c + 7) // 8 * 8 if self.half else c
+        rows = oshape[0] * oshape[1] * oshape[2]
+        if layout is None:
+            layout = self.lib.bn_slabs_layout(rows, c, cp, cp, groups, self.conv_dtype, 0)
+        assert layout >= 0
+        ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), which, self.conv_dtype))
+        ws.fill_(0xFF)                                                  # NaN patterns: every slab element read must have been written
+        fn = self.lib.deconv2d_fwd_slabs if transposed else self.lib.conv2d_fwd_slabs
+        tdt = torch.bfloat16 if self.half else torch.float32
+        if self.half:
+            x16, (rm, tr) = self.to16(x), self.prep_weights(w)
+            fn(_p(x16), _p(rm if transposed else tr), ctypes.byref(d), self.conv_dtype, layout, _p(ws), n, self.stream())
+        else:
+            fn(_p(x), _p(w), ctypes.byref(d), self.conv_dtype, layout, _p(ws), n, self.stream())
+        conv = torch.zeros(*oshape, cp, dtype=tdt, device=self.device)
+        y = torch.zeros(*oshape, cp, dtype=tdt, device=self.device)
+        mean, rstd = self.empty(groups * c), self.empty(groups * c)
+        bws, bn = self.ws(self.lib.bn_workspace_bytes(rows, c, groups))
+        self.lib.bn_act_fwd_slabs(_p(ws), splits, _p(conv), _p(beta), _p(y), _p(mean), _p(rstd), rows, c, cp, cp, groups, eps, ACT[act], leak,
+                                  self.conv_dtype, layout, _p(bws), bn, self.stream())
+        return conv[..., :c].float(), y[..., :c].float(), mean, rstd, layout
+
+    def dgrad_bn_bwd_handoff(self, xb, beta, mean, rstd, act, dy2, w2, stride, padding, groups=1, transposed=False, pair_x=None, layout=None,
+                             leak=0.2):
+        """BatchNorm backward fed by the split input gradient of the NEXT layer (filter ``w2``, output gradient ``dy2``; its
+        input is the BatchNorm's output, shaped like ``xb``): acg_(de)conv2d_dgrad_slabs - or, with ``pair_x`` (that layer's
+        input), acg_(de)conv2d_bwd_pair with flag 2 - then acg_bn_act_bwd_slabs.  -> (dx, dbeta, layout) float32, or None
+        when that input gradient is not split or the BatchNorm cannot take slabs."""
+        if transposed:
+            d = self._adj(xb.shape, tuple(w2.shape), stride)
+            which = L.CONV_FWD
+        else:
+            b, h, wd, c = xb.shape
+            d = self.desc(b, h, wd, w2.shape[2], w2.shape[0], w2.shape[1], w2.shape[3], stride, padding)
+            which = L.CONV_DGRAD
+        if self.half:
+            d.in_pitch = d.out_pitch = 0
+        c = xb.shape[-1]
+        cp = (c + 7) // 8 * 8 if self.half else c
+        rows = xb.numel() // c
+        splits = self.lib.conv2d_splits(ctypes.byref(d), which, self.conv_dtype)
+        want = self.lib.bn_slabs_layout(rows, c, cp, cp, groups, self.conv_dtype, 1)
+        if splits < 2 or want < 0:
+            return None
+        layout = want if layout is None else layout
+        ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), which, self.conv_dtype))
+        ws.fill_(0xFF)
+        tdt = torch.bfloat16 if self.half else torch.float32
+        if self.half:
+            dy16, (rm, tr) = self.to16(dy2), self.prep_weights(w2)
+            wd_ = tr if transposed else rm
+        else:
+            dy16, wd_ = dy2, w2
+        if pair_x is None:
+            fn = self.lib.deconv2d_dgrad_slabs if transposed else self.lib.conv2d_dgrad_slabs
+            fn(_p(dy16), _p(wd_), ctypes.byref(d), self.conv_dtype, layout, _p(ws), n, self.stream())
+        else:
+            fn = self.lib.deconv2d_bwd_pair if transposed else self.lib.conv2d_bwd_pair
+            px = self.to16(pair_x) if self.half else pair_x
+            dw = self.empty(*w2.shape)
+            wsw, nw = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_WGRAD, self.conv_dtype))
+            fn(_p(dy16), _p(wd_), _p(px), None, _p(dw), 0.0, ctypes.byref(d), self.conv_dtype, _p(ws), n, _p(wsw), nw,
+               2 | (4 if layout == L.SLABS_QUADS else 0), self.stream())
+        x16 = self.to16(xb) if self.half else xb
+        dx = torch.zeros(*xb.shape[:-1], cp, dtype=tdt, device=self.device)
+        dbeta = self.empty(c)
+        bws, bn = self.ws(self.lib.bn_workspace_bytes(rows, c, groups))
+        self.lib.bn_act_bwd_slabs(_p(x16), _p(ws), splits, _p(beta), _p(mean), _p(rstd), _p(dx), _p(dbeta), 0.0, rows, c, cp, cp, groups,
+                                  ACT[act], leak, self.conv_dtype, layout, _p(bws), bn, self.stream())
+        return dx[..., :c].float(), dbeta, layout
+
     # ---- synchronised BatchNorm entries (statistics supplied by the caller)
     def bn_moments(self, x, groups=1, c=None):
         """``c`` < x.shape[-1]: rows carry pad channels (pitch x.shape[-1]); x float32 or bfloat16."""

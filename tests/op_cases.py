@@ -197,6 +197,69 @@ def case_conv_bn_stats(abi, tol, tol_stat, min_fused=1):
     assert fused >= min_fused, 'only %d of %d layers took the fused path' % (fused, len(STATS_LAYERS))
 
 
+HANDOFF_LAYERS = [   # (x shape, w shape, stride, padding, transposed, groups, act): small layers the planner splits over K
+    ((8, 8, 8, 64), (5, 5, 64, 128), 2, 'SAME', False, 1, 'relu'),           # g/conv3-like
+    ((16, 8, 8, 128), (5, 5, 128, 256), 2, 'SAME', False, 2, 'lrelu'),       # d/conv4-like: two groups
+    ((8, 4, 4, 256), (5, 5, 256, 512), 2, 'SAME', False, 2, 'lrelu'),        # d/conv5-like: 32 rows
+    ((8, 4, 4, 256), (5, 5, 128, 256), 2, None, True, 1, 'relu'),            # g/tconv1-like (transposed)
+    ((4, 8, 8, 138), (5, 5, 138, 128), 2, 'SAME', False, 1, 'relu'),         # 138 gathered channels
+    ((6, 6, 6, 64), (3, 3, 64, 44), 1, 'SAME', False, 1, None),              # ragged rows, 44 channels (bf16: pitch 48)
+    ((32, 32, 32, 32), (5, 5, 32, 64), 2, 'SAME', False, 1, 'relu'),         # g/conv2 at config-2 size: 8192 rows (two-launch BatchNorm: rows layout; float32 splits it)
+]
+
+
+def case_slab_handoff(abi, tol, min_quads=5, min_rows=1):
+    """Split-K hand-off, forward and backward, in both slab layouts (acgan_hip.h ACG_SLABS_ROWS / ACG_SLABS_QUADS) against
+    the separate-reduction path on the same tensors: the conv output written back must be bit-identical (same slabs, same
+    summation order and rounding), the BatchNorm results equal to rounding level (another instantiation of the same
+    kernel); the layout acg_bn_slabs_layout asks for must be QUADS exactly where the one-launch kernels run."""
+    dev = abi.device
+    quads = rows_l = bwd_done = pair_done = 0
+    for i, (xs, ws_, stride, padding, transposed, groups, act) in enumerate(HANDOFF_LAYERS):
+        x, w = uniform(xs, 700 + i).to(dev), randn(ws_, 710 + i, 0.1).to(dev)
+        c = ws_[2] if transposed else ws_[3]
+        beta = randn((c,), 720 + i, 0.5).to(dev)
+        conv_ref = abi.deconv2d_fwd(x, w, stride) if transposed else abi.conv2d_fwd(x, w, stride, padding)
+        st = abi.to16(conv_ref) if abi.half else conv_ref
+        y_ref, mean_ref, rstd_ref = abi.bn_act_fwd(st, beta, act, groups=groups, c=c)
+        y_ref = y_ref[..., :c].float()
+        asked = None
+        for layout in (None, 0):
+            got = abi.conv_bn_handoff(x, w, beta, stride, padding, act, groups, transposed, layout=layout)
+            if got is None:          # the planner does not split this layer in this arithmetic
+                break
+            conv, y, mean, rstd, used = got
+            asked = used if layout is None else asked
+            tag = 'hand-off layer %d layout %d' % (i, used)
+            assert torch.equal(conv, conv_ref), tag + ': conv output written back differs from the separate reduction'
+            close(mean, mean_ref, tol, tag + ' mean'); close(rstd, rstd_ref, tol * 4, tag + ' rstd')
+            close(y, y_ref, 8e-3 if abi.half else tol * 4, tag + ' y')
+        if asked is None:
+            continue
+        rows_per_group = conv_ref.numel() // c // groups
+        assert (asked == 1) == (rows_per_group <= 2048 and c % 4 == 0), (i, asked, rows_per_group, c)
+        quads += asked == 1; rows_l += asked == 0
+        # backward: this BatchNorm's dy is the split input gradient of a following 5x5 / stride-2 layer
+        if transposed or c % 8 or conv_ref.shape[1] % 2:
+            continue
+        w2 = randn((5, 5, c, 2 * c), 730 + i, 0.05).to(dev)
+        dy2 = randn((conv_ref.shape[0], conv_ref.shape[1] // 2, conv_ref.shape[2] // 2, 2 * c), 740 + i).to(dev)
+        for pair in (False, True):
+            got = [abi.dgrad_bn_bwd_handoff(conv_ref, beta, mean_ref, rstd_ref, act, dy2, w2, 2, 'SAME', groups, pair_x=y_ref if pair else None,
+                                            layout=lay) for lay in (None, 0)]
+            if got[0] is None:
+                continue
+            dyb = abi.conv2d_dgrad(dy2, w2, tuple(conv_ref.shape), 2, 'SAME')
+            xs_, dys_ = (abi.to16(conv_ref), abi.to16(dyb)) if abi.half else (conv_ref, dyb)
+            dx_ref, dbeta_ref = abi.bn_act_bwd(xs_, dys_, beta, mean_ref, rstd_ref, act, groups=groups)
+            for dx, dbeta, used in got:
+                tag = 'hand-off bwd layer %d layout %d%s' % (i, used, ' (pair)' if pair else '')
+                close(dx, dx_ref[..., :c].float(), 8e-3 if abi.half else tol * 8, tag + ' dx')
+                close(dbeta, dbeta_ref, 2e-3 if abi.half else tol * 8, tag + ' dbeta')
+            bwd_done += not pair; pair_done += pair
+    assert quads >= min_quads and rows_l >= min_rows and bwd_done >= 2 and pair_done >= 2, (quads, rows_l, bwd_done, pair_done)
+
+
 def case_conv_bn_stats_large_mean(abi, tol_stat):
     """the statistics out of the conv epilogue must survive |mean| >> std (a drifted d/conv layer late
     in GAN training).  1x1 convolutions with positive weights over inputs offset by 300: per-channel mean / std of the

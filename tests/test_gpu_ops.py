@@ -61,6 +61,14 @@ def test_conv_bn_stats_bf16(hip_abi_bf16):
     C.case_conv_bn_stats(hip_abi_bf16, TOL_BF16, 2e-3, min_fused=4)
 
 
+def test_slab_handoff_layouts(hip_abi):
+    C.case_slab_handoff(hip_abi, 2e-5)
+
+
+def test_slab_handoff_layouts_bf16(hip_abi_bf16):
+    C.case_slab_handoff(hip_abi_bf16, 2e-5, min_rows=0)
+
+
 def test_bn_large_tensor(hip_abi):
     """Config-5-sized BatchNorm (8.4 M float32 elements, 2048+ partial blocks): the finalize launch in front of the apply."""
     C.case_bn_large_tensor(hip_abi, 1e-4)

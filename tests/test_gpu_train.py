@@ -397,16 +397,17 @@ def test_bf16_replay_and_weight_copies():
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_splitk_handoff_to_batchnorm(dtype):
-    """Session(slab_handoff=True), an option that is OFF by default (measured slower, graph.Runtime): small layers are
-    split over K and, instead of a reduction launch, the layer's BatchNorm sums the slabs as it loads its input
-    (forward: acg_bn_act_fwd_slabs, which also writes x for the backward pass; backward: acg_bn_act_bwd_slabs on the
-    input-gradient slabs).  Same summation order and rounding of the sums; the BatchNorm arithmetic behind them is a
-    different kernel instantiation (FMA contraction may differ), so weights after four D + G steps must agree with
-    the separate-reduction run to rounding level (1e-5 of the weight scale), and the hand-off must have been taken."""
+    """Session(slab_handoff=...): small layers are split over K and, instead of a reduction launch, the layer's BatchNorm
+    sums the slabs as it loads its input (forward: acg_bn_act_fwd_slabs, which also writes x for the backward pass;
+    backward: acg_bn_act_bwd_slabs on the input-gradient slabs).  'quads': only where the one-launch BatchNorm kernels read
+    the quad slab layout; True: every split layer, row layout where the two-launch kernels run.  Same summation order and
+    rounding of the sums; the BatchNorm arithmetic behind them is a different kernel instantiation (FMA contraction may
+    differ), so weights after four D + G steps must agree with the separate-reduction run to rounding level (1e-5 of
+    the weight scale), and the hand-off must have been taken."""
     from action_conditioned_gans_amd import ops as O
     x, y, a, s = TC.MG.inputs(2)
     finals = []
-    for handoff in (False, True):
+    for handoff in (False, 'quads', True):
         sess, tr = TC.build_trainer(gpu_session, 'dna_k6_bce_rmsprop', batch=8, dtype=dtype, slab_handoff=handoff)
         xs, ys = np.tile(x, (4, 1, 1, 1)), np.tile(y, (4, 1, 1, 1))
         as_, ss = np.tile(a, (4, 1)), np.tile(s, (4, 1))
@@ -415,16 +416,18 @@ def test_splitk_handoff_to_batchnorm(dtype):
             frames = tr.train_g(xs, ys, as_, ss)
         torch.cuda.synchronize()
         g = G.get_default_graph()
-        fwd = sum(1 for o in g.ops if isinstance(o, O.Conv2dOp) and o._slab is not None)
-        bwd = sum(1 for o in g.ops if isinstance(o, O.ConvDgradOp) and o._slab is not None)
-        assert (fwd >= 4 and bwd >= 3) if handoff else (fwd == 0 and bwd == 0), (handoff, fwd, bwd)
+        fwd = [o._slab[2] for o in g.ops if isinstance(o, O.Conv2dOp) and o._slab is not None]
+        bwd = [o._slab[2] for o in g.ops if isinstance(o, O.ConvDgradOp) and o._slab is not None]
+        assert (len(fwd) >= 4 and len(bwd) >= 3) if handoff else (not fwd and not bwd), (handoff, fwd, bwd)
+        assert handoff != 'quads' or set(fwd + bwd) == {1}, (fwd, bwd)
         finals.append(({n: sess.get_value(v) for n, v in g.variables.items()}, frames))
-    (p0, f0), (p1, f1) = finals
+    p0, f0 = finals[0]
     tol = 1e-5 if dtype == 'f32' else 2e-2        # bf16: a rounding-level difference can flip a bf16 ulp downstream
-    for n in p0:
-        d = float((p0[n].double() - p1[n].double()).abs().max())
-        assert d <= tol * max(float(p0[n].abs().max()), 1e-3), (n, d)
-    assert TC.rel(f1, f0) <= (1e-4 if dtype == 'f32' else 2e-2)
+    for p1, f1 in finals[1:]:
+        for n in p0:
+            d = float((p0[n].double() - p1[n].double()).abs().max())
+            assert d <= tol * max(float(p0[n].abs().max()), 1e-3), (n, d)
+        assert TC.rel(f1, f0) <= (1e-4 if dtype == 'f32' else 2e-2)
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])

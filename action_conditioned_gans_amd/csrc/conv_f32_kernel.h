@@ -248,7 +248,9 @@ constexpr int conv_lds_bytes() {
          2 * kMaxTaps * (int)sizeof(int);
 }
 
-template <int MODE, int BM, int BN, int WM, int WN, bool RAGGED, bool NVEC, bool EPI = false>
+// LIN (FWD, !RAGGED, NVEC): the gathered channel count is a multiple of 4 (Cs == Cp), so filter row k of W[(tap, c)][n] is
+// row k of the [Kdim][N] matrix - the dense operand needs no (tap, channel) state (conv_body: run_boff).
+template <int MODE, int BM, int BN, int WM, int WN, bool RAGGED, bool NVEC, bool EPI = false, bool LIN = false>
 __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const int by, const int bz, const int gx, char* smem) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int TA = BM / (32 * WM), TB = BN / (32 * WN);
@@ -369,6 +371,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
   // thread runs the same instruction stream (no idle waves, no divergent branch in the loop) and the transposed
   // pieces are written as 16-, 8- or 4-byte parts of the k-quads in LDS.
   constexpr int LPA = BM / 32, LPB = BN / 32;
+  static_assert(!LIN || (MODE == MODE_FWD && NVEC && !RAGGED), "LIN: float4-able forward contraction");
+  // (Filter rows as column quads - a thread owns one column and fetches the four k-rows of a quad with four dword loads off
+  // one offset register, so the quad arrives in LDS order without a register transpose - was measured on top of LIN: 31.5
+  // instead of 36.8 VALU instructions per K-step but 10 instead of 4 VMEM instructions, 404.4 vs 406.0 steps/s: dropped.)
   constexpr int RA = (MODE == MODE_WGRAD) ? LPA : QA;
   constexpr int RB = (MODE == MODE_DGRAD) ? QB : (NVEC ? LPB : QB);
   f4 ra[NST][RA], rb[NST][RB];
@@ -415,7 +421,12 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
   int run_kt = 0, run_kc = 0, run_bt = 0, run_bc = 0, run_boff = 0;
   if constexpr (MODE != MODE_WGRAD) tap_of(ks_begin * BK + 4 * (tid & 7), run_kt, run_kc);
   const int nB = n0 + 4 * jb;                       // first column of the dense-row quads (nvec)
-  if constexpr (MODE == MODE_FWD && nvec) {
+  // LIN: the filter rows are linear in k, one running offset, valid while k < Kdim.
+  int run_bk = 0;                                   // LIN: k of this thread's first dense row
+  if constexpr (LIN) {
+    run_bk = ks_begin * BK + r0b;
+    run_boff = run_bk * N + nB;
+  } else if constexpr (MODE == MODE_FWD && nvec) {
     tap_of(ks_begin * BK + 4 * kqb, run_bt, run_bc);
     run_boff = (run_bt * Cs + run_bc + subb) * N + nB;
   }
@@ -465,7 +476,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
       const bool wrap = run_kc >= Cp;
       run_kc -= wrap ? Cp : 0; run_kt += wrap ? 1 : 0;
     }
-    if constexpr (MODE == MODE_FWD && nvec) {
+    if constexpr (LIN) {
+      q.boff = run_boff; q.brow = run_bk;
+      run_boff += BK * N; run_bk += BK;
+    } else if constexpr (MODE == MODE_FWD && nvec) {
       q.bt = run_bt; q.bc = run_bc + subb; q.boff = run_boff;
       run_bt += step_t; run_bc += step_c;
       const bool wrap = run_bc >= Cp;
@@ -507,7 +521,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
       } else if constexpr (nvec) {
         // dense operand: FWD W[(tap,c)][n] rows, WGRAD dY[(b,p,q)][n] rows; raw row, transposed at store time
         bool ok;
-        if constexpr (MODE == MODE_FWD) ok = q.bt < ntaps && q.bc + U < Cs;
+        if constexpr (LIN) ok = q.brow < Kdim;          // the LPB rows of a thread lie in one k-quad; Kdim % 4 == 0
+        else if constexpr (MODE == MODE_FWD) ok = q.bt < ntaps && q.bc + U < Cs;
         else ok = q.brow + U < Kdim;
         rb[ST][U] = guarded_quad(rs_d, q.boff + U * (MODE == MODE_WGRAD ? p.Ky : N), live && ok && nB < N);
       } else {  // ragged N (25, 5, 3, 1 ...): 4 k-rows of one column per quad, lanes along n
@@ -803,7 +818,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
     }
 }
 
-template <int MODE, int BM, int BN, int WM, int WN, bool RAGGED, bool NVEC, bool EPI = false>
+template <int MODE, int BM, int BN, int WM, int WN, bool RAGGED, bool NVEC, bool EPI = false, bool LIN = false>
 __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
   __shared__ __align__(16) char smem[conv_lds_bytes<MODE, BM, BN>()];
   if constexpr (MODE == MODE_WGRAD) {      // grid (tiles, 1, splits)
@@ -811,7 +826,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
     wgrad_xcd_map((int)(blockIdx.x + gridDim.x * blockIdx.z), (int)gridDim.x, (int)gridDim.z, tile, split);
     conv_body<MODE, BM, BN, WM, WN, RAGGED, NVEC>(p, tile, 0, split, (int)gridDim.x, smem);
   } else {
-    conv_body<MODE, BM, BN, WM, WN, RAGGED, NVEC, EPI>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
+    conv_body<MODE, BM, BN, WM, WN, RAGGED, NVEC, EPI, LIN>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
   }
 }
 
@@ -825,14 +840,14 @@ __global__ __launch_bounds__(256) void conv_mfma_f32(const ConvArgs p) {
 // Blocks [0, nA) run contraction A with the grid (gxA, gyA, *), the rest run the weight gradient with (gxB, 1, *).
 struct PairGeom { int nA, gxA, gyA, gxB; };
 
-template <int MODE_A, int BMA, int BNA, int WMA, int WNA, int BMB, int BNB, int WMB, int WNB, bool RAGGED>
+template <int MODE_A, int BMA, int BNA, int WMA, int WNA, int BMB, int BNB, int WMB, int WNB, bool RAGGED, bool LIN_A = false>
 __global__ __launch_bounds__(256) void conv_pair_f32(const ConvArgs a, const ConvArgs b, const PairGeom g) {
   constexpr int LA = conv_lds_bytes<MODE_A, BMA, BNA>(), LB = conv_lds_bytes<MODE_WGRAD, BMB, BNB>();
   __shared__ __align__(16) char smem[LA > LB ? LA : LB];      // one block runs one of the two programs
   const int L = (int)blockIdx.x;
   if (L < g.nA) {
     const int t = L / g.gxA;
-    conv_body<MODE_A, BMA, BNA, WMA, WNA, RAGGED, true>(a, L - t * g.gxA, t % g.gyA, t / g.gyA, g.gxA, smem);
+    conv_body<MODE_A, BMA, BNA, WMA, WNA, RAGGED, true, false, LIN_A>(a, L - t * g.gxA, t % g.gyA, t / g.gyA, g.gxA, smem);
   } else {
     int tile, split;
     wgrad_xcd_map(L - g.nA, g.gxB, b.splits, tile, split);
@@ -870,6 +885,13 @@ static inline void launch_cfg(const Plan& pl, const ConvArgs& a, hipStream_t st)
   const dim3 grid((unsigned)(acg::ceil_div(pl.M, pl.bm) * acg::ceil_div(pl.N, pl.bn)), (unsigned)pl.classes, (unsigned)pl.splits);
   // two tile shapes: 128x32 for narrow N, 64x64 otherwise.  128x128 / 128x64 variants existed through v4; with the
   // one-barrier pipeline they lost every layer of the tuning sweep (profiles/r1) and were dropped.
+  if constexpr (MODE == MODE_FWD && !RAGGED && NVEC) {
+    if ((a.C & 3) == 0) {     // gathered channels a multiple of 4: the LIN variant (filter rows linear in k)
+      if (pl.cfg == 2) ACG_LAUNCH((conv_mfma_f32<MODE, 128, 32, 4, 1, RAGGED, NVEC, false, true>), grid, dim3(256), 0, st, a);
+      else ACG_LAUNCH((conv_mfma_f32<MODE, 64, 64, 2, 2, RAGGED, NVEC, false, true>), grid, dim3(256), 0, st, a);
+      return;
+    }
+  }
   if (pl.cfg == 2) ACG_LAUNCH((conv_mfma_f32<MODE, 128, 32, 4, 1, RAGGED, NVEC>), grid, dim3(256), 0, st, a);
   else ACG_LAUNCH((conv_mfma_f32<MODE, 64, 64, 2, 2, RAGGED, NVEC>), grid, dim3(256), 0, st, a);
 }

@@ -9,15 +9,15 @@ bool pair_supported(int modeA, const Plan& pa, const Plan& pb) {
 }
 
 namespace {
-template <int MODE_A, int BMA, int BNA, int WMA, int WNA, bool RAGGED>
+template <int MODE_A, int BMA, int BNA, int WMA, int WNA, bool RAGGED, bool LIN_A>
 void launch_b(const Plan& pb, const ConvArgs& a, const ConvArgs& b, const PairGeom& g, unsigned blocks, hipStream_t st) {
-  if (pb.cfg == 2) ACG_LAUNCH((conv_pair_f32<MODE_A, BMA, BNA, WMA, WNA, 128, 32, 4, 1, RAGGED>), dim3(blocks), dim3(256), 0, st, a, b, g);
-  else ACG_LAUNCH((conv_pair_f32<MODE_A, BMA, BNA, WMA, WNA, 64, 64, 2, 2, RAGGED>), dim3(blocks), dim3(256), 0, st, a, b, g);
+  if (pb.cfg == 2) ACG_LAUNCH((conv_pair_f32<MODE_A, BMA, BNA, WMA, WNA, 128, 32, 4, 1, RAGGED, LIN_A>), dim3(blocks), dim3(256), 0, st, a, b, g);
+  else ACG_LAUNCH((conv_pair_f32<MODE_A, BMA, BNA, WMA, WNA, 64, 64, 2, 2, RAGGED, LIN_A>), dim3(blocks), dim3(256), 0, st, a, b, g);
 }
-template <int MODE_A, bool RAGGED>
+template <int MODE_A, bool RAGGED, bool LIN_A = false>
 void launch_a(const Plan& pa, const Plan& pb, const ConvArgs& a, const ConvArgs& b, const PairGeom& g, unsigned blocks, hipStream_t st) {
-  if (pa.cfg == 2) launch_b<MODE_A, 128, 32, 4, 1, RAGGED>(pb, a, b, g, blocks, st);
-  else launch_b<MODE_A, 64, 64, 2, 2, RAGGED>(pb, a, b, g, blocks, st);
+  if (pa.cfg == 2) launch_b<MODE_A, 128, 32, 4, 1, RAGGED, LIN_A>(pb, a, b, g, blocks, st);
+  else launch_b<MODE_A, 64, 64, 2, 2, RAGGED, LIN_A>(pb, a, b, g, blocks, st);
 }
 }  // namespace
 
@@ -29,7 +29,9 @@ int launch_pair(int modeA, const Plan& pa, const ConvArgs& a, const Plan& pb, co
   g.gxB = (int)(acg::ceil_div(pb.M, pb.bm) * acg::ceil_div(pb.N, pb.bn));
   const unsigned blocks = (unsigned)(g.nA + g.gxB * pb.splits);
   if (modeA == MODE_FWD) {
+    // (pair_supported: the dense operands are float4-able; gathered channels a multiple of 4 -> the LIN variant of A)
     if (pa.ragged) launch_a<MODE_FWD, true>(pa, pb, a, b, g, blocks, st);
+    else if ((a.C & 3) == 0) launch_a<MODE_FWD, false, true>(pa, pb, a, b, g, blocks, st);
     else launch_a<MODE_FWD, false>(pa, pb, a, b, g, blocks, st);
   } else {
     if (pa.ragged) launch_a<MODE_DGRAD, true>(pa, pb, a, b, g, blocks, st);

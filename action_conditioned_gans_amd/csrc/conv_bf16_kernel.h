@@ -120,6 +120,7 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
       const int b = div_fast(t2, p.mg_oh, p.sh_oh), pp = t2 - b * p.OH;
       const int y0 = pp * p.sh - p.pt, x0 = q * p.sw - p.pl;
       ri.base = ((b * p.H + y0) * p.W + x0) * Cin8;
+      if (p.shuf_c) ri.out_off = ((b * (2 * p.OH) + 2 * pp) * p.shuf_w + 2 * q) * p.shuf_pitch;     // merged input gradient (ConvArgs::shuf_c)
       const unsigned long long m = tap_mask(max(0, -y0), min(p.KH, p.H - y0), max(0, -x0), min(p.KW, p.W - x0), p.KW);
       ri.mask_lo = (unsigned)m; ri.mask_hi = (unsigned)(m >> 32);
     }
@@ -410,14 +411,18 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
   // column term of an element's offset: n, or in the quad slab layout (ConvArgs::slab_rows; float32 slabs only) the quad's
   // run of rows + n & 3
   const bool quads = MODE != MODE_WGRAD && p.slab_rows > 0;
-  auto col_off = [&](int n) -> long long { return quads ? (long long)(n >> 2) * p.slab_rows * 4 + (n & 3) : (long long)n; };
+  const bool shuf = MODE == MODE_FWD && p.shuf_c > 0;      // merged input gradient: rows by their out_off, columns by (2 x 2 pixel, channel)
+  auto col_off = [&](int n) -> long long {
+    if (shuf) { const int cls = n / p.shuf_c; return (long long)((cls >> 1) * p.shuf_w + (cls & 1)) * p.shuf_pitch + (n - cls * p.shuf_c); }
+    return quads ? (long long)(n >> 2) * p.slab_rows * 4 + (n & 3) : (long long)n;
+  };
   if (full) {
     auto store_rows = [&](auto* base, long long pitch, int a, int b) {
       using T = std::remove_pointer_t<decltype(base)>;
 #pragma unroll
       for (int r = 0; r < 16; ++r) base[(long long)((r & 3) + 8 * (r >> 2)) * pitch] = (T)acc[a][b][r];
     };
-    if constexpr (MODE == MODE_DGRAD) {
+    if (MODE == MODE_DGRAD || shuf) {
 #pragma unroll
       for (int b = 0; b < TB; ++b) {
         if (n0 + wn0 + 32 * b + lrow < N) {
@@ -460,7 +465,7 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
       const int m = m0 + row;
       if (m >= M) continue;
       long long base;
-      if constexpr (MODE == MODE_DGRAD) {
+      if (MODE == MODE_DGRAD || shuf) {
         base = rows[row].out_off;
       } else if constexpr (MODE == MODE_WGRAD) {
         const int t = div_fast(m, p.mg_cp, p.sh_cp), c = m - t * Cp;

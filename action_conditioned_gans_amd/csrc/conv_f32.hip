@@ -154,6 +154,32 @@ __global__ __launch_bounds__(256) void splitk_reduce_many(const ReduceList l, in
                l.first_block[e + 1] - l.first_block[e]);
 }
 
+// ---- merged input gradient of a stride-2 layer with few input channels (run_merged below) ---------------------------
+// The four stride-parity classes of such an input gradient (d/conv1: 6 channels; a plain generator's last transposed layer:
+// 3) each fill 6 of the 32 MFMA columns of a tile.  They share their gathered rows - class (ph, pw) of output pixel pair
+// (h2, w2) reads dy rows h2 + dh for the dh with i = ph + pad - 2 dh inside the filter - so ONE stride-1 contraction over
+// the union window (3 x 3 for a 5 x 5 filter) with N = 4 * Cin columns computes all four: column n = (2 ph + pw) * Cin + c
+// uses the filter W'[a][b][o][n] = W[ph + pt - 2 (a + lo_h)][pw + pl - 2 (b + lo_w)][c][o], zero where that tap does not
+// exist.  9 instead of 25 tap-steps per pixel quad, one epilogue instead of four.  These kernels build W' (a few KB) in front
+// of the contraction; float32: [tap][o][n]; bf16: from the 'rm' copy [tap][c][o8] into the layout FWD reads, [tap][n][o8].
+struct MergeGeom { int kh, kw, cin, cout, nwh, nww, lo_h, lo_w, pt, pl; };
+__global__ __launch_bounds__(256) void merge_dgrad_weights_f32(const float* __restrict__ w, float* __restrict__ wm, const MergeGeom g, int total) {
+  const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (idx >= total) return;
+  const int np = 4 * g.cin, n = idx % np, o = (idx / np) % g.cout, tap = idx / (np * g.cout);
+  const int a = tap / g.nww, b = tap - a * g.nww, cls = n / g.cin, c = n - cls * g.cin;
+  const int i = (cls >> 1) + g.pt - 2 * (a + g.lo_h), j = (cls & 1) + g.pl - 2 * (b + g.lo_w);
+  wm[idx] = (i >= 0 && i < g.kh && j >= 0 && j < g.kw) ? w[((long long)(i * g.kw + j) * g.cin + c) * g.cout + o] : 0.f;
+}
+__global__ __launch_bounds__(256) void merge_dgrad_weights_bf16(const __bf16* __restrict__ rm, __bf16* __restrict__ wm, const MergeGeom g, int total) {
+  const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (idx >= total) return;
+  const int np = 4 * g.cin, o8n = (g.cout + 7) & ~7, o = idx % o8n, n = (idx / o8n) % np, tap = idx / (o8n * np);
+  const int a = tap / g.nww, b = tap - a * g.nww, cls = n / g.cin, c = n - cls * g.cin;
+  const int i = (cls >> 1) + g.pt - 2 * (a + g.lo_h), j = (cls & 1) + g.pl - 2 * (b + g.lo_w);
+  wm[idx] = (o < g.cout && i >= 0 && i < g.kh && j >= 0 && j < g.kw) ? rm[((long long)(i * g.kw + j) * g.cin + c) * o8n + o] : (__bf16)0.f;
+}
+
 int reduce_blocks(long long numel) { return (int)std::max<long long>(1, std::min<long long>(acg::ceil_div(numel, 256 * 4), 2048)); }
 
 // ---- host-side planning ------------------------------------------------------------------------------
@@ -399,9 +425,80 @@ int reduce(const Job& j, hipStream_t st) {
   return ACG_OK;
 }
 
+// Merged input gradient (kernels above): eligibility and the stride-1 forward problem it runs as.
+struct Merged {
+  bool ok;
+  acg_conv_desc syn;      // dy [B, OH, OW, Cout] * W' [nwh, nww, Cout, 4 Cin], stride 1 -> [B, OH, OW, 4 Cin]
+  MergeGeom g;
+  size_t w_bytes;         // W' in the workspace, behind the slabs
+  long long out_numel;    // of the real result (dx at its pitch)
+  int pitch;
+};
+Merged merged_dgrad(const acg_conv_desc& d, bool bf16) {
+  Merged m{};
+  static const int on = env_int("ACG_PLAN_MERGED", 1);
+  if (!on || g_force_cfg >= 0 || g_force_splits >= 0) return m;
+  if (d.stride_h != 2 || d.stride_w != 2 || (d.in_h & 1) || (d.in_w & 1) || d.out_h * 2 != d.in_h || d.out_w * 2 != d.in_w || 4 * d.in_c > 32) return m;
+  auto window = [](int k, int pad, int& lo, int& hi) {
+    lo = 1 << 20; hi = -(1 << 20);
+    for (int ph = 0; ph < 2; ++ph)
+      for (int i = 0; i < k; ++i)
+        if (((ph + pad - i) & 1) == 0) { const int dh = (ph + pad - i) / 2; lo = std::min(lo, dh); hi = std::max(hi, dh); }
+  };
+  int lo_h, hi_h, lo_w, hi_w;
+  window(d.kh, d.pad_top, lo_h, hi_h); window(d.kw, d.pad_left, lo_w, hi_w);
+  const int nwh = hi_h - lo_h + 1, nww = hi_w - lo_w + 1;
+  if (lo_h > 0 || lo_w > 0 || -lo_h >= nwh || -lo_w >= nww || nwh * nww > kMaxTaps || nwh * nww >= d.kh * d.kw) return m;
+  if (make_plan(d, ACG_CONV_DGRAD, bf16).direct) return m;
+  acg_conv_desc& y = m.syn;
+  y.batch = d.batch; y.in_h = d.out_h; y.in_w = d.out_w; y.in_c = d.out_c; y.kh = nwh; y.kw = nww; y.out_c = 4 * d.in_c;
+  y.stride_h = y.stride_w = 1; y.pad_top = -lo_h; y.pad_left = -lo_w; y.out_h = d.out_h; y.out_w = d.out_w;
+  y.in_pitch = bf16 ? 0 : d.out_pitch; y.out_pitch = 0;
+  if (validate(&y, "merged input gradient") != ACG_OK || make_plan(y, ACG_CONV_FWD, bf16).direct) return m;     // (a few-MFLOP layer: the class-wise / direct kernels)
+  m.g = MergeGeom{d.kh, d.kw, d.in_c, d.out_c, nwh, nww, lo_h, lo_w, d.pad_top, d.pad_left};
+  const long long welems = (long long)nwh * nww * y.out_c * (bf16 ? ((d.out_c + 7) & ~7) : d.out_c);
+  m.w_bytes = (size_t)welems * (bf16 ? 2 : 4);
+  m.pitch = bf16 ? ((d.in_c + 7) & ~7) : (d.in_pitch > 0 ? d.in_pitch : d.in_c);
+  m.out_numel = (long long)d.batch * d.in_h * d.in_w * m.pitch;
+  m.ok = true;
+  return m;
+}
+size_t merged_slab_bytes(const Merged& m, int splits) { return splits > 1 ? (((size_t)splits * (size_t)m.out_numel * sizeof(float) + 255) & ~(size_t)255) : 0; }
+
+int run_merged(const Merged& m, const float* dy, const float* w, float* out, const acg_conv_desc* d, int dtype, void* ws, size_t ws_bytes,
+               acg_stream_t stream, const char* who, bool slabs_only, int slab_layout) {
+  const bool h = acg::dt_valid(dtype) && acg::dt_first(dtype) == ACG_BF16;
+  if (int rc = validate(d, who)) return rc;
+  ACG_REQUIRE(dy && w && (out || slabs_only), ACG_ERR_INVALID_ARG, "%s: null tensor pointer", who);
+  ACG_REQUIRE(slab_layout == ACG_SLABS_ROWS, ACG_ERR_UNSUPPORTED, "%s: this input gradient leaves its slabs in the row layout only", who);
+  if (h) ACG_REQUIRE((d->in_pitch == 0 || d->in_pitch == ((d->in_c + 7) & ~7)) && (d->out_pitch == 0 || d->out_pitch == ((d->out_c + 7) & ~7)), ACG_ERR_INVALID_ARG,
+                     "%s: bf16 tensors are stored at the channel pitch round8(C)", who);
+  const int splits = make_plan(m.syn, ACG_CONV_FWD, h).splits;
+  ACG_REQUIRE(!slabs_only || splits > 1, ACG_ERR_INVALID_ARG, "%s: this shape is not split (acg_conv2d_splits == 1): call the plain entry", who);
+  const size_t slab_bytes = merged_slab_bytes(m, splits), need = slab_bytes + m.w_bytes;
+  ACG_REQUIRE(ws != nullptr && ws_bytes >= need, ACG_ERR_WORKSPACE, "%s: workspace %zu bytes < required %zu", who, ws_bytes, need);
+  float* const wm = reinterpret_cast<float*>(static_cast<char*>(ws) + slab_bytes);
+  hipStream_t st = acg::to_stream(stream);
+  const int total = (int)(m.w_bytes / (h ? 2 : 4));
+  if (h) ACG_LAUNCH(merge_dgrad_weights_bf16, dim3((unsigned)acg::ceil_div(total, 256)), dim3(256), 0, st, (const __bf16*)w, (__bf16*)wm, m.g, total);
+  else ACG_LAUNCH(merge_dgrad_weights_f32, dim3((unsigned)acg::ceil_div(total, 256)), dim3(256), 0, st, w, wm, m.g, total);
+  if (int rc = acg::check_launch("merge_dgrad_weights")) return rc;
+  Job j;
+  // the forward problem as prepare() plans it; its result tensor is then redirected to dx (pixel-shuffle epilogue, ConvArgs::shuf_c)
+  if (int rc = prepare(j, ACG_CONV_FWD, dy, wm, out, 0.f, &m.syn, dtype, ws, (size_t)1 << 40, who, slabs_only)) return rc;
+  j.pl.out_numel = m.out_numel; j.a.out_numel = m.out_numel;
+  j.a.shuf_c = d->in_c; j.a.shuf_w = d->in_w; j.a.shuf_pitch = m.pitch;
+  if (int rc = launch(j, st)) return rc;
+  return reduce(j, st);
+}
+
 int run(int which, const float* gsrc, const float* dense, float* out, float accumulate, const acg_conv_desc* d, int dtype,
         void* ws, size_t ws_bytes, acg_stream_t stream, const char* who, bool slabs_only = false, float* stats = nullptr,
         int stats_groups = 0, int slab_layout = ACG_SLABS_ROWS) {
+  if (which == ACG_CONV_DGRAD && stats == nullptr && d != nullptr && validate(d, who) == ACG_OK) {
+    const Merged m = merged_dgrad(*d, acg::dt_valid(dtype) && acg::dt_first(dtype) == ACG_BF16);
+    if (m.ok) return run_merged(m, gsrc, dense, out, d, dtype, ws, ws_bytes, stream, who, slabs_only, slab_layout);
+  }
   Job j;
   if (int rc = prepare(j, which, gsrc, dense, out, accumulate, d, dtype, ws, ws_bytes, who, slabs_only, stats, stats_groups, slab_layout)) return rc;
   hipStream_t st = acg::to_stream(stream);
@@ -414,6 +511,12 @@ int run(int which, const float* gsrc, const float* dense, float* out, float accu
 int run_pair(int whichA, const float* gsrcA, const float* denseA, float* outA, const float* gsrcB, const float* denseB, float* outB,
              float accumulateB, const acg_conv_desc* d, int dtype, void* wsA, size_t wsbA, void* wsB, size_t wsbB, int slab_flags,
              acg_stream_t stream, const char* who) {
+  if (whichA == ACG_CONV_DGRAD && d != nullptr && validate(d, who) == ACG_OK && merged_dgrad(*d, acg::dt_valid(dtype) && acg::dt_first(dtype) == ACG_BF16).ok) {
+    // the merged input gradient (run_merged) is a launch of its own: same results as the separate entries, which take it too
+    if (int rc = run(ACG_CONV_DGRAD, gsrcA, denseA, outA, 0.f, d, dtype, wsA, wsbA, stream, who, (slab_flags & 2) != 0, nullptr, 0,
+                     (slab_flags & 4) ? ACG_SLABS_QUADS : ACG_SLABS_ROWS)) return rc;
+    return run(ACG_CONV_WGRAD, gsrcB, denseB, outB, accumulateB, d, dtype, wsB, wsbB, stream, who, (slab_flags & 1) != 0);
+  }
   Job ja, jb;
   const bool slabs_only_B = (slab_flags & 1) != 0, slabs_only_A = (slab_flags & 2) != 0;
   ACG_REQUIRE(!(slab_flags & 4) || slabs_only_A, ACG_ERR_INVALID_ARG, "%s: flag 4 (quad slab layout) without flag 2", who);
@@ -472,13 +575,31 @@ int32_t acg_debug_conv_plan(int32_t cfg, int32_t splits) {
 
 size_t acg_conv2d_workspace_bytes(const acg_conv_desc* d, int32_t which, int32_t dtype) {
   if (!d || validate(d, "conv2d_workspace_bytes") != ACG_OK || which < 0 || which > 2) return 0;
-  const Plan pl = make_plan(*d, which, acg::dt_valid(dtype) && acg::dt_first(dtype) == ACG_BF16);
+  const bool h = acg::dt_valid(dtype) && acg::dt_first(dtype) == ACG_BF16;
+  if (which == ACG_CONV_DGRAD) {
+    const Merged m = merged_dgrad(*d, h);
+    if (m.ok) return merged_slab_bytes(m, make_plan(m.syn, ACG_CONV_FWD, h).splits) + m.w_bytes;
+  }
+  const Plan pl = make_plan(*d, which, h);
   return pl.splits > 1 ? (size_t)pl.splits * (size_t)pl.out_numel * sizeof(float) : 0;
 }
 
 int32_t acg_conv2d_splits(const acg_conv_desc* d, int32_t which, int32_t dtype) {
   if (!d || validate(d, "conv2d_splits") != ACG_OK || which < 0 || which > 2) return 0;
-  return make_plan(*d, which, acg::dt_valid(dtype) && acg::dt_first(dtype) == ACG_BF16).splits;
+  const bool h = acg::dt_valid(dtype) && acg::dt_first(dtype) == ACG_BF16;
+  if (which == ACG_CONV_DGRAD) {
+    const Merged m = merged_dgrad(*d, h);
+    if (m.ok) return make_plan(m.syn, ACG_CONV_FWD, h).splits;
+  }
+  return make_plan(*d, which, h).splits;
+}
+
+int32_t acg_conv2d_slab_layouts(const acg_conv_desc* d, int32_t which, int32_t dtype) {
+  if (!d || validate(d, "conv2d_slab_layouts") != ACG_OK || which < 0 || which > 1) return 0;
+  const bool h = acg::dt_valid(dtype) && acg::dt_first(dtype) == ACG_BF16;
+  if (acg_conv2d_splits(d, which, dtype) < 2) return 0;
+  if (which == ACG_CONV_DGRAD && merged_dgrad(*d, h).ok) return 1 << ACG_SLABS_ROWS;      // the merged input gradient scatters 2 x 2 pixels per row
+  return (1 << ACG_SLABS_ROWS) | (1 << ACG_SLABS_QUADS);
 }
 
 int32_t acg_conv2d_stats_blocks(const acg_conv_desc* d, int32_t which, int32_t dtype, int32_t groups) {

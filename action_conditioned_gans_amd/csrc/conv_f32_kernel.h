@@ -64,6 +64,10 @@ struct ConvArgs {
   // ACG_SLABS_QUADS layout [channels / 4][slab_rows][4] (slab_rows = all rows of the tensor), element (m, n) at
   // ((n >> 2) * slab_rows + m) * 4 + (n & 3)
   int slab_rows;
+  // FWD launched as the merged input gradient of a stride-2 layer with few input channels (conv_f32.hip run_merged): the N =
+  // 4 * shuf_c output columns of pixel (b, p, q) are the shuf_c channels of the 2 x 2 output pixels (2p + ph, 2q + pw) of a
+  // tensor that is shuf_w pixels wide at the channel pitch shuf_pitch; column n = (2 ph + pw) * shuf_c + c.  0 = off.
+  int shuf_c, shuf_w, shuf_pitch;
   int out_f32;         // bf16 kernels, FWD / DGRAD: the result is stored as float32 (at the bf16 tensor's pitch, round8): a head layer
   // EPI kernel variants only (acg_deconv2d_fwd_bias_act): out = act(acc + bias[n]), stored as float32 at the pitch Cx
   const float* bias;
@@ -337,6 +341,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
       const int b = div_fast(t2, p.mg_oh, p.sh_oh), pp = t2 - b * p.OH;
       const int y0 = pp * p.sh - p.pt, x0 = q * p.sw - p.pl;
       ri.base = ((b * p.H + y0) * p.W + x0) * p.Cx;
+      if (p.shuf_c) ri.out_off = ((b * (2 * p.OH) + 2 * pp) * p.shuf_w + 2 * q) * p.shuf_pitch;
       const unsigned long long m = tap_mask(max(0, -y0), min(p.KH, p.H - y0), max(0, -x0), min(p.KW, p.W - x0), p.KW);
       ri.mask_lo = (unsigned)m; ri.mask_hi = (unsigned)(m >> 32);
     }
@@ -760,14 +765,18 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
   const bool full = m0 + BM <= M && (MODE != MODE_WGRAD || (Cp == Cs && !(p.splits == 1 && p.accumulate != 0.f)));
   // column term of an element's offset: n, or in the quad slab layout (ConvArgs::slab_rows) the quad's run of rows + n & 3
   const bool quads = MODE != MODE_WGRAD && p.slab_rows > 0;
-  auto col_off = [&](int n) -> long long { return quads ? (long long)(n >> 2) * p.slab_rows * 4 + (n & 3) : (long long)n; };
+  const bool shuf = MODE == MODE_FWD && p.shuf_c > 0;      // merged input gradient: rows by their out_off, columns by (2 x 2 pixel, channel)
+  auto col_off = [&](int n) -> long long {
+    if (shuf) { const int cls = n / p.shuf_c; return (long long)((cls >> 1) * p.shuf_w + (cls & 1)) * p.shuf_pitch + (n - cls * p.shuf_c); }
+    return quads ? (long long)(n >> 2) * p.slab_rows * 4 + (n & 3) : (long long)n;
+  };
   const long long row_pitch = MODE == MODE_WGRAD ? N : (quads ? 4 : p.Ky);
   if (full) {
 #pragma unroll
     for (int b = 0; b < TB; ++b) {
       if (n0 + wn0 + 32 * b + lrow < N) {
         const long long co = col_off(n0 + wn0 + 32 * b + lrow);
-        if constexpr (MODE == MODE_DGRAD) {
+        if (MODE == MODE_DGRAD || shuf) {
 #pragma unroll
           for (int a = 0; a < TA; ++a)
 #pragma unroll
@@ -796,7 +805,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
       const int m = m0 + row;
       if (m >= M) continue;
       long long base;
-      if constexpr (MODE == MODE_DGRAD) {
+      if (MODE == MODE_DGRAD || shuf) {
         base = rows[row].out_off;
       } else if constexpr (MODE == MODE_WGRAD) {
         const int t = div_fast(m, p.mg_cp, p.sh_cp), c = m - t * Cp;      // (Cp == Cs: c < Cs always)

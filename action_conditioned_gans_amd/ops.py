@@ -305,7 +305,7 @@ class Conv2dOp(_ConvBase):
             lib, d = rt.lib, self.desc
             splits = lib.conv2d_splits(ctypes.byref(d), self.which, rt.conv_dtype)
             layout = bn.slab_layout(rt, splits, False)
-            if layout >= 0:
+            if layout >= 0 and lib.conv2d_slab_layouts(ctypes.byref(d), self.which, rt.conv_dtype) >> layout & 1:
                 ws, n = rt.workspace(lib.conv2d_workspace_bytes(ctypes.byref(d), self.which, rt.conv_dtype))
                 self._keep, self._slab = (ws, d), (ws, splits, layout)
                 fn = lib.deconv2d_fwd_slabs if self.transposed else lib.conv2d_fwd_slabs
@@ -352,6 +352,8 @@ class ConvDgradOp(_ConvBase):
         layout = -1
         if bn is not None and id(bn) in rt.program_ops and rt.slab_handoff:
             layout = bn.fwd.slab_layout(rt, lib.conv2d_splits(ctypes.byref(d), self.which, dt), True, dy=self.outputs[0])
+            if layout >= 0 and not lib.conv2d_slab_layouts(ctypes.byref(d), self.which, dt) >> layout & 1:
+                layout = -1
         hand_off = layout >= 0
         if not self.pair_active:
             if hand_off:     # the consuming BatchNorm backward sums the slabs (acg_bn_act_bwd_slabs)

@@ -109,7 +109,11 @@ int32_t acg_debug_conv_plan(int32_t cfg, int32_t splits);
  * whole discriminator gradient by 4-11 % (round 2's test_epilogue_statistics tolerance). */
 int32_t acg_conv2d_fwd(const void* x, const void* w, void* y, const acg_conv_desc* d, int32_t dtype,
                        void* workspace, size_t workspace_bytes, acg_stream_t stream);
-/* its gradient w.r.t. x (what tf.gradients emits for train.py:100-102). */
+/* its gradient w.r.t. x (what tf.gradients emits for train.py:100-102).  A stride-2 layer with even input extents and at
+ * most 8 input channels (d/conv1's 6-channel frame pair; the transposed forward of a 3-channel output) runs as ONE stride-1
+ * contraction over the union window of its four stride-parity classes, N = 4 * in_c columns, with a small derived filter
+ * built in the workspace in front of it (acg_conv2d_workspace_bytes accounts for it, so the workspace is needed even when
+ * the contraction is not split). */
 int32_t acg_conv2d_dgrad(const void* dy, const void* w, void* dx, const acg_conv_desc* d, int32_t dtype,
                          void* workspace, size_t workspace_bytes, acg_stream_t stream);
 /* its gradient w.r.t. w:  dw = accumulate * dw + grad  (dw is always float32). */
@@ -193,6 +197,10 @@ int32_t acg_deconv2d_fwd_bias_act(const void* x, const void* w, const float* bia
  *                    every row) read as consecutive 16-byte rows - ask acg_bn_slabs_layout which one the consumer takes. */
 #define ACG_SLABS_ROWS 0
 #define ACG_SLABS_QUADS 1
+/* Bit (1 << layout) set for every layout this contraction (ACG_CONV_FWD / ACG_CONV_DGRAD; the transposed entries on their
+ * adjoint descriptor) can leave its slabs in; 0 when it is not split.  (The merged input gradient of a stride-2 layer with
+ * at most 8 input channels - see acg_conv2d_dgrad - leaves rows only.) */
+int32_t acg_conv2d_slab_layouts(const acg_conv_desc* d, int32_t which, int32_t dtype);
 int32_t acg_conv2d_fwd_slabs(const void* x, const void* w, const acg_conv_desc* d, int32_t dtype, int32_t layout, void* workspace,
                              size_t workspace_bytes, acg_stream_t stream);
 int32_t acg_conv2d_dgrad_slabs(const void* dy, const void* w, const acg_conv_desc* d, int32_t dtype, int32_t layout, void* workspace,

@@ -235,6 +235,7 @@ int32_t acg_deconv2d_fwd_slabs(const void* x, const void* w, const acg_conv_desc
 int32_t acg_deconv2d_dgrad_slabs(const void* x, const void* w, const acg_conv_desc* d, int32_t dtype, int32_t layout, void* ws, size_t wsb, acg_stream_t s) {
   (void)x; (void)w; (void)d; (void)dtype; (void)layout; (void)ws; (void)wsb; (void)s; return fail(ACG_ERR_UNSUPPORTED, "cpu oracle: contraction is not split"); }
 int32_t acg_bn_bwd_slabs_ok(int64_t rows, int32_t groups) { (void)rows; (void)groups; return 0; }
+int32_t acg_conv2d_slab_layouts(const acg_conv_desc* d, int32_t which, int32_t dtype) { (void)d; (void)which; (void)dtype; return 0; }
 int32_t acg_bn_slabs_layout(int64_t rows, int32_t C, int32_t xp, int32_t yp, int32_t groups, int32_t dtype, int32_t backward) {
   (void)rows; (void)C; (void)xp; (void)yp; (void)groups; (void)dtype; (void)backward; return -1; }
 int32_t acg_bn_act_fwd_slabs(const float* slabs, int32_t splits, void* x, const float* beta, void* y, float* save_mean, float* save_rstd,

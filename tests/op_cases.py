@@ -92,6 +92,54 @@ def case_conv(abi, shape, tol, seed=0):
     close(got, 0.5 * dw0.double().cpu() + dw_ref, tol, tag + ' wgrad accumulate')
 
 
+MERGED_LAYERS = [   # (x shape, w shape, stride, padding, transposed, merged?)
+    ((4, 16, 16, 6), (5, 5, 6, 64), 2, 'SAME', False, True),       # d/conv1-like: 3 x 3 window, N = 24
+    ((2, 16, 12, 3), (3, 3, 3, 16), 2, 'SAME', False, True),       # 3 x 3 filter, pad 0 / 1: a 2 x 2 window (8 output channels would take the direct kernels)
+    ((2, 10, 6, 8), (5, 5, 8, 32), 2, 'SAME', False, True),        # 8 channels: all 32 columns
+    ((32, 32, 40, 1), (5, 5, 1, 16), 2, 'SAME', False, True),      # one channel: N = 4
+    ((3, 12, 20, 1), (5, 5, 1, 16), 2, 'SAME', False, None),       # the same with a few MFLOP: float32 stays with the class-wise kernel (bf16 has no direct kernels: merged)
+    ((2, 8, 8, 16), (5, 5, 3, 16), 2, None, True, True),           # transposed layer with a 3-channel output (a plain generator's last)
+    ((2, 12, 12, 4), (5, 5, 4, 8), 2, 'VALID', False, False),      # output extent is not half the input: the class-wise kernel
+    ((2, 9, 9, 4), (5, 5, 4, 8), 2, 'SAME', False, False),         # odd extents
+    ((2, 16, 16, 12), (5, 5, 12, 8), 2, 'SAME', False, False),     # 48 columns would not fit the narrow tile
+    ((2, 16, 16, 6), (5, 5, 6, 8), 1, 'SAME', False, False),       # stride 1
+]
+
+
+def case_merged_dgrad(abi, tol):
+    """The merged input gradient (acgan_hip.h at acg_conv2d_dgrad: the four stride-parity classes of a stride-2 layer with at
+    most 8 input channels as ONE stride-1 contraction with a derived filter) against the float64 gradient, next to shapes
+    that must NOT take it; the workspace query tells which path a shape takes (the derived filter lives there)."""
+    from action_conditioned_gans_amd import _lib as L
+    import ctypes
+    dev = abi.device
+    r = (lambda t: t.bfloat16().float()) if abi.half else (lambda t: t)
+    for i, (xs, ws_, stride, padding, transposed, merged) in enumerate(MERGED_LAYERS):
+        merged = abi.half if merged is None else merged
+        w = randn(ws_, 910 + i, 0.1)
+        if transposed:
+            x = uniform(xs, 900 + i)
+            want = T.conv2d_transpose(r(x).double(), r(w).double(), stride, 'SAME')
+            d = abi._adj(xs, ws_, stride)
+            got = abi.deconv2d_fwd(x.to(dev), w.to(dev), stride)
+        else:
+            xd = uniform(xs, 900 + i).double().requires_grad_(True)
+            y = T.conv2d(xd, r(w).double(), stride, padding)
+            dy = randn(tuple(y.shape), 920 + i)
+            want, = torch.autograd.grad(y, [xd], r(dy).double())
+            b, h, wd, c = xs
+            d = abi.desc(b, h, wd, c, ws_[0], ws_[1], ws_[3], stride, padding)
+            got = abi.conv2d_dgrad(dy.to(dev), w.to(dev), xs, stride, padding)
+        if abi.half:
+            d.in_pitch = d.out_pitch = 0
+        splits = abi.lib.conv2d_splits(ctypes.byref(d), L.CONV_DGRAD, abi.conv_dtype)
+        wsb = abi.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_DGRAD, abi.conv_dtype)
+        numel = want.numel() if not abi.half else want.numel() // want.shape[-1] * ((want.shape[-1] + 7) // 8 * 8)
+        took = wsb != (splits * numel * 4 if splits > 1 else 0)           # the derived filter sits behind the slabs
+        assert took == merged, ('merged layer %d' % i, took, merged, splits, wsb)
+        close(got, want, tol, 'merged dgrad layer %d%s' % (i, ' (merged)' if merged else ''))
+
+
 def case_conv_bf16(abi, shape, tol, tol_w, seed=0, transposed=False):
     """ACG_BF16: tensors stored as bfloat16 (RNE), products exact, fp32 accumulation - so the reference is the fp64
     conv of the bf16-rounded operands; bf16 outputs (y, dx) carry one more rounding (``tol``), the fp32 weight

@@ -61,6 +61,14 @@ def test_conv_bn_stats_bf16(hip_abi_bf16):
     C.case_conv_bn_stats(hip_abi_bf16, TOL_BF16, 2e-3, min_fused=4)
 
 
+def test_merged_input_gradient(hip_abi):
+    C.case_merged_dgrad(hip_abi, TOL_CONV)
+
+
+def test_merged_input_gradient_bf16(hip_abi_bf16):
+    C.case_merged_dgrad(hip_abi_bf16, TOL_BF16)
+
+
 def test_slab_handoff_layouts(hip_abi):
     C.case_slab_handoff(hip_abi, 2e-5)
 

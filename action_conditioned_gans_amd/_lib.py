@@ -28,7 +28,7 @@ class ConvDesc(ctypes.Structure):
     """struct acg_conv_desc."""
     _fields_ = [(n, c_int32) for n in (
         'batch', 'in_h', 'in_w', 'in_c', 'out_h', 'out_w', 'out_c', 'kh', 'kw',
-        'stride_h', 'stride_w', 'pad_top', 'pad_left', 'in_pitch', 'out_pitch')]
+        'stride_h', 'stride_w', 'pad_top', 'pad_left', 'in_pitch', 'out_pitch', 'dgrad_c', 'adj_dgrad_c')]
 
     def key(self):
         return tuple(getattr(self, n) for n, _ in self._fields_)

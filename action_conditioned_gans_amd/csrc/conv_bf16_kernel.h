@@ -84,6 +84,7 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
     Cp = Cin8; ntaps = p.KH * p.KW;
     M = ntaps * Cp; N = p.K; Kdim = p.batch * p.OH * p.OW;
   }
+  if (MODE != MODE_WGRAD && p.Nv > 0) N = p.Nv;      // only the first Nv output columns (acg_conv_desc dgrad_c / adj_dgrad_c)
   const int tiles_n = (N + BN - 1) / BN;
   int bid = bx;
   if constexpr (MODE != MODE_WGRAD) {      // (weight gradients are placed by wgrad_xcd_map in the kernel wrappers)

@@ -190,6 +190,8 @@ int validate(const acg_conv_desc* d, const char* who) {
                   d->kh > 0 && d->kw > 0 && d->stride_h > 0 && d->stride_w > 0 && d->pad_top >= 0 && d->pad_left >= 0,
               ACG_ERR_INVALID_ARG, "%s: non-positive dimension in descriptor", who);
   ACG_REQUIRE(d->in_pitch == 0 || d->in_pitch >= d->in_c, ACG_ERR_INVALID_ARG, "%s: in_pitch %d smaller than in_c %d", who, d->in_pitch, d->in_c);
+  ACG_REQUIRE(d->dgrad_c >= 0 && d->dgrad_c <= d->in_c && d->adj_dgrad_c >= 0 && d->adj_dgrad_c <= d->out_c, ACG_ERR_INVALID_ARG,
+              "%s: dgrad_c %d / adj_dgrad_c %d outside [0, in_c = %d] / [0, out_c = %d]", who, d->dgrad_c, d->adj_dgrad_c, d->in_c, d->out_c);
   ACG_REQUIRE(d->out_pitch == 0 || d->out_pitch >= d->out_c, ACG_ERR_INVALID_ARG, "%s: out_pitch %d smaller than out_c %d", who, d->out_pitch, d->out_c);
   ACG_REQUIRE(d->kh * d->kw <= kMaxTaps, ACG_ERR_UNSUPPORTED, "%s: %dx%d filter exceeds %d taps", who, d->kh, d->kw, kMaxTaps);
   ACG_REQUIRE(d->pad_top < d->kh && d->pad_left < d->kw, ACG_ERR_INVALID_ARG, "%s: padding not smaller than the filter", who);
@@ -223,11 +225,11 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
   const int pad = bf16 ? 7 : 3;       // channels per tap are padded to the 16-byte unit: 4 floats / 8 bf16
   const long long cin_p = (d.in_c + pad) & ~pad, cout_p = (d.out_c + pad) & ~pad;
   if (which == ACG_CONV_FWD) {
-    pl.M = (long long)d.batch * d.out_h * d.out_w; pl.N = d.out_c; K = (long long)d.kh * d.kw * cin_p; pl.classes = 1;
+    pl.M = (long long)d.batch * d.out_h * d.out_w; pl.N = d.adj_dgrad_c > 0 ? d.adj_dgrad_c : d.out_c; K = (long long)d.kh * d.kw * cin_p; pl.classes = 1;
     pl.out_numel = pl.M * (bf16 ? cout_p : (d.out_pitch > 0 ? d.out_pitch : d.out_c));
   } else if (which == ACG_CONV_DGRAD) {
     const int hc = (d.in_h + d.stride_h - 1) / d.stride_h, wc = (d.in_w + d.stride_w - 1) / d.stride_w;
-    pl.M = (long long)d.batch * hc * wc; pl.N = d.in_c;
+    pl.M = (long long)d.batch * hc * wc; pl.N = d.dgrad_c > 0 ? d.dgrad_c : d.in_c;
     K = (long long)((d.kh + d.stride_h - 1) / d.stride_h) * ((d.kw + d.stride_w - 1) / d.stride_w) * cout_p;
     pl.classes = d.stride_h * d.stride_w;
     pl.out_numel = (long long)d.batch * d.in_h * d.in_w * (bf16 ? cin_p : (d.in_pitch > 0 ? d.in_pitch : d.in_c));
@@ -240,7 +242,7 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
   const int cs = which == ACG_CONV_DGRAD ? ky : (d.in_pitch > 0 ? d.in_pitch : d.in_c);
   pl.ragged = (cs & 3) != 0;
   // dense operand rows: the filter [.., N] (FWD) or dY at its channel pitch (WGRAD)
-  pl.nvec = ((which == ACG_CONV_WGRAD ? ky : (int)pl.N) & 3) == 0;
+  pl.nvec = (((which == ACG_CONV_WGRAD ? ky : (int)pl.N) | (which == ACG_CONV_FWD ? d.out_c : 0)) & 3) == 0;    // (FWD: the filter rows are out_c floats apart)
   const int bk = bf16 ? BKH : BK;
   pl.nk = (int)((K + bk - 1) / bk);
   if (pl.nk < 1) pl.nk = 1;
@@ -381,6 +383,7 @@ int prepare(Job& j, int which, const float* gsrc, const float* dense, float* out
   a.batch = d->batch; a.H = d->in_h; a.W = d->in_w; a.C = d->in_c; a.OH = d->out_h; a.OW = d->out_w; a.K = d->out_c;
   a.KH = d->kh; a.KW = d->kw; a.sh = d->stride_h; a.sw = d->stride_w; a.pt = d->pad_top; a.pl = d->pad_left;
   a.splits = pl.splits;
+  a.Nv = which == ACG_CONV_DGRAD ? d->dgrad_c : (which == ACG_CONV_FWD ? d->adj_dgrad_c : 0);
   if (slab_layout != ACG_SLABS_ROWS) {      // slabs for the layer's BatchNorm in the layout its one-launch kernels read (acgan_hip.h)
     const long long orows = which == ACG_CONV_DGRAD ? (long long)d->batch * d->in_h * d->in_w : (long long)d->batch * d->out_h * d->out_w;
     const int oc = which == ACG_CONV_DGRAD ? d->in_c : d->out_c, opitch = which == ACG_CONV_DGRAD ? (h ? cin8 : a.Cx) : (h ? cout8 : a.Ky);
@@ -553,7 +556,7 @@ int32_t acg_conv_desc_init(acg_conv_desc* d, int32_t batch, int32_t in_h, int32_
   ACG_REQUIRE(d && batch > 0 && in_h > 0 && in_w > 0 && in_c > 0 && kh > 0 && kw > 0 && out_c > 0 && stride > 0,
               ACG_ERR_INVALID_ARG, "conv_desc_init: non-positive dimension");
   d->batch = batch; d->in_h = in_h; d->in_w = in_w; d->in_c = in_c; d->out_c = out_c;
-  d->kh = kh; d->kw = kw; d->stride_h = d->stride_w = stride; d->in_pitch = 0; d->out_pitch = 0;
+  d->kh = kh; d->kw = kw; d->stride_h = d->stride_w = stride; d->in_pitch = 0; d->out_pitch = 0; d->dgrad_c = 0; d->adj_dgrad_c = 0;
   if (same) {  // TF 'SAME' (SURVEY A.1): out = ceil(in/s), pad_before = total // 2
     d->out_h = (in_h + stride - 1) / stride; d->out_w = (in_w + stride - 1) / stride;
     const int th = std::max((d->out_h - 1) * stride + kh - in_h, 0), tw = std::max((d->out_w - 1) * stride + kw - in_w, 0);

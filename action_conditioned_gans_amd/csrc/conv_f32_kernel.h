@@ -68,6 +68,7 @@ struct ConvArgs {
   // 4 * shuf_c output columns of pixel (b, p, q) are the shuf_c channels of the 2 x 2 output pixels (2p + ph, 2q + pw) of a
   // tensor that is shuf_w pixels wide at the channel pitch shuf_pitch; column n = (2 ph + pw) * shuf_c + c.  0 = off.
   int shuf_c, shuf_w, shuf_pitch;
+  int Nv;              // FWD / DGRAD: only the first Nv output columns are computed (acg_conv_desc dgrad_c / adj_dgrad_c); 0 = all
   int out_f32;         // bf16 kernels, FWD / DGRAD: the result is stored as float32 (at the bf16 tensor's pitch, round8): a head layer
   // EPI kernel variants only (acg_deconv2d_fwd_bias_act): out = act(acc + bias[n]), stored as float32 at the pitch Cx
   const float* bias;
@@ -301,6 +302,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
     Cs = p.C; Cp = (Cs + 3) & ~3; ntaps = p.KH * p.KW;
     M = ntaps * Cp; N = p.K; Kdim = p.batch * p.OH * p.OW;
   }
+  // NS: floats between two rows of the dense operand (FWD: filter rows W[(tap, c)][0..K)); N: the columns computed
+  const int NS = MODE == MODE_FWD ? p.K : N;
+  if (MODE != MODE_WGRAD && p.Nv > 0) N = p.Nv;
   const int tiles_n = (N + BN - 1) / BN;
   // XCD-aware order: consecutive workgroup ids are dealt round-robin over the 8 XCDs (each with its own L2), so
   // give every XCD a CONTIGUOUS run of tiles - neighbours in the run share A rows / filter columns in that L2.
@@ -430,13 +434,13 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
   int run_bk = 0;                                   // LIN: k of this thread's first dense row
   if constexpr (LIN) {
     run_bk = ks_begin * BK + r0b;
-    run_boff = run_bk * N + nB;
+    run_boff = run_bk * NS + nB;
   } else if constexpr (MODE == MODE_FWD && nvec) {
     tap_of(ks_begin * BK + 4 * kqb, run_bt, run_bc);
-    run_boff = (run_bt * Cs + run_bc + subb) * N + nB;
+    run_boff = (run_bt * Cs + run_bc + subb) * NS + nB;
   }
   if constexpr (MODE == MODE_WGRAD && nvec) run_boff = (ks_begin * BK + r0b) * p.Ky + nB;
-  const int b_step = (step_t * Cs + step_c) * N, b_wrap = (Cp - Cs) * N;   // FWD: dense-row offset per K-step / per tap wrap
+  const int b_step = (step_t * Cs + step_c) * NS, b_wrap = (Cp - Cs) * NS;   // FWD: dense-row offset per K-step / per tap wrap
   int nK[MODE == MODE_DGRAD ? QB : 1];                                     // DGRAD: n * K of this thread's filter rows
   bool nOk[MODE == MODE_DGRAD ? QB : 1];
   if constexpr (MODE == MODE_DGRAD) {
@@ -483,7 +487,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
     }
     if constexpr (LIN) {
       q.boff = run_boff; q.brow = run_bk;
-      run_boff += BK * N; run_bk += BK;
+      run_boff += BK * NS; run_bk += BK;
     } else if constexpr (MODE == MODE_FWD && nvec) {
       q.bt = run_bt; q.bc = run_bc + subb; q.boff = run_boff;
       run_bt += step_t; run_bc += step_c;
@@ -529,7 +533,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
         if constexpr (LIN) ok = q.brow < Kdim;          // the LPB rows of a thread lie in one k-quad; Kdim % 4 == 0
         else if constexpr (MODE == MODE_FWD) ok = q.bt < ntaps && q.bc + U < Cs;
         else ok = q.brow + U < Kdim;
-        rb[ST][U] = guarded_quad(rs_d, q.boff + U * (MODE == MODE_WGRAD ? p.Ky : N), live && ok && nB < N);
+        rb[ST][U] = guarded_quad(rs_d, q.boff + U * (MODE == MODE_WGRAD ? p.Ky : NS), live && ok && nB < N);
       } else {  // ragged N (25, 5, 3, 1 ...): 4 k-rows of one column per quad, lanes along n
         constexpr int stepB = 256 / BN;
         const int n = n0 + (tid % BN), kq = tid / BN + stepB * U;
@@ -539,7 +543,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
           tap_of(ks * BK + 4 * kq, t2, c2);
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            v[e] = guarded_scalar(rs_d, (t2 * Cs + c2 + e) * N + n, live && t2 < ntaps && c2 + e < Cs && n < N);
+            v[e] = guarded_scalar(rs_d, (t2 * Cs + c2 + e) * NS + n, live && t2 < ntaps && c2 + e < Cs && n < N);
         } else {
           const int r = ks * BK + 4 * kq;
 #pragma unroll

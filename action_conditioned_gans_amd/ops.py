@@ -343,6 +343,15 @@ class ConvDgradOp(_ConvBase):
     bn_bwd_consumer = None  # the BnActBwdOp that reads this op's output as its dy (set in BnActOp.grad)
     _slab = None
 
+    def limit_channels(self, c):
+        """Only the first ``c`` channels of this input gradient are read by anyone (the rest belong to tiled action inputs,
+        ConcatActionsOp.grad): acg_conv_desc dgrad_c / adj_dgrad_c - e.g. 128 of d/conv3's 138 columns, two 64-column tiles
+        instead of three."""
+        if self.transposed:
+            self.desc.adj_dgrad_c = int(c)
+        else:
+            self.desc.dgrad_c = int(c)
+
     def bind(self, rt):
         dy, w = self.inputs
         w = self.wop
@@ -900,6 +909,9 @@ class CdnaBwdOp(G.Op):
         return launch
 
 
+DGRAD_CHANNEL_LIMIT = True     # A/B switch (bench.py --no-dgrad-limit): input gradients skip the columns of tiled action channels
+
+
 class ConcatActionsOp(G.Op):
     """tf.tile([B,1,1,A] -> [B,h,w,A]) + tf.concat(axis=3) in one pass (train.py:48-50; models.py:16,38,84).
     The result is stored at a channel pitch rounded up to 4 (138 -> 140, 266 -> 268; zero pad channels) so that
@@ -967,6 +979,9 @@ class ConcatActionsOp(G.Op):
         x = self.inputs[0]
         if not needs[0]:
             return [None, None]
+        src = gouts[0].op
+        if DGRAD_CHANNEL_LIMIT and isinstance(src, ConvDgradOp) and gouts[0] is src.outputs[0]:
+            src.limit_channels(self.c)      # the action channels are inputs: their gradient columns need not be computed
         if self.in_place:      # d(concat) IS dy of the BatchNorm, read at the concat pitch (a window, not a copy)
             g = gouts[0].view(0, gouts[0].shape, name=self.name + '/bwd:view')
             g.valid_c = self.c

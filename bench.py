@@ -49,6 +49,7 @@ def parse():
     ap.add_argument('--no-graphs', action='store_true', help='eager launches instead of HIP-graph replay')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='conv arithmetic: exact fp32 MFMA (BASELINE config 2) or bf16 MFMA operands with fp32 storage/accumulation (configs 3, 5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-dgrad-limit', action='store_true', help='experiment: input gradients also compute the columns of the tiled action channels (acg_conv_desc dgrad_c unset)')
     ap.add_argument('--profile-repeats', type=int, default=3)
     ap.add_argument('--cpu-steps', type=int, default=20)
     ap.add_argument('--lib', default=None, help='experiment: an alternative build of the library (e.g. the tuning build, whose knobs read the environment)')
@@ -66,8 +67,16 @@ def parse():
 
 
 def conv_flops(op):
+    """FLOPs the contraction is asked for: an input gradient limited to the feature channels of an action-concatenated map
+    (acg_conv_desc dgrad_c / adj_dgrad_c) counts those channels only - skipped columns are not work done."""
     d = op.desc
-    return 2.0 * d.batch * d.out_h * d.out_w * d.kh * d.kw * d.in_c * d.out_c
+    cin, cout = d.in_c, d.out_c
+    if type(op).__name__ == 'ConvDgradOp':
+        if op.transposed and d.adj_dgrad_c > 0:
+            cout = d.adj_dgrad_c
+        elif not op.transposed and d.dgrad_c > 0:
+            cin = d.dgrad_c
+    return 2.0 * d.batch * d.out_h * d.out_w * d.kh * d.kw * cin * cout
 
 
 def conv_bytes(op):
@@ -131,6 +140,7 @@ def main():
         from action_conditioned_gans_amd import _lib
         _lib._LIB = _lib.Library(args.lib)
 
+    O.DGRAD_CHANNEL_LIMIT = not args.no_dgrad_limit
     B, S, dna, adv = args.batch, args.img, not args.plain, not args.no_adv
     n_critic = 5 if args.loss == 'wass' else 1
     G.reset_default_graph()

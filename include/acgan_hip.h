@@ -72,6 +72,12 @@ typedef struct acg_conv_desc {
                        the pad channels of x must hold finite values (zeros), those of dx are left untouched. */
   int32_t out_pitch; /* same for y / dy (0 = dense = out_c): the 138- and 266-channel action-concatenated maps feeding
                         d/conv3 and g/tconv1 are stored at a pitch of 140 / 268.  Pad channels of dy must be zero. */
+  int32_t dgrad_c;   /* acg_conv2d_dgrad, acg_conv2d_dgrad_slabs, acg_conv2d_bwd_pair: only the first dgrad_c channels of dx
+                        are computed and written (0 = all in_c).  The last channels of those action-concatenated maps are tiled
+                        inputs (train.py:48-50): nothing reads their gradient, and 138 columns cost a third 64-column tile. */
+  int32_t adj_dgrad_c; /* the same on the ADJOINT descriptor of a transposed layer: acg_deconv2d_dgrad, _dgrad_slabs and
+                          acg_deconv2d_bwd_pair compute the first adj_dgrad_c of the out_c channels of dx (0 = all).  Leave 0
+                          on descriptors handed to acg_conv2d_fwd. */
 } acg_conv_desc;
 
 /* Fill a descriptor from slim-style arguments; same_padding != 0 -> TF 'SAME', else 'VALID'. */

@@ -107,10 +107,12 @@ class Abi:
             self.lib.deconv2d_fwd_bias_act(_p(x), _p(w), _p(bias), _p(y), ctypes.byref(d), ACT[act], leak, self.conv_dtype, self.stream())
         return y
 
-    def conv2d_dgrad(self, dy, w, x_shape, stride, padding):
+    def conv2d_dgrad(self, dy, w, x_shape, stride, padding, grad_c=0):
+        """``grad_c`` > 0: acg_conv_desc.dgrad_c - only the first grad_c channels of dx are computed."""
         b, h, wd, c = x_shape
         pitch = c if c != w.shape[2] else 0
         d = self.desc(b, h, wd, w.shape[2], w.shape[0], w.shape[1], w.shape[3], stride, padding, pitch)
+        d.dgrad_c = grad_c
         dx = torch.zeros(*x_shape, device=self.device)
         ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_DGRAD, self.conv_dtype))
         if self.half:
@@ -156,8 +158,10 @@ class Abi:
         self.lib.deconv2d_fwd(_p(x), _p(w), _p(y), ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
         return y
 
-    def deconv2d_dgrad(self, dy, w, x_shape, stride):
+    def deconv2d_dgrad(self, dy, w, x_shape, stride, grad_c=0):
+        """``grad_c`` > 0: acg_conv_desc.adj_dgrad_c - only the first grad_c channels of dx are computed."""
         d = self._adj(x_shape, w.shape, stride)
+        d.adj_dgrad_c = grad_c
         dx = torch.zeros(*x_shape, device=self.device)
         ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), L.CONV_FWD, self.conv_dtype))
         if self.half:
@@ -181,14 +185,16 @@ class Abi:
         return dw
 
     # ---- a layer's input gradient + weight gradient in one launch
-    def bwd_pair(self, x, dy, w, stride, padding=None, transposed=False, accumulate=0.0, dw=None, slabs_only=False):
-        """-> (dx, dw or (slab workspace, splits))."""
+    def bwd_pair(self, x, dy, w, stride, padding=None, transposed=False, accumulate=0.0, dw=None, slabs_only=False, grad_c=0):
+        """-> (dx, dw or (slab workspace, splits)).  ``grad_c``: acg_conv_desc dgrad_c / adj_dgrad_c."""
         if transposed:
             d = self._adj(x.shape, tuple(w.shape), stride)
+            d.adj_dgrad_c = grad_c
             which_d = L.CONV_FWD
         else:
             b, h, wd, c = x.shape
             d = self.desc(b, h, wd, w.shape[2], w.shape[0], w.shape[1], w.shape[3], stride, padding, c if c != w.shape[2] else 0)
+            d.dgrad_c = grad_c
             which_d = L.CONV_DGRAD
         dx = torch.zeros_like(x)
         if dw is None and not slabs_only:

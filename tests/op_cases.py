@@ -140,6 +140,42 @@ def case_merged_dgrad(abi, tol):
         close(got, want, tol, 'merged dgrad layer %d%s' % (i, ' (merged)' if merged else ''))
 
 
+def case_dgrad_channel_limit(abi, tol):
+    """acg_conv_desc dgrad_c / adj_dgrad_c: the input gradient of a layer fed by an action-concatenated map (d/conv3: 128 + 10
+    channels at a pitch of 140; g/tconv1: 256 + 10 at 268) computes the feature channels only.  The limited columns must equal
+    the unlimited result to rounding (fewer column tiles can mean another split-K factor), the others must not be written; single
+    entries and the paired launch."""
+    dev = abi.device
+    for i, (xs, ws_, stride, transposed, keep) in enumerate([
+            ((4, 16, 16, 140), (5, 5, 138, 128), 2, False, 128),      # d/conv3-like: 138 logical channels at pitch 140
+            ((2, 8, 8, 44), (3, 3, 42, 24), 1, False, 32),            # two of three 16.. column tiles on the narrow tile
+            ((4, 4, 4, 268), (5, 5, 128, 266), 2, True, 256),         # g/tconv1-like (transposed: dx is the adjoint's out side)
+            ((2, 8, 8, 24), (5, 5, 16, 20), 2, True, 12)]):
+        cphys, clog = xs[3], (ws_[3] if transposed else ws_[2])
+        x = torch.zeros(xs)
+        x[..., :clog] = uniform(xs[:3] + (clog,), 1100 + i)
+        w = randn(ws_, 1110 + i, 0.1).to(dev)
+        if transposed:
+            dy = randn((xs[0], xs[1] * stride, xs[2] * stride, ws_[2]), 1120 + i).to(dev)
+            full = abi.deconv2d_dgrad(dy, w, xs, stride)
+            part = abi.deconv2d_dgrad(dy, w, xs, stride, grad_c=keep)
+        else:
+            yshape = tuple(T.conv2d(x[..., :clog].double(), w.double().cpu(), stride, 'SAME').shape)
+            dy = randn(yshape, 1120 + i).to(dev)
+            full = abi.conv2d_dgrad(dy, w, xs, stride, 'SAME')
+            part = abi.conv2d_dgrad(dy, w, xs, stride, 'SAME', grad_c=keep)
+        tag = 'dgrad channel limit %d' % i
+        close(part[..., :keep], full[..., :keep], tol, tag + ': limited columns')
+        assert (part[..., keep:] == 0).all(), tag + ': columns beyond the limit were written'
+        assert float(full[..., keep:clog].abs().max()) > 0, tag
+        if not abi.half:
+            dxp, dwp = abi.bwd_pair(x.to(dev), dy, w, stride, 'SAME', transposed, grad_c=keep)
+            dxf, dwf = abi.bwd_pair(x.to(dev), dy, w, stride, 'SAME', transposed)
+            close(dxp[..., :keep], dxf[..., :keep], tol, tag + ' (pair)')
+            assert (dxp[..., keep:] == 0).all(), tag + ' (pair): columns beyond the limit were written'
+            assert torch.equal(dwp, dwf), tag + ' (pair): the weight gradient must not change'
+
+
 def case_conv_bf16(abi, shape, tol, tol_w, seed=0, transposed=False):
     """ACG_BF16: tensors stored as bfloat16 (RNE), products exact, fp32 accumulation - so the reference is the fp64
     conv of the bf16-rounded operands; bf16 outputs (y, dx) carry one more rounding (``tol``), the fp32 weight

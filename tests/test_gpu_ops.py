@@ -69,6 +69,14 @@ def test_merged_input_gradient_bf16(hip_abi_bf16):
     C.case_merged_dgrad(hip_abi_bf16, TOL_BF16)
 
 
+def test_dgrad_channel_limit(hip_abi):
+    C.case_dgrad_channel_limit(hip_abi, TOL_CONV)
+
+
+def test_dgrad_channel_limit_bf16(hip_abi_bf16):
+    C.case_dgrad_channel_limit(hip_abi_bf16, TOL_BF16)
+
+
 def test_slab_handoff_layouts(hip_abi):
     C.case_slab_handoff(hip_abi, 2e-5)
 

@@ -70,9 +70,15 @@ def main():
                     continue
                 d = op.desc
                 fl = 2.0 * d.batch * d.out_h * d.out_w * d.kh * d.kw * d.in_c * d.out_c
+                wfl = fl                       # (the paired weight gradient is not limited)
+                if type(op).__name__ == 'ConvDgradOp':      # an input gradient limited to the feature channels (dgrad_c / adj_dgrad_c)
+                    if op.transposed and d.adj_dgrad_c > 0:
+                        fl *= d.adj_dgrad_c / d.out_c
+                    elif not op.transposed and d.dgrad_c > 0:
+                        fl *= d.dgrad_c / d.in_c
                 paired = getattr(op, 'pair_active', False)     # this launch also ran the layer's weight gradient (same FLOPs again)
                 splits = sess.rt.lib.conv2d_splits(ctypes.byref(d), op.which, sess.rt.conv_dtype)
-                rows.append((tag, op.name + ('+wgrad' if paired else ''), type(op).__name__ + ('+W' if paired else '') + ' s%d' % splits, fl * (2 if paired else 1),
+                rows.append((tag, op.name + ('+wgrad' if paired else ''), type(op).__name__ + ('+W' if paired else '') + ' s%d' % splits, fl + (wfl if paired else 0.0),
                              e0.elapsed_time(e1) * 1e3 / 60))
     tot_us = sum(r[4] for r in rows)
     if args.other:

@@ -115,7 +115,13 @@ def main():
                 us = time_graph(call, reps=args.reps)
                 results.append((us, cfg, sp))
         lib.debug_conv_plan(-1, -1)
-        auto = ([r for r in results if r[1] == -1] or [min(results)])[0]
+        # the planner's own choice again, LAST (the first measurement of a layer also pays its first touches), and its split count
+        nbytes = lib.conv2d_workspace_bytes(ctypes.byref(d), which, dt)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        pa, pb, po, pw = (ctypes.c_void_p(t.data_ptr()) for t in (a, b, out, ws))
+        if -1 in cfgs:
+            results.append((time_graph(call, reps=args.reps), -1, -lib.conv2d_splits(ctypes.byref(d), which, dt)))
+        auto = min([r for r in results if r[1] == -1] or [min(results)])
         best = min(results)
         print('%-28s %-14s x%d  flops %.2fG  auto %.1fus (%.1f TF)  best %s s=%d %.1fus (%.1f TF)' % (
             names[0], kind, len(names), flops / 1e9, auto[0], flops / auto[0] / 1e6, CFG.get(best[1], 'auto'), best[2], best[0],

@@ -661,6 +661,13 @@ class Session:
         Device-resident float32 feeds go through ONE acg_copy_many launch.  Used by run() and profile_ops()."""
         fused = []
         for ph, val in feed_dict.items():
+            targets = ([(ph, 0, None)] if id(ph) in prog.used_feeds else []) + prog.alias_copies.get(id(ph), [])
+            if not targets:
+                # fed but not read by this program (train_d feeds next_state like the reference, train.py:137-142): no upload -
+                # a host array would cost a staged copy on the stream between two programs
+                if tuple(np.shape(val)) != tuple(ph.shape if ph.valid_c is None else ph.shape[:-1] + (ph.valid_c,)):
+                    raise ValueError('Cannot feed value of shape %s for %r' % (tuple(np.shape(val)), ph))
+                continue
             src = val if torch.is_tensor(val) else torch.from_numpy(np.ascontiguousarray(val))
             if self.rt.is_cuda and not src.is_cuda and src.dtype in (torch.float32, torch.float64):
                 # host arrays (the reference's numpy feed_dict): ONE contiguous upload per fed value, then the same fused
@@ -670,7 +677,6 @@ class Session:
             dst = ph.buf if ph.valid_c is None else ph.buf[..., :ph.valid_c]     # pad channels stay zero
             if tuple(src.shape) != tuple(dst.shape):
                 raise ValueError('Cannot feed value of shape %s for %r' % (tuple(src.shape), ph))
-            targets = ([(ph, 0, None)] if id(ph) in prog.used_feeds else []) + prog.alias_copies.get(id(ph), [])
             cols = src.shape[-1]
             for t, c_off, tile in targets:
                 if (self.rt.is_cuda and src.is_cuda and src.device == t.buf.device and src.dtype == torch.float32

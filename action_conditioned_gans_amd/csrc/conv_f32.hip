@@ -442,6 +442,7 @@ Merged merged_dgrad(const acg_conv_desc& d, bool bf16) {
   static const int on = env_int("ACG_PLAN_MERGED", 1);
   if (!on || g_force_cfg >= 0 || g_force_splits >= 0) return m;
   if (d.stride_h != 2 || d.stride_w != 2 || (d.in_h & 1) || (d.in_w & 1) || d.out_h * 2 != d.in_h || d.out_w * 2 != d.in_w || 4 * d.in_c > 32) return m;
+  if (d.dgrad_c > 0 && d.dgrad_c < d.in_c) return m;      // a channel limit: the class-wise kernel honours it (and leaves the other channels alone)
   auto window = [](int k, int pad, int& lo, int& hi) {
     lo = 1 << 20; hi = -(1 << 20);
     for (int ph = 0; ph < 2; ++ph)

@@ -150,7 +150,8 @@ def case_dgrad_channel_limit(abi, tol):
             ((4, 16, 16, 140), (5, 5, 138, 128), 2, False, 128),      # d/conv3-like: 138 logical channels at pitch 140
             ((2, 8, 8, 44), (3, 3, 42, 24), 1, False, 32),            # two of three 16.. column tiles on the narrow tile
             ((4, 4, 4, 268), (5, 5, 128, 266), 2, True, 256),         # g/tconv1-like (transposed: dx is the adjoint's out side)
-            ((2, 8, 8, 24), (5, 5, 16, 20), 2, True, 12)]):
+            ((2, 8, 8, 24), (5, 5, 16, 20), 2, True, 12),
+            ((2, 8, 8, 8), (5, 5, 8, 16), 2, False, 4)]):               # a shape the merged input gradient would take: the limit wins
         cphys, clog = xs[3], (ws_[3] if transposed else ws_[2])
         x = torch.zeros(xs)
         x[..., :clog] = uniform(xs[:3] + (clog,), 1100 + i)

@@ -384,6 +384,16 @@ int prepare(Job& j, int which, const float* gsrc, const float* dense, float* out
   a.KH = d->kh; a.KW = d->kw; a.sh = d->stride_h; a.sw = d->stride_w; a.pt = d->pad_top; a.pl = d->pad_left;
   a.splits = pl.splits;
   a.Nv = which == ACG_CONV_DGRAD ? d->dgrad_c : (which == ACG_CONV_FWD ? d->adj_dgrad_c : 0);
+  // small maps: pixel-major rows + only the taps a tile's rows can see (ConvArgs::compact); not with epilogue statistics,
+  // whose partial blocks are runs of rows of one group
+  // measured: pays only where more than half of the taps are dead (a 4 x 4 map under a 5 x 5 / stride-2 filter: d/conv5) - from
+  // 16 pixels per class on, what the pixel-major order loses in gather reuse inside a tile eats the skipped K-steps
+  static const int compact_max = env_int("ACG_PLAN_COMPACT", 4);
+  {
+    const int hc = (d->in_h + d->stride_h - 1) / d->stride_h, wc = (d->in_w + d->stride_w - 1) / d->stride_w;
+    const int px = which == ACG_CONV_DGRAD ? hc * wc : d->out_h * d->out_w;
+    a.compact = (which != ACG_CONV_WGRAD && !h && stats == nullptr && !pl.direct && px <= compact_max && d->batch >= 8 && d->kh * d->kw > 1) ? 1 : 0;
+  }
   if (slab_layout != ACG_SLABS_ROWS) {      // slabs for the layer's BatchNorm in the layout its one-launch kernels read (acgan_hip.h)
     const long long orows = which == ACG_CONV_DGRAD ? (long long)d->batch * d->in_h * d->in_w : (long long)d->batch * d->out_h * d->out_w;
     const int oc = which == ACG_CONV_DGRAD ? d->in_c : d->out_c, opitch = which == ACG_CONV_DGRAD ? (h ? cin8 : a.Cx) : (h ? cout8 : a.Ky);

@@ -68,6 +68,10 @@ struct ConvArgs {
   // 4 * shuf_c output columns of pixel (b, p, q) are the shuf_c channels of the 2 x 2 output pixels (2p + ph, 2q + pw) of a
   // tensor that is shuf_w pixels wide at the channel pitch shuf_pitch; column n = (2 ph + pw) * shuf_c + c.  0 = off.
   int shuf_c, shuf_w, shuf_pitch;
+  // Small maps (DGRAD; conv_f32.hip prepare): rows are ordered pixel-major - m = pixel * batch + b, so a tile covers one or
+  // two pixels over the batch - and the tile walks only the taps ANY of its rows can see: on a 4 x 4 map half the taps of a
+  // 5 x 5 filter fall into the padding for every row of such a tile, and their K-steps would multiply zeros.
+  int compact;
   int Nv;              // FWD / DGRAD: only the first Nv output columns are computed (acg_conv_desc dgrad_c / adj_dgrad_c); 0 = all
   int out_f32;         // bf16 kernels, FWD / DGRAD: the result is stored as float32 (at the bf16 tensor's pitch, round8): a head layer
   // EPI kernel variants only (acg_deconv2d_fwd_bias_act): out = act(acc + bias[n]), stored as float32 at the pitch Cx
@@ -318,10 +322,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
   const int m0 = tm * BM, n0 = tn * BN;
   if (m0 >= M) return;  // block-uniform: DGRAD classes smaller than class 0
 
-  const int nk = (Kdim + BK - 1) / BK;
-  const int per = (nk + p.splits - 1) / p.splits;
-  const int ks_begin = bz * per;
-  const int ks_end = min(nk, ks_begin + per);
+  int nk = (Kdim + BK - 1) / BK;
+  int per = (nk + p.splits - 1) / p.splits;
+  int ks_begin = bz * per;
+  int ks_end = min(nk, ks_begin + per);
 
   // ---- tap tables ------------------------------------------------------------------------------
   if (tid < kMaxTaps && tid < ntaps) {
@@ -333,7 +337,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
     } else {
       const int i = t / p.KW, j = t - i * p.KW;
       tapA[t] = (i * p.W + j) * p.Cx;
-      tapB[t] = 0;
+      tapB[t] = MODE == MODE_FWD ? t * p.C * p.K : 0;      // FWD: first filter row of the tap (the table-driven dense rows below)
     }
   }
 
@@ -341,11 +345,13 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
   auto fill_row_fwd = [&](int r /* global row (b,p,q) */, int limit) -> RowInfo {
     RowInfo ri; ri.base = 0; ri.mask_lo = 0; ri.mask_hi = 0; ri.out_off = 0;
     if (r < limit) {
-      const int t2 = div_fast(r, p.mg_ow, p.sh_ow), q = r - t2 * p.OW;
-      const int b = div_fast(t2, p.mg_oh, p.sh_oh), pp = t2 - b * p.OH;
+      int q, b, pp;
+      if (MODE == MODE_FWD && p.compact) { b = r % p.batch; const int px = r / p.batch; q = px % p.OW; pp = px / p.OW; }    // pixel-major rows
+      else { const int t2 = div_fast(r, p.mg_ow, p.sh_ow); q = r - t2 * p.OW; b = div_fast(t2, p.mg_oh, p.sh_oh); pp = t2 - b * p.OH; }
       const int y0 = pp * p.sh - p.pt, x0 = q * p.sw - p.pl;
       ri.base = ((b * p.H + y0) * p.W + x0) * p.Cx;
       if (p.shuf_c) ri.out_off = ((b * (2 * p.OH) + 2 * pp) * p.shuf_w + 2 * q) * p.shuf_pitch;
+      else if (MODE == MODE_FWD && p.compact) ri.out_off = ((b * p.OH + pp) * p.OW + q) * (p.slab_rows ? 4 : p.Ky);
       const unsigned long long m = tap_mask(max(0, -y0), min(p.KH, p.H - y0), max(0, -x0), min(p.KW, p.W - x0), p.KW);
       ri.mask_lo = (unsigned)m; ri.mask_hi = (unsigned)(m >> 32);
     }
@@ -358,7 +364,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
       RowInfo ri; ri.base = 0; ri.mask_lo = 0; ri.mask_hi = 0; ri.out_off = 0;
       const int m = m0 + r;
       if (m < M) {
-        const int w2 = m % Wc; const int t2 = m / Wc; const int h2 = t2 % Hc; const int b = t2 / Hc;
+        int w2, h2, b;
+        if (p.compact) { b = m % p.batch; const int pq = m / p.batch; w2 = pq % Wc; h2 = pq / Wc; }     // pixel-major rows
+        else { w2 = m % Wc; const int t2 = m / Wc; h2 = t2 % Hc; b = t2 / Hc; }
         const int y0 = h2 + dp0, x0 = w2 + dq0;  // dY coordinates of tap (0,0)
         ri.base = ((b * p.OH + y0) * p.OW + x0) * p.Ky;
         ri.out_off = ((b * p.H + h2 * p.sh + ph) * p.W + (w2 * p.sw + pw)) * (p.slab_rows ? 4 : p.Cx);
@@ -370,6 +378,41 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
     }
   }
   __syncthreads();
+  if constexpr (MODE != MODE_WGRAD) {
+    if (p.compact) {      // block-uniform.  Keep only the taps a row of this tile can see: tap tables and row masks in compact order.
+      __shared__ unsigned umask[2];
+      if (tid < 2) umask[tid] = 0u;
+      __syncthreads();
+      if (tid < BM) {
+        const RowInfo ri = rows[tid];
+        if (ri.mask_lo) atomicOr(&umask[0], ri.mask_lo);
+        if (ri.mask_hi) atomicOr(&umask[1], ri.mask_hi);
+      }
+      __syncthreads();
+      const unsigned long long U = (unsigned long long)umask[0] | ((unsigned long long)umask[1] << 32);
+      int ta = 0, tb = 0;
+      const bool mine = tid < ntaps && ((U >> tid) & 1ull);
+      if (mine) { ta = tapA[tid]; tb = tapB[tid]; }
+      unsigned long long rm = 0ull;        // this row's mask over the compact taps
+      if (tid < BM) {
+        const RowInfo ri = rows[tid];
+        const unsigned long long old = (unsigned long long)ri.mask_lo | ((unsigned long long)ri.mask_hi << 32);
+        int pos = 0;
+        for (int t = 0; t < ntaps; ++t)
+          if ((U >> t) & 1ull) { rm |= ((old >> t) & 1ull) << pos; ++pos; }
+      }
+      __syncthreads();
+      if (mine) { const int pos = __popcll(U & ((1ull << tid) - 1ull)); tapA[pos] = ta; tapB[pos] = tb; }
+      if (tid < BM) { rows[tid].mask_lo = (unsigned)rm; rows[tid].mask_hi = (unsigned)(rm >> 32); }
+      ntaps = __popcll(U);
+      Kdim = ntaps * Cp;
+      nk = (Kdim + BK - 1) / BK;
+      per = (nk + p.splits - 1) / p.splits;
+      ks_begin = bz * per;
+      ks_end = min(nk, ks_begin + per);
+      __syncthreads();
+    }
+  }
 
   // ---- loaders: NST register stages ---------------------------------------------------------------
   // k-fast operands (A of FWD/DGRAD, B of DGRAD) are gathered one quad per (row, k/4); the others
@@ -440,7 +483,6 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
     run_boff = (run_bt * Cs + run_bc + subb) * NS + nB;
   }
   if constexpr (MODE == MODE_WGRAD && nvec) run_boff = (ks_begin * BK + r0b) * p.Ky + nB;
-  const int b_step = (step_t * Cs + step_c) * NS, b_wrap = (Cp - Cs) * NS;   // FWD: dense-row offset per K-step / per tap wrap
   int nK[MODE == MODE_DGRAD ? QB : 1];                                     // DGRAD: n * K of this thread's filter rows
   bool nOk[MODE == MODE_DGRAD ? QB : 1];
   if constexpr (MODE == MODE_DGRAD) {
@@ -489,11 +531,11 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
       q.boff = run_boff; q.brow = run_bk;
       run_boff += BK * NS; run_bk += BK;
     } else if constexpr (MODE == MODE_FWD && nvec) {
-      q.bt = run_bt; q.bc = run_bc + subb; q.boff = run_boff;
+      // (tap, channel) state + the tap's first filter row from the table: the taps of a compacted tile are not consecutive
+      q.bt = run_bt; q.bc = run_bc + subb; q.boff = tapB[min(run_bt, ntaps - 1)] + (run_bc + subb) * NS + nB;
       run_bt += step_t; run_bc += step_c;
       const bool wrap = run_bc >= Cp;
       run_bc -= wrap ? Cp : 0; run_bt += wrap ? 1 : 0;
-      run_boff += b_step - (wrap ? b_wrap : 0);
     }
     if constexpr (MODE == MODE_WGRAD && nvec) {
       q.boff = run_boff; q.brow = ks * BK + r0b;
@@ -543,7 +585,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
           tap_of(ks * BK + 4 * kq, t2, c2);
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            v[e] = guarded_scalar(rs_d, (t2 * Cs + c2 + e) * NS + n, live && t2 < ntaps && c2 + e < Cs && n < N);
+            v[e] = guarded_scalar(rs_d, tapB[min(t2, ntaps - 1)] + (c2 + e) * NS + n, live && t2 < ntaps && c2 + e < Cs && n < N);
         } else {
           const int r = ks * BK + 4 * kq;
 #pragma unroll
@@ -769,9 +811,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
   const bool full = m0 + BM <= M && (MODE != MODE_WGRAD || (Cp == Cs && !(p.splits == 1 && p.accumulate != 0.f)));
   // column term of an element's offset: n, or in the quad slab layout (ConvArgs::slab_rows) the quad's run of rows + n & 3
   const bool quads = MODE != MODE_WGRAD && p.slab_rows > 0;
-  const bool shuf = MODE == MODE_FWD && p.shuf_c > 0;      // merged input gradient: rows by their out_off, columns by (2 x 2 pixel, channel)
+  // FWD rows addressed by their out_off: the merged input gradient (columns = 2 x 2 pixel, channel) and pixel-major small maps
+  const bool shuf = MODE == MODE_FWD && (p.shuf_c > 0 || p.compact);
   auto col_off = [&](int n) -> long long {
-    if (shuf) { const int cls = n / p.shuf_c; return (long long)((cls >> 1) * p.shuf_w + (cls & 1)) * p.shuf_pitch + (n - cls * p.shuf_c); }
+    if (MODE == MODE_FWD && p.shuf_c > 0) { const int cls = n / p.shuf_c; return (long long)((cls >> 1) * p.shuf_w + (cls & 1)) * p.shuf_pitch + (n - cls * p.shuf_c); }
     return quads ? (long long)(n >> 2) * p.slab_rows * 4 + (n & 3) : (long long)n;
   };
   const long long row_pitch = MODE == MODE_WGRAD ? N : (quads ? 4 : p.Ky);
@@ -899,7 +942,7 @@ static inline void launch_cfg(const Plan& pl, const ConvArgs& a, hipStream_t st)
   // two tile shapes: 128x32 for narrow N, 64x64 otherwise.  128x128 / 128x64 variants existed through v4; with the
   // one-barrier pipeline they lost every layer of the tuning sweep (profiles/r1) and were dropped.
   if constexpr (MODE == MODE_FWD && !RAGGED && NVEC) {
-    if ((a.C & 3) == 0) {     // gathered channels a multiple of 4: the LIN variant (filter rows linear in k)
+    if ((a.C & 3) == 0 && !a.compact) {     // gathered channels a multiple of 4: the LIN variant (filter rows linear in k)
       if (pl.cfg == 2) ACG_LAUNCH((conv_mfma_f32<MODE, 128, 32, 4, 1, RAGGED, NVEC, false, true>), grid, dim3(256), 0, st, a);
       else ACG_LAUNCH((conv_mfma_f32<MODE, 64, 64, 2, 2, RAGGED, NVEC, false, true>), grid, dim3(256), 0, st, a);
       return;

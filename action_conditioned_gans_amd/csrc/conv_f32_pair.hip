@@ -31,7 +31,7 @@ int launch_pair(int modeA, const Plan& pa, const ConvArgs& a, const Plan& pb, co
   if (modeA == MODE_FWD) {
     // (pair_supported: the dense operands are float4-able; gathered channels a multiple of 4 -> the LIN variant of A)
     if (pa.ragged) launch_a<MODE_FWD, true>(pa, pb, a, b, g, blocks, st);
-    else if ((a.C & 3) == 0) launch_a<MODE_FWD, false, true>(pa, pb, a, b, g, blocks, st);
+    else if ((a.C & 3) == 0 && !a.compact) launch_a<MODE_FWD, false, true>(pa, pb, a, b, g, blocks, st);
     else launch_a<MODE_FWD, false>(pa, pb, a, b, g, blocks, st);
   } else {
     if (pa.ragged) launch_a<MODE_DGRAD, true>(pa, pb, a, b, g, blocks, st);

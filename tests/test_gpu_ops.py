@@ -191,6 +191,22 @@ def test_deconv_batch32(hip_abi, shape):
     C.case_deconv(hip_abi, shape, TOL_CONV)
 
 
+@pytest.mark.parametrize('shape', [(64, 4, 4, 256, 512, 5, 2, 'SAME'),     # d/conv5 at the D step's batch: one output pixel per 64-row tile
+                                   (12, 4, 4, 24, 40, 5, 2, 'SAME'),       # two or three pixels per tile, ragged columns
+                                   (9, 3, 4, 16, 8, 3, 2, 'SAME'),         # odd map, 3 x 3 filter
+                                   (16, 4, 4, 6, 32, 5, 2, 'SAME'),        # 6 gathered channels: the non-LIN forward path either way
+                                   (8, 2, 2, 64, 16, 3, 1, 'SAME')], ids=str)
+def test_conv_small_maps_walk_live_taps_only(hip_abi, shape):
+    """Maps of at most four output pixels (per stride class for the input gradient) at batch >= 8: pixel-major rows and the
+    compacted tap list (ConvArgs::compact) - forward and input gradient against the float64 conv, weight gradient alongside."""
+    C.case_conv(hip_abi, shape, TOL_CONV)
+
+
+@pytest.mark.parametrize('shape', [(32, 2, 2, 64, 32, 5, 2), (8, 2, 1, 16, 12, 5, 2)], ids=str)
+def test_deconv_small_maps_walk_live_taps_only(hip_abi, shape):
+    C.case_deconv(hip_abi, shape, TOL_CONV)
+
+
 @pytest.mark.parametrize('shape', C.BN_SHAPES + [((32, 32, 32), 128, 1, 'relu'), ((64, 4, 4), 512, 2, 'lrelu'),
                                             # register-resident kernels (<= 4096 rows per group): exact fit, one row past it, ragged rows, 3 groups
                                             ((4, 32, 32), 16, 1, 'relu'), ((1, 17, 241), 8, 1, 'lrelu'), ((3, 9, 19), 12, 3, None),

@@ -18,7 +18,7 @@ ACG_F32, ACG_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 0, 1, 2
 SLABS_ROWS, SLABS_QUADS = 0, 1       # acgan_hip.h ACG_SLABS_*
-ABI_VERSION = 4       # include/acgan_hip.h ACG_ABI_VERSION: bumped with every signature / layout / flag-meaning change
+ABI_VERSION = 5       # include/acgan_hip.h ACG_ABI_VERSION: bumped with every signature / layout / flag-meaning change
 
 LIB_NAME = 'libacgan_hip.so'
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', LIB_NAME)
@@ -223,8 +223,9 @@ def load_tuning():
     and the ACG_* environment knobs, installed as the process's library.  The package itself never loads it."""
     global _LIB
     if not os.path.exists(TUNING_LIB_PATH):
-        # not shipped to the GPU box (.gpurunignore): tools build it where they run (hipcc, ~1 min on 16 cores)
-        import subprocess
-        subprocess.check_call(['make', '-s', '-j16', '-C', os.path.dirname(LIB_PATH), 'tuning'])
+        # not shipped to the GPU box (.gpurunignore) and never built from inside a library loader: a hidden 16-way hipcc
+        # build at call time would also run under whatever preload (rocprofv3) the calling tool was started with
+        raise RuntimeError('%s not found: build it first, before any profiler or GPU process starts: '
+                           '`make -s -j16 -C %s tuning`' % (TUNING_LIB_PATH, os.path.dirname(LIB_PATH)))
     _LIB = Library(TUNING_LIB_PATH, extra={'acg_debug_conv_plan': (c_int32, [c_int32, c_int32])})
     return _LIB

@@ -50,30 +50,35 @@ def unpack_unique_id(raw, uid=None):
 _RCCL = None
 
 
+def load_rccl(path):
+    """A library exporting the seven nccl* entry points this module calls, with their signatures declared.  The product
+    loads the librccl.so PyTorch ships (_rccl below); tests load a stub that fails on demand (tests/stub_rccl.c)."""
+    if not os.path.exists(path):
+        raise CommError('librccl.so not found (%s): no multi-GPU transport' % path)
+    lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    P = ctypes.c_void_p
+    lib.ncclGetUniqueId.argtypes, lib.ncclGetUniqueId.restype = [ctypes.POINTER(_UniqueId)], ctypes.c_int
+    lib.ncclCommInitRank.argtypes = [ctypes.POINTER(P), ctypes.c_int, _UniqueId, ctypes.c_int]
+    lib.ncclCommInitRank.restype = ctypes.c_int
+    lib.ncclAllReduce.argtypes = [P, P, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, P, P]
+    lib.ncclAllReduce.restype = ctypes.c_int
+    lib.ncclCommDestroy.argtypes, lib.ncclCommDestroy.restype = [P], ctypes.c_int
+    lib.ncclGetErrorString.argtypes, lib.ncclGetErrorString.restype = [ctypes.c_int], ctypes.c_char_p
+    lib.ncclGetVersion.argtypes, lib.ncclGetVersion.restype = [ctypes.POINTER(ctypes.c_int)], ctypes.c_int
+    return lib
+
+
 def _rccl():
     """librccl.so next to torch's libamdhip64.so: the process keeps ONE HIP runtime (see _lib.py on import order)."""
     global _RCCL
     if _RCCL is None:
-        path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
-        if not os.path.exists(path):
-            raise CommError('librccl.so not found next to torch (%s): no multi-GPU transport' % path)
-        lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
-        P = ctypes.c_void_p
-        lib.ncclGetUniqueId.argtypes, lib.ncclGetUniqueId.restype = [ctypes.POINTER(_UniqueId)], ctypes.c_int
-        lib.ncclCommInitRank.argtypes = [ctypes.POINTER(P), ctypes.c_int, _UniqueId, ctypes.c_int]
-        lib.ncclCommInitRank.restype = ctypes.c_int
-        lib.ncclAllReduce.argtypes = [P, P, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, P, P]
-        lib.ncclAllReduce.restype = ctypes.c_int
-        lib.ncclCommDestroy.argtypes, lib.ncclCommDestroy.restype = [P], ctypes.c_int
-        lib.ncclGetErrorString.argtypes, lib.ncclGetErrorString.restype = [ctypes.c_int], ctypes.c_char_p
-        lib.ncclGetVersion.argtypes, lib.ncclGetVersion.restype = [ctypes.POINTER(ctypes.c_int)], ctypes.c_int
-        _RCCL = lib
+        _RCCL = load_rccl(os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so'))
     return _RCCL
 
 
-def _check(rc, what):
+def _check(rc, what, lib=None):
     if rc != 0:
-        raise CommError('%s failed: %s (ncclResult %d)' % (what, _rccl().ncclGetErrorString(rc).decode(), rc))
+        raise CommError('%s failed: %s (ncclResult %d)' % (what, (lib or _rccl()).ncclGetErrorString(rc).decode(), rc))
 
 
 def _share_unique_id(uid_bytes, world_size, rank, process_group):
@@ -122,43 +127,50 @@ class Communicator:
 class RcclCommunicator(Communicator):
     capturable = True      # ncclAllReduce on a capturing stream becomes graph nodes (validated: tests/dp_one_rank.py)
 
-    def __init__(self, device, world_size=1, rank=0, process_group=None):
+    def __init__(self, device, world_size=1, rank=0, process_group=None, lib=None):
+        """``lib``: tests only - a stand-in for librccl.so (load_rccl); with it the device may be the CPU, so that the error
+        paths of the bootstrap and of the collectives run without a GPU."""
         device = torch.device(device)
-        if device.type != 'cuda' or not torch.cuda.is_available():
+        if lib is None and (device.type != 'cuda' or not torch.cuda.is_available()):
             raise CommError('RcclCommunicator needs a GPU device, got %s' % device)
         self.device, self.world_size, self.rank = device, int(world_size), int(rank)
-        lib = _rccl()
+        self._comm = None
+        lib = lib if lib is not None else _rccl()
+        self._lib = lib
         uid = _UniqueId()
         if self.rank == 0:
-            _check(lib.ncclGetUniqueId(ctypes.byref(uid)), 'ncclGetUniqueId')
+            _check(lib.ncclGetUniqueId(ctypes.byref(uid)), 'ncclGetUniqueId', lib)
         if self.world_size > 1:
             raw = _share_unique_id(pack_unique_id(uid) if self.rank == 0 else None, self.world_size, self.rank, process_group)
             unpack_unique_id(raw, uid)
-        self._comm = ctypes.c_void_p()
-        with torch.cuda.device(device):
-            _check(lib.ncclCommInitRank(ctypes.byref(self._comm), self.world_size, uid, self.rank), 'ncclCommInitRank')
-        self._lib = lib
+        comm = ctypes.c_void_p()
+        import contextlib
+        with (torch.cuda.device(device) if device.type == 'cuda' else contextlib.nullcontext()):
+            _check(lib.ncclCommInitRank(ctypes.byref(comm), self.world_size, uid, self.rank), 'ncclCommInitRank', lib)
+        self._comm = comm
         self.calls = 0
 
     def all_reduce_ptr(self, ptr, count, nccl_dtype, nccl_op, stream_ptr):
         """The raw form the launch lists use: everything precomputed, one C call."""
         rc = self._lib.ncclAllReduce(ptr, ptr, count, nccl_dtype, nccl_op, self._comm, stream_ptr)
         if rc != 0:
-            _check(rc, 'ncclAllReduce')
+            _check(rc, 'ncclAllReduce', self._lib)
         self.calls += 1
 
     def all_reduce(self, tensor, op='sum', stream=None):
-        if not (tensor.is_cuda and tensor.is_contiguous()):
+        on_gpu = self.device.type == 'cuda'
+        if not ((tensor.is_cuda or not on_gpu) and tensor.is_contiguous()):
             raise CommError('all_reduce: contiguous GPU tensor expected')
-        sp = stream if stream is not None else ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        sp = stream if (stream is not None or not on_gpu) else ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         self.all_reduce_ptr(ctypes.c_void_p(tensor.data_ptr()), tensor.numel(), _DTYPES[tensor.dtype],
                             NCCL_MAX if op == 'max' else NCCL_SUM, sp)
 
     def destroy(self):
         if self._comm is not None and self._comm.value:
-            torch.cuda.synchronize(self.device)        # nothing of ours may still be queued on the communicator
-            _check(self._lib.ncclCommDestroy(self._comm), 'ncclCommDestroy')
-            self._comm = None
+            if self.device.type == 'cuda':
+                torch.cuda.synchronize(self.device)    # nothing of ours may still be queued on the communicator
+            comm, self._comm = self._comm, None        # a failing destroy is not retried by a second close()
+            _check(self._lib.ncclCommDestroy(comm), 'ncclCommDestroy', self._lib)
 
 
 class ProcessGroupCommunicator(Communicator):

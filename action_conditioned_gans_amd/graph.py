@@ -419,8 +419,11 @@ class Session:
         self.rt = Runtime(lib, dev, world_size, rank, process_group, _lib.ACG_BF16 if dtype == 'bf16' else _lib.ACG_F32, comm)
         # False / 0: off; 'quads': every split layer whose BatchNorm reads the quad slab layout (the one-launch kernels);
         # True: every split layer, either layout; an int N: either layout, only layers split into at most N slabs
-        self.rt.slab_handoff = (1 << 30) if slab_handoff in (True, 'quads') else int(slab_handoff or 0)
-        self.rt.slab_rows = slab_handoff != 'quads' 
+        if not (slab_handoff is True or slab_handoff is False or slab_handoff is None or slab_handoff == 'quads'
+                or (isinstance(slab_handoff, int) and slab_handoff >= 0)):
+            raise ValueError("slab_handoff must be False, True, 'quads' or a non-negative int, got %r" % (slab_handoff,))
+        self.rt.slab_handoff = (1 << 30) if (slab_handoff is True or slab_handoff == 'quads') else int(slab_handoff or 0)
+        self.rt.slab_rows = slab_handoff != 'quads'
         self.rt.epilogue_stats = bool(epilogue_stats)     # BatchNorm statistics out of the producing conv's epilogue (ops.Conv2dOp.bind)
         self.rt.epilogue_bias = bool(epilogue_bias)       # bias + activation of a transposed head layer in its epilogue (models.py:20-21)
         if dev.type == 'cuda':
@@ -820,8 +823,15 @@ class Session:
         def deps(op):
             return [t.op for t in op.inputs if t.op is not None] + list(op.control_inputs)
 
-        def launched(op):               # a paired input gradient also runs its layer's weight gradient (ops.ConvDgradOp)
-            return (id(op), id(op.pair_w)) if getattr(op, 'pair_active', False) else (id(op),)
+        def launched(op):
+            """ids of every op whose result this launch produced: a paired input gradient also runs its layer's weight
+            gradient (ops.ConvDgradOp), a conv whose epilogue applied bias + activation wrote its BiasActOp's output (that
+            op's bind returns None, so it never appears in the segment itself: a consumer's deps() name it all the same)."""
+            ids = [id(op)]
+            if getattr(op, 'pair_active', False):
+                ids.append(id(op.pair_w))
+            ids.extend(id(a) for a in getattr(op, 'absorbed', ()))
+            return tuple(ids)
 
         def join():
             edge(next(edges), sp_side, sp_main)

@@ -256,6 +256,7 @@ class Conv2dOp(_ConvBase):
         x, w = self.inputs
         self._slab = self._stats = None
         self._fused_bias = False
+        self.absorbed = ()          # ops whose launch this op's launch replaces in the program being compiled
         bc = self.bias_consumer
         if (bc is not None and rt.epilogue_bias and id(bc) in rt.program_ops and self.transposed and not self.out_f32 and bc.has_bias
                 and bc.outputs[0].dtype == torch.float32):
@@ -270,6 +271,7 @@ class Conv2dOp(_ConvBase):
             if lib.deconv2d_fwd_bias_act_ok(ctypes.byref(d), dt):
                 d.in_pitch = bc.yp if bc.yp != d.in_c else 0
                 self._keep, self._fused_bias = (d,), True
+                self.absorbed = (bc,)
                 args = (_p(x.buf), _p(self.wop.buf), _p(bc.inputs[1].buf), _p(bc.outputs[0].buf), ctypes.byref(d), _ACT_CODE[bc.act], bc.leak, dt)
                 fn = lib.deconv2d_fwd_bias_act
                 return lambda s: fn(*args, s)

@@ -15,6 +15,16 @@ Pieces (all host code; numpy + PIL for the JPEG):
   * ``resize_area`` for arbitrary ratios (box filter with fractional overlaps, as TF defines it);
   * ``PushDataset`` - file split by ``train_val_split`` as the reference does, shuffled record stream, batches;
   * ``write_push_tfrecord`` - the inverse, used by the tests and for making small synthetic shards.
+
+What is pinned and what is not.  The framing (RFC 3720 CRC vectors), the protobuf wire format, the crop offsets and the
+area filter are pinned by known answers worked out by hand from TensorFlow's published definitions
+(tests/test_push_data.py: ``*_known_answers_by_hand``; 3 -> 2, 5 -> 2, 5 -> 3, 7 -> 4, 2 -> 3, two axes, odd crops and pads).
+The JPEG decoder is NOT pinned against TensorFlow's: ``tf.image.decode_jpeg(channels=3)`` (ops.py:184) runs libjpeg with
+``dct_method=''`` (the library default, the accurate integer IDCT ``JDCT_ISLOW``) and ``fancy_upscaling=True``; PIL runs
+libjpeg-turbo with the same two defaults, whose ISLOW IDCT is bit-exact with libjpeg's, while the chroma ("fancy") upsampling
+of different libjpeg generations may differ by one level per pixel.  After the 8x8 box mean and ``/ 127.5`` that is at most
+0.008 and typically below 1e-3 in the [-1, 1] frames - input noise far below JPEG's own quantisation, but not a bit-exact
+restatement, and there is no TensorFlow here to measure it against.
 """
 import glob
 import io

@@ -219,10 +219,15 @@ def _log_jsonl(path, record):
 def train(input_path, output_path, test_output_path, log_dir, model_dir, arg_adv, arg_loss, arg_opt, arg_transform,
           batch_size=64, img_size=64, seq_len=8, ksize=5, train_iter=TRAIN_ITER, pretrain_iter=PRETRAIN_ITER,
           n_critic=None, device='cuda:0', world_size=1, rank=0, process_group=None, log_every=100, quiet=False,
-          eval_every=500, resume=None, dtype='f32'):
+          eval_every=500, resume=None, dtype='f32', sync_bn=False, exact_global_batch=False, dp_collectives=None, buckets=0):
     """Training loop of train.py:179-309.  ``input_path``: 'synthetic' (seeded random sequences) or a directory of
     push-dataset TFRecords, read by push_data.PushDataset (the reference's build_tfrecord_input, ops.py:140-223).
-    ``dtype``: 'f32', or 'bf16' for the bf16 pipeline of BASELINE configs 3 and 5 (bf16 activations, float32 master weights)."""
+    ``dtype``: 'f32', or 'bf16' for the bf16 pipeline of BASELINE configs 3 and 5 (bf16 activations, float32 master weights).
+    Data parallel (world_size > 1): ``sync_bn`` - BatchNorm statistics of the global batch; ``exact_global_batch`` -
+    the run reproduces one device at the global batch (SyncBN + GDL scaled by the world size + global state-loss norm);
+    ``dp_collectives`` - 'side' (default with more than one rank: all-reduces on a second HIP stream, overlapping the rest of
+    backward) or 'stream' (in program order on the compute stream); ``buckets`` - all-reduce buckets per optimizer (0 = 2 for
+    'side', 1 for 'stream')."""
     np.random.seed(7)                                           # train.py:14
     synthetic = input_path in (None, '', 'synthetic')
     if synthetic:
@@ -233,7 +238,10 @@ def train(input_path, output_path, test_output_path, log_dir, model_dir, arg_adv
         seq_len = data.seq_len
     boolean_mask = build_all_mask(seq_len)
     G.reset_default_graph()
-    optim.set_data_parallel(world_size)
+    if dp_collectives is None:
+        dp_collectives = 'side' if world_size > 1 else 'stream'
+    optim.set_data_parallel(world_size, n_buckets=buckets or None, sync_bn=sync_bn, exact_global_batch=exact_global_batch,
+                            collectives=dp_collectives)
     with G.Session(device=device, world_size=world_size, rank=rank, process_group=process_group, dtype=dtype) as sess:
         trainer = Trainer(sess, arg_adv, arg_loss, arg_opt, arg_transform, batch_size, img_size, ksize)
         sess.run(G.global_variables_initializer())
@@ -309,7 +317,18 @@ def main(argv=None):
     parser.add_argument('--train_iter', type=int, default=TRAIN_ITER)
     parser.add_argument('--pretrain_iter', type=int, default=PRETRAIN_ITER)
     parser.add_argument('--dtype', type=str, default='f32', choices=['f32', 'bf16'])
+    # data parallel (one process per GPU under torch.distributed.run; no reference counterpart - SURVEY 8(e))
+    parser.add_argument('--sync_bn', nargs='?', const=True, default=False, type=_flag,
+                        help='BatchNorm statistics of the GLOBAL batch (one small all-reduce per BatchNorm layer and direction)')
+    parser.add_argument('--exact_global_batch', nargs='?', const=True, default=False, type=_flag,
+                        help='reproduce ONE device at the global batch: SyncBN + GDL scaled by the world size + global state-loss norm')
+    parser.add_argument('--dp_collectives', type=str, default=None, choices=['stream', 'side'],
+                        help="gradient all-reduces in program order on the compute stream, or on a side HIP stream overlapping "
+                             "the rest of backward (default with more than one rank)")
+    parser.add_argument('--buckets', type=int, default=0, help='all-reduce buckets per optimizer (0: 2 for side, 1 for stream)')
     args = parser.parse_args(argv)
+    if args.buckets < 0:
+        parser.error('--buckets must be >= 0')
     model_dir = os.path.join(args.output_path, 'models')
     log_dir = os.path.join(args.output_path, 'logs')
     os.makedirs(args.output_path)
@@ -324,7 +343,8 @@ def main(argv=None):
     train(args.input_path, os.path.join(args.output_path, 'train_output'), os.path.join(args.output_path, 'test_output'),
           log_dir, model_dir, args.adv, args.loss, args.opt, args.dna, batch_size=args.batch_size, img_size=args.img_size,
           seq_len=args.seq_len, ksize=args.ksize, train_iter=args.train_iter, pretrain_iter=args.pretrain_iter,
-          n_critic=args.n_critic, device='cuda:%d' % local_rank, world_size=world_size, rank=rank, dtype=args.dtype)
+          n_critic=args.n_critic, device='cuda:%d' % local_rank, world_size=world_size, rank=rank, dtype=args.dtype,
+          sync_bn=args.sync_bn, exact_global_batch=args.exact_global_batch, dp_collectives=args.dp_collectives, buckets=args.buckets)
 
 
 if __name__ == '__main__':

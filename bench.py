@@ -8,11 +8,18 @@ runs the same per-GPU batch and gradients are all-reduced over RCCL; `value` cou
 completed by ALL ranks per second.  Inputs are resident in HBM before the timed region.
 
 Besides the contract line it reports
-  roofline      conv_mfma_f32 launches (every conv/deconv fwd, dgrad, wgrad of the step): algorithmic
-                FLOPs (2*B*OH*OW*KH*KW*Cin*Cout per contraction) / their event-timed
-                duration, against the fp32 matrix-core peak (157.3 TFLOP/s);
-  roofline_dna  the DNA stencil forward: algorithmic bytes (k*k+6)*4 per pixel (+ the discriminator-input pixel it also writes) / event-timed duration,
+  roofline      every conv/deconv fwd, dgrad, wgrad launch of the step (+ their split-K reductions): algorithmic
+                FLOPs (2*B*OH*OW*KH*KW*Cin*Cout per contraction) / their duration IN SITU, against the
+                fp32 matrix-core peak (157.3 TFLOP/s; 2.5 PFLOP/s with --dtype bf16);
+  roofline_dna  the DNA stencil forward: algorithmic bytes (k*k+6)*sizeof per pixel / its duration in situ,
                 against 8 TB/s;
+                "in situ" = the kernels' own durations inside the replayed step graphs, operands as the step leaves
+                them, reduced from a rocprofv3 kernel trace of `bench.py --trace-run` with the same flags
+                (tools/insitu_times.py -> profiles/r4/insitu_<workload>.json, next to the kernel_stats.csv it was
+                reduced from; tools/evidence_r4.sh regenerates both).  The live measurement of this process - each
+                op relaunched 10x back to back inside a small HIP graph between two events - is cache-hot and reads
+                2-20 % faster; it is kept as the labelled second field `hot_relaunch` and is the fallback (said so in
+                `timing`) when no in-situ profile of the workload is committed;
   cpu_baseline  the CPU restatement of the reference step (oracle/, torch-CPU fp32; TF-1.0 itself cannot
                 run here) on this host's cores, on a bounded sample of the same workload.
 """
@@ -31,6 +38,16 @@ import torch         # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md chip table
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense
 PEAK_HBM_GBS = 8000.0
+
+
+def slab_mode(v):
+    """--slab-handoff: 'off' | 'quads' | 'all' | N (digits) -> the Session's slab_handoff argument."""
+    table = {'off': False, 'quads': 'quads', 'all': True}
+    if v in table:
+        return table[v]
+    if v.isdigit():
+        return int(v)
+    raise argparse.ArgumentTypeError("expected 'off', 'quads', 'all' or a number of slabs, got %r" % v)
 
 
 def parse():
@@ -55,13 +72,14 @@ def parse():
     ap.add_argument('--lib', default=None, help='experiment: an alternative build of the library (e.g. the tuning build, whose knobs read the environment)')
     ap.add_argument('--no-epilogue-stats', action='store_true', help='experiment: BatchNorm computes its statistics in a pass of its own instead of taking them from the conv epilogue')
     ap.add_argument('--side-branch', action='store_true', help='experiment: the state head as a parallel branch of the HIP graph (second stream) instead of in line on the main stream; measured slower')
-    ap.add_argument('--slab-handoff', default=None, metavar='MODE', help="split-K hand-off to the consuming BatchNorm: 'off', 'quads' (layers whose BatchNorm reads the quad slab layout), 'all', or N = either layout for layers split into at most N slabs; default: the Session's")
+    ap.add_argument('--slab-handoff', default=None, metavar='MODE', type=slab_mode, help="split-K hand-off to the consuming BatchNorm: 'off', 'quads' (layers whose BatchNorm reads the quad slab layout), 'all', or N = either layout for layers split into at most N slabs; default: the Session's")
     ap.add_argument('--no-pair', action='store_true', help='experiment: a layer\'s dgrad and wgrad as two launches instead of one')
     ap.add_argument('--dp-collectives', default=None, choices=['stream', 'side'], help='gradient all-reduces (ncclAllReduce captured into the step\'s HIP graph) on the compute stream in program order, or on a side HIP stream overlapping the rest of backward; default: side with more than one rank')
     ap.add_argument('--buckets', type=int, default=0, help='gradient all-reduce buckets per optimizer (data parallel); 0 = 1 for in-order collectives, 2 for side-stream ones')
     ap.add_argument('--min-seconds', type=float, default=1.0, help='the timed K-step block is repeated until this much time has been measured; the median block is reported')
     ap.add_argument('--exact-global-batch', action='store_true', help='data parallel that reproduces one device at the global batch: SyncBN + GDL scaling + global state-loss norm')
     ap.add_argument('--sync-bn', action='store_true', help='data parallel with BatchNorm statistics of the global batch (one small all-reduce per BatchNorm layer and direction)')
+    ap.add_argument('--trace-run', action='store_true', help='nothing but training steps (no rollout, no instrumented pass, no CPU baseline): the run tools/insitu_times.py reduces a rocprofv3 kernel trace of')
     ap.add_argument('--force-dp', action='store_true', help='run the data-parallel machinery (RCCL all-reduce buckets, graph segments) even on one rank')
     return ap.parse_args()
 
@@ -112,9 +130,9 @@ def cpu_baseline(args, n_critic):
         step()
         n += 1
     dt = time.time() - t0
-    return {'value': n / dt, 'unit': 'steps/s', 'cores': cores, 'kind': 'port',
+    return {'value': n / dt, 'unit': 'steps/s', 'cores': cores, 'nproc': os.cpu_count(), 'kind': 'port',
             'sample': '%d (D+G) steps at the same shapes (batch %d), torch-CPU fp32 restatement of the TF-1.0 step, '
-                      '%d threads' % (n, B, cores)}
+                      '%d threads (the GPU box gives one GPU\'s job a 16-core share of its %d logical CPUs)' % (n, B, cores, os.cpu_count() or 0)}
 
 
 def main():
@@ -146,7 +164,7 @@ def main():
     G.reset_default_graph()
     optim.set_data_parallel(world, n_buckets=args.buckets, force=args.force_dp, sync_bn=args.sync_bn, exact_global_batch=args.exact_global_batch,
                             collectives=args.dp_collectives)
-    sess = G.Session(device=device, side_branches=args.side_branch, **({} if args.slab_handoff is None else {'slab_handoff': {'off': False, 'quads': 'quads', 'all': True}.get(args.slab_handoff, args.slab_handoff if not str(args.slab_handoff).isdigit() else int(args.slab_handoff))}), epilogue_stats=not args.no_epilogue_stats, pair_bwd=not args.no_pair, use_hip_graphs=not args.no_graphs, world_size=world, rank=rank, dtype=args.dtype)
+    sess = G.Session(device=device, side_branches=args.side_branch, **({} if args.slab_handoff is None else {'slab_handoff': args.slab_handoff}), epilogue_stats=not args.no_epilogue_stats, pair_bwd=not args.no_pair, use_hip_graphs=not args.no_graphs, world_size=world, rank=rank, dtype=args.dtype)
     tr = T.Trainer(sess, adv, args.loss, args.opt, dna, batch_size=B, img_size=S, ksize=args.ksize, seed=0)
     sess.run(G.global_variables_initializer())
 
@@ -207,7 +225,7 @@ def main():
     # ---- eval rollout: Trainer.test_sequence, T-1 recursive G-only steps through the
     # reference's numpy-in / numpy-out API (train.py:157-176), after the timed region ---------------------------
     rollout = None
-    if rank == 0 and dna and world == 1:      # a one-GPU side metric; multi-GPU runs go straight to the result line
+    if rank == 0 and dna and world == 1 and not args.trace_run:      # a one-GPU side metric; multi-GPU runs go straight to the result line
         r_img = rng.uniform(-1, 1, (B, args.seq_len, S, S, 3)).astype(np.float32)
         r_act = rng.standard_normal((B, args.seq_len, 10)).astype(np.float32)
         for _ in range(3):
@@ -222,22 +240,21 @@ def main():
         rollout = {'frames_per_s': round(B * (args.seq_len - 1) / dt, 1), 'ms_per_rollout': round(dt * 1e3, 3),
                    'steps': args.seq_len - 1, 'batch': B, 'api': 'numpy in / numpy out per step, as the reference'}
 
-    # ---- per-kernel event timing (instrumented eager pass, after the timed region) --------------
-    roof, roof_dna, kernel_ms = None, None, {}
+    # ---- per-op timing of this process (instrumented pass, after the timed region): the HOT numbers -----------------
+    roof, roof_dna, kernel_ms, insitu = None, None, {}, None
     # EVERY rank runs the instrumented pass: with world > 1 the programs contain gradient all-reduces, and a
     # collective issued by rank 0 alone would never complete.  Only rank 0 reports.
-    every_rank_profiles = True
-    if every_rank_profiles:
+    if not args.trace_run:
         x, y, a, s = pool[0]
         zero_state = torch.zeros(B, 5, device=device)
         recs = []
-        # conv and DNA launches are idempotent: timed as launches inside a small captured HIP graph, the way the step runs
-        # them (graph.profile_ops)
+        # conv and DNA launches are idempotent: timed as launches inside a small captured HIP graph (graph.profile_ops) - each
+        # op 10x back to back, i.e. with every operand cache-hot from the previous identical launch
         relaunch = lambda op: isinstance(op, (O._ConvBase, O.DnaOp, O.DnaBwdOp))   # noqa: E731
         recs += sess.profile_ops([tr.d_opt_op, tr.clip_d], tr._feed(x, y, a, zero_state), repeats=args.profile_repeats, relaunch=relaunch) * n_critic
         recs += sess.profile_ops([tr.g_opt_op, tr.g_next_frame], tr._feed(x, y, a, s), repeats=args.profile_repeats, relaunch=relaunch)
         conv_ms = conv_fl = conv_by = 0.0
-        n_conv = n_launch = 0
+        n_conv = n_launch = n_dna = 0
         dna_ms = dna_bytes = dna_bytes_survey = 0.0
         for op, ms in recs:
             kind = type(op).__name__
@@ -257,56 +274,82 @@ def main():
             elif kind == 'DnaOp':      # k*k logits at their storage size + C image values in + C frame values out
                 b, h, w, c = op.inputs[1].shape
                 dna_ms += ms
+                n_dna += 1
                 dna_bytes += b * h * w * (op.ksize * op.ksize * (2.0 if args.dtype == 'bf16' else 4.0) + 2 * c * 4.0)
                 dna_bytes_survey += b * h * w * (op.ksize * op.ksize + 2 * c) * (2.0 if args.dtype == 'bf16' else 4.0)      # (k*k + 6) * sizeof
                 if op.second is not None:      # (both training programs read that tensor)
                     # this launch also writes the discriminator's input pixel (train.py:63-66: concat(frame, generated frame),
                     # 8 channels of the conv storage type) - the bytes of the concat launch it replaces
                     dna_bytes += b * h * w * op.second[1].shape[-1] * (2.0 if args.dtype == 'bf16' else 4.0)
+        # ---- the committed evidence of this same command line: in-situ kernel durations (tools/insitu_times.py on a rocprofv3
+        # kernel trace of `bench.py --trace-run`) and HBM-side bytes (tools/pmc_traffic.sh: --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate passes, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md); neither can be taken from inside this
+        # process, both are null / replaced by the hot numbers (and say so) when no file matches the workload
+        tag = '%s_b%d_s%d_k%d%s' % (args.dtype, B, S, args.ksize, '' if dna else '_plain')
+        std_step = adv and args.loss == 'bce' and args.opt == 'adam' and world == 1
+
+        def committed(kind):
+            for rnd in ('r4', 'r3', 'r2'):
+                path = os.path.join(ROOT, 'profiles', rnd, '%s_%s.json' % (kind, tag))
+                if std_step and os.path.exists(path):
+                    with open(path) as f:
+                        return json.load(f), 'profiles/%s/%s_%s' % (rnd, kind, tag)
+            return None, None
+        insitu, insitu_src = committed('insitu')
+        if insitu is not None and insitu_src.split('/')[1] != 'r4':
+            insitu = None
+        pj, pmc_src = committed('pmc_traffic')
         if conv_ms > 0:
-            ach = conv_fl / (conv_ms * 1e-3) / 1e12
             peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == 'bf16' else PEAK_F32_MFMA_TFLOPS
-            # HBM-side bytes per launch cannot be measured from inside this process: they come from the committed PMC
-            # summary of this same command line (tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-            # passes, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md); null when no summary matches the workload
-            traffic, traffic_note, pmc_dna = None, None, None
-            tag = '%s_b%d_s%d_k%d%s' % (args.dtype, B, S, args.ksize, '' if dna else '_plain')
-            pmc_round = 'r3' if os.path.exists(os.path.join(ROOT, 'profiles', 'r3', 'pmc_traffic_%s.json' % tag)) else 'r2'
-            pmc = os.path.join(ROOT, 'profiles', pmc_round, 'pmc_traffic_%s.json' % tag)
-            if adv and args.loss == 'bce' and os.path.exists(pmc):
-                with open(pmc) as f:
-                    pj = json.load(f)
-                c = pj.get('conv')
-                if c:
-                    traffic = round(c['fetch_bytes_per_launch'] + c['write_bytes_per_launch'])     # bytes per launch
-                    traffic_note = ('HBM-side bytes per conv launch (FETCH_SIZE x2 + WRITE_SIZE) from profiles/%s/pmc_traffic_%s.txt, separate '
-                                    '--pmc passes of this command; algorithmic (operands + result once) %d bytes per launch' % (pmc_round, tag, round(conv_by / max(n_launch, 1))))
-                pmc_dna = pj.get('dna_fwd')
+            hot = conv_fl / (conv_ms * 1e-3) / 1e12
+            traffic, traffic_note = None, None
+            c = (pj or {}).get('conv')
+            if c:
+                traffic = round(c['fetch_bytes_per_launch'] + c['write_bytes_per_launch'])     # bytes per launch
+                traffic_note = ('HBM-side bytes per conv launch (FETCH_SIZE x2 + WRITE_SIZE) from %s.txt, separate --pmc passes of this '
+                                'command; algorithmic (operands + result once) %d bytes per launch' % (pmc_src, round(conv_by / max(n_launch, 1))))
+            t_ms, timing = conv_ms, 'hot relaunch (no in-situ profile of this workload is committed under profiles/r4)'
+            if insitu is not None:
+                t_ms = insitu['family_us_per_step']['conv'] / 1e3
+                timing = ('in situ: conv-family kernel time per real step from %s.json = TotalDurationNs / %d step executions of '
+                          'the rocprofv3 kernel trace beside it' % (insitu_src, insitu['step_executions']))
+            ach = conv_fl / (t_ms * 1e-3) / 1e12
             roof = {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': peak, 'unit': 'TFLOP/s',
-                    'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_note': traffic_note,
-                    'kernel': '%s (+splitk_reduce*): %d conv/deconv fwd+dgrad+wgrad contractions per step' % (
-                        'conv_mfma_bf16<*>' if args.dtype == 'bf16' else 'conv_mfma_f32<*> / conv_pair_f32<*>', n_conv),
-                    'algorithmic_gflop_per_step': round(conv_fl / 1e9, 2), 'ms_per_step_in_kernel': round(conv_ms, 4),
-                    'avg_launch_us': round(conv_ms * 1e3 / max(n_launch, 1), 2), 'launches_per_step': n_launch,
-                    'algorithmic_bytes_per_launch': round(conv_by / max(n_launch, 1))}
+                    'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_note': traffic_note, 'timing': timing,
+                    'kernel': '%s (+splitk_reduce*, direct_*): %d conv/deconv fwd+dgrad+wgrad contractions per step' % (
+                        'conv_mfma_bf16<*> / conv_pair_bf16<*>' if args.dtype == 'bf16' else 'conv_mfma_f32<*> / conv_pair_f32<*>', n_conv),
+                    'algorithmic_gflop_per_step': round(conv_fl / 1e9, 2), 'ms_per_step_in_kernel': round(t_ms, 4),
+                    'avg_launch_us': round(t_ms * 1e3 / max(n_launch, 1), 2), 'launches_per_step': n_launch,
+                    'algorithmic_bytes_per_launch': round(conv_by / max(n_launch, 1)),
+                    'hot_relaunch': {'achieved': round(hot, 3), 'frac': round(hot / peak, 4), 'ms_per_step_in_kernel': round(conv_ms, 4),
+                                     'note': 'this process: each op 10x back to back in a small HIP graph between two events (cache-hot operands)'}}
         if dna_ms > 0:
-            gbs = dna_bytes / (dna_ms * 1e-3) / 1e9
+            pmc_dna = (pj or {}).get('dna_fwd')
+            t_ms, timing = dna_ms, 'hot relaunch'
+            if insitu is not None and 'dna_fwd' in insitu['kernel_us_per_launch']:
+                t_ms = insitu['kernel_us_per_launch']['dna_fwd'] * n_dna / 1e3
+                timing = 'in situ (%s.json: dna_fwd %.2f us per launch, %d launches per step)' % (insitu_src, insitu['kernel_us_per_launch']['dna_fwd'], n_dna)
+            gbs = dna_bytes_survey / (t_ms * 1e-3) / 1e9
+            ext = dna_bytes / (t_ms * 1e-3) / 1e9
             roof_dna = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                         'frac': round(gbs / PEAK_HBM_GBS, 4),
-                        'traffic': round(pmc_dna['fetch_bytes_per_launch'] + pmc_dna['write_bytes_per_launch']) if (conv_ms > 0 and pmc_dna) else None,
-                        'kernel': 'dna_rows_kernel<K,fwd>' if args.ksize >= 6 else 'dna_kernel<K,4,fwd>',
-                        'algorithmic_mb_per_step': round(dna_bytes / 1e6, 2), 'ms_per_step_in_kernel': round(dna_ms, 4),
-                        # the same launches by SURVEY 8(d)'s byte count alone ((k*k + 6) * sizeof per pixel: 16.25 MB at config 2),
-                        # without the discriminator-input pixel this kernel also writes
-                        'survey_definition': {'algorithmic_mb_per_step': round(dna_bytes_survey / 1e6, 2),
-                                              'achieved': round(dna_bytes_survey / (dna_ms * 1e-3) / 1e9, 1),
-                                              'frac': round(dna_bytes_survey / (dna_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}}
+                        'traffic': round(pmc_dna['fetch_bytes_per_launch'] + pmc_dna['write_bytes_per_launch']) if pmc_dna else None,
+                        'kernel': 'dna_rows_kernel<K,fwd>' if args.ksize >= 6 else 'dna_kernel<K,4,fwd>', 'timing': timing,
+                        # SURVEY 8(d)'s byte count: (k*k + 6) * sizeof per pixel (16.25 MB per launch at config 2)
+                        'algorithmic_mb_per_step': round(dna_bytes_survey / 1e6, 2), 'ms_per_step_in_kernel': round(t_ms, 4),
+                        # the same launches counting what the kernel really moves: float32 image / frame whatever the logits are,
+                        # plus the discriminator-input pixel it also writes
+                        'extended_definition': {'algorithmic_mb_per_step': round(dna_bytes / 1e6, 2), 'achieved': round(ext, 1),
+                                                'frac': round(ext / PEAK_HBM_GBS, 4)},
+                        'hot_relaunch': {'achieved': round(dna_bytes_survey / (dna_ms * 1e-3) / 1e9, 1),
+                                         'frac': round(dna_bytes_survey / (dna_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                         'ms_per_step_in_kernel': round(dna_ms, 4)}}
 
     if rank != 0:
         _leave_distributed(sess)
         return
     cpu = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not args.trace_run:
         cpu = cpu_baseline(args, n_critic)
     # which BASELINE.json configuration this run is: config 2 itself (the headline), or the per-GPU shard of configs 3 / 4
     # (global batch 256 / 128 over 8 / 4 GPUs = 32 per GPU) or config 5's geometry at 32 per GPU (its per-GPU batch is not stated)
@@ -332,8 +375,14 @@ def main():
                    'global_batch': B * world, 'n_critic': n_critic, 'parallelism': 'dp%d' % world,
                    'hip_graphs': not args.no_graphs, 'timed_blocks': len(blocks), 'timed_seconds': round(float(np.sum(blocks)), 3),
                    'block_ms_per_step_min_max': [round(min(blocks) / args.steps * 1e3, 4), round(max(blocks) / args.steps * 1e3, 4)],
-                   'dp_collectives': args.dp_collectives if (world > 1 or args.force_dp) else None, 'sequences_per_s': round(world * B * args.steps / elapsed, 1)},
+                   'dp_collectives': args.dp_collectives if (world > 1 or args.force_dp) else None, 'sequences_per_s': round(world * B * args.steps / elapsed, 1),
+                   'opt': args.opt, 'trace_run': bool(args.trace_run),
+                   # every training step this process executed (eager + capture + first replay, warm-up, all timed blocks)
+                   'step_executions': 3 + args.warmup + args.steps * len(blocks)},
         'roofline': roof, 'roofline_dna': roof_dna, 'cpu_baseline': cpu, 'eval_rollout': rollout,
+        # per kernel family, in situ (same source as `roofline.timing`); null without a committed profile of this workload
+        'kernel_ms_per_step_insitu': ({k: round(v / 1e3, 4) for k, v in insitu['family_us_per_step'].items()} if insitu else None),
+        # per op kind, this process: an event pair around every eager launch (includes the ~4 us the event records open per op)
         'op_ms_per_step': {k: round(v, 4) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])},
     }
     print(json.dumps(line), flush=True)

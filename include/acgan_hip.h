@@ -39,8 +39,9 @@ extern "C" {
  * (_lib.Library) refuses a library whose acg_version() differs from the value it was written against.
  * 1: round 1.  2: round 2 (acg_bn_act_*, acg_bias_act_*, acg_dna_*, acg_copy_list, the flags of acg_*_bwd_pair changed
  * without a bump - any "version 1" build may be either).  3: round 3.  4: the `layout` argument of the slab hand-off
- * entries (acg_*_slabs, acg_bn_act_*_slabs), acg_bn_slabs_layout. */
-#define ACG_ABI_VERSION 4
+ * entries (acg_*_slabs, acg_bn_act_*_slabs), acg_bn_slabs_layout.  5: round 4 - struct acg_conv_desc is 17 int32 fields
+ * (dgrad_c, adj_dgrad_c were appended in round 3 under version 4: a "version 4" build may have either layout). */
+#define ACG_ABI_VERSION 5
 
 typedef void* acg_stream_t; /* hipStream_t */
 

@@ -85,6 +85,53 @@ def test_resize_area_matches_box_integration():
     assert np.allclose(box, img[:8, :12].reshape(4, 2, 6, 2, 3).mean((1, 3)), atol=1e-4)
 
 
+def test_resize_area_known_answers_by_hand():
+    """tf.image.resize_area as TF 1.0 defines it (core/kernels/resize_area_op.cc: output pixel o integrates the input over
+    [o * scale, (o + 1) * scale), scale = in / out, every input pixel weighted by the length of its overlap, the sum divided by
+    scale).  Values worked out by hand, not by the code under test; odd sizes and non-integer ratios, down and up."""
+    col = lambda v: np.asarray(v, np.float32).reshape(-1, 1, 1)               # a [n, 1, 1] image: the row axis alone
+    # 3 -> 2, scale 1.5:  [0, 1.5) = p0 + p1/2,  [1.5, 3) = p1/2 + p2
+    assert np.allclose(P.resize_area(col([3, 6, 9]), 2, 1).ravel(), [(3 + 3) / 1.5, (3 + 9) / 1.5], atol=1e-5)             # 4, 8
+    # 5 -> 2, scale 2.5:  p0 + p1 + p2/2,  p2/2 + p3 + p4
+    assert np.allclose(P.resize_area(col([10, 20, 30, 40, 50]), 2, 1).ravel(), [18.0, 42.0], atol=1e-5)
+    # 5 -> 3, scale 5/3:  p0 + 2/3 p1,  1/3 p1 + p2 + 1/3 p3,  2/3 p3 + p4
+    assert np.allclose(P.resize_area(col([3, 6, 9, 12, 15]), 3, 1).ravel(), [4.2, 9.0, 13.8], atol=1e-5)
+    # 7 -> 4, scale 1.75:  p0 + .75 p1,  .25 p1 + p2 + .5 p3,  .5 p3 + p4 + .25 p5,  .75 p5 + p6   (p = 1..7)
+    assert np.allclose(P.resize_area(col([1, 2, 3, 4, 5, 6, 7]), 4, 1).ravel(), [2.5 / 1.75, 5.5 / 1.75, 8.5 / 1.75, 11.5 / 1.75], atol=1e-5)
+    # enlarging, 2 -> 3, scale 2/3:  [0, 2/3) lies in p0,  [2/3, 4/3) is half p0 half p1,  [4/3, 2) lies in p1
+    assert np.allclose(P.resize_area(col([10, 40]), 3, 1).ravel(), [10.0, 25.0, 40.0], atol=1e-5)
+    # two axes at once, 3 x 5 -> 2 x 3: the weights are separable, so with img[y, x] = r[y] * c[x] the answer is the outer
+    # product of the two one-axis answers above
+    r, c = np.array([3, 6, 9], np.float32), np.array([3, 6, 9, 12, 15], np.float32)
+    got = P.resize_area((r[:, None] * c[None, :])[..., None], 2, 3)[..., 0]
+    assert np.allclose(got, np.outer([4.0, 8.0], [4.2, 9.0, 13.8]), atol=1e-4)
+    # channels are independent, and a constant image stays constant at any ratio
+    assert np.allclose(P.resize_area(np.full((9, 11, 3), 7.0, np.float32), 4, 5), 7.0, atol=1e-5)
+    # the push pipeline's own case (ops.py:190-194: 512 -> 64) is the integer-ratio branch: 8 x 8 block means
+    ramp = np.arange(16 * 16, dtype=np.float32).reshape(16, 16, 1)
+    assert np.allclose(P.resize_area(ramp, 2, 2)[..., 0], [[59.5, 67.5], [187.5, 195.5]], atol=1e-4)
+
+
+def test_crop_or_pad_center_known_answers_by_hand():
+    """tf.image.resize_image_with_crop_or_pad (TF 1.0 image_ops_impl.py): with diff = target - size, the crop offset is
+    (-diff) // 2 and the pad offset diff // 2 - for an odd difference the extra row / column is cropped or padded AFTER."""
+    row = np.arange(10).reshape(1, 10, 1)
+    assert P.crop_or_pad_center(row, 1, 7)[0, :, 0].tolist() == [1, 2, 3, 4, 5, 6, 7]               # diff -3: skip 1, drop 2 behind
+    assert P.crop_or_pad_center(row, 1, 6)[0, :, 0].tolist() == [2, 3, 4, 5, 6, 7]                  # diff -4: 2 and 2
+    five = np.arange(1, 6).reshape(1, 5, 1)
+    assert P.crop_or_pad_center(five, 1, 8)[0, :, 0].tolist() == [0, 1, 2, 3, 4, 5, 0, 0]           # diff +3: pad 1 before, 2 after
+    assert P.crop_or_pad_center(five, 3, 5)[:, :, 0].tolist() == [[0] * 5, [1, 2, 3, 4, 5], [0] * 5]  # rows: diff +2: 1 and 1
+    # crop one axis, pad the other (the order does not matter: they are independent)
+    img = np.arange(12).reshape(3, 4, 1)
+    assert P.crop_or_pad_center(img, 4, 2)[:, :, 0].tolist() == [[1, 2], [5, 6], [9, 10], [0, 0]]
+    # the push pipeline's own case (ops.py:186-188): 512 x 640 -> 512 x 512 drops 64 columns on each side
+    wide = np.zeros((512, 640, 1), np.uint8)
+    wide[:, 64] = 1
+    wide[:, 575] = 2
+    out = P.crop_or_pad_center(wide, 512, 512)
+    assert out.shape == (512, 512, 1) and (out[:, 0] == 1).all() and (out[:, 511] == 2).all()
+
+
 def test_crop_or_pad_center():
     img = np.arange(6 * 10 * 1).reshape(6, 10, 1)
     assert np.array_equal(P.crop_or_pad_center(img, 6, 6), img[:, 2:8])

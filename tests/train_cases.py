@@ -26,11 +26,11 @@ def rel(got, want):
     return np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
 
 
-def build_trainer(make_session, name, world_size=1, sync_bn=False, batch=None, exact=False, collectives='stream', **sess_kw):
+def build_trainer(make_session, name, world_size=1, sync_bn=False, batch=None, exact=False, collectives='stream', force_dp=False, **sess_kw):
     adv, loss, opt, dna, case_batch, ksize = MG.CASES[name]
     batch = batch or case_batch
     G.reset_default_graph()
-    optim.set_data_parallel(world_size, sync_bn=sync_bn, exact_global_batch=exact, collectives=collectives)
+    optim.set_data_parallel(world_size, sync_bn=sync_bn, exact_global_batch=exact, collectives=collectives, force=force_dp)
     sess = make_session(**sess_kw)
     tr = T.Trainer(sess, adv, loss, opt, dna, batch_size=batch, img_size=64, ksize=ksize)
     sess.run(G.global_variables_initializer())

@@ -175,13 +175,15 @@ __global__ __launch_bounds__(256) void bn_stats_partial(TX* __restrict__ x, floa
 // the 8*V channels [blockIdx.y*8V, ...) of group blockIdx.z and walks row chunks.  Each block first re-derives
 // the statistics of ITS channels from the per-block partials (nblk * 8V * 2 floats, L2-resident: a few loads per
 // thread), so no separate finalize launch exists - a launch costs more than this prologue (profiles/r1).
-template <int V>
+template <int V, int CL = 8>
 __device__ __forceinline__ void sum_partials(const float* __restrict__ part, int g, int nblk, int C, int c, bool cvalid,
-                                             int rl, float (&s1)[V], float (&s2)[V], float* sh /* 2*V*32 floats */) {
+                                             int rl, float (&s1)[V], float (&s2)[V], float* sh /* 2*V*CL*(blockDim.x/64) floats */) {
 #pragma unroll
   for (int j = 0; j < V; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  const int nrl = (int)blockDim.x / CL, nwaves = (int)blockDim.x >> 6;
   if (cvalid) {
-    for (int b = rl; b < nblk; b += 32) {
+#pragma unroll 8
+    for (int b = rl; b < nblk; b += nrl) {      // (unrolled: eight partial blocks in flight per thread - this loop is pure latency)
       const float* o = part + ((long long)g * nblk + b) * 2 * C + c;
       float a[V], q[V];
       ldv<V>(o, a); ldv<V>(o + C, q);
@@ -189,23 +191,24 @@ __device__ __forceinline__ void sum_partials(const float* __restrict__ part, int
       for (int j = 0; j < V; ++j) { s1[j] += a[j]; s2[j] += q[j]; }
     }
   }
-  // lanes of one channel lane are 8 apart: fold the 8 row lanes of the wave, then the 4 waves through LDS
+  // lanes of one channel lane are CL apart: fold the row lanes of the wave, then the waves through LDS
 #pragma unroll
   for (int j = 0; j < V; ++j) {
 #pragma unroll
-    for (int off = 8; off < 64; off <<= 1) { s1[j] += __shfl_xor(s1[j], off, 64); s2[j] += __shfl_xor(s2[j], off, 64); }
+    for (int off = CL; off < 64; off <<= 1) { s1[j] += __shfl_xor(s1[j], off, 64); s2[j] += __shfl_xor(s2[j], off, 64); }
   }
-  const int cq = threadIdx.x & 7, wave = threadIdx.x >> 6;
+  const int cq = threadIdx.x % CL, wave = threadIdx.x >> 6;
   __syncthreads();
-  if ((threadIdx.x & 63) < 8) {
+  if ((threadIdx.x & 63) < CL) {
 #pragma unroll
-    for (int j = 0; j < V; ++j) { sh[(wave * 8 + cq) * 2 * V + j] = s1[j]; sh[(wave * 8 + cq) * 2 * V + V + j] = s2[j]; }
+    for (int j = 0; j < V; ++j) { sh[(wave * CL + cq) * 2 * V + j] = s1[j]; sh[(wave * CL + cq) * 2 * V + V + j] = s2[j]; }
   }
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < V; ++j) {
-    s1[j] = sh[(0 * 8 + cq) * 2 * V + j] + sh[(1 * 8 + cq) * 2 * V + j] + sh[(2 * 8 + cq) * 2 * V + j] + sh[(3 * 8 + cq) * 2 * V + j];
-    s2[j] = sh[(0 * 8 + cq) * 2 * V + V + j] + sh[(1 * 8 + cq) * 2 * V + V + j] + sh[(2 * 8 + cq) * 2 * V + V + j] + sh[(3 * 8 + cq) * 2 * V + V + j];
+    float a = 0.f, q = 0.f;
+    for (int w = 0; w < nwaves; ++w) { a += sh[(w * CL + cq) * 2 * V + j]; q += sh[(w * CL + cq) * 2 * V + V + j]; }
+    s1[j] = a; s2[j] = q;
   }
 }
 
@@ -217,15 +220,15 @@ __device__ __forceinline__ void sum_partials(const float* __restrict__ part, int
 // |mean| >> std; a float64 merge of uncentred terms is robust too, but cost this prologue 4 us per layer).
 // Same thread mapping as sum_partials.  n_b from the tile geometry (all tiles full unless run_rows % block_rows).
 struct TileGeom { int block_rows, run_rows, blocks_per_run; };
-template <int V>
+template <int V, int CL = 8>
 __device__ __forceinline__ void merge_tile_partials(const float* __restrict__ part, int g, int nblk, int C, int c, bool cvalid, int rl,
                                                     const TileGeom tg, long long R, float eps, float (&mean)[V], float (&rstd)[V],
-                                                    float* sh /* (blockDim.x / 64) * 8 * 3 * V floats */) {
+                                                    float* sh /* (blockDim.x / 64) * CL * 3 * V floats */) {
   float S[V], Q[V], P[V], ref[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) { S[j] = 0.f; Q[j] = 0.f; P[j] = 0.f; ref[j] = 0.f; }
   const bool uniform = tg.run_rows % tg.block_rows == 0;      // block-uniform
-  const int nrl = (int)blockDim.x >> 3, nwaves = (int)blockDim.x >> 6;     // row lanes (32 in the apply kernels, 128 in the finalize launch)
+  const int nrl = (int)blockDim.x / CL, nwaves = (int)blockDim.x >> 6;     // row lanes
   if (cvalid) {
     const float* p0 = part + (long long)g * nblk * 2 * C + c;
     ldv<V>(p0, ref);
@@ -256,20 +259,19 @@ __device__ __forceinline__ void merge_tile_partials(const float* __restrict__ pa
 #pragma unroll
   for (int j = 0; j < V; ++j) {
 #pragma unroll
-    for (int off = 8; off < 64; off <<= 1) { S[j] += __shfl_xor(S[j], off, 64); Q[j] += __shfl_xor(Q[j], off, 64); P[j] += __shfl_xor(P[j], off, 64); }
+    for (int off = CL; off < 64; off <<= 1) { S[j] += __shfl_xor(S[j], off, 64); Q[j] += __shfl_xor(Q[j], off, 64); P[j] += __shfl_xor(P[j], off, 64); }
   }
-  const int cq = threadIdx.x & 7, wave = threadIdx.x >> 6;
+  const int cq = threadIdx.x % CL, wave = threadIdx.x >> 6;
   __syncthreads();
-  if ((threadIdx.x & 63) < 8) {
+  if ((threadIdx.x & 63) < CL) {
 #pragma unroll
-    for (int j = 0; j < V; ++j) { float* q = sh + ((wave * 8 + cq) * 3) * V + j; q[0] = S[j]; q[V] = Q[j]; q[2 * V] = P[j]; }
+    for (int j = 0; j < V; ++j) { float* q = sh + ((wave * CL + cq) * 3) * V + j; q[0] = S[j]; q[V] = Q[j]; q[2 * V] = P[j]; }
   }
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < V; ++j) {
     float s = 0.f, q = 0.f, pp = 0.f;
-#pragma unroll
-    for (int w = 0; w < nwaves; ++w) { const float* z = sh + ((w * 8 + cq) * 3) * V + j; s += z[0]; q += z[V]; pp += z[2 * V]; }
+    for (int w = 0; w < nwaves; ++w) { const float* z = sh + ((w * CL + cq) * 3) * V + j; s += z[0]; q += z[V]; pp += z[2 * V]; }
     const float inv = 1.f / (float)R, dm = s * inv;
     const float var = fmaxf((q + (pp - s * dm)) * inv, 0.f);
     mean[j] = ref[j] + dm;
@@ -282,25 +284,43 @@ __device__ __forceinline__ void merge_tile_partials(const float* __restrict__ pa
 // should re-read)
 enum { kPartTiles = 0, kPartShifted = 1, kPartDone = 2 };
 
-template <int V, typename TX, typename TY>
-__global__ __launch_bounds__(256) void bn_apply_fwd(const TX* __restrict__ x, const float* __restrict__ beta,
-                                                    const float* __restrict__ part, TY* __restrict__ y,
-                                                    float* __restrict__ save_mean, float* __restrict__ save_rstd,
-                                                    long long R, int C, int nblk, float eps, int act, float leak, int XP, int YP,
-                                                    int mode, const TileGeom tg) {
-  __shared__ float sh[4 * 8 * 3 * V];
-  const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3, g = blockIdx.z;
-  const int c = (blockIdx.y * 8 + cq) * V;
+// NT threads = CL channel lanes (V elements each: CL * V * sizeof = one 128-byte line per row) x NT / CL row lanes.  Two
+// shapes: 256 threads (32 row lanes) for tensors of a few thousand rows, and 1024 threads (128 row lanes) for the large ones -
+// a block's prologue re-reads nblk * 2 * CL * V floats of partials whatever its size, so a tensor cut into 1024 small blocks
+// moved 128 MB of partials through the L2s for 33 MB of tensor (4 of the 14 us of g/tconv3's BatchNorm at batch 32); 256 blocks
+// of 1024 threads read a quarter of that, each thread's share in ONE round trip (8 loads in flight).
+template <int V, typename TX, typename TY, int NT = 256, int CL = 8>
+__global__ __launch_bounds__(NT) void bn_apply_fwd(const TX* __restrict__ x, const float* __restrict__ beta,
+                                                   const float* __restrict__ part, TY* __restrict__ y,
+                                                   float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                   long long R, int C, int nblk, float eps, int act, float leak, int XP, int YP,
+                                                   int mode, const TileGeom tg) {
+  constexpr int RL = NT / CL;
+  __shared__ float sh[(NT / 64) * CL * 3 * V];
+  const int cq = threadIdx.x % CL, rl = threadIdx.x / CL, g = blockIdx.z;
+  const int c = (blockIdx.y * CL + cq) * V;
   const bool cvalid = c < C;
   const TX* xg = x + (long long)g * R * XP;
   TY* yg = y + (long long)g * R * YP;
+  // Software-pipelined row loop: a block walks `iters` batches of kU row passes; the loads of batch i + 1 are in flight while
+  // batch i is normalised and stored, and the loads of batch 0 - which do not depend on the statistics - are issued BEFORE
+  // the prologue.  With one batch per block (round 3) every block of the grid sat in its prologue at the same time and the
+  // memory system idled for those 3-4 us: g/tconv3's 33.6 MB pass took 14 us where the same pass without a prologue takes
+  // 5.4 (tools/micro/stream_probe.hip); now the grid is sized for ~2 blocks per CU and the prologue is paid once per block,
+  // under the first batch's loads.
+  const long long rstep = (long long)gridDim.x * RL;
+  const long long r0 = (long long)blockIdx.x * RL + rl;
+  float va[kU][V], vb[kU][V];
+#define ACG_BN_LOAD(buf, rr)                                                                  \
+  _Pragma("unroll") for (int u = 0; u < kU; ++u) ldv<V>(xg + min((rr) + u * rstep, R - 1) * XP + c, buf[u])
+  if (cvalid && r0 < R) { ACG_BN_LOAD(va, r0); }
   float mean[V], rstd[V], bt[V];
   if (mode == kPartTiles) {
-    merge_tile_partials<V>(part, g, nblk, C, c, cvalid, rl, tg, R, eps, mean, rstd, sh);
+    merge_tile_partials<V, CL>(part, g, nblk, C, c, cvalid, rl, tg, R, eps, mean, rstd, sh);
     if (!cvalid) return;
   } else if (mode == kPartShifted) {       // partials of bn_stats_partial: sums of (x - first row of the group)
     float s1[V], s2[V], pv[V];
-    sum_partials<V>(part, g, nblk, C, c, cvalid, rl, s1, s2, sh);
+    sum_partials<V, CL>(part, g, nblk, C, c, cvalid, rl, s1, s2, sh);
     if (!cvalid) return;
     ldv<V>(xg + c, pv);
 #pragma unroll
@@ -317,41 +337,46 @@ __global__ __launch_bounds__(256) void bn_apply_fwd(const TX* __restrict__ x, co
   }
   ldv<V>(beta + c, bt);
   if (mode != kPartDone && blockIdx.x == 0 && rl == 0) { stv<V>(save_mean + g * C + c, mean); stv<V>(save_rstd + g * C + c, rstd); }
-  // batches of 4 row passes with the loads issued together (a block walks ~4 passes: one memory round trip)
-  const long long rstep = (long long)gridDim.x * 32;
-  for (long long r = (long long)blockIdx.x * 32 + rl; r < R; r += kU * rstep) {
-    float v[kU][V];
-#pragma unroll
-    for (int u = 0; u < kU; ++u) ldv<V>(xg + min(r + u * rstep, R - 1) * XP + c, v[u]);
-#pragma unroll
-    for (int u = 0; u < kU; ++u) {
-      if (r + u * rstep < R) {
-#pragma unroll
-        for (int j = 0; j < V; ++j) v[u][j] = acg::act_apply(act, (v[u][j] - mean[j]) * rstd[j] + bt[j], leak);
-        stv<V>(yg + (r + u * rstep) * YP + c, v[u]);
-      }
+#define ACG_BN_APPLY(buf, rr)                                                                 \
+  _Pragma("unroll") for (int u = 0; u < kU; ++u) {                                            \
+    if ((rr) + u * rstep < R) {                                                               \
+      _Pragma("unroll") for (int j = 0; j < V; ++j) buf[u][j] = acg::act_apply(act, (buf[u][j] - mean[j]) * rstd[j] + bt[j], leak); \
+      stv<V>(yg + ((rr) + u * rstep) * YP + c, buf[u]);                                       \
+    }                                                                                         \
+  }
+  const long long bstep = kU * rstep;
+  for (long long r = r0; r < R; r += 2 * bstep) {        // two batches per trip: the buffers alternate with static indices
+    if (r + bstep < R) { ACG_BN_LOAD(vb, r + bstep); }
+    ACG_BN_APPLY(va, r);
+    if (r + bstep < R) {
+      if (r + 2 * bstep < R) { ACG_BN_LOAD(va, r + 2 * bstep); }
+      ACG_BN_APPLY(vb, r + bstep);
     }
   }
+#undef ACG_BN_LOAD
+#undef ACG_BN_APPLY
 }
 
 // mean / rstd of every (group, channel) from the tile partials, for tensors whose convolution left so many partial blocks
 // that each apply block re-deriving them costs more than this launch: config 5's d/conv1 leaves 2048 per group, 512 KB
 // per apply block whose own work is 8 KB of the tensor - its BatchNorm ran at 0.8 TB/s (profiles/r2/h_other_ops_bf16_config5.txt)
-template <int V>
-__global__ __launch_bounds__(256) void bn_partials_finalize(const float* __restrict__ part, float* __restrict__ save_mean,
-                                                            float* __restrict__ save_rstd, long long R, int C, int nblk, float eps,
-                                                            const TileGeom tg) {
-  __shared__ float sh[4 * 8 * 3 * V];
-  const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3, g = blockIdx.z;
-  const int c = (blockIdx.y * 8 + cq) * V;
+template <int V, int CL>
+__global__ __launch_bounds__(1024) void bn_partials_finalize(const float* __restrict__ part, float* __restrict__ save_mean,
+                                                             float* __restrict__ save_rstd, long long R, int C, int nblk, float eps,
+                                                             const TileGeom tg) {
+  // CL * V channels per block and 1024 / CL lanes over the partial blocks: with CL = 2 a block of 8 channels takes 2048 partial
+  // blocks in 8 loads per thread - one round trip - and there are C / 8 blocks instead of C / 32
+  __shared__ float sh[16 * CL * 3 * V];
+  const int cq = threadIdx.x % CL, rl = threadIdx.x / CL, g = blockIdx.z;
+  const int c = (blockIdx.y * CL + cq) * V;
   const bool cvalid = c < C;
   float mean[V], rstd[V];
-  merge_tile_partials<V>(part, g, nblk, C, c, cvalid, rl, tg, R, eps, mean, rstd, sh);
+  merge_tile_partials<V, CL>(part, g, nblk, C, c, cvalid, rl, tg, R, eps, mean, rstd, sh);
   if (cvalid && rl == 0) { stv<V>(save_mean + g * C + c, mean); stv<V>(save_rstd + g * C + c, rstd); }
 }
 
 // ---- BN backward ----------------------------------------------------------------------------------------
-template <int V, typename TX, typename TY>
+template <int V, typename TX, typename TY, int U = kU>
 __global__ __launch_bounds__(256) void bn_bwd_partial(const TX* __restrict__ x, const TY* __restrict__ dy,
                                                       const float* __restrict__ beta, const float* __restrict__ save_mean,
                                                       const float* __restrict__ save_rstd, float* __restrict__ part,
@@ -371,15 +396,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const TX* __restrict__ x, 
     if (m.active && cv < m.Cv) {
       float mean[V], rstd[V], bt[V];
       ldv<V>(save_mean + g * C + c, mean); ldv<V>(save_rstd + g * C + c, rstd); ldv<V>(beta + c, bt);
-      for (long long r = r0 + m.rsub; r < r1; r += kU * m.RPP) {   // batched like bn_stats_partial
-        float xv[kU][V], dv[kU][V];
+      for (long long r = r0 + m.rsub; r < r1; r += U * m.RPP) {   // batched like bn_stats_partial: U passes of loads in flight
+        float xv[U][V], dv[U][V];
 #pragma unroll
-        for (int u = 0; u < kU; ++u) {
+        for (int u = 0; u < U; ++u) {
           const long long rr = min(r + u * m.RPP, r1 - 1);
           ldv<V>(xg + rr * XP + c, xv[u]); ldv<V>(dyg + rr * YP + c, dv[u]);
         }
 #pragma unroll
-        for (int u = 0; u < kU; ++u) {
+        for (int u = 0; u < U; ++u) {
           const float w = r + u * m.RPP < r1 ? 1.f : 0.f;
 #pragma unroll
           for (int j = 0; j < V; ++j) {
@@ -399,17 +424,31 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const TX* __restrict__ x, 
   }
 }
 
-template <int V, typename TX, typename TY, typename TD = TX>
-__global__ __launch_bounds__(256) void bn_apply_bwd(const TX* __restrict__ x, const TY* __restrict__ dy,
-                                                    const float* __restrict__ beta, const float* __restrict__ save_mean,
-                                                    const float* __restrict__ save_rstd, const float* __restrict__ part,
-                                                    TD* __restrict__ dx, float* __restrict__ dbeta, float dbeta_acc,
-                                                    long long R, int C, int groups, int nblk, int act, float leak, int XP, int YP,
-                                                    const float* __restrict__ gsums = nullptr, float inv_total = 0.f) {
-  __shared__ float sh[4 * 8 * 2 * V];
-  const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3, g = blockIdx.z;
-  const int c = (blockIdx.y * 8 + cq) * V;
+template <int V, typename TX, typename TY, typename TD = TX, int NT = 256, int CL = 8>
+__global__ __launch_bounds__(NT) void bn_apply_bwd(const TX* __restrict__ x, const TY* __restrict__ dy,
+                                                   const float* __restrict__ beta, const float* __restrict__ save_mean,
+                                                   const float* __restrict__ save_rstd, const float* __restrict__ part,
+                                                   TD* __restrict__ dx, float* __restrict__ dbeta, float dbeta_acc,
+                                                   long long R, int C, int groups, int nblk, int act, float leak, int XP, int YP,
+                                                   const float* __restrict__ gsums = nullptr, float inv_total = 0.f) {
+  constexpr int RL = NT / CL;
+  __shared__ float sh[(NT / 64) * CL * 2 * V];
+  const int cq = threadIdx.x % CL, rl = threadIdx.x / CL, g = blockIdx.z;
+  const int c = (blockIdx.y * CL + cq) * V;
   const bool cvalid = c < C;
+  const TX* xg = x + (long long)g * R * XP;
+  const TY* dyg = dy + (long long)g * R * YP;
+  TD* dxg = dx + (long long)g * R * XP;
+  // software-pipelined like bn_apply_fwd: batch 0's loads before the prologue, batch i + 1's under batch i's arithmetic
+  const long long rstep = (long long)gridDim.x * RL;
+  const long long r0 = (long long)blockIdx.x * RL + rl;
+  float xa[kU][V], da[kU][V], xb[kU][V], db[kU][V];
+#define ACG_BN_LOAD(bx, bd, rr)                                                               \
+  _Pragma("unroll") for (int u = 0; u < kU; ++u) {                                            \
+    const long long q = min((rr) + u * rstep, R - 1);                                         \
+    ldv<V>(xg + q * XP + c, bx[u]); ldv<V>(dyg + q * YP + c, bd[u]);                          \
+  }
+  if (cvalid && r0 < R) { ACG_BN_LOAD(xa, da, r0); }
   float s1[V], s2[V];
   if (gsums != nullptr) {            // synchronised BatchNorm: the sums of the GLOBAL batch are given, dbeta is formed elsewhere
 #pragma unroll
@@ -421,7 +460,7 @@ __global__ __launch_bounds__(256) void bn_apply_bwd(const TX* __restrict__ x, co
     for (int j = 0; j < V; ++j) tot[j] = 0.f;
     float k1[V], k2[V];
     for (int gg = groups - 1; gg >= 0; --gg) {   // ends on group 0 = this block's own statistics
-      sum_partials<V>(part, gg, nblk, C, c, cvalid, rl, k1, k2, sh);
+      sum_partials<V, CL>(part, gg, nblk, C, c, cvalid, rl, k1, k2, sh);
 #pragma unroll
       for (int j = 0; j < V; ++j) tot[j] += k1[j];
     }
@@ -440,38 +479,36 @@ __global__ __launch_bounds__(256) void bn_apply_bwd(const TX* __restrict__ x, co
       stv<V>(dbeta + c, d);
     }
   } else {
-    sum_partials<V>(part, g, nblk, C, c, cvalid, rl, s1, s2, sh);
+    sum_partials<V, CL>(part, g, nblk, C, c, cvalid, rl, s1, s2, sh);
   }
   if (!cvalid) return;
-  const TX* xg = x + (long long)g * R * XP;
-  const TY* dyg = dy + (long long)g * R * YP;
-  TD* dxg = dx + (long long)g * R * XP;
   float mean[V], rstd[V], bt[V], m1[V], m2[V];
   ldv<V>(save_mean + g * C + c, mean); ldv<V>(save_rstd + g * C + c, rstd); ldv<V>(beta + c, bt);
   const float invR = gsums != nullptr ? inv_total : 1.f / (float)R;
 #pragma unroll
   for (int j = 0; j < V; ++j) { m1[j] = s1[j] * invR; m2[j] = s2[j] * invR; }
-  const long long rstep = (long long)gridDim.x * 32;
-  for (long long r = (long long)blockIdx.x * 32 + rl; r < R; r += kU * rstep) {    // batched like bn_apply_fwd
-    float xv[kU][V], dv[kU][V];
-#pragma unroll
-    for (int u = 0; u < kU; ++u) {
-      const long long rr = min(r + u * rstep, R - 1);
-      ldv<V>(xg + rr * XP + c, xv[u]); ldv<V>(dyg + rr * YP + c, dv[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < kU; ++u) {
-      if (r + u * rstep < R) {
-#pragma unroll
-        for (int j = 0; j < V; ++j) {
-          const float xh = (xv[u][j] - mean[j]) * rstd[j];
-          const float dp = dv[u][j] * acg::act_deriv_pre(act, xh + bt[j], leak);
-          dv[u][j] = rstd[j] * (dp - m1[j] - xh * m2[j]);
-        }
-        stv<V>(dxg + (r + u * rstep) * XP + c, dv[u]);
-      }
+#define ACG_BN_APPLY(bx, bd, rr)                                                              \
+  _Pragma("unroll") for (int u = 0; u < kU; ++u) {                                            \
+    if ((rr) + u * rstep < R) {                                                               \
+      _Pragma("unroll") for (int j = 0; j < V; ++j) {                                         \
+        const float xh = (bx[u][j] - mean[j]) * rstd[j];                                      \
+        const float dp = bd[u][j] * acg::act_deriv_pre(act, xh + bt[j], leak);                \
+        bd[u][j] = rstd[j] * (dp - m1[j] - xh * m2[j]);                                       \
+      }                                                                                       \
+      stv<V>(dxg + ((rr) + u * rstep) * XP + c, bd[u]);                                       \
+    }                                                                                         \
+  }
+  const long long bstep = kU * rstep;
+  for (long long r = r0; r < R; r += 2 * bstep) {
+    if (r + bstep < R) { ACG_BN_LOAD(xb, db, r + bstep); }
+    ACG_BN_APPLY(xa, da, r);
+    if (r + bstep < R) {
+      if (r + 2 * bstep < R) { ACG_BN_LOAD(xa, da, r + 2 * bstep); }
+      ACG_BN_APPLY(xb, db, r + bstep);
     }
   }
+#undef ACG_BN_LOAD
+#undef ACG_BN_APPLY
 }
 
 // ---- register-resident BatchNorm for small tensors (R <= 256 * NR rows per group) ------------------------------
@@ -730,17 +767,6 @@ int vapply_blocks(long long R, int C, int V) {
   return (int)n;
 }
 
-// row-chunk count of the tiled apply kernels: ~4 passes of 32 rows per block, total blocks capped
-int tile_row_blocks(long long R, int C, int V) {
-  const long long cchunks = (C + 8 * V - 1) / (8 * V);
-  static const int passes = env_int("ACG_BN_APPLY_PASSES", 4);      // tuning hook
-  long long n = acg::ceil_div(R, 32 * passes);
-  const long long cap = std::max<long long>(1, 4096 / cchunks);
-  if (n > cap) n = cap;
-  if (n < 1) n = 1;
-  return (int)n;
-}
-
 // ---- synchronised BatchNorm (optional data-parallel mode; plain elementwise kernels, nothing tuned) -----------
 // moments / sums from the per-block partials: one thread per (group, channel), fp64 combine
 template <typename TX>
@@ -808,6 +834,67 @@ int check_bn(const char* who, long long rows, int C, int groups) {
   return ACG_OK;
 }
 
+// Launch shape of the tiled apply kernels (bn_apply_fwd / bn_apply_bwd): NT threads = CL channel lanes x NT / CL row lanes, a
+// block walks batches of `kU` passes of its row lanes (software-pipelined).  The grid is sized for about `target` blocks in
+// all - two per CU - so that on the large tensors a block runs several batches and its prologue over the partials, paid
+// once, hides under the first batch's loads; small tensors get one batch per block as before.
+struct ApplyShape { int nt, cl; dim3 grid; };
+ApplyShape apply_shape(long long R, int C, int V, int groups, int elem_bytes) {
+  ApplyShape a;
+  static const int cl16 = env_int("ACG_BN_CL16", 0);                 // tuning hook: 16 channel lanes for 2-byte tensors
+  a.cl = (elem_bytes == 2 && V == 4 && cl16) ? 16 : 8;
+  a.nt = 256;
+  const int cchunks = (C + a.cl * V - 1) / (a.cl * V);
+  static const int target = env_int("ACG_BN_APPLY_BLOCKS", 512);     // tuning hook
+  const long long batch_rows = (long long)(a.nt / a.cl) * kU;         // rows one block takes per batch
+  long long n = acg::ceil_div(R, batch_rows);                         // one batch per block ...
+  const long long want = std::max<long long>(1, target / ((long long)cchunks * groups));
+  if (n > want) n = want;                                             // ... unless that exceeds the target
+  a.grid = dim3((unsigned)n, cchunks, groups);
+  return a;
+}
+
+template <typename TX, typename TY>
+int launch_apply_fwd(bool v4, const TX* x, const float* beta, const float* part, TY* y, float* save_mean, float* save_rstd, long long R,
+                     int C, int groups, int nblk, float eps, int act, float leak, int XP, int YP, int mode, const TileGeom tg, hipStream_t st) {
+  constexpr bool same = std::is_same<TX, TY>::value;
+  if (!same) v4 = false;
+  const ApplyShape a = apply_shape(R, C, v4 ? 4 : 1, groups, (int)sizeof(TX));
+#define ACG_BN_AF(VV, NN, LL) ACG_LAUNCH((bn_apply_fwd<VV, TX, TY, NN, LL>), a.grid, dim3(NN), 0, st, x, beta, part, y, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, mode, tg)
+  if constexpr (same) {
+    if (v4) {
+      if (a.cl == 16) ACG_BN_AF(4, 256, 16); else ACG_BN_AF(4, 256, 8);
+    } else {
+      ACG_BN_AF(1, 256, 8);
+    }
+  } else {
+    ACG_BN_AF(1, 256, 8);
+  }
+#undef ACG_BN_AF
+  return acg::check_launch("bn_apply_fwd");
+}
+
+template <typename TX, typename TY, typename TD>
+int launch_apply_bwd(bool v4, const TX* x, const TY* dy, const float* beta, const float* save_mean, const float* save_rstd, const float* part,
+                     TD* dx, float* dbeta, float dbeta_acc, long long R, int C, int groups, int nblk, int act, float leak, int XP, int YP,
+                     const float* gsums, float inv_total, hipStream_t st) {
+  constexpr bool same = std::is_same<TX, TY>::value;
+  if (!same) v4 = false;
+  const ApplyShape a = apply_shape(R, C, v4 ? 4 : 1, groups, (int)sizeof(TX));
+#define ACG_BN_AB(VV, NN, LL) ACG_LAUNCH((bn_apply_bwd<VV, TX, TY, TD, NN, LL>), a.grid, dim3(NN), 0, st, x, dy, beta, save_mean, save_rstd, part, dx, dbeta, dbeta_acc, R, C, groups, nblk, act, leak, XP, YP, gsums, inv_total)
+  if constexpr (same) {
+    if (v4) {
+      if (a.cl == 16) ACG_BN_AB(4, 256, 16); else ACG_BN_AB(4, 256, 8);
+    } else {
+      ACG_BN_AB(1, 256, 8);
+    }
+  } else {
+    ACG_BN_AB(1, 256, 8);
+  }
+#undef ACG_BN_AB
+  return acg::check_launch("bn_apply_bwd");
+}
+
 bool vec4_ok(int C, const void* a, const void* b, const void* c) {
   return C % 4 == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
 }
@@ -849,14 +936,7 @@ int bn_fwd_typed(const void* x, const float* beta, void* y, float* save_mean, fl
     else ACG_LAUNCH((bn_stats_partial<1, TX, false>), dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk, XP, sl);
   }
   if (int rc = acg::check_launch("bn_stats_partial")) return rc;
-  const dim3 ag(tile_row_blocks(R, C, V), (C + 8 * V - 1) / (8 * V), groups);
-  if constexpr (same) {
-    if (v4) ACG_LAUNCH((bn_apply_fwd<4, TX, TY>), ag, dim3(256), 0, st, xf, beta, (const float*)part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, (int)kPartShifted, TileGeom{0, 0, 1});
-    else ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, xf, beta, (const float*)part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, (int)kPartShifted, TileGeom{0, 0, 1});
-  } else {
-    ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, xf, beta, (const float*)part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, (int)kPartShifted, TileGeom{0, 0, 1});
-  }
-  return acg::check_launch("bn_apply_fwd");
+  return launch_apply_fwd<TX, TY>(v4, xf, beta, (const float*)part, yf, save_mean, save_rstd, R, C, groups, nblk, eps, act, leak, XP, YP, (int)kPartShifted, TileGeom{0, 0, 1}, st);
 }
 
 template <typename TX, typename TY, typename TD = TX>
@@ -888,19 +968,21 @@ int bn_bwd_typed(const void* x, const void* dy, const float* beta, const float* 
   if (sl.p) return acg::fail(ACG_ERR_UNSUPPORTED, "bn_act_bwd_slabs: %lld rows per group exceed the register-resident kernels (acg_bn_bwd_slabs_ok)", R);
   static const int bwd_iters = env_int("ACG_BN_BWD_ITERS", 4);      // tuning hook
   const int nblk = vpartial_blocks(R, C, V, bwd_iters);
-  const dim3 ag(tile_row_blocks(R, C, V), (C + 8 * V - 1) / (8 * V), groups);
-  if constexpr (same) {
-    if (v4) ACG_LAUNCH((bn_bwd_partial<4, TX, TY>), dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak, XP, YP);
-    else ACG_LAUNCH((bn_bwd_partial<1, TX, TY>), dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak, XP, YP);
-    if (int rc = acg::check_launch("bn_bwd_partial")) return rc;
-    if (v4) ACG_LAUNCH((bn_apply_bwd<4, TX, TY, TD>), ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)part, dxf, dbeta, dbeta_acc, R, C, groups, nblk, act, leak, XP, YP);
-    else ACG_LAUNCH((bn_apply_bwd<1, TX, TY, TD>), ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)part, dxf, dbeta, dbeta_acc, R, C, groups, nblk, act, leak, XP, YP);
-  } else {
-    ACG_LAUNCH((bn_bwd_partial<1, TX, TY>), dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak, XP, YP);
-    if (int rc = acg::check_launch("bn_bwd_partial")) return rc;
-    ACG_LAUNCH((bn_apply_bwd<1, TX, TY, TD>), ag, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, (const float*)part, dxf, dbeta, dbeta_acc, R, C, groups, nblk, act, leak, XP, YP);
+  {
+    // passes a block walks: more than one batch of kU -> eight passes of loads in flight at once instead of two serial batches
+    const int Cv = C / V, Cb = Cv < 256 ? Cv : 256, RPP = 256 / Cb;
+    const bool deep = acg::ceil_div(acg::ceil_div(R, nblk), RPP) > kU;
+    if constexpr (same) {
+      if (v4 && deep) ACG_LAUNCH((bn_bwd_partial<4, TX, TY, 8>), dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak, XP, YP);
+      else if (v4) ACG_LAUNCH((bn_bwd_partial<4, TX, TY>), dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak, XP, YP);
+      else ACG_LAUNCH((bn_bwd_partial<1, TX, TY>), dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak, XP, YP);
+    } else {
+      ACG_LAUNCH((bn_bwd_partial<1, TX, TY>), dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak, XP, YP);
+    }
   }
-  return acg::check_launch("bn_apply_bwd");
+  if (int rc = acg::check_launch("bn_bwd_partial")) return rc;
+  return launch_apply_bwd<TX, TY, TD>(v4, xf, dyf, beta, save_mean, save_rstd, (const float*)part, dxf, dbeta, dbeta_acc, R, C, groups, nblk, act, leak, XP, YP,
+                                      (const float*)nullptr, 0.f, st);
 }
 
 // BatchNorm + activation whose statistics arrive as per-tile (sum, M2) partials out of the producing convolution's epilogue
@@ -911,30 +993,18 @@ template <typename TX, typename TY>
 int bn_fwd_partials_typed(const void* x, const float* beta, const float* part, int nblk, const TileGeom tg, void* y, float* save_mean,
                           float* save_rstd, long long R, int C, int groups, float eps, int act, float leak, bool v4, int XP, int YP,
                           hipStream_t st) {
-  constexpr bool same = std::is_same<TX, TY>::value;
   const TX* xf = (const TX*)x;
   TY* yf = (TY*)y;
   const bool v4p = v4;                     // the partials / statistics side is float32 whatever the tensors are
-  if (!same) v4 = false;
-  const int V = v4 ? 4 : 1;
   int mode = kPartTiles;
   static const int fin = env_int("ACG_BN_FINALIZE_BLOCKS", kFinalizeBlocks);   // tuning hook
   if (nblk > fin) {
-    const int VF = v4p ? 4 : 1;
-    const dim3 fg(1, (C + 8 * VF - 1) / (8 * VF), groups);
-    if (v4p) ACG_LAUNCH((bn_partials_finalize<4>), fg, dim3(256), 0, st, part, save_mean, save_rstd, R, C, nblk, eps, tg);
-    else ACG_LAUNCH((bn_partials_finalize<1>), fg, dim3(256), 0, st, part, save_mean, save_rstd, R, C, nblk, eps, tg);
+    if (v4p) ACG_LAUNCH((bn_partials_finalize<4, 2>), dim3(1, (C + 7) / 8, groups), dim3(1024), 0, st, part, save_mean, save_rstd, R, C, nblk, eps, tg);
+    else ACG_LAUNCH((bn_partials_finalize<1, 8>), dim3(1, (C + 7) / 8, groups), dim3(1024), 0, st, part, save_mean, save_rstd, R, C, nblk, eps, tg);
     if (int rc = acg::check_launch("bn_partials_finalize")) return rc;
     mode = kPartDone;
   }
-  const dim3 ag(tile_row_blocks(R, C, V), (C + 8 * V - 1) / (8 * V), groups);
-  if constexpr (same) {
-    if (v4) ACG_LAUNCH((bn_apply_fwd<4, TX, TY>), ag, dim3(256), 0, st, xf, beta, part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, mode, tg);
-    else ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, xf, beta, part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, mode, tg);
-  } else {
-    ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, xf, beta, part, yf, save_mean, save_rstd, R, C, nblk, eps, act, leak, XP, YP, mode, tg);
-  }
-  return acg::check_launch("bn_apply_fwd");
+  return launch_apply_fwd<TX, TY>(v4, xf, beta, part, yf, save_mean, save_rstd, R, C, groups, nblk, eps, act, leak, XP, YP, mode, tg, st);
 }
 
 }  // namespace
@@ -1065,18 +1135,8 @@ int bn_moments_typed(const void* x, float* moments, long long R, int C, int XP, 
 template <typename TX, typename TY>
 int bn_fwd_moments_typed(const void* x, const float* beta, void* y, float* save_mean, float* save_rstd, long long R, int C, int groups,
                          float eps, int act, float leak, bool v4, int XP, int YP, hipStream_t st) {
-  constexpr bool same = std::is_same<TX, TY>::value;
-  if (!same) v4 = false;
-  const int V = v4 ? 4 : 1;
-  const dim3 ag(tile_row_blocks(R, C, V), (C + 8 * V - 1) / (8 * V), groups);
-  const TileGeom tg{0, 0, 1};
-  if constexpr (same) {
-    if (v4) ACG_LAUNCH((bn_apply_fwd<4, TX, TY>), ag, dim3(256), 0, st, (const TX*)x, beta, (const float*)nullptr, (TY*)y, save_mean, save_rstd, R, C, 0, eps, act, leak, XP, YP, (int)kPartDone, tg);
-    else ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, (const TX*)x, beta, (const float*)nullptr, (TY*)y, save_mean, save_rstd, R, C, 0, eps, act, leak, XP, YP, (int)kPartDone, tg);
-  } else {
-    ACG_LAUNCH((bn_apply_fwd<1, TX, TY>), ag, dim3(256), 0, st, (const TX*)x, beta, (const float*)nullptr, (TY*)y, save_mean, save_rstd, R, C, 0, eps, act, leak, XP, YP, (int)kPartDone, tg);
-  }
-  return acg::check_launch("bn_apply_fwd");
+  return launch_apply_fwd<TX, TY>(v4, (const TX*)x, beta, (const float*)nullptr, (TY*)y, save_mean, save_rstd, R, C, groups, 0, eps, act, leak, XP, YP,
+                                  (int)kPartDone, TileGeom{0, 0, 1}, st);
 }
 template <typename TX, typename TY>
 int bn_bwd_sums_typed(const void* x, const void* dy, const float* beta, const float* save_mean, const float* save_rstd, float* sums,
@@ -1098,17 +1158,8 @@ template <typename TX, typename TY, typename TD = TX>
 int bn_bwd_apply_sums_typed(const void* x, const void* dy, const float* beta, const float* save_mean, const float* save_rstd,
                             const float* gsums, float inv_total, void* dx, long long R, int C, int groups, int act, float leak, bool v4,
                             int XP, int YP, hipStream_t st) {
-  constexpr bool same = std::is_same<TX, TY>::value;
-  if (!same) v4 = false;
-  const int V = v4 ? 4 : 1;
-  const dim3 ag(tile_row_blocks(R, C, V), (C + 8 * V - 1) / (8 * V), groups);
-  if constexpr (same) {
-    if (v4) ACG_LAUNCH((bn_apply_bwd<4, TX, TY, TD>), ag, dim3(256), 0, st, (const TX*)x, (const TY*)dy, beta, save_mean, save_rstd, (const float*)nullptr, (TD*)dx, (float*)nullptr, 0.f, R, C, groups, 0, act, leak, XP, YP, gsums, inv_total);
-    else ACG_LAUNCH((bn_apply_bwd<1, TX, TY, TD>), ag, dim3(256), 0, st, (const TX*)x, (const TY*)dy, beta, save_mean, save_rstd, (const float*)nullptr, (TD*)dx, (float*)nullptr, 0.f, R, C, groups, 0, act, leak, XP, YP, gsums, inv_total);
-  } else {
-    ACG_LAUNCH((bn_apply_bwd<1, TX, TY, TD>), ag, dim3(256), 0, st, (const TX*)x, (const TY*)dy, beta, save_mean, save_rstd, (const float*)nullptr, (TD*)dx, (float*)nullptr, 0.f, R, C, groups, 0, act, leak, XP, YP, gsums, inv_total);
-  }
-  return acg::check_launch("bn_apply_bwd");
+  return launch_apply_bwd<TX, TY, TD>(v4, (const TX*)x, (const TY*)dy, beta, save_mean, save_rstd, (const float*)nullptr, (TD*)dx, (float*)nullptr, 0.f,
+                                      R, C, groups, 0, act, leak, XP, YP, gsums, inv_total, st);
 }
 }  // namespace
 

@@ -466,7 +466,20 @@ def test_epilogue_statistics_match_the_statistics_pass(dtype):
     # ~1/30 of dy, so a 2e-3 relative perturbation of the normalised logits is 5-10 % of the gradient.  That is the floor of
     # ANY two bf16 runs of this model (the bf16-vs-oracle tests above sit at cosine 0.9967 = 8 %); measured here with eight
     # distinct samples: D 6.3e-2, G 4.6e-2 (G: ~200 of the frame-loss kinks flip under a 1e-4 change of the frame).
+    # Round 4: the bf16 discriminator bar is no longer a number picked to pass.  The oracle's bf16-storage emulation is run
+    # twice on THESE inputs and weights, the second time with d/conv1's conv output perturbed by 1e-7 (what another summation
+    # order does): that difference - 4.2e-2 here - is the model's own sensitivity, independent of any kernel
+    # (tests/bf16_head_sensitivity.py; profiles/r4/n_bf16_head_sensitivity.txt shows that it does not move when the head's
+    # neighbourhood is kept in float32, only when whole layers of D leave bf16).  Two HIP runs differ at EVERY BatchNorm of G and
+    # D, not at one: they may differ by at most twice that.
     tols = {'f32': (2e-5, 5e-3), 'bf16': (0.1, 0.1)}[dtype]
+    if dtype == 'bf16':
+        import bf16_head_sensitivity as HS
+        from oracle import models as OM
+        floor = HS.run_to_run_floor(OM.init_params(True, batch=8, ksize=5, seed=TC.MG.PARAM_SEED, dtype=torch.float32), xs, ys, as_)
+        print('oracle run-to-run floor of the bf16 D gradient on these inputs: %.3g' % floor)
+        assert 1e-2 < floor < 6e-2, floor
+        tols = (2.0 * floor, 0.1)
     for a0, a1, who, tol in zip(g0, g1, ('d', 'g'), tols):
         err = float((a0 - a1).norm() / a0.norm())
         print('epilogue statistics vs pass, %s, %s gradient: relative difference %.3g' % (dtype, who, err))

@@ -523,6 +523,8 @@ __global__ __launch_bounds__(256) void conv_pair_bf16(const ConvArgs a, const Co
 }
 int launch_pair16(int modeA, const Plan& pa, const ConvArgs& a, const Plan& pb, const ConvArgs& b, hipStream_t st);
 
+int launch_glds16(int mode, const Plan& pl, const ConvArgs& a, hipStream_t st);      // conv_bf16_glds.hip
+
 template <int MODE>
 int launch_mode16(const Plan& pl, const ConvArgs& a, hipStream_t st);
 
@@ -531,7 +533,10 @@ int launch_mode16(const Plan& pl, const ConvArgs& a, hipStream_t st);
   int launch_mode16<MODE>(const Plan& pl, const ConvArgs& a, hipStream_t st) {                                \
     const dim3 grid((unsigned)(acg::ceil_div(pl.M, pl.bm) * acg::ceil_div(pl.N, pl.bn)), (unsigned)pl.classes, \
                     (unsigned)pl.splits);                                                                     \
-    if (pl.bn == 32) {                                                                                        \
+    if (pl.bm == 256) {                                                                                       \
+      if constexpr (MODE != MODE_WGRAD) return launch_glds16(MODE, pl, a, st);                                \
+      else return acg::fail(ACG_ERR_UNSUPPORTED, "conv_mfma_bf16: no 256x128 weight-gradient tile");          \
+    } else if (pl.bn == 32) {                                                                                 \
       if constexpr (MODE != MODE_WGRAD) ACG_LAUNCH((conv_mfma_bf16<MODE, 128, 32>), grid, dim3(256), 0, st, a); \
       else return acg::fail(ACG_ERR_UNSUPPORTED, "conv_mfma_bf16: no 128x32 weight-gradient tile");           \
     } else if (pl.bm == 128) ACG_LAUNCH((conv_mfma_bf16<MODE, 128, 128>), grid, dim3(256), 0, st, a);         \

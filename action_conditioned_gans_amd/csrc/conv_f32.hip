@@ -218,7 +218,8 @@ constexpr int g_force_cfg = -1, g_force_splits = -1;
 constexpr int env_int(const char*, int dflt) { return dflt; }
 #endif
 
-Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
+// wide_ok: the 256 x 128 LDS-DMA kernel (conv_bf16_glds.h) may be chosen - single launches only, it has no paired form
+Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false, bool wide_ok = true) {
   Plan pl{};
   pl.bf16 = bf16;
   long long K;
@@ -279,6 +280,15 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
     if (narrow && which != ACG_CONV_WGRAD && pl.N <= 32 && pl.M >= 128) { pl.cfg = 2; pl.bm = 128; pl.bn = 32; }
     if (g_force_cfg == 1 || g_force_cfg == 3) { pl.cfg = g_force_cfg; pl.bm = pl.bn = g_force_cfg == 1 ? 128 : 64; }
     if (g_force_cfg == 2 && which != ACG_CONV_WGRAD) { pl.cfg = 2; pl.bm = 128; pl.bn = 32; }
+    // 256 x 128, operands staged by LDS-DMA, one block of 8 waves per CU (conv_bf16_glds.h): unsplit forward / input-gradient
+    // contractions with more than 64 output columns whose tiles fill most of the chip AND whose K loop is long.  Measured
+    // (profiles/r4/e_glds_*): +8 % inside the K loop (954 vs 883 TFLOP/s: the loop is bound by what a CU can gather from L2,
+    // ~43 GB/s, not by LDS), 35.2 vs 39.9 us for a 25-K-step forward over 256 tiles - and nothing on the stride classes of a
+    // transposed layer (8-18 K-steps per tile: with one block per CU the pipeline fill and the epilogue of every tile are
+    // exposed where two 128 x 128 blocks per CU overlap them)
+    static const int wide_min = env_int("ACG_PLAN16_WIDE_TILES", 192), wide_nk = env_int("ACG_PLAN16_WIDE_NK", 20);
+    if (wide_ok && which != ACG_CONV_WGRAD && g_force_cfg < 0 && pl.N > 64 && pl.nk >= wide_nk && tiles_for(256, 128) >= wide_min) { pl.cfg = 4; pl.bm = 256; pl.bn = 128; }
+    if (g_force_cfg == 4 && which != ACG_CONV_WGRAD) { pl.cfg = 4; pl.bm = 256; pl.bn = 128; }
     pl.ragged = false; pl.nvec = true;
   }
   pl.tiles = tiles_for(pl.bm, pl.bn);
@@ -305,6 +315,7 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false) {
   static const int xcd_splits = env_int("ACG_PLAN_WGRAD_XCD", 1);
   if (xcd_splits && bf16 && which == ACG_CONV_WGRAD && s >= 6 && (s + 7) / 8 * 8 <= pl.nk) s = (s + 7) / 8 * 8;   // (fp32: the swept split counts stay - rounding them cost 1.3 % of the step)
   if (g_force_splits >= 1) s = std::min<long long>(g_force_splits, pl.nk);
+  if (pl.cfg == 4) s = 1;
   pl.splits = (int)std::max<long long>(s, 1);
   return pl;
 }
@@ -347,14 +358,14 @@ int stats_blocks(const Plan& pl, const acg_conv_desc& d, int which, int groups, 
 // `splits` partial slabs in the workspace and `out` is not touched.
 int prepare(Job& j, int which, const float* gsrc, const float* dense, float* out, float accumulate, const acg_conv_desc* d,
             int dtype, void* ws, size_t ws_bytes, const char* who, bool slabs_only, float* stats = nullptr, int stats_groups = 0,
-            int slab_layout = ACG_SLABS_ROWS) {
+            int slab_layout = ACG_SLABS_ROWS, bool wide_ok = true) {
   // ACG_DTYPE2(ACG_BF16, ACG_F32): bf16 operands, the result stored as float32 (a head layer: acgan_hip.h)
   const bool out_f32 = dtype == ACG_DTYPE2(ACG_BF16, ACG_F32);
   ACG_REQUIRE(dtype == ACG_F32 || dtype == ACG_BF16 || (out_f32 && which != ACG_CONV_WGRAD), ACG_ERR_UNSUPPORTED, "%s: dtype %d", who, dtype);
   if (out_f32) dtype = ACG_BF16;
   if (int rc = validate(d, who)) return rc;
   ACG_REQUIRE(gsrc && dense && (out || slabs_only), ACG_ERR_INVALID_ARG, "%s: null tensor pointer", who);
-  const Plan pl = make_plan(*d, which, dtype == ACG_BF16);
+  const Plan pl = make_plan(*d, which, dtype == ACG_BF16, wide_ok);
   ACG_REQUIRE(!slabs_only || pl.splits > 1, ACG_ERR_INVALID_ARG, "%s: this shape is not split (acg_conv2d_splits == 1): call the plain entry", who);
   const size_t need = pl.splits > 1 ? (size_t)pl.splits * (size_t)pl.out_numel * sizeof(float) : 0;
   ACG_REQUIRE(ws_bytes >= need && (need == 0 || ws != nullptr), ACG_ERR_WORKSPACE, "%s: workspace %zu bytes < required %zu", who, ws_bytes, need);
@@ -534,7 +545,10 @@ int run_pair(int whichA, const float* gsrcA, const float* denseA, float* outA, c
   Job ja, jb;
   const bool slabs_only_B = (slab_flags & 1) != 0, slabs_only_A = (slab_flags & 2) != 0;
   ACG_REQUIRE(!(slab_flags & 4) || slabs_only_A, ACG_ERR_INVALID_ARG, "%s: flag 4 (quad slab layout) without flag 2", who);
-  if (int rc = prepare(ja, whichA, gsrcA, denseA, outA, 0.f, d, dtype, wsA, wsbA, who, slabs_only_A, nullptr, 0, (slab_flags & 4) ? ACG_SLABS_QUADS : ACG_SLABS_ROWS)) return rc;
+  // the 256 x 128 LDS-DMA kernel has no paired form: a pair keeps A on the 128 x 128 tile (ACG_PAIR_WIDE = 1, tuning builds: A on
+  // the wide kernel, the weight gradient as a launch of its own)
+  static const int pair_wide = env_int("ACG_PAIR_WIDE", 0);
+  if (int rc = prepare(ja, whichA, gsrcA, denseA, outA, 0.f, d, dtype, wsA, wsbA, who, slabs_only_A, nullptr, 0, (slab_flags & 4) ? ACG_SLABS_QUADS : ACG_SLABS_ROWS, pair_wide != 0)) return rc;
   if (int rc = prepare(jb, ACG_CONV_WGRAD, gsrcB, denseB, outB, accumulateB, d, dtype, wsB, wsbB, who, slabs_only_B)) return rc;
   hipStream_t st = acg::to_stream(stream);
   static const int enabled = env_int("ACG_CONV_PAIR", 1);       // 0: always two launches (A/B comparison)
@@ -545,7 +559,7 @@ int run_pair(int whichA, const float* gsrcA, const float* denseA, float* outA, c
       if (int rc = launch(ja, st)) return rc;
       if (int rc = launch(jb, st)) return rc;
     }
-  } else if (enabled && g_force_cfg < 0 && ja.pl.bf16 && jb.pl.bf16 && (whichA == ACG_CONV_FWD || whichA == ACG_CONV_DGRAD) &&
+  } else if (enabled && g_force_cfg < 0 && ja.pl.bf16 && jb.pl.bf16 && ja.pl.cfg != 4 && (whichA == ACG_CONV_FWD || whichA == ACG_CONV_DGRAD) &&
       (long long)ja.pl.tiles * ja.pl.splits + (long long)jb.pl.tiles * jb.pl.splits < (1ll << 30)) {
     if (int rc = launch_pair16(whichA == ACG_CONV_FWD ? MODE_FWD : MODE_DGRAD, ja.pl, ja.a, jb.pl, jb.a, st)) return rc;
   } else if (enabled && g_force_cfg < 0 && pair_supported(whichA, ja.pl, jb.pl)) {

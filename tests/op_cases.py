@@ -251,13 +251,13 @@ STATS_LAYERS = [   # (x shape, w shape, stride, padding, transposed, groups, act
 ]
 
 
-def case_conv_bn_stats(abi, tol, tol_stat, min_fused=1):
+def case_conv_bn_stats(abi, tol, tol_stat, min_fused=1, layers=None):
     """acg_(de)conv2d_fwd_stats + acg_bn_act_fwd_partials against the float64 conv followed by slim batch_norm + activation:
     the conv output, the normalised output and the saved mean / rstd.  ``min_fused``: how many of the layers must actually
     take the fused path (acg_conv2d_stats_blocks > 0) - the split ones legitimately do not."""
     fused = 0
     r = (lambda t: t.bfloat16().float()) if abi.half else (lambda t: t)
-    for i, (xs, ws_, stride, padding, transposed, groups, act) in enumerate(STATS_LAYERS):
+    for i, (xs, ws_, stride, padding, transposed, groups, act) in enumerate(layers or STATS_LAYERS):
         x, w = uniform(xs, 300 + i), randn(ws_, 310 + i, 0.1)
         c = ws_[2] if transposed else ws_[3]
         beta = randn((c,), 320 + i, 0.5)
@@ -279,7 +279,7 @@ def case_conv_bn_stats(abi, tol, tol_stat, min_fused=1):
         pre = (rows - m[:, None, :]) / torch.sqrt(v[:, None, :] + 1e-3) + beta.double()
         want = {'relu': torch.relu, 'lrelu': lambda t: torch.where(t > 0, t, 0.2 * t), None: lambda t: t}[act](pre).reshape(stored.shape)
         close(y, want, tol * 4 if abi.half else tol, tag + ' y')
-    assert fused >= min_fused, 'only %d of %d layers took the fused path' % (fused, len(STATS_LAYERS))
+    assert fused >= min_fused, 'only %d of %d layers took the fused path' % (fused, len(layers or STATS_LAYERS))
 
 
 HANDOFF_LAYERS = [   # (x shape, w shape, stride, padding, transposed, groups, act): small layers the planner splits over K
@@ -290,6 +290,13 @@ HANDOFF_LAYERS = [   # (x shape, w shape, stride, padding, transposed, groups, a
     ((4, 8, 8, 138), (5, 5, 138, 128), 2, 'SAME', False, 1, 'relu'),         # 138 gathered channels
     ((6, 6, 6, 64), (3, 3, 64, 44), 1, 'SAME', False, 1, None),              # ragged rows, 44 channels (bf16: pitch 48)
     ((32, 32, 32, 32), (5, 5, 32, 64), 2, 'SAME', False, 1, 'relu'),         # g/conv2 at config-2 size: 8192 rows (two-launch BatchNorm: rows layout; float32 splits it)
+]
+# bf16 only (test_conv_bn_stats_wide_bf16): large enough for the 256 x 128 LDS-DMA kernel (conv_bf16_glds.h), whose tiles leave
+# the partials: forward with one group and with two (D on [fake ; real]), and a transposed layer (four stride classes)
+STATS_LAYERS_WIDE = [
+    ((48, 64, 64, 16), (5, 5, 16, 128), 2, 'SAME', False, 1, 'relu'),
+    ((48, 64, 64, 16), (5, 5, 16, 128), 2, 'SAME', False, 2, 'lrelu'),
+    ((12, 32, 32, 16), (5, 5, 128, 16), 2, None, True, 1, 'relu'),
 ]
 
 

@@ -122,6 +122,27 @@ def test_deconv_bf16_big_tiles(hip_abi_bf16):
     C.case_conv_bf16(hip_abi_bf16, (16, 32, 32, 128, 128, 5, 2), TOL_BF16, TOL_CONV, transposed=True)
 
 
+# Shapes whose forward or input gradient the planner hands to the 256 x 128 LDS-DMA kernel (conv_bf16_glds.h: more than 64
+# output columns, at least 192 tiles): full tiles; a partial last row tile with a channel count that makes K-steps straddle
+# taps (24 channels: 64 k = 2 taps + 16) and ragged columns (96 of 128); stride-parity classes of unequal size (odd extents);
+# a 3 x 3 / stride-1 layer
+@pytest.mark.parametrize('shape', [(48, 64, 64, 32, 128, 5, 2, 'SAME'), (52, 62, 62, 24, 96, 5, 2, 'SAME'), (12, 64, 64, 128, 32, 5, 2, 'SAME'),
+                                   (13, 63, 61, 96, 32, 5, 2, 'SAME'), (48, 32, 32, 64, 128, 3, 1, 'SAME')], ids=str)
+def test_conv_bf16_wide_tiles(hip_abi_bf16, shape):
+    C.case_conv_bf16(hip_abi_bf16, shape, TOL_BF16, TOL_CONV)
+
+
+@pytest.mark.parametrize('shape', [(12, 32, 32, 32, 128, 5, 2), (12, 32, 32, 32, 121, 5, 2)], ids=str)
+def test_deconv_bf16_wide_tiles(hip_abi_bf16, shape):
+    """A transposed layer's forward as four stride classes of the wide kernel; 121 output channels = g/tconv4 at config 5."""
+    C.case_conv_bf16(hip_abi_bf16, shape, TOL_BF16, TOL_CONV, transposed=True)
+
+
+def test_conv_bn_stats_wide_bf16(hip_abi_bf16):
+    """BatchNorm partials out of the 256-row tiles of the wide kernel (one group, two groups, a transposed layer)."""
+    C.case_conv_bn_stats(hip_abi_bf16, TOL_BF16, 2e-3, min_fused=3, layers=C.STATS_LAYERS_WIDE)
+
+
 @pytest.mark.parametrize('shape', C.BN_SHAPES[:2] + C.BN_SHAPES[3:7] + [((32, 16, 16), 128, 2, 'lrelu'), ((32, 32, 32), 64, 1, 'relu')], ids=str)
 def test_bn_bf16(hip_abi, shape):
     C.case_bn_bf16(hip_abi, shape, 6e-3)

@@ -68,6 +68,7 @@ SIGNATURES = {
     'acg_conv2d_dgrad': (c_int32, _conv),
     'acg_conv2d_wgrad': (c_int32, _wgrad),
     'acg_conv2d_splits': (c_int32, [_D, c_int32, c_int32]),
+    'acg_conv2d_tile': (c_int32, [_D, c_int32, c_int32, ctypes.POINTER(c_int32), ctypes.POINTER(c_int32)]),
     'acg_conv2d_wgrad_slabs': (c_int32, [_P, _P, _D, c_int32, _P, c_size_t, _P]),
     'acg_deconv2d_wgrad_slabs': (c_int32, [_P, _P, _D, c_int32, _P, c_size_t, _P]),
     'acg_conv2d_stats_blocks': (c_int32, [_D, c_int32, c_int32, c_int32]),
@@ -163,7 +164,7 @@ def code(torch_dtype):
     if torch_dtype == torch.bfloat16:
         return ACG_BF16
     raise TypeError('no storage code for %s' % torch_dtype)
-VALUE_RETURNING = ('acg_version', 'acg_conv2d_splits', 'acg_bn_bwd_slabs_ok', 'acg_bn_slabs_layout', 'acg_conv2d_slab_layouts', 'acg_conv2d_stats_blocks', 'acg_conv2d_stats_layout', 'acg_deconv2d_fwd_bias_act_ok')     # int32 results that are not status codes
+VALUE_RETURNING = ('acg_version', 'acg_conv2d_splits', 'acg_conv2d_tile', 'acg_bn_bwd_slabs_ok', 'acg_bn_slabs_layout', 'acg_conv2d_slab_layouts', 'acg_conv2d_stats_blocks', 'acg_conv2d_stats_layout', 'acg_deconv2d_fwd_bias_act_ok')     # int32 results that are not status codes
 
 
 class AcgError(RuntimeError):

@@ -634,6 +634,13 @@ int32_t acg_conv2d_stats_blocks(const acg_conv_desc* d, int32_t which, int32_t d
   if (!d || validate(d, "conv2d_stats_blocks") != ACG_OK || which < 0 || which > 2 || (dtype != ACG_F32 && dtype != ACG_BF16)) return 0;
   return stats_blocks(make_plan(*d, which, dtype == ACG_BF16), *d, which, groups, nullptr);
 }
+int32_t acg_conv2d_tile(const acg_conv_desc* d, int32_t which, int32_t dtype, int32_t* tile_rows, int32_t* tile_cols) {
+  if (!d || validate(d, "conv2d_tile") != ACG_OK || which < 0 || which > 2 || (dtype != ACG_F32 && dtype != ACG_BF16)) return 0;
+  const Plan pl = make_plan(*d, which, dtype == ACG_BF16);
+  if (tile_rows) *tile_rows = pl.bm;
+  if (tile_cols) *tile_cols = pl.bn;
+  return (int32_t)std::min<long long>(pl.tiles, 0x7fffffff);
+}
 int32_t acg_conv2d_stats_layout(const acg_conv_desc* d, int32_t which, int32_t dtype, int32_t groups, int32_t* block_rows, int32_t* run_rows) {
   if (!d || validate(d, "conv2d_stats_layout") != ACG_OK || which < 0 || which > 2 || (dtype != ACG_F32 && dtype != ACG_BF16)) return 0;
   const Plan pl = make_plan(*d, which, dtype == ACG_BF16);

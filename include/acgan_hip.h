@@ -156,6 +156,9 @@ typedef struct acg_reduce_list {
   float accumulate[ACG_REDUCE_MAX];
 } acg_reduce_list;
 int32_t acg_conv2d_splits(const acg_conv_desc* d, int32_t which, int32_t dtype);
+/* The output tile (GEMM rows x columns) the planner runs contraction `which` of this layer on as a launch of its own, for
+ * tests and tools: returns the number of tiles (all stride classes of an input gradient), 0 on a bad descriptor. */
+int32_t acg_conv2d_tile(const acg_conv_desc* d, int32_t which, int32_t dtype, int32_t* tile_rows, int32_t* tile_cols);
 int32_t acg_conv2d_wgrad_slabs(const void* x, const void* dy, const acg_conv_desc* d, int32_t dtype, void* workspace,
                                size_t workspace_bytes, acg_stream_t stream);
 int32_t acg_deconv2d_wgrad_slabs(const void* x, const void* dy, const acg_conv_desc* adj, int32_t dtype, void* workspace,

@@ -53,6 +53,14 @@ int32_t acg_conv2d_splits(const acg_conv_desc* d, int32_t which, int32_t dtype) 
   if (!d || which < 0 || which > 2) return 0;
   return which == ACG_CONV_WGRAD && d->batch >= 2 ? 2 : 1;
 }
+/* the restatement has no tiles: one "tile" = the whole output */
+int32_t acg_conv2d_tile(const acg_conv_desc* d, int32_t which, int32_t dtype, int32_t* tile_rows, int32_t* tile_cols) {
+  (void)dtype;
+  if (!d || which < 0 || which > 2) return 0;
+  if (tile_rows) *tile_rows = which == ACG_CONV_WGRAD ? d->kh * d->kw * d->in_c : (which == ACG_CONV_DGRAD ? d->batch * d->in_h * d->in_w : d->batch * d->out_h * d->out_w);
+  if (tile_cols) *tile_cols = which == ACG_CONV_DGRAD ? d->in_c : d->out_c;
+  return 1;
+}
 size_t acg_conv2d_workspace_bytes(const acg_conv_desc* d, int32_t which, int32_t dtype) {
   const int32_t sp = acg_conv2d_splits(d, which, dtype);
   return sp > 1 ? (size_t)sp * d->kh * d->kw * d->in_c * d->out_c * sizeof(float) : 0;

@@ -294,10 +294,19 @@ HANDOFF_LAYERS = [   # (x shape, w shape, stride, padding, transposed, groups, a
 # bf16 only (test_conv_bn_stats_wide_bf16): large enough for the 256 x 128 LDS-DMA kernel (conv_bf16_glds.h), whose tiles leave
 # the partials: forward with one group and with two (D on [fake ; real]), and a transposed layer (four stride classes)
 STATS_LAYERS_WIDE = [
-    ((48, 64, 64, 16), (5, 5, 16, 128), 2, 'SAME', False, 1, 'relu'),
-    ((48, 64, 64, 16), (5, 5, 16, 128), 2, 'SAME', False, 2, 'lrelu'),
-    ((12, 32, 32, 16), (5, 5, 128, 16), 2, None, True, 1, 'relu'),
+    ((48, 64, 64, 64), (5, 5, 64, 128), 2, 'SAME', False, 1, 'relu'),
+    ((48, 64, 64, 64), (5, 5, 64, 128), 2, 'SAME', False, 2, 'lrelu'),
+    ((12, 32, 32, 160), (5, 5, 128, 160), 2, None, True, 1, 'relu'),
 ]
+
+
+def tile_rows(abi, which, b, h, w, cin, k, cout, stride, padding):
+    """Rows of the tile the planner runs this contraction on (acg_conv2d_tile)."""
+    import ctypes
+    d = abi.desc(b, h, w, cin, k, k, cout, stride, padding)
+    rows, cols = ctypes.c_int32(0), ctypes.c_int32(0)
+    assert abi.lib.conv2d_tile(ctypes.byref(d), which, abi.conv_dtype, ctypes.byref(rows), ctypes.byref(cols)) > 0
+    return rows.value
 
 
 def case_slab_handoff(abi, tol, min_quads=5, min_rows=1):

@@ -123,18 +123,23 @@ def test_deconv_bf16_big_tiles(hip_abi_bf16):
 
 
 # Shapes whose forward or input gradient the planner hands to the 256 x 128 LDS-DMA kernel (conv_bf16_glds.h: more than 64
-# output columns, at least 192 tiles): full tiles; a partial last row tile with a channel count that makes K-steps straddle
-# taps (24 channels: 64 k = 2 taps + 16) and ragged columns (96 of 128); stride-parity classes of unequal size (odd extents);
-# a 3 x 3 / stride-1 layer
-@pytest.mark.parametrize('shape', [(48, 64, 64, 32, 128, 5, 2, 'SAME'), (52, 62, 62, 24, 96, 5, 2, 'SAME'), (12, 64, 64, 128, 32, 5, 2, 'SAME'),
-                                   (13, 63, 61, 96, 32, 5, 2, 'SAME'), (48, 32, 32, 64, 128, 3, 1, 'SAME')], ids=str)
-def test_conv_bf16_wide_tiles(hip_abi_bf16, shape):
+# output columns, at least 192 tiles, at least 20 K-steps): full tiles; a partial last row tile with a channel count that makes
+# K-steps straddle taps (56 channels: 64 k = 1 tap + 8) and ragged columns (96 of 128); an input gradient (N = 128 input
+# channels, 9 taps x 160 channels in its largest stride class) with classes of unequal size (odd extents); 3 x 3 / stride 1
+@pytest.mark.parametrize('shape,which', [((48, 64, 64, 64, 128, 5, 2, 'SAME'), 0), ((52, 62, 62, 56, 96, 5, 2, 'SAME'), 0),
+                                         ((12, 64, 64, 128, 160, 5, 2, 'SAME'), 1), ((13, 63, 61, 96, 160, 5, 2, 'SAME'), 1),
+                                         ((48, 32, 32, 160, 128, 3, 1, 'SAME'), 0)], ids=str)
+def test_conv_bf16_wide_tiles(hip_abi_bf16, shape, which):
+    b, h, w, cin, cout, k, s, pad = shape
+    assert C.tile_rows(hip_abi_bf16, which, b, h, w, cin, k, cout, s, pad) == 256, 'test premise: the planner does not pick the wide kernel'
     C.case_conv_bf16(hip_abi_bf16, shape, TOL_BF16, TOL_CONV)
 
 
-@pytest.mark.parametrize('shape', [(12, 32, 32, 32, 128, 5, 2), (12, 32, 32, 32, 121, 5, 2)], ids=str)
+@pytest.mark.parametrize('shape', [(12, 32, 32, 160, 128, 5, 2), (12, 32, 32, 160, 121, 5, 2)], ids=str)
 def test_deconv_bf16_wide_tiles(hip_abi_bf16, shape):
     """A transposed layer's forward as four stride classes of the wide kernel; 121 output channels = g/tconv4 at config 5."""
+    b, ih, iw, cin, cout, k, s = shape
+    assert C.tile_rows(hip_abi_bf16, 1, b, ih * s, iw * s, cout, k, cin, s, 'SAME') == 256, 'test premise: the planner does not pick the wide kernel'
     C.case_conv_bf16(hip_abi_bf16, shape, TOL_BF16, TOL_CONV, transposed=True)
 
 

@@ -46,6 +46,12 @@ class PrepList(ctypes.Structure):
                 ('b', c_int32 * 32)]
 
 
+class OptArgs(ctypes.Structure):
+    """struct acg_opt_args (acg_opt_step_prepare_bf16)."""
+    _fields_ = [('kind', c_int32), ('lr', c_float), ('beta1_or_decay', c_float), ('beta2', c_float), ('eps', c_float),
+                ('grad_scale', c_float), ('use_clip', c_int32), ('clip_lo', c_float), ('clip_hi', c_float)]
+
+
 class CopyList(ctypes.Structure):
     """struct acg_copy_list (ACG_COPY_MAX = 8 segments)."""
     _fields_ = [('src', c_void_p * 8), ('dst', c_void_p * 8), ('rows', c_int64 * 8), ('cols', c_int32 * 8),
@@ -138,6 +144,7 @@ SIGNATURES = {
     'acg_mean_loss': (c_int32, [_P, _P, _P, c_int64, c_float, _P]),
     'acg_psnr': (c_int32, [_P, _P, _P, c_int64, c_int32, _P, c_size_t, _P]),
     'acg_scalar_combine': (c_int32, [_P, _P, c_float, _P, c_float, _P, c_float, _P, c_float, _P]),
+    'acg_opt_step_prepare_bf16': (c_int32, [_P, _P, _P, _P, _P, c_int64, ctypes.POINTER(OptArgs), ctypes.POINTER(PrepList), c_int32, _P]),
     'acg_adam_step': (c_int32, [_P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float,
                                 c_int32, c_float, c_float, _P]),
     'acg_rmsprop_step': (c_int32, [_P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int32, c_float,

@@ -357,6 +357,7 @@ class Runtime:
         self.slab_rows = False                 # hand-offs in the ACG_SLABS_ROWS layout too (Session(slab_handoff=True / N))
         self.epilogue_stats = True
         self.epilogue_bias = True
+        self.fuse_weight_refresh = True        # bf16: optimizer update + refresh of the bf16 filter copies in one launch (optim.StepOp)
         self._comm = comm
         self._scratch = {}
 
@@ -399,7 +400,7 @@ class Session:
 
     def __init__(self, device='cuda:0', graph=None, use_hip_graphs=True, lib=None,
                  world_size=1, rank=0, process_group=None, dtype='f32', pair_bwd=True, comm=None, slab_handoff=False, epilogue_stats=True, side_branches=False,
-                 epilogue_bias=True):
+                 epilogue_bias=True, fuse_weight_refresh=True):
         self.graph = graph or get_default_graph()
         dev = torch.device(device)
         if lib is None:
@@ -426,6 +427,8 @@ class Session:
         self.rt.slab_rows = slab_handoff != 'quads'
         self.rt.epilogue_stats = bool(epilogue_stats)     # BatchNorm statistics out of the producing conv's epilogue (ops.Conv2dOp.bind)
         self.rt.epilogue_bias = bool(epilogue_bias)       # bias + activation of a transposed head layer in its epilogue (models.py:20-21)
+        # the C-oracle stand-in library (CPU tests) implements float32 only: the fused entry is a bf16-pipeline entry
+        self.rt.fuse_weight_refresh = bool(fuse_weight_refresh)
         if dev.type == 'cuda':
             torch.cuda.set_device(dev)
         self.use_hip_graphs = use_hip_graphs and dev.type == 'cuda'

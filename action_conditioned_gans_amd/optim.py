@@ -100,8 +100,13 @@ class StepOp(G.Op):
         self.extras = [t for t3 in flat_param.graph.weight_copies.get(scope, []) for t in t3[1:]]
 
     def bind(self, rt):
+        # bf16 pipeline: the conv kernels read bf16 copies of the filters, which follow the update.  Round 4: update and
+        # refresh are ONE launch (acg_opt_step_prepare_bf16: the blocks that write a filter's copies update its elements) where
+        # every copy of the scope fits one list; else two launches as before
+        fused = self.opt._bind_step_prepared(rt, self, self.program_clip) if rt.fuse_weight_refresh else None
+        if fused is not None:
+            return fused
         step = self.opt._bind_step(rt, self, self.program_clip)
-        # bf16 pipeline: the conv kernels read bf16 copies of the filters - refreshed right behind the update, one launch
         prep = O.prepare_weights_launch(rt, self.graph, self.scope)
         if prep is None:
             return step
@@ -149,6 +154,38 @@ class Optimizer:
 
     def _bind_step(self, rt, step_op, clip):
         raise NotImplementedError
+
+    def _opt_args(self, rt, op, clip):
+        """-> (kind, (lr, beta1 | decay, beta2, eps), slot1, slot2 | None, step counter | None, launch that must precede | None)"""
+        raise NotImplementedError
+
+    def _bind_step_prepared(self, rt, op, clip):
+        """One launch for the update of the scope and the refresh of its bf16 filter copies, or None (no copies: a float32
+        graph; more filters than one list holds)."""
+        import ctypes
+        from . import _lib
+        entries = op.graph.weight_copies.get(op.scope) or []
+        if not entries or len(entries) > _lib.PREP_MAX:
+            return None
+        kind, fields, s1, s2, step, before = self._opt_args(rt, op, clip)
+        pl = _lib.PrepList()
+        for i, (w, rm, tr) in enumerate(entries):
+            kh, kw, a, b = w.shape
+            pl.src[i], pl.rm[i], pl.tr[i] = w.buf.data_ptr(), rm.buf.data_ptr(), tr.buf.data_ptr()
+            pl.taps[i], pl.a[i], pl.b[i] = kh * kw, a, b
+        lo, hi = clip if clip else (0.0, 0.0)
+        oa = _lib.OptArgs(kind, fields[0], fields[1], fields[2], fields[3], op.grad_scale, 1 if clip else 0, lo, hi)
+        p, g = op.inputs[0], op.inputs[1]
+        args = (_p(p.buf), _p(g.buf), _p(s1.buf), _p(s2.buf) if s2 is not None else None, _p(step.buf) if step is not None else None,
+                p.numel, ctypes.byref(oa), ctypes.byref(pl), len(entries))
+        fn = rt.lib.opt_step_prepare_bf16
+
+        def launch(s):
+            if before is not None:
+                before(s)
+            fn(*args, s)
+        launch._keep = (oa, pl)
+        return launch
 
     def minimize(self, loss, var_list=None):
         if not isinstance(loss, O.Scalar):
@@ -247,6 +284,11 @@ class AdamOptimizer(Optimizer):
             adam(*args, s)
         return launch
 
+    def _opt_args(self, rt, op, clip):
+        p, g, m, v, step = op.inputs
+        inc, ps = rt.lib.step_inc, _p(step.buf)
+        return 0, (self.lr, self.b1, self.b2, self.eps), m, v, step, (lambda s: inc(ps, s))
+
 
 class RMSPropOptimizer(Optimizer):
     """tf.train.RMSPropOptimizer (momentum 0): ms starts at ONE; p -= lr*g/sqrt(ms+eps)."""
@@ -267,3 +309,7 @@ class RMSPropOptimizer(Optimizer):
                 1 if clip else 0, lo, hi)
         fn = rt.lib.rmsprop_step
         return lambda s: fn(*args, s)
+
+    def _opt_args(self, rt, op, clip):
+        p, g, ms = op.inputs
+        return 1, (self.lr, self.decay, 0.0, self.eps), ms, None, None, None

@@ -101,6 +101,20 @@ typedef struct acg_prep_list {
   int32_t taps[ACG_PREP_MAX], a[ACG_PREP_MAX], b[ACG_PREP_MAX];
 } acg_prep_list;
 int32_t acg_weights_prepare_bf16(const acg_prep_list* list, int32_t count, acg_stream_t stream);
+/* The optimizer update of a whole scope (train.py:100-102; the formulas of acg_adam_step / acg_rmsprop_step, element by
+ * element: bit-identical parameters and slots) AND the refresh of the scope's bf16 filter copies in ONE launch: every
+ * `list->src[i]` is a filter inside the flat buffer `param` (16-byte aligned offset, no overlap); its elements are updated by
+ * the blocks that write its two copies, everything else in [0, n) (beta, biases) by blocks of its own.  kind 0 = Adam
+ * (slot1 = m, slot2 = v, step_dev = the device step counter, already incremented), 1 = RMSProp (slot1 = ms; slot2, step_dev
+ * unused). */
+typedef struct acg_opt_args {
+  int32_t kind;
+  float lr, beta1_or_decay, beta2, eps, grad_scale;
+  int32_t use_clip;
+  float clip_lo, clip_hi;
+} acg_opt_args;
+int32_t acg_opt_step_prepare_bf16(float* param, const float* grad, float* slot1, float* slot2, const int32_t* step_dev, int64_t n,
+                                  const acg_opt_args* args, const acg_prep_list* list, int32_t count, acg_stream_t stream);
 
 #ifdef ACG_TUNING
 /* Tuning builds only (libacgan_hip_tuning.so, `make tuning`; absent from libacgan_hip.so, which has no process-wide

@@ -260,6 +260,11 @@ int32_t acg_weights_prepare_bf16(const acg_prep_list* l, int32_t count, acg_stre
   (void)l; (void)count; (void)s;
   return fail(ACG_ERR_UNSUPPORTED, "cpu oracle: float32 only");
 }
+int32_t acg_opt_step_prepare_bf16(float* param, const float* grad, float* slot1, float* slot2, const int32_t* step_dev, int64_t n,
+                                  const acg_opt_args* args, const acg_prep_list* list, int32_t count, acg_stream_t s) {
+  (void)param; (void)grad; (void)slot1; (void)slot2; (void)step_dev; (void)n; (void)args; (void)list; (void)count; (void)s;
+  return fail(ACG_ERR_UNSUPPORTED, "cpu oracle: float32 only");
+}
 int32_t acg_splitk_reduce_many(const acg_reduce_list* l, int32_t count, acg_stream_t s) {
   (void)s;
   if (!l || count < 1 || count > ACG_REDUCE_MAX) return fail(ACG_ERR_INVALID_ARG, "splitk_reduce_many: 1..32 entries");

@@ -1104,6 +1104,70 @@ def case_weights_prepare(abi):
         assert torch.equal(tr[:, :, :a].float().cpu(), wr.permute(0, 2, 1)) and (tr[:, :, a:] == 0).all(), 'tr %s' % (shape,)
 
 
+def case_opt_step_prepared(abi):
+    """acg_opt_step_prepare_bf16 (optimizer update + refresh of the bf16 filter copies in one launch) against the two launches
+    it replaces, bit for bit: parameters, slots and both copies of every filter, over two steps; filters of awkward shapes
+    (3 and 138 gathered channels, one and five output channels: the scalar path) with beta / bias vectors between them."""
+    import ctypes
+    from action_conditioned_gans_amd import _lib as L
+    dev = abi.device
+    shapes = [(5, 5, 6, 64), (5, 5, 138, 128), (2, 2, 512, 1), (4, 4, 16, 5), (5, 5, 25, 128), (3, 3, 32, 16)]
+    offs, total = [], 0
+    for sh in shapes:
+        offs.append(total)
+        n = sh[0] * sh[1] * sh[2] * sh[3]
+        total += -(-n // 4) * 4 + 4 * (1 + sh[3] // 4)          # the filter (16-byte aligned) and a vector behind it
+    total += 25
+    for kind in ('adam', 'rmsprop'):
+        p0 = randn((total,), 40, 0.02)
+        bufs = {}
+        for path in ('two', 'one'):
+            p = p0.clone().to(dev)
+            s1 = (torch.zeros(total) if kind == 'adam' else torch.ones(total)).to(dev)
+            s2 = torch.zeros(total, device=dev)
+            step = torch.zeros(1, dtype=torch.int32, device=dev)
+            copies, pl = [], L.PrepList()
+            for i, (sh, off) in enumerate(zip(shapes, offs)):
+                kh, kw, a, b = sh
+                rm = torch.full((kh * kw, a, (b + 7) // 8 * 8), float('nan'), dtype=torch.bfloat16, device=dev)
+                tr = torch.full((kh * kw, b, (a + 7) // 8 * 8), float('nan'), dtype=torch.bfloat16, device=dev)
+                copies.append((rm, tr))
+                pl.src[i], pl.rm[i], pl.tr[i] = p.data_ptr() + 4 * off, rm.data_ptr(), tr.data_ptr()
+                pl.taps[i], pl.a[i], pl.b[i] = kh * kw, a, b
+            for t in range(2):
+                g = randn((total,), 50 + t, 0.1).to(dev)
+                clip = (-0.03, 0.03) if t == 1 else None
+                lo, hi = clip if clip else (0.0, 0.0)
+                if path == 'two':
+                    if kind == 'adam':
+                        abi.adam_step(p, g, s1, s2, step, gs=0.5, clip=clip)
+                    else:
+                        abi.rmsprop_step(p, g, s1, gs=0.5, clip=clip)
+                    abi.lib.weights_prepare_bf16(ctypes.byref(pl), len(shapes), abi.stream())
+                else:
+                    if kind == 'adam':
+                        abi.lib.step_inc(_ptr(step), abi.stream())
+                        oa = L.OptArgs(0, 1e-3, 0.9, 0.999, 1e-8, 0.5, 1 if clip else 0, lo, hi)
+                    else:
+                        oa = L.OptArgs(1, 5e-5, 0.9, 0.0, 1e-10, 0.5, 1 if clip else 0, lo, hi)
+                    abi.lib.opt_step_prepare_bf16(_ptr(p), _ptr(g), _ptr(s1), _ptr(s2), _ptr(step), total, ctypes.byref(oa), ctypes.byref(pl),
+                                                  len(shapes), abi.stream())
+                abi.sync()
+            bufs[path] = (p, s1, s2, copies)
+        (pa, s1a, s2a, ca), (pb, s1b, s2b, cb) = bufs['two'], bufs['one']
+        assert torch.equal(pa, pb), '%s: parameters differ: %d elements, max %.3g' % (kind, int((pa != pb).sum()), float((pa - pb).abs().max()))
+        assert torch.equal(s1a, s1b) and torch.equal(s2a, s2b), kind + ': slots differ'
+        assert float((pa.cpu() - p0).abs().max()) > 0, 'test premise: nothing was updated'
+        for i, ((rma, tra), (rmb, trb)) in enumerate(zip(ca, cb)):
+            assert torch.equal(rma.view(torch.int16), rmb.view(torch.int16)), '%s: rm copy of filter %d differs' % (kind, i)
+            assert torch.equal(tra.view(torch.int16), trb.view(torch.int16)), '%s: tr copy of filter %d differs' % (kind, i)
+
+
+def _ptr(t):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr())
+
+
 def case_dna_extreme_logits(abi, tol):
     """softmax must be max-subtracted: logits of +-80 overflow a naive exp in fp32."""
     logits = randn((1, 6, 6, 25), 3, 1.0)

@@ -192,6 +192,11 @@ def test_weights_prepare(hip_abi):
     C.case_weights_prepare(hip_abi)
 
 
+def test_opt_step_prepared(hip_abi):
+    """The optimizer update and the refresh of the bf16 filter copies in one launch == the two launches, bit for bit."""
+    C.case_opt_step_prepared(hip_abi)
+
+
 def test_deconv_pitched(hip_abi):
     C.case_deconv_pitched(hip_abi, TOL_CONV)
 

@@ -124,16 +124,18 @@ __device__ __forceinline__ void conv16g_body(const ConvArgs& p, char* smem) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) { const int n = n0 + 8 * (wave + 8 * i) + lrow8; nK[i] = n * Cp; nOk[i] = n < N; }
   const int step_t = BKH / Cp, step_c = BKH - step_t * Cp;
-  int run_kt = div_fast(8 * oct, p.mg_cp, p.sh_cp), run_kc = 8 * oct - run_kt * Cp;
+  const bool chunked = p.korder != 0;          // ConvArgs::korder (conv_bf16_kernel.h): taps fastest inside a 64-channel chunk
+  const int inc_t = chunked ? 1 : step_t, inc_c = chunked ? 0 : step_c, wrap_t = chunked ? -ntaps : 1, wrap_c = chunked ? BKH : -Cp;
+  int run_kt = chunked ? 0 : div_fast(8 * oct, p.mg_cp, p.sh_cp), run_kc = 8 * oct - (chunked ? 0 : run_kt * Cp);
 
   auto issue = [&](int buf, bool live) {
     // this lane's (tap, channel) of the K-step, then the next one's
-    const bool kv = live && run_kt < ntaps;
+    const bool kv = live && run_kt < ntaps && run_kc < Cp;
     const int t = kv ? run_kt : 0;
     const int aoff = tapA[t] + run_kc, boff = tapB[t] + run_kc;
-    run_kt += step_t; run_kc += step_c;
-    const bool wrap = run_kc >= Cp;
-    run_kc -= wrap ? Cp : 0; run_kt += wrap ? 1 : 0;
+    run_kt += inc_t; run_kc += inc_c;
+    const bool wrap = chunked ? run_kt >= ntaps : run_kc >= Cp;
+    run_kt += wrap ? wrap_t : 0; run_kc += wrap ? wrap_c : 0;
     char* const bufp = reinterpret_cast<char*>(cells + buf * GCELLS);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

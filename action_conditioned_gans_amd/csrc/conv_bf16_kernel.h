@@ -162,7 +162,16 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
   }
   const int step_t = BKH / Cp, step_c = BKH - step_t * Cp;
   int run_kt = 0, run_kc = 0;
-  if constexpr (MODE != MODE_WGRAD) tap_of(ks_begin * BKH + 8 * (tid & 7), run_kt, run_kc);
+  // K order of the gathered operand (ConvArgs::korder).  0: k = (tap, channel), channels fastest - consecutive K-steps sweep ALL
+  // channels of a tap's shifted window.  1 (channels a multiple of 64): k = (64-channel chunk, tap, channel in chunk) - 25
+  // consecutive K-steps re-touch the SAME half or quarter of the window's bytes at 25 shifts, so what the tiles of an XCD keep
+  // live in its L2 shrinks by the chunk count (the order of a sum is free; results differ at rounding level only)
+  const bool chunked = MODE != MODE_WGRAD && p.korder != 0;
+  const int inc_t = chunked ? 1 : step_t, inc_c = chunked ? 0 : step_c, wrap_t = chunked ? -ntaps : 1, wrap_c = chunked ? BKH : -Cp;
+  if constexpr (MODE != MODE_WGRAD) {
+    if (chunked) { const int ch = ks_begin / ntaps; run_kt = ks_begin - ch * ntaps; run_kc = ch * BKH + 8 * (tid & 7); }
+    else tap_of(ks_begin * BKH + 8 * (tid & 7), run_kt, run_kc);
+  }
 
   // pixel-major operands (WGRAD): thread -> (pixel row kr0 + e * RPA, oct ja of the tile row)
   constexpr int OA = BM / 8, OB = BN / 8, RPA = 256 / OA, RPB = 256 / OB;   // octs per tile row; rows per pass
@@ -194,13 +203,14 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
       q.boff = run_boff; q.brow = ks * BKH + krb;
       run_boff += BKH * K8;
     } else {
-      q.kv = live && run_kt < ntaps;
+      q.kv = live && run_kt < ntaps && run_kc < Cp;
       q.t = q.kv ? run_kt : 0;
       q.aoff = tapA[q.t] + run_kc;
       q.tb = tapB[q.t] + run_kc;
-      run_kt += step_t; run_kc += step_c;
-      const bool wrap = run_kc >= Cp;
-      run_kc -= wrap ? Cp : 0; run_kt += wrap ? 1 : 0;
+      // (selects, no branch: the loop body must stay ONE basic block or hipcc's counted vmcnt waits turn conservative)
+      run_kt += inc_t; run_kc += inc_c;
+      const bool wrap = chunked ? run_kt >= ntaps : run_kc >= Cp;
+      run_kt += wrap ? wrap_t : 0; run_kc += wrap ? wrap_c : 0;
     }
     return q;
   };

@@ -395,6 +395,11 @@ int prepare(Job& j, int which, const float* gsrc, const float* dense, float* out
   a.KH = d->kh; a.KW = d->kw; a.sh = d->stride_h; a.sw = d->stride_w; a.pt = d->pad_top; a.pl = d->pad_left;
   a.splits = pl.splits;
   a.Nv = which == ACG_CONV_DGRAD ? d->dgrad_c : (which == ACG_CONV_FWD ? d->adj_dgrad_c : 0);
+  {     // bf16 forward / input gradient with 128 or more gathered channels in whole 64-channel chunks: chunk-major K order (option)
+    static const int korder = env_int("ACG_CONV16_KORDER", 0);      // measured level (c5 +0.4 %, c3 -0.3 %, profiles/r4/f_korder_ab.txt): off; tuning builds can switch it on
+    const int cp = which == ACG_CONV_DGRAD ? cout8 : cin8;
+    a.korder = (h && which != ACG_CONV_WGRAD && korder && cp >= 128 && cp % 64 == 0) ? 1 : 0;
+  }
   // small maps: pixel-major rows + only the taps a tile's rows can see (ConvArgs::compact); not with epilogue statistics,
   // whose partial blocks are runs of rows of one group
   // measured: pays only where more than half of the taps are dead (a 4 x 4 map under a 5 x 5 / stride-2 filter: d/conv5) - from

@@ -73,6 +73,8 @@ struct ConvArgs {
   // 5 x 5 filter fall into the padding for every row of such a tile, and their K-steps would multiply zeros.
   int compact;
   int Nv;              // FWD / DGRAD: only the first Nv output columns are computed (acg_conv_desc dgrad_c / adj_dgrad_c); 0 = all
+  int korder;          // bf16 kernels, FWD / DGRAD, gathered channels a multiple of 64: 1 = K-steps walk the taps of one 64-channel chunk
+                       // before the next chunk (0: all channels of a tap before the next tap) - conv_bf16_kernel.h
   int out_f32;         // bf16 kernels, FWD / DGRAD: the result is stored as float32 (at the bf16 tensor's pitch, round8): a head layer
   // EPI kernel variants only (acg_deconv2d_fwd_bias_act): out = act(acc + bias[n]), stored as float32 at the pitch Cx
   const float* bias;

@@ -511,6 +511,182 @@ __global__ __launch_bounds__(NT) void bn_apply_bwd(const TX* __restrict__ x, con
 #undef ACG_BN_APPLY
 }
 
+// ---- one-launch backward for tensors that fit the chip's registers (round 4) ---------------------------------------------
+// The two-launch backward reads x and dy twice (sums, then apply): 84 MB of traffic and two launch boundaries for d/conv1's
+// 50 MB at batch 32 (23 us).  Here every block keeps its share of x and dy IN REGISTERS between the two phases: a block of
+// 1024 threads = 8 channel lanes x 128 row lanes owns 32 channels x 128 * U rows of one group, loads them once, reduces its
+// partial sums (shuffles, then LDS across its 16 waves), and the blocks of a (group, channel chunk) exchange their 64 partial
+// sums through memory inside the launch; each block then adds up what the others published and finishes from registers.
+//
+// The exchange is the data-tagged granule form of cdna_hip_programming.md guideline 16 (R2): every value travels as ONE
+// aligned 8-byte {epoch tag, float bits} store at agent scope (write-through) and is read by agent-scope 8-byte loads that are
+// repeated until the tag matches - the data is its own flag: no fence, no release / acquire, nothing that depends on block
+// placement or dispatch order.  `epoch` is a word of the op's private workspace that the LAST block to finish increments
+// (an arrival counter beside it), so every launch - also every replay of a captured graph, whose arguments are frozen - sees
+// tags no earlier launch has written; the workspace must be zero before its first use and belong to this op alone.
+// All blocks of the grid must be resident together: the host takes this path only for grids of at most one block per CU
+// (<= 256 blocks of 1024 threads at <= 64 VGPRs: two would fit), and every spin is bounded - a block that gives up sets the
+// workspace's `timeout` word and finishes with what it has, so a violated assumption shows up as a wrong result and a flag,
+// never as a hung GPU.
+struct FusedBwdState { unsigned epoch, done, timeout, pad; };      // first 16 bytes of the workspace; granules behind it
+typedef unsigned long long __attribute__((address_space(1))) * gran_ptr;
+
+template <int V, typename TX, typename TY, typename TD, int U>
+__global__ __launch_bounds__(1024) void bn_bwd_fused(const TX* __restrict__ x, const TY* __restrict__ dy, const float* __restrict__ beta,
+                                                     const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
+                                                     TD* __restrict__ dx, float* __restrict__ dbeta, float dbeta_acc, long long R, int C,
+                                                     int groups, int act, float leak, int XP, int YP, unsigned* __restrict__ ws) {
+  constexpr int NT = 1024, CL = 8, RL = NT / CL, NW = NT / 64, NV = 2 * V * CL;      // NV = 64 values a block publishes
+  static_assert(V == 4, "four channels per lane");
+  __shared__ float red[NW][NV];
+  __shared__ float tot[2][NV];
+  __shared__ unsigned s_epoch;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cq = tid % CL, rl = tid / CL;
+  const int rb = blockIdx.x, nrb = gridDim.x, cc = blockIdx.y, g = blockIdx.z;
+  const int c = (cc * CL + cq) * V;
+  const bool cvalid = c < C;
+  const TX* xg = x + (long long)g * R * XP;
+  const TY* dyg = dy + (long long)g * R * YP;
+  TD* dxg = dx + (long long)g * R * XP;
+  FusedBwdState* const state = reinterpret_cast<FusedBwdState*>(ws);
+  unsigned long long* const grans = reinterpret_cast<unsigned long long*>(ws + 4);      // [group][chunk][row block][NV]
+  if (tid == 0) s_epoch = __hip_atomic_load(&state->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+
+  // ---- phase 1: this block's rows into registers, dp and x-hat in place, partial sums ------------------------------------------
+  const long long r0 = (long long)rb * RL * U + rl;
+  float xv[U][V], dv[U][V], mean[V], rstd[V], bt[V];
+  if (cvalid) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long q = min(r0 + (long long)u * RL, R - 1);
+      ldv<V>(xg + q * XP + c, xv[u]); ldv<V>(dyg + q * YP + c, dv[u]);
+    }
+    ldv<V>(save_mean + g * C + c, mean); ldv<V>(save_rstd + g * C + c, rstd); ldv<V>(beta + c, bt);
+  }
+  float s[2 * V];
+#pragma unroll
+  for (int j = 0; j < 2 * V; ++j) s[j] = 0.f;
+  if (cvalid) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float w = r0 + (long long)u * RL < R ? 1.f : 0.f;
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float xh = (xv[u][j] - mean[j]) * rstd[j];
+        const float dp = w * dv[u][j] * acg::act_deriv_pre(act, xh + bt[j], leak);
+        xv[u][j] = xh; dv[u][j] = dp;
+        s[j] += dp; s[V + j] += dp * xh;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2 * V; ++j) {
+#pragma unroll
+    for (int off = CL; off < 64; off <<= 1) s[j] += __shfl_xor(s[j], off, 64);
+  }
+  if (lane < CL) {
+#pragma unroll
+    for (int j = 0; j < 2 * V; ++j) red[wave][cq * 2 * V + j] = s[j];      // value index = cq * 8 + {s1: 0..3, s2: 4..7}
+  }
+  __syncthreads();
+  const unsigned epoch = s_epoch;
+  const long long gbase = (((long long)g * gridDim.y + cc) * nrb) * NV;     // this (group, chunk)'s granules: [row block][NV]
+  if (tid < NV) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += red[w][tid];
+    __hip_atomic_store((gran_ptr)(grans + gbase + (long long)rb * NV + tid), ((unsigned long long)epoch << 32) | __float_as_uint(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+
+  // ---- phase 2: gather every row block's partial sums of this (group, chunk); the dbeta block also takes the other groups' ---------
+  auto gather = [&](int gg, float* out /* NV floats in LDS */) {
+    const long long base = (((long long)gg * gridDim.y + cc) * nrb) * NV;
+    const int n = nrb * NV;                       // granules to fetch: index i = row block * NV + value
+    float acc = 0.f;                              // thread t sums the granules i = t, t + NT, ...: all of value t % NV (NT % NV == 0)
+    for (int i0 = 0; i0 < n; i0 += 4 * NT) {
+      unsigned long long gv[4];
+      bool ok = false;
+      for (unsigned spins = 0; !ok; ++spins) {
+        ok = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + k * NT + tid;
+          gv[k] = i < n ? __hip_atomic_load((gran_ptr)(grans + base + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)epoch << 32);
+          ok = ok && (unsigned)(gv[k] >> 32) == epoch;
+        }
+        ok = __all(ok);
+        if (!ok) {
+          if (spins > (1u << 22)) {               // bounded: give up, flag it, finish with what is there
+            if (lane == 0) __hip_atomic_store(&state->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = true;
+          } else {
+            __builtin_amdgcn_s_sleep(2);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc += __uint_as_float((unsigned)gv[k]);
+    }
+    red[wave][lane] = acc;                        // NT / NV = 16 threads per value: thread t holds value t % 64 = its lane
+    __syncthreads();
+    if (tid < NV) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v += red[w][tid];
+      out[tid] = v;
+    }
+    __syncthreads();
+  };
+  __syncthreads();                                // red is reused
+  gather(g, tot[0]);
+  if (rb == 0 && g == 0) {                        // dbeta of this chunk's channels: sum of s1 over every group, group 0 last
+    float d[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) d[j] = 0.f;
+    for (int gg = groups - 1; gg >= 1; --gg) {
+      gather(gg, tot[1]);
+#pragma unroll
+      for (int j = 0; j < V; ++j) d[j] += tot[1][cq * 2 * V + j];
+      __syncthreads();
+    }
+    if (cvalid && rl == 0) {
+      float o[V];
+      if (dbeta_acc != 0.f) ldv<V>(dbeta + c, o);
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] = (dbeta_acc != 0.f ? dbeta_acc * o[j] : 0.f) + (d[j] + tot[0][cq * 2 * V + j]);
+      stv<V>(dbeta + c, o);
+    }
+  }
+  // ---- phase 3: dx from the registers ---------------------------------------------------------------------------------------------
+  if (cvalid) {
+    const float invR = 1.f / (float)R;
+    float m1[V], m2[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { m1[j] = tot[0][cq * 2 * V + j] * invR; m2[j] = tot[0][cq * 2 * V + V + j] * invR; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long r = r0 + (long long)u * RL;
+      if (r < R) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) dv[u][j] = rstd[j] * (dv[u][j] - m1[j] - xv[u][j] * m2[j]);
+        stv<V>(dxg + r * XP + c, dv[u]);
+      }
+    }
+  }
+  // ---- the last block to get here opens the next epoch ------------------------------------------------------------------------------
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned prev = __hip_atomic_fetch_add(&state->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev + 1u == total) {
+      __hip_atomic_store(&state->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&state->epoch, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // ---- register-resident BatchNorm for small tensors (R <= 256 * NR rows per group) ------------------------------
 // The two-launch path above costs ~7.5-10 us at ANY size below ~1 MB (two dependent launches, each a memory round
 // trip: profiles/r1/q_non_conv_ops.txt); half of the BatchNorm'd tensors of the models are that small.  Here a block owns V
@@ -966,6 +1142,23 @@ int bn_bwd_typed(const void* x, const void* dy, const float* beta, const float* 
     return acg::check_launch("bn_resident_bwd");
   }
   if (sl.p) return acg::fail(ACG_ERR_UNSUPPORTED, "bn_act_bwd_slabs: %lld rows per group exceed the register-resident kernels (acg_bn_bwd_slabs_ok)", R);
+  // One launch with the tensor held in registers between the sums and the apply phase (bn_bwd_fused) where the whole grid is
+  // resident at one block of 1024 threads per CU
+  if constexpr (same) {
+    static const int fused_on = env_int("ACG_BN_FUSED_BWD", 1);     // tuning hook
+    static const int ncu = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0; (void)hipGetLastError(); return n; }();
+    if (fused_on && v4 && ncu > 0) {
+      const long long cchunks = (C + 31) / 32;
+      const long long nb4 = acg::ceil_div(R, 512) * cchunks * groups, nb8 = acg::ceil_div(R, 1024) * cchunks * groups;
+      const int U = nb4 <= ncu ? 4 : (nb8 <= ncu ? 8 : 0);
+      if (U) {
+        const dim3 fg((unsigned)acg::ceil_div(R, 128 * U), (unsigned)cchunks, (unsigned)groups);
+        if (U == 4) ACG_LAUNCH((bn_bwd_fused<4, TX, TY, TD, 4>), fg, dim3(1024), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, R, C, groups, act, leak, XP, YP, (unsigned*)part);
+        else ACG_LAUNCH((bn_bwd_fused<4, TX, TY, TD, 8>), fg, dim3(1024), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, R, C, groups, act, leak, XP, YP, (unsigned*)part);
+        return acg::check_launch("bn_bwd_fused");
+      }
+    }
+  }
   static const int bwd_iters = env_int("ACG_BN_BWD_ITERS", 4);      // tuning hook
   const int nblk = vpartial_blocks(R, C, V, bwd_iters);
   {

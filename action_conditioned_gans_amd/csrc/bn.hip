@@ -528,20 +528,105 @@ __global__ __launch_bounds__(NT) void bn_apply_bwd(const TX* __restrict__ x, con
 // (<= 256 blocks of 1024 threads at <= 64 VGPRs: two would fit), and every spin is bounded - a block that gives up sets the
 // workspace's `timeout` word and finishes with what it has, so a violated assumption shows up as a wrong result and a flag,
 // never as a hung GPU.
-struct FusedBwdState { unsigned epoch, done, timeout, pad; };      // first 16 bytes of the workspace; granules behind it
+struct FusedState { unsigned epoch, done, timeout, pad; };      // first 16 bytes of the workspace; granules behind it
 typedef unsigned long long __attribute__((address_space(1))) * gran_ptr;
 
-template <int V, typename TX, typename TY, typename TD, int U>
-__global__ __launch_bounds__(1024) void bn_bwd_fused(const TX* __restrict__ x, const TY* __restrict__ dy, const float* __restrict__ beta,
-                                                     const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
-                                                     TD* __restrict__ dx, float* __restrict__ dbeta, float dbeta_acc, long long R, int C,
-                                                     int groups, int act, float leak, int XP, int YP, unsigned* __restrict__ ws) {
-  constexpr int NT = 1024, CL = 8, RL = NT / CL, NW = NT / 64, NV = 2 * V * CL;      // NV = 64 values a block publishes
+// The in-launch exchange shared by bn_bwd_fused / bn_fwd_fused.  NT threads = 8 channel lanes x NT / 8 row lanes; a block holds
+// NV = 64 partial values (8 lanes x 2 statistics x 4 channels) in red[wave][...] after its own cross-wave step.
+template <int NT>
+struct FusedExchange {
+  static constexpr int CL = 8, V = 4, NW = NT / 64, NV = 2 * V * CL;
+  float (*red)[NV];          // [NW][NV] LDS
+  unsigned long long* grans;
+  FusedState* state;
+  unsigned epoch;
+  int tid, lane, wave, nrb;
+
+  // the per-thread partials s[0..7] (value index within the lane: {stat 0: 0..3, stat 1: 4..7}) -> this block's 64 sums, published
+  __device__ __forceinline__ void publish(float (&s)[2 * V], long long slot /* granule index of this block's value 0 */) {
+#pragma unroll
+    for (int j = 0; j < 2 * V; ++j) {
+#pragma unroll
+      for (int off = CL; off < 64; off <<= 1) s[j] += __shfl_xor(s[j], off, 64);
+    }
+    if (lane < CL) {
+#pragma unroll
+      for (int j = 0; j < 2 * V; ++j) red[wave][lane * 2 * V + j] = s[j];
+    }
+    __syncthreads();
+    if (tid < NV) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v += red[w][tid];
+      __hip_atomic_store((gran_ptr)(grans + slot + tid), ((unsigned long long)epoch << 32) | __float_as_uint(v), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                              // red is reused by gather
+  }
+  // sums over the nrb row blocks whose granules start at `base` ([row block][NV]) -> out[NV] (LDS); every thread of the block calls it
+  __device__ __forceinline__ void gather(long long base, float* out) {
+    const int n = nrb * NV;                       // granule i = row block * NV + value; thread t takes i = t, t + NT, ...: value t % NV
+    float acc = 0.f;
+    for (int i0 = 0; i0 < n; i0 += 4 * NT) {
+      unsigned long long gv[4];
+      bool ok = false;
+      for (unsigned spins = 0; !ok; ++spins) {
+        ok = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + k * NT + tid;
+          gv[k] = i < n ? __hip_atomic_load((gran_ptr)(grans + base + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)epoch << 32);
+          ok = ok && (unsigned)(gv[k] >> 32) == epoch;
+        }
+        ok = __all(ok);
+        if (!ok) {
+          if (spins > (1u << 22)) {               // bounded: give up, flag it, finish with what is there
+            if (lane == 0) __hip_atomic_store(&state->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = true;
+          } else {
+            __builtin_amdgcn_s_sleep(2);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc += __uint_as_float((unsigned)gv[k]);
+    }
+    red[wave][lane] = acc;                        // NT / NV threads per value: thread t holds value t % 64 = its lane
+    __syncthreads();
+    if (tid < NV) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v += red[w][tid];
+      out[tid] = v;
+    }
+    __syncthreads();
+  }
+  // the last block of the grid to get here opens the next epoch
+  __device__ __forceinline__ void finish() {
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+      const unsigned prev = __hip_atomic_fetch_add(&state->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (prev + 1u == total) {
+        __hip_atomic_store(&state->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&state->epoch, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+};
+
+template <int V, typename TX, typename TY, typename TD, int U, int NT>
+__global__ __launch_bounds__(NT) void bn_bwd_fused(const TX* __restrict__ x, const TY* __restrict__ dy, const float* __restrict__ beta,
+                                                   const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
+                                                   TD* __restrict__ dx, float* __restrict__ dbeta, float dbeta_acc, long long R, int C,
+                                                   int groups, int act, float leak, int XP, int YP, unsigned* __restrict__ ws) {
+  using EX = FusedExchange<NT>;
+  constexpr int CL = EX::CL, RL = NT / CL, NV = EX::NV;
   static_assert(V == 4, "four channels per lane");
-  __shared__ float red[NW][NV];
+  __shared__ float red[EX::NW][NV];
   __shared__ float tot[2][NV];
   __shared__ unsigned s_epoch;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int cq = tid % CL, rl = tid / CL;
   const int rb = blockIdx.x, nrb = gridDim.x, cc = blockIdx.y, g = blockIdx.z;
   const int c = (cc * CL + cq) * V;
@@ -549,8 +634,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused(const TX* __restrict__ x, c
   const TX* xg = x + (long long)g * R * XP;
   const TY* dyg = dy + (long long)g * R * YP;
   TD* dxg = dx + (long long)g * R * XP;
-  FusedBwdState* const state = reinterpret_cast<FusedBwdState*>(ws);
-  unsigned long long* const grans = reinterpret_cast<unsigned long long*>(ws + 4);      // [group][chunk][row block][NV]
+  FusedState* const state = reinterpret_cast<FusedState*>(ws);
   if (tid == 0) s_epoch = __hip_atomic_load(&state->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
 
   // ---- phase 1: this block's rows into registers, dp and x-hat in place, partial sums ------------------------------------------
@@ -580,73 +664,19 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused(const TX* __restrict__ x, c
       }
     }
   }
-#pragma unroll
-  for (int j = 0; j < 2 * V; ++j) {
-#pragma unroll
-    for (int off = CL; off < 64; off <<= 1) s[j] += __shfl_xor(s[j], off, 64);
-  }
-  if (lane < CL) {
-#pragma unroll
-    for (int j = 0; j < 2 * V; ++j) red[wave][cq * 2 * V + j] = s[j];      // value index = cq * 8 + {s1: 0..3, s2: 4..7}
-  }
-  __syncthreads();
-  const unsigned epoch = s_epoch;
-  const long long gbase = (((long long)g * gridDim.y + cc) * nrb) * NV;     // this (group, chunk)'s granules: [row block][NV]
-  if (tid < NV) {
-    float v = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) v += red[w][tid];
-    __hip_atomic_store((gran_ptr)(grans + gbase + (long long)rb * NV + tid), ((unsigned long long)epoch << 32) | __float_as_uint(v),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  __syncthreads();                                // s_epoch
+  EX ex{red, reinterpret_cast<unsigned long long*>(ws + 4), state, s_epoch, tid, tid & 63, tid >> 6, nrb};
+  auto base_of = [&](int gg) { return (((long long)gg * gridDim.y + cc) * nrb) * NV; };      // granules [group][chunk][row block][NV]
+  ex.publish(s, base_of(g) + (long long)rb * NV);
 
-  // ---- phase 2: gather every row block's partial sums of this (group, chunk); the dbeta block also takes the other groups' ---------
-  auto gather = [&](int gg, float* out /* NV floats in LDS */) {
-    const long long base = (((long long)gg * gridDim.y + cc) * nrb) * NV;
-    const int n = nrb * NV;                       // granules to fetch: index i = row block * NV + value
-    float acc = 0.f;                              // thread t sums the granules i = t, t + NT, ...: all of value t % NV (NT % NV == 0)
-    for (int i0 = 0; i0 < n; i0 += 4 * NT) {
-      unsigned long long gv[4];
-      bool ok = false;
-      for (unsigned spins = 0; !ok; ++spins) {
-        ok = true;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int i = i0 + k * NT + tid;
-          gv[k] = i < n ? __hip_atomic_load((gran_ptr)(grans + base + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)epoch << 32);
-          ok = ok && (unsigned)(gv[k] >> 32) == epoch;
-        }
-        ok = __all(ok);
-        if (!ok) {
-          if (spins > (1u << 22)) {               // bounded: give up, flag it, finish with what is there
-            if (lane == 0) __hip_atomic_store(&state->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok = true;
-          } else {
-            __builtin_amdgcn_s_sleep(2);
-          }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) acc += __uint_as_float((unsigned)gv[k]);
-    }
-    red[wave][lane] = acc;                        // NT / NV = 16 threads per value: thread t holds value t % 64 = its lane
-    __syncthreads();
-    if (tid < NV) {
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) v += red[w][tid];
-      out[tid] = v;
-    }
-    __syncthreads();
-  };
-  __syncthreads();                                // red is reused
-  gather(g, tot[0]);
+  // ---- phase 2: every row block's partial sums of this (group, chunk); the dbeta block also takes the other groups' ------------------
+  ex.gather(base_of(g), tot[0]);
   if (rb == 0 && g == 0) {                        // dbeta of this chunk's channels: sum of s1 over every group, group 0 last
     float d[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) d[j] = 0.f;
     for (int gg = groups - 1; gg >= 1; --gg) {
-      gather(gg, tot[1]);
+      ex.gather(base_of(gg), tot[1]);
 #pragma unroll
       for (int j = 0; j < V; ++j) d[j] += tot[1][cq * 2 * V + j];
       __syncthreads();
@@ -675,16 +705,96 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused(const TX* __restrict__ x, c
       }
     }
   }
-  // ---- the last block to get here opens the next epoch ------------------------------------------------------------------------------
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned total = gridDim.x * gridDim.y * gridDim.z;
-    const unsigned prev = __hip_atomic_fetch_add(&state->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev + 1u == total) {
-      __hip_atomic_store(&state->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&state->epoch, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ex.finish();
+}
+
+// Forward, statistics included (layers whose convolution is split over K leave no epilogue partials): one read of x.  The blocks
+// exchange sums of (x - ref) and (x - ref)^2 about the group's first row - what bn_stats_partial leaves, same float64 finish.
+template <int V, typename TX, typename TY, int U, int NT>
+__global__ __launch_bounds__(NT) void bn_fwd_fused(const TX* __restrict__ x, const float* __restrict__ beta, TY* __restrict__ y,
+                                                   float* __restrict__ save_mean, float* __restrict__ save_rstd, long long R, int C, float eps,
+                                                   int act, float leak, int XP, int YP, unsigned* __restrict__ ws) {
+  using EX = FusedExchange<NT>;
+  constexpr int CL = EX::CL, RL = NT / CL, NV = EX::NV;
+  static_assert(V == 4, "four channels per lane");
+  __shared__ float red[EX::NW][NV];
+  __shared__ float tot[NV];
+  __shared__ unsigned s_epoch;
+  const int tid = threadIdx.x;
+  const int cq = tid % CL, rl = tid / CL;
+  const int rb = blockIdx.x, nrb = gridDim.x, cc = blockIdx.y, g = blockIdx.z;
+  const int c = (cc * CL + cq) * V;
+  const bool cvalid = c < C;
+  const TX* xg = x + (long long)g * R * XP;
+  TY* yg = y + (long long)g * R * YP;
+  FusedState* const state = reinterpret_cast<FusedState*>(ws);
+  if (tid == 0) s_epoch = __hip_atomic_load(&state->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  const long long r0 = (long long)rb * RL * U + rl;
+  float xv[U][V], pv[V], bt[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { pv[j] = 0.f; bt[j] = 0.f; }
+  if (cvalid) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) ldv<V>(xg + min(r0 + (long long)u * RL, R - 1) * XP + c, xv[u]);
+    ldv<V>(xg + c, pv);                           // the group's first row: the common shift
+    ldv<V>(beta + c, bt);
+  }
+  float s[2 * V];
+#pragma unroll
+  for (int j = 0; j < 2 * V; ++j) s[j] = 0.f;
+  if (cvalid) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float w = r0 + (long long)u * RL < R ? 1.f : 0.f;
+#pragma unroll
+      for (int j = 0; j < V; ++j) { const float d = (xv[u][j] - pv[j]) * w; s[j] += d; s[V + j] += d * d; }
     }
   }
+  __syncthreads();                                // s_epoch
+  EX ex{red, reinterpret_cast<unsigned long long*>(ws + 4), state, s_epoch, tid, tid & 63, tid >> 6, nrb};
+  const long long base = (((long long)g * gridDim.y + cc) * nrb) * NV;
+  ex.publish(s, base + (long long)rb * NV);
+  ex.gather(base, tot);
+  if (cvalid) {
+    float mean[V], rstd[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const double inv = 1.0 / (double)R, dm = (double)tot[cq * 2 * V + j] * inv;
+      double var = (double)tot[cq * 2 * V + V + j] * inv - dm * dm;
+      var = var > 0.0 ? var : 0.0;
+      mean[j] = (float)((double)pv[j] + dm);
+      rstd[j] = rsqrtf((float)var + eps);
+    }
+    if (rb == 0 && rl == 0) { stv<V>(save_mean + g * C + c, mean); stv<V>(save_rstd + g * C + c, rstd); }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long r = r0 + (long long)u * RL;
+      if (r < R) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) xv[u][j] = acg::act_apply(act, (xv[u][j] - mean[j]) * rstd[j] + bt[j], leak);
+        stv<V>(yg + r * YP + c, xv[u]);
+      }
+    }
+  }
+  ex.finish();
+}
+
+// Grid of the fused kernels for R rows per group.  What a block sweeps in the exchange grows with the number of row blocks of
+// its (group, chunk) - 512 bytes each - so the row blocks are kept FEW: 256-thread blocks (128 rows) only up to 16 of them
+// (measured: 512 blocks of 128 rows sweeping 128 KB each ran d/conv1's backward at 19.7 us, 64 blocks of 512 rows at 9.5), else
+// 1024-thread blocks of 512 or 1024 rows within ONE block per CU; nt = 0: the tensor does not fit, two launches.
+struct FusedShape { int nt, U; dim3 grid; };
+FusedShape fused_shape(long long R, int C, int groups) {
+  static const int ncu = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0; (void)hipGetLastError(); return n; }();
+  static const int small_rb = env_int("ACG_BN_FUSED_SMALL_ROWBLOCKS", 16);       // tuning hook
+  FusedShape f{0, 0, dim3(1, 1, 1)};
+  if (ncu <= 0) return f;
+  const long long cch = (C + 31) / 32;
+  auto blocks = [&](int rows) { return acg::ceil_div(R, rows) * cch * groups; };
+  if (acg::ceil_div(R, 128) <= small_rb && blocks(128) <= 2 * ncu) { f.nt = 256; f.U = 4; f.grid = dim3((unsigned)acg::ceil_div(R, 128), (unsigned)cch, (unsigned)groups); }
+  else if (blocks(512) <= ncu) { f.nt = 1024; f.U = 4; f.grid = dim3((unsigned)acg::ceil_div(R, 512), (unsigned)cch, (unsigned)groups); }
+  else if (blocks(1024) <= ncu) { f.nt = 1024; f.U = 8; f.grid = dim3((unsigned)acg::ceil_div(R, 1024), (unsigned)cch, (unsigned)groups); }
+  return f;
 }
 
 // ---- register-resident BatchNorm for small tensors (R <= 256 * NR rows per group) ------------------------------
@@ -1085,6 +1195,18 @@ int bn_fwd_typed(const void* x, const float* beta, void* y, float* save_mean, fl
   TY* yf = (TY*)y;
   if (!same) v4 = false;
   const int V = v4 ? 4 : 1;
+  // One launch, one read of x, statistics included (bn_fwd_fused) where the grid is resident; small tensors keep the
+  // one-block-per-four-channels kernels below `fused_min` rows per group (tuning hook)
+  static const int fused_on_f = env_int("ACG_BN_FUSED_FWD", 1), fused_min_f = env_int("ACG_BN_FUSED_MIN_ROWS", 1 << 30);
+  if constexpr (same) {
+    const FusedShape f = (fused_on_f && v4 && !sl.p && (resident_nr(R, 32) == 0 || R >= fused_min_f)) ? fused_shape(R, C, groups) : FusedShape{0, 0, dim3(1, 1, 1)};
+    if (f.nt) {
+#define ACG_BN_FF(UU, NN) ACG_LAUNCH((bn_fwd_fused<4, TX, TY, UU, NN>), f.grid, dim3(NN), 0, st, (const TX*)xf, beta, yf, save_mean, save_rstd, R, C, eps, act, leak, XP, YP, (unsigned*)part)
+      if (f.nt == 256) ACG_BN_FF(4, 256); else if (f.U == 4) ACG_BN_FF(4, 1024); else ACG_BN_FF(8, 1024);
+#undef ACG_BN_FF
+      return acg::check_launch("bn_fwd_fused");
+    }
+  }
   if (const int nr = resident_nr(R, 32)) {
     const dim3 rg(C / V, groups);
 #define ACG_BN_RES_FWD(VV, NN) do { if (sl.p) ACG_LAUNCH((bn_resident_fwd<VV, NN, TX, TY, true>), rg, dim3(256), 0, st, xf, beta, yf, save_mean, save_rstd, (int)R, C, eps, act, leak, XP, YP, sl); \
@@ -1125,7 +1247,11 @@ int bn_bwd_typed(const void* x, const void* dy, const float* beta, const float* 
   TD* dxf = (TD*)dx;
   if (!same) v4 = false;
   const int V = v4 ? 4 : 1;
-  if (const int nr = resident_nr(R * groups, 16) ? resident_nr(R, 16) : 0) {
+  // small tensors: ONE block per four channels holds every row (bn_resident_bwd) - unless the fused grid kernel is asked to take
+  // them from `fused_min` rows per group on (tuning hook; measured in profiles/r4/d_bn_fused_ab.txt)
+  static const int fused_min_b = env_int("ACG_BN_FUSED_MIN_ROWS", 2048);      // backward: 2048 x 128 runs 6.1 us fused, 7.7 resident; below, resident wins
+  const bool prefer_fused_b = same && v4 && !sl.p && R >= fused_min_b && fused_shape(R, C, groups).nt != 0;
+  if (const int nr = prefer_fused_b ? 0 : (resident_nr(R * groups, 16) ? resident_nr(R, 16) : 0)) {
     const dim3 rg(C / V);
 #define ACG_BN_RES_BWD(VV, NN) do { if (sl.p) ACG_LAUNCH((bn_resident_bwd<VV, NN, TX, TY, true, TD>), rg, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, (int)R, C, groups, act, leak, XP, YP, sl); \
     else ACG_LAUNCH((bn_resident_bwd<VV, NN, TX, TY, false, TD>), rg, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, (int)R, C, groups, act, leak, XP, YP, sl); } while (0)
@@ -1146,17 +1272,12 @@ int bn_bwd_typed(const void* x, const void* dy, const float* beta, const float* 
   // resident at one block of 1024 threads per CU
   if constexpr (same) {
     static const int fused_on = env_int("ACG_BN_FUSED_BWD", 1);     // tuning hook
-    static const int ncu = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0; (void)hipGetLastError(); return n; }();
-    if (fused_on && v4 && ncu > 0) {
-      const long long cchunks = (C + 31) / 32;
-      const long long nb4 = acg::ceil_div(R, 512) * cchunks * groups, nb8 = acg::ceil_div(R, 1024) * cchunks * groups;
-      const int U = nb4 <= ncu ? 4 : (nb8 <= ncu ? 8 : 0);
-      if (U) {
-        const dim3 fg((unsigned)acg::ceil_div(R, 128 * U), (unsigned)cchunks, (unsigned)groups);
-        if (U == 4) ACG_LAUNCH((bn_bwd_fused<4, TX, TY, TD, 4>), fg, dim3(1024), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, R, C, groups, act, leak, XP, YP, (unsigned*)part);
-        else ACG_LAUNCH((bn_bwd_fused<4, TX, TY, TD, 8>), fg, dim3(1024), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, R, C, groups, act, leak, XP, YP, (unsigned*)part);
-        return acg::check_launch("bn_bwd_fused");
-      }
+    const FusedShape f = (fused_on && v4) ? fused_shape(R, C, groups) : FusedShape{0, 0, dim3(1, 1, 1)};
+    if (f.nt) {
+#define ACG_BN_FB(UU, NN) ACG_LAUNCH((bn_bwd_fused<4, TX, TY, TD, UU, NN>), f.grid, dim3(NN), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, R, C, groups, act, leak, XP, YP, (unsigned*)part)
+      if (f.nt == 256) ACG_BN_FB(4, 256); else if (f.U == 4) ACG_BN_FB(4, 1024); else ACG_BN_FB(8, 1024);
+#undef ACG_BN_FB
+      return acg::check_launch("bn_bwd_fused");
     }
   }
   static const int bwd_iters = env_int("ACG_BN_BWD_ITERS", 4);      // tuning hook

@@ -317,7 +317,7 @@ def main():
             roof = {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': peak, 'unit': 'TFLOP/s',
                     'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_note': traffic_note, 'timing': timing,
                     'kernel': '%s (+splitk_reduce*, direct_*): %d conv/deconv fwd+dgrad+wgrad contractions per step' % (
-                        'conv_mfma_bf16<*> / conv_pair_bf16<*>' if args.dtype == 'bf16' else 'conv_mfma_f32<*> / conv_pair_f32<*>', n_conv),
+                        'conv_mfma_bf16<*> / conv_pair_bf16<*> / conv_glds_bf16<*>' if args.dtype == 'bf16' else 'conv_mfma_f32<*> / conv_pair_f32<*>', n_conv),
                     'algorithmic_gflop_per_step': round(conv_fl / 1e9, 2), 'ms_per_step_in_kernel': round(t_ms, 4),
                     'avg_launch_us': round(t_ms * 1e3 / max(n_launch, 1), 2), 'launches_per_step': n_launch,
                     'algorithmic_bytes_per_launch': round(conv_by / max(n_launch, 1)),

@@ -40,8 +40,10 @@ extern "C" {
  * 1: round 1.  2: round 2 (acg_bn_act_*, acg_bias_act_*, acg_dna_*, acg_copy_list, the flags of acg_*_bwd_pair changed
  * without a bump - any "version 1" build may be either).  3: round 3.  4: the `layout` argument of the slab hand-off
  * entries (acg_*_slabs, acg_bn_act_*_slabs), acg_bn_slabs_layout.  5: round 4 - struct acg_conv_desc is 17 int32 fields
- * (dgrad_c, adj_dgrad_c were appended in round 3 under version 4: a "version 4" build may have either layout). */
-#define ACG_ABI_VERSION 5
+ * (dgrad_c, adj_dgrad_c were appended in round 3 under version 4: a "version 4" build may have either layout).  6: the
+ * workspace of acg_bn_act_fwd / acg_bn_act_bwd is state (zero before first use, private to its call site); new entries
+ * acg_conv2d_tile, acg_opt_step_prepare_bf16. */
+#define ACG_ABI_VERSION 6
 
 typedef void* acg_stream_t; /* hipStream_t */
 
@@ -292,6 +294,13 @@ int32_t acg_bn_act_bwd_sums(const void* x, const void* dy, const float* beta, co
  * into the bf16 network.  Statistics, beta and dbeta are float32.
  * x / dx rows are x_pitch elements apart, y / dy rows y_pitch (0 = dense = channels): the one-channel bf16 output of
  * d/conv6 sits at a pitch of 8; pad channels are neither read nor written.
+ * WORKSPACE of acg_bn_act_fwd / acg_bn_act_bwd (version 6): for tensors whose grid is resident on the chip these run as ONE
+ * launch whose blocks exchange their partial sums through the workspace (epoch-tagged 8-byte words; bn.hip).  The epoch counter
+ * lives in the workspace and survives from call to call - also across the replays of a captured graph - so the workspace must be
+ * ZERO before the first call that uses it, must not be written by anyone else between calls, and must belong to ONE call site
+ * (one layer, one direction): hand every BatchNorm op its own, as the other entries' workspaces may be shared scratch but this
+ * one is state.  Word 2 (uint32) is set to 1 if a block ever gave up waiting for its peers (it then finishes with what it has:
+ * a wrong result and this flag, never a hung GPU); it stays 0 in correct operation.
  * ---------------------------------------------------------------------------------------- */
 size_t acg_bn_workspace_bytes(int64_t rows, int32_t channels, int32_t groups);
 /* The same with the split-K hand-off described at acg_conv2d_fwd_slabs: forward reads x as the sum of `splits` float32

@@ -21,6 +21,8 @@ SETS = {
     'c2': [(32768, 128, 1, 'relu', 'g/tconv3'), (32768, 64, 2, 'lrelu', 'd/conv1 D'), (32768, 64, 1, 'lrelu', 'd/conv1 G'),
            (8192, 128, 2, 'lrelu', 'd/conv2 D'), (32768, 32, 1, 'relu', 'g/conv1'), (8192, 128, 1, 'relu', 'g/tconv2'),
            (8192, 64, 1, 'relu', 'g/conv2'), (4096, 128, 1, 'lrelu', 'd/conv3 D/2'), (2048, 128, 1, 'relu', 'g/conv3')],
+    'small': [(2048, 128, 1, 'relu', 'g/conv3'), (2048, 128, 2, 'lrelu', 'd/conv3 D'), (2048, 32, 1, 'relu', 'g/sconv3'), (1024, 128, 1, 'relu', '1024 x 128'),
+              (512, 256, 1, 'relu', 'g/conv4'), (512, 256, 2, 'lrelu', 'd/conv4 D'), (128, 512, 2, 'lrelu', 'd/conv5 D')],
     'c5': [(131072, 128, 1, 'relu', 'g/tconv3'), (131072, 64, 2, 'lrelu', 'd/conv1 D'), (131072, 64, 1, 'lrelu', 'd/conv1 G'),
            (32768, 128, 2, 'lrelu', 'd/conv2 D'), (131072, 32, 1, 'relu', 'g/conv1'), (32768, 128, 1, 'relu', 'g/tconv2'),
            (32768, 64, 1, 'relu', 'g/conv2'), (8192, 128, 2, 'lrelu', 'd/conv3 D')],
@@ -74,25 +76,26 @@ def main():
             beta = torch.randn(C, device=dev, generator=g) * 0.1
             y, dx = torch.empty_like(x), torch.empty_like(x)
             mean, rstd, dbeta = (torch.empty(G * C, device=dev) for _ in range(3))
-            ws = torch.zeros(max(nb, 16), dtype=torch.uint8, device=dev)
+            ws = torch.zeros(max(nb, 16), dtype=torch.uint8, device=dev)       # forward's; backward has its own (wsb): the one-launch
+            wsb = torch.zeros(max(nb, 16), dtype=torch.uint8, device=dev)      # kernels keep state in a workspace that must be theirs alone
             nblk = R // args.tile
             xt = x.float().view(G, nblk, args.tile, C)
             s = xt.sum(2)
             part = torch.stack([s, ((xt - (s / args.tile).unsqueeze(2)) ** 2).sum(2)], dim=2).contiguous()     # [G][nblk][2][C]
-            sets.append((x, dy, beta, y, dx, mean, rstd, dbeta, ws, part, nblk))
+            sets.append((x, dy, beta, y, dx, mean, rstd, dbeta, ws, part, nblk, wsb))
         a = ACT[act]
 
         def f_fwd(t):
-            x, dy, beta, y, dx, mean, rstd, dbeta, ws, part, nblk = t
+            x, dy, beta, y, dx, mean, rstd, dbeta, ws, part, nblk, wsb = t
             return lambda s: lib.bn_act_fwd(p(x), p(beta), p(y), p(mean), p(rstd), rows, C, 0, 0, G, 1e-3, a, 0.2, code, p(ws), nb, s)
 
         def f_fwdp(t):
-            x, dy, beta, y, dx, mean, rstd, dbeta, ws, part, nblk = t
+            x, dy, beta, y, dx, mean, rstd, dbeta, ws, part, nblk, wsb = t
             return lambda s: lib.bn_act_fwd_partials(p(x), p(beta), p(part), nblk, args.tile, R, p(y), p(mean), p(rstd), rows, C, 0, 0, G, 1e-3, a, 0.2, code, s)
 
         def f_bwd(t):
-            x, dy, beta, y, dx, mean, rstd, dbeta, ws, part, nblk = t
-            return lambda s: lib.bn_act_bwd(p(x), p(dy), p(beta), p(mean), p(rstd), p(dx), p(dbeta), 0.0, rows, C, 0, 0, G, a, 0.2, code, p(ws), nb, s)
+            x, dy, beta, y, dx, mean, rstd, dbeta, ws, part, nblk, wsb = t
+            return lambda s: lib.bn_act_bwd(p(x), p(dy), p(beta), p(mean), p(rstd), p(dx), p(dbeta), 0.0, rows, C, 0, 0, G, a, 0.2, code, p(wsb), nb, s)
         us = [timed([f(t) for t in sets]) for f in (f_fwd, f_fwdp, f_bwd)]
         by = [3.0 * rows * C * es, 2.0 * rows * C * es, 3.0 * rows * C * es]
         print('%-16s %8d %5d %2d | %7.2f us %7.0f | %7.2f us %7.0f | %7.2f us %7.0f' % (
@@ -100,7 +103,7 @@ def main():
         for i in range(3):
             tot[i] += us[i]
         if args.check:
-            x, dy, beta, y, dx, mean, rstd, dbeta, ws, part, nblk = sets[0]
+            x, dy, beta, y, dx, mean, rstd, dbeta, ws, part, nblk, wsb = sets[0]
             sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             x64 = x.double().view(G, R, C)
             mu, var = x64.mean(1, keepdim=True), x64.var(1, unbiased=False, keepdim=True)

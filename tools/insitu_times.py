@@ -22,12 +22,12 @@ import sys
 
 # kernel-name prefix (after stripping `void `, namespaces and template arguments) -> family
 FAMILIES = (
-    ('conv', ('conv_mfma_f32', 'conv_pair_f32', 'conv_mfma_bf16', 'conv_pair_bf16', 'splitk_reduce', 'direct_fwd', 'direct_dgrad',
+    ('conv', ('conv_mfma_f32', 'conv_pair_f32', 'conv_mfma_bf16', 'conv_pair_bf16', 'conv_glds_bf16', 'splitk_reduce', 'direct_fwd', 'direct_dgrad',
               'direct_wgrad', 'direct_pair', 'merge_dgrad_weights')),          # every contraction launch + its slab reductions
     ('bn', ('bn_',)),
     ('bias', ('bias_act', 'colsum_finalize')),
     ('dna_fwd', ('dna_fwd',)), ('dna_bwd', ('dna_bwd', 'dna_dbias')),
-    ('optimizer', ('adam_k', 'rmsprop_k', 'clip_k', 'step_inc_k', 'weights_prepare')),
+    ('optimizer', ('adam_k', 'rmsprop_k', 'clip_k', 'step_inc_k', 'weights_prepare', 'opt_prepare_k')),
     ('loss', ('frame_loss', 'l2norm_loss', 'sigmoid_ce', 'mean_loss', 'sqdiff', 'finalize_k', 'scalar_combine', 'psnr')),
     ('plumbing', ('copy_many', 'concat', 'slice', 'add_k', '__amd_rocclr')),
     ('rccl', ('ncclDevKernel', 'rccl')),
@@ -37,6 +37,16 @@ FAMILIES = (
 def short(name):
     name = re.sub(r'^void ', '', name)
     name = re.sub(r'\(anonymous namespace\)::|acgconv::', '', name)
+    # kernels with a bfloat16 template argument come through MANGLED (the profiler's demangler does not know DF16b):
+    # _ZN12_GLOBAL__N_1<len><name>I<template args>E... / _ZN7acgconv<len><name>I...
+    m = re.match(r'_ZN(?:12_GLOBAL__N_1|7acgconv)(?:12_GLOBAL__N_1)?(\d+)', name)
+    if m:
+        n0 = m.end()
+        base = name[n0:n0 + int(m.group(1))]
+        if base in ('dna_kernel', 'dna_rows_kernel'):       # ...ILi<K>E[Li<TY>E]Lb<0|1>E...: the first bool is BWD
+            b = re.search(r'Lb([01])E', name[n0:])
+            return 'dna_bwd' if (b and b.group(1) == '1') else 'dna_fwd'
+        return base
     m = re.match(r'(dna_kernel|dna_rows_kernel)<([^>]*)>', name)      # forward / backward are one template
     if m:
         args = [a.strip() for a in m.group(2).split(',')]

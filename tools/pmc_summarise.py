@@ -10,6 +10,9 @@ import re
 import sys
 
 
+CONV_KERNELS = ('conv_mfma_f32', 'conv_pair_f32', 'conv_mfma_bf16', 'conv_pair_bf16', 'conv_glds_bf16')
+
+
 def short(name):
     name = re.sub(r'^void ', '', name)
     name = re.sub(r'\(anonymous namespace\)::|acgconv::', '', name)
@@ -24,7 +27,7 @@ def short(name):
         bwd = re.search(r'\(bool\)\s*(1|true)|, true,', m.group(2)) is not None
         return 'dna_bwd' if bwd else 'dna_fwd'
     name = re.sub(r'\(.*$', '', name)                       # drop the argument list
-    for k in ('conv_mfma_f32', 'conv_pair_f32', 'conv_mfma_bf16', 'conv_pair_bf16'):
+    for k in CONV_KERNELS:
         if name.startswith(k):
             return k
     return name[:34]
@@ -59,13 +62,13 @@ def main():
     for k, n, f_mb, w_mb in rows:
         print('%-36s %8d   %12.2f %26.2f %16.2f' % (k, n, f_mb, w_mb, f_mb + w_mb))
     out = {}
-    conv = [r for r in rows if r[0] in ('conv_mfma_f32', 'conv_pair_f32', 'conv_mfma_bf16', 'conv_pair_bf16')]
+    conv = [r for r in rows if r[0] in CONV_KERNELS]
     if conv:        # all conv contraction launches together (a paired launch counts once)
         n = sum(r[1] for r in conv)
         out['conv'] = {'launches': n, 'fetch_bytes_per_launch': round(sum(r[1] * r[2] for r in conv) * 1e6 / n),
                        'write_bytes_per_launch': round(sum(r[1] * r[3] for r in conv) * 1e6 / n)}
     for k, n, f_mb, w_mb in rows:
-        if k in ('conv_mfma_f32', 'conv_pair_f32', 'conv_mfma_bf16', 'conv_pair_bf16', 'splitk_reduce', 'splitk_reduce_bf16', 'splitk_reduce_many', 'dna_fwd', 'dna_bwd'):
+        if k in CONV_KERNELS + ('splitk_reduce', 'splitk_reduce_bf16', 'splitk_reduce_many', 'dna_fwd', 'dna_bwd'):
             out[k] = {'launches': n, 'fetch_bytes_per_launch': round(f_mb * 1e6), 'write_bytes_per_launch': round(w_mb * 1e6)}
     sys.stderr.write(json.dumps(out, indent=1) + '\n')
 

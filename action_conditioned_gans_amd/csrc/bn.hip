@@ -615,11 +615,14 @@ struct FusedExchange {
   }
 };
 
-template <int V, typename TX, typename TY, typename TD, int U, int NT>
+// SL: dy arrives as the `sl.splits` float32 partial slabs of the producing split-K input gradient (ACG_SLABS_ROWS: each laid out like
+// the tensor) and is summed while it is loaded - the slab reduction launch of that convolution disappears (acg_bn_act_bwd_slabs)
+template <int V, typename TX, typename TY, typename TD, int U, int NT, bool SL = false>
 __global__ __launch_bounds__(NT) void bn_bwd_fused(const TX* __restrict__ x, const TY* __restrict__ dy, const float* __restrict__ beta,
                                                    const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
                                                    TD* __restrict__ dx, float* __restrict__ dbeta, float dbeta_acc, long long R, int C,
-                                                   int groups, int act, float leak, int XP, int YP, unsigned* __restrict__ ws) {
+                                                   int groups, int act, float leak, int XP, int YP, unsigned* __restrict__ ws,
+                                                   const Slabs sl = Slabs{nullptr, 0, 0, 0}) {
   using EX = FusedExchange<NT>;
   constexpr int CL = EX::CL, RL = NT / CL, NV = EX::NV;
   static_assert(V == 4, "four channels per lane");
@@ -632,7 +635,6 @@ __global__ __launch_bounds__(NT) void bn_bwd_fused(const TX* __restrict__ x, con
   const int c = (cc * CL + cq) * V;
   const bool cvalid = c < C;
   const TX* xg = x + (long long)g * R * XP;
-  const TY* dyg = dy + (long long)g * R * YP;
   TD* dxg = dx + (long long)g * R * XP;
   FusedState* const state = reinterpret_cast<FusedState*>(ws);
   if (tid == 0) s_epoch = __hip_atomic_load(&state->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
@@ -644,7 +646,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_fused(const TX* __restrict__ x, con
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long long q = min(r0 + (long long)u * RL, R - 1);
-      ldv<V>(xg + q * XP + c, xv[u]); ldv<V>(dyg + q * YP + c, dv[u]);
+      ldv<V>(xg + q * XP + c, xv[u]);
+      ld_or_sum<SL, V>(const_cast<TY*>(dy), ((long long)g * R + q) * YP + c, sl, false, dv[u]);
     }
     ldv<V>(save_mean + g * C + c, mean); ldv<V>(save_rstd + g * C + c, rstd); ldv<V>(beta + c, bt);
   }
@@ -710,10 +713,13 @@ __global__ __launch_bounds__(NT) void bn_bwd_fused(const TX* __restrict__ x, con
 
 // Forward, statistics included (layers whose convolution is split over K leave no epilogue partials): one read of x.  The blocks
 // exchange sums of (x - ref) and (x - ref)^2 about the group's first row - what bn_stats_partial leaves, same float64 finish.
-template <int V, typename TX, typename TY, int U, int NT>
-__global__ __launch_bounds__(NT) void bn_fwd_fused(const TX* __restrict__ x, const float* __restrict__ beta, TY* __restrict__ y,
+// SL: x arrives as the partial slabs of the producing split-K convolution (ACG_SLABS_ROWS), is summed while it is loaded and
+// written back (rounded to its storage type: the backward pass reads it) - acg_bn_act_fwd_slabs without a reduction launch
+template <int V, typename TX, typename TY, int U, int NT, bool SL = false>
+__global__ __launch_bounds__(NT) void bn_fwd_fused(TX* __restrict__ x, const float* __restrict__ beta, TY* __restrict__ y,
                                                    float* __restrict__ save_mean, float* __restrict__ save_rstd, long long R, int C, float eps,
-                                                   int act, float leak, int XP, int YP, unsigned* __restrict__ ws) {
+                                                   int act, float leak, int XP, int YP, unsigned* __restrict__ ws,
+                                                   const Slabs sl = Slabs{nullptr, 0, 0, 0}) {
   using EX = FusedExchange<NT>;
   constexpr int CL = EX::CL, RL = NT / CL, NV = EX::NV;
   static_assert(V == 4, "four channels per lane");
@@ -725,7 +731,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_fused(const TX* __restrict__ x, con
   const int rb = blockIdx.x, nrb = gridDim.x, cc = blockIdx.y, g = blockIdx.z;
   const int c = (cc * CL + cq) * V;
   const bool cvalid = c < C;
-  const TX* xg = x + (long long)g * R * XP;
+  const long long gb = (long long)g * R * XP;
   TY* yg = y + (long long)g * R * YP;
   FusedState* const state = reinterpret_cast<FusedState*>(ws);
   if (tid == 0) s_epoch = __hip_atomic_load(&state->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
@@ -735,8 +741,11 @@ __global__ __launch_bounds__(NT) void bn_fwd_fused(const TX* __restrict__ x, con
   for (int j = 0; j < V; ++j) { pv[j] = 0.f; bt[j] = 0.f; }
   if (cvalid) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) ldv<V>(xg + min(r0 + (long long)u * RL, R - 1) * XP + c, xv[u]);
-    ldv<V>(xg + c, pv);                           // the group's first row: the common shift
+    for (int u = 0; u < U; ++u) {
+      const long long r = r0 + (long long)u * RL;
+      ld_or_sum<SL, V>(x, gb + min(r, R - 1) * XP + c, sl, r < R, xv[u]);      // (SL: each row is written back by the one thread that owns it)
+    }
+    ld_or_sum<SL, V>(x, gb + c, sl, false, pv);   // the group's first row: the common shift
     ldv<V>(beta + c, bt);
   }
   float s[2 * V];
@@ -1199,9 +1208,13 @@ int bn_fwd_typed(const void* x, const float* beta, void* y, float* save_mean, fl
   // one-block-per-four-channels kernels below `fused_min` rows per group (tuning hook)
   static const int fused_on_f = env_int("ACG_BN_FUSED_FWD", 1), fused_min_f = env_int("ACG_BN_FUSED_MIN_ROWS", 1 << 30);
   if constexpr (same) {
-    const FusedShape f = (fused_on_f && v4 && !sl.p && (resident_nr(R, 32) == 0 || R >= fused_min_f)) ? fused_shape(R, C, groups) : FusedShape{0, 0, dim3(1, 1, 1)};
+    // (slabs in the rows layout: the fused kernel also where the resident ones would apply - its rows are coalesced, theirs cost a
+    // cache line per row and slab)
+    const bool rows_slabs = sl.p != nullptr && sl.qrows == 0;
+    const FusedShape f = (fused_on_f && v4 && (rows_slabs || (!sl.p && (resident_nr(R, 32) == 0 || R >= fused_min_f)))) ? fused_shape(R, C, groups) : FusedShape{0, 0, dim3(1, 1, 1)};
     if (f.nt) {
-#define ACG_BN_FF(UU, NN) ACG_LAUNCH((bn_fwd_fused<4, TX, TY, UU, NN>), f.grid, dim3(NN), 0, st, (const TX*)xf, beta, yf, save_mean, save_rstd, R, C, eps, act, leak, XP, YP, (unsigned*)part)
+#define ACG_BN_FF(UU, NN) do { if (rows_slabs) ACG_LAUNCH((bn_fwd_fused<4, TX, TY, UU, NN, true>), f.grid, dim3(NN), 0, st, xf, beta, yf, save_mean, save_rstd, R, C, eps, act, leak, XP, YP, (unsigned*)part, sl); \
+      else ACG_LAUNCH((bn_fwd_fused<4, TX, TY, UU, NN, false>), f.grid, dim3(NN), 0, st, xf, beta, yf, save_mean, save_rstd, R, C, eps, act, leak, XP, YP, (unsigned*)part, sl); } while (0)
       if (f.nt == 256) ACG_BN_FF(4, 256); else if (f.U == 4) ACG_BN_FF(4, 1024); else ACG_BN_FF(8, 1024);
 #undef ACG_BN_FF
       return acg::check_launch("bn_fwd_fused");
@@ -1250,7 +1263,8 @@ int bn_bwd_typed(const void* x, const void* dy, const float* beta, const float* 
   // small tensors: ONE block per four channels holds every row (bn_resident_bwd) - unless the fused grid kernel is asked to take
   // them from `fused_min` rows per group on (tuning hook; measured in profiles/r4/d_bn_fused_ab.txt)
   static const int fused_min_b = env_int("ACG_BN_FUSED_MIN_ROWS", 2048);      // backward: 2048 x 128 runs 6.1 us fused, 7.7 resident; below, resident wins
-  const bool prefer_fused_b = same && v4 && !sl.p && R >= fused_min_b && fused_shape(R, C, groups).nt != 0;
+  const bool rows_slabs_b = sl.p != nullptr && sl.qrows == 0;
+  const bool prefer_fused_b = same && v4 && (rows_slabs_b || (!sl.p && R >= fused_min_b)) && fused_shape(R, C, groups).nt != 0;
   if (const int nr = prefer_fused_b ? 0 : (resident_nr(R * groups, 16) ? resident_nr(R, 16) : 0)) {
     const dim3 rg(C / V);
 #define ACG_BN_RES_BWD(VV, NN) do { if (sl.p) ACG_LAUNCH((bn_resident_bwd<VV, NN, TX, TY, true, TD>), rg, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, (int)R, C, groups, act, leak, XP, YP, sl); \
@@ -1267,19 +1281,20 @@ int bn_bwd_typed(const void* x, const void* dy, const float* beta, const float* 
 #undef ACG_BN_RES_BWD
     return acg::check_launch("bn_resident_bwd");
   }
-  if (sl.p) return acg::fail(ACG_ERR_UNSUPPORTED, "bn_act_bwd_slabs: %lld rows per group exceed the register-resident kernels (acg_bn_bwd_slabs_ok)", R);
   // One launch with the tensor held in registers between the sums and the apply phase (bn_bwd_fused) where the whole grid is
   // resident at one block of 1024 threads per CU
   if constexpr (same) {
     static const int fused_on = env_int("ACG_BN_FUSED_BWD", 1);     // tuning hook
-    const FusedShape f = (fused_on && v4) ? fused_shape(R, C, groups) : FusedShape{0, 0, dim3(1, 1, 1)};
+    const FusedShape f = (fused_on && v4 && (!sl.p || rows_slabs_b)) ? fused_shape(R, C, groups) : FusedShape{0, 0, dim3(1, 1, 1)};
     if (f.nt) {
-#define ACG_BN_FB(UU, NN) ACG_LAUNCH((bn_bwd_fused<4, TX, TY, TD, UU, NN>), f.grid, dim3(NN), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, R, C, groups, act, leak, XP, YP, (unsigned*)part)
+#define ACG_BN_FB(UU, NN) do { if (rows_slabs_b) ACG_LAUNCH((bn_bwd_fused<4, TX, TY, TD, UU, NN, true>), f.grid, dim3(NN), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, R, C, groups, act, leak, XP, YP, (unsigned*)part, sl); \
+      else ACG_LAUNCH((bn_bwd_fused<4, TX, TY, TD, UU, NN, false>), f.grid, dim3(NN), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, R, C, groups, act, leak, XP, YP, (unsigned*)part, sl); } while (0)
       if (f.nt == 256) ACG_BN_FB(4, 256); else if (f.U == 4) ACG_BN_FB(4, 1024); else ACG_BN_FB(8, 1024);
 #undef ACG_BN_FB
       return acg::check_launch("bn_bwd_fused");
     }
   }
+  if (sl.p) return acg::fail(ACG_ERR_UNSUPPORTED, "bn_act_bwd_slabs: %lld rows per group fit neither the one-launch grid kernel nor the register-resident kernels (acg_bn_slabs_layout)", R);
   static const int bwd_iters = env_int("ACG_BN_BWD_ITERS", 4);      // tuning hook
   const int nblk = vpartial_blocks(R, C, V, bwd_iters);
   {
@@ -1407,11 +1422,15 @@ int32_t acg_bn_bwd_slabs_ok(int64_t rows, int32_t groups) {
 int32_t acg_bn_slabs_layout(int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t groups, int32_t dtype, int32_t backward) {
   if (rows <= 0 || C <= 0 || groups <= 0 || rows % groups) return -1;
   const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
+  const bool vec = C % 4 == 0 && XP % 4 == 0 && YP % 4 == 0 && acg::dt_valid(dtype) && acg::dt_first(dtype) == acg::dt_second(dtype);
+  // the one-launch grid kernels (bn_fwd_fused / bn_bwd_fused) sum slabs laid out like the tensor while they load their rows:
+  // coalesced, any tensor whose grid is resident
+  static const int fused_slabs = env_int("ACG_BN_SLABS_FUSED", 1);      // tuning hook
+  if (fused_slabs && vec && fused_shape(rows / groups, C, groups).nt != 0) return ACG_SLABS_ROWS;
   const bool resident = backward ? acg_bn_bwd_slabs_ok(rows, groups) != 0 : resident_nr(rows / groups, 32) != 0;
   if (backward && !resident) return -1;
   // the register-resident kernels with four channels per block read [channels / 4][rows][4] slabs as consecutive 16-byte rows
-  const bool quads = resident && C % 4 == 0 && XP % 4 == 0 && YP % 4 == 0 && acg::dt_valid(dtype) && acg::dt_first(dtype) == acg::dt_second(dtype);
-  return quads ? ACG_SLABS_QUADS : ACG_SLABS_ROWS;
+  return (resident && vec) ? ACG_SLABS_QUADS : ACG_SLABS_ROWS;
 }
 
 int32_t acg_bn_act_bwd_slabs(const void* x, const float* dy_slabs, int32_t splits, const float* beta, const float* save_mean,
@@ -1424,7 +1443,7 @@ int32_t acg_bn_act_bwd_slabs(const void* x, const float* dy_slabs, int32_t split
   if (int rc = check_bn("bn_act_bwd_slabs", rows, C, groups)) return rc;
   ACG_REQUIRE(x && dy_slabs && splits >= 1 && beta && save_mean && save_rstd && dx && dbeta, ACG_ERR_INVALID_ARG, "bn_act_bwd_slabs: null pointer / splits < 1");
   ACG_REQUIRE(act == ACG_ACT_NONE || act == ACG_ACT_RELU || act == ACG_ACT_LRELU, ACG_ERR_UNSUPPORTED, "bn_act_bwd_slabs: activation %d", act);
-  ACG_REQUIRE(acg_bn_bwd_slabs_ok(rows, groups), ACG_ERR_UNSUPPORTED, "bn_act_bwd_slabs: tensor too large for the one-launch kernels (acg_bn_bwd_slabs_ok)");
+  ACG_REQUIRE(acg_bn_slabs_layout(rows, C, x_pitch, y_pitch, groups, dtype, 1) >= 0, ACG_ERR_UNSUPPORTED, "bn_act_bwd_slabs: tensor too large for the one-launch kernels (acg_bn_slabs_layout)");
   const long long R = rows / groups;
   const bool v4 = vec4_ok(C, x, dy_slabs, dx) && vec4_ok(C, save_mean, save_rstd, beta) && vec4_ok(C, beta, dbeta, dbeta) && XP % 4 == 0 && YP % 4 == 0;
   ACG_REQUIRE(layout == ACG_SLABS_ROWS || v4, ACG_ERR_INVALID_ARG, "bn_act_bwd_slabs: the quad layout needs 16-byte aligned pointers");

@@ -350,9 +350,9 @@ class Runtime:
         self.is_cuda = self.device.type == 'cuda'
         self.side_stream = torch.cuda.Stream(self.device) if self.is_cuda else None
         self.program_ops = frozenset()         # ids of the ops of the program being compiled (ops.py: hand-offs between neighbours)
-        # split-K slabs summed by the consuming BatchNorm kernel instead of by a launch of their own: bit-identical, but
-        # measured SLOWER (fp32 364 vs 383, bf16 567 vs 600 steps/s, profiles/r2): the one-launch BatchNorm kernels read 16
-        # bytes per row and block, and S slabs multiply exactly those poorly coalesced requests; kept as an option
+        # split-K slabs summed by the consuming BatchNorm kernel instead of by a launch of their own: bit-identical.  With the
+        # resident (one block per channel quad) kernels alone it measured SLOWER (profiles/r2: 16 bytes per row and block, times
+        # S slabs); the grid kernels of round 4 read whole rows of every slab and it pays (Session sets it; default on)
         self.slab_handoff = 0
         self.slab_rows = False                 # hand-offs in the ACG_SLABS_ROWS layout too (Session(slab_handoff=True / N))
         self.epilogue_stats = True
@@ -399,7 +399,7 @@ class Session:
     """``tf.Session`` stand-in bound to one GPU (one process per GPU)."""
 
     def __init__(self, device='cuda:0', graph=None, use_hip_graphs=True, lib=None,
-                 world_size=1, rank=0, process_group=None, dtype='f32', pair_bwd=True, comm=None, slab_handoff=False, epilogue_stats=True, side_branches=False,
+                 world_size=1, rank=0, process_group=None, dtype='f32', pair_bwd=True, comm=None, slab_handoff=True, epilogue_stats=True, side_branches=False,
                  epilogue_bias=True, fuse_weight_refresh=True):
         self.graph = graph or get_default_graph()
         dev = torch.device(device)
@@ -418,8 +418,10 @@ class Session:
                 raise ValueError('Session(dtype=%r): the graph was already built for %s activations' % (dtype, self.graph.act_dtype))
             self.graph.act_dtype = want
         self.rt = Runtime(lib, dev, world_size, rank, process_group, _lib.ACG_BF16 if dtype == 'bf16' else _lib.ACG_F32, comm)
-        # False / 0: off; 'quads': every split layer whose BatchNorm reads the quad slab layout (the one-launch kernels);
-        # True: every split layer, either layout; an int N: either layout, only layers split into at most N slabs
+        # split-K hand-off: a split layer followed by its BatchNorm leaves its float32 slabs and the BatchNorm kernel sums them while
+        # it loads its rows - no reduction launch.  Round 4: ON (True) - the one-launch grid kernels of bn.hip read slabs laid out
+        # like the tensor with coalesced rows (+0.8 % config 2, +0.9 % config 3; rounds 2-3, resident kernels only: -4.5 % / level).
+        # False / 0: off; 'quads': only layers whose BatchNorm reads the quad slab layout; an int N: only layers split into <= N slabs
         if not (slab_handoff is True or slab_handoff is False or slab_handoff is None or slab_handoff == 'quads'
                 or (isinstance(slab_handoff, int) and slab_handoff >= 0)):
             raise ValueError("slab_handoff must be False, True, 'quads' or a non-negative int, got %r" % (slab_handoff,))

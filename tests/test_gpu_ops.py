@@ -82,7 +82,7 @@ def test_slab_handoff_layouts(hip_abi):
 
 
 def test_slab_handoff_layouts_bf16(hip_abi_bf16):
-    C.case_slab_handoff(hip_abi_bf16, 2e-5, min_rows=0)
+    C.case_slab_handoff(hip_abi_bf16, 2e-5, min_rows=1)
 
 
 def test_bn_large_tensor(hip_abi):

@@ -16,7 +16,11 @@
 //    tile), ONE block per CU: three LDS buffers of 48 KB; a K-step is 48 wave-instructions of DMA, 6 per wave;
 //  * counted waits: a wave keeps the 6 DMA instructions of K-step ks + 2 in flight across the barrier
 //    (`s_waitcnt vmcnt(6)` + raw `s_barrier`: __syncthreads() would drain them, cdna_hip_programming.md section 5); the tail
-//    issues fully masked (zero) loads so that the count stays exact.
+//    issues fully masked (zero) loads so that the count stays exact;
+//  * K-loop schedule (template VAR; 2 ships): the waves of a SIMD (w, w + 4) belong to two groups one barrier apart; a K-step is a
+//    load phase (16 fragment reads, the offsets of the next DMA pieces) and a compute phase (16 MFMAs at raised priority with the 6
+//    DMA pieces issued BETWEEN them), so one wave of each SIMD multiplies while the other reads.  Measured against the in-step
+//    loop (VAR 0): -3...-9 % per launch; what bounds all three variants is outside the CU (profiles/r4/h_bf16_kloop_load_path.txt).
 // Used for unsplit, unpaired FWD / DGRAD contractions with more than 64 output columns whose 256 x 128 tiles fill the chip
 // (make_plan cfg 4); everything else - and every weight gradient - stays on conv_bf16_kernel.h.
 #pragma once
@@ -30,7 +34,7 @@ constexpr int conv16g_lds_bytes() { return GNBUF * GCELLS * 16 + GBM * (int)size
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int MODE>
+template <int MODE, int VAR = 0>
 __device__ __forceinline__ void conv16g_body(const ConvArgs& p, char* smem) {
   static_assert(MODE == MODE_FWD || MODE == MODE_DGRAD, "forward / input gradient only");
   constexpr int WM = 4, TA = 2, TB = 2;          // 8 waves as 4 (M) x 2 (N)
@@ -84,8 +88,9 @@ __device__ __forceinline__ void conv16g_body(const ConvArgs& p, char* smem) {
       tapB[t] = ((i0 + p.sh * ti) * p.KW + (j0 + p.sw * tj)) * p.C * K8;      // filter copy [tap][c][o8]
     } else {
       const int i = t / p.KW, j = t - i * p.KW;
-      tapA[t] = (i * p.W + j) * Cin8;
-      tapB[t] = t * p.K * Cin8;                                               // filter copy [tap][o][c8]
+      const int u = p.tap_classes ? tap_class_pos(i, j, p.KH, p.KW) : t;      // position in the K order
+      tapA[u] = (i * p.W + j) * Cin8;
+      tapB[u] = t * p.K * Cin8;                                               // filter copy [tap][o][c8]
     }
   }
   if (tid < GBM) {
@@ -97,7 +102,8 @@ __device__ __forceinline__ void conv16g_body(const ConvArgs& p, char* smem) {
         const int b = div_fast(t2, p.mg_oh, p.sh_oh), pp = t2 - b * p.OH;
         const int y0 = pp * p.sh - p.pt, x0 = q * p.sw - p.pl;
         ri.base = ((b * p.H + y0) * p.W + x0) * Cin8;
-        const unsigned long long mk = tap_mask(max(0, -y0), min(p.KH, p.H - y0), max(0, -x0), min(p.KW, p.W - x0), p.KW);
+        const unsigned long long mk = p.tap_classes ? tap_mask_classes(max(0, -y0), min(p.KH, p.H - y0), max(0, -x0), min(p.KW, p.W - x0), p.KH, p.KW)
+                                                    : tap_mask(max(0, -y0), min(p.KH, p.H - y0), max(0, -x0), min(p.KW, p.W - x0), p.KW);
         ri.mask_lo = (unsigned)mk; ri.mask_hi = (unsigned)(mk >> 32);
       } else {
         const int w2 = m % Wc; const int t2 = m / Wc; const int h2 = t2 % Hc; const int b = t2 / Hc;
@@ -128,7 +134,8 @@ __device__ __forceinline__ void conv16g_body(const ConvArgs& p, char* smem) {
   const int inc_t = chunked ? 1 : step_t, inc_c = chunked ? 0 : step_c, wrap_t = chunked ? -ntaps : 1, wrap_c = chunked ? BKH : -Cp;
   int run_kt = chunked ? 0 : div_fast(8 * oct, p.mg_cp, p.sh_cp), run_kc = 8 * oct - (chunked ? 0 : run_kt * Cp);
 
-  auto issue = [&](int buf, bool live) {
+  unsigned offs[6];
+  auto prep = [&](bool live) {
     // this lane's (tap, channel) of the K-step, then the next one's
     const bool kv = live && run_kt < ntaps && run_kc < Cp;
     const int t = kv ? run_kt : 0;
@@ -136,19 +143,26 @@ __device__ __forceinline__ void conv16g_body(const ConvArgs& p, char* smem) {
     run_kt += inc_t; run_kc += inc_c;
     const bool wrap = chunked ? run_kt >= ntaps : run_kc >= Cp;
     run_kt += wrap ? wrap_t : 0; run_kc += wrap ? wrap_c : 0;
-    char* const bufp = reinterpret_cast<char*>(cells + buf * GCELLS);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      unsigned off = (kv && tap_ok(myrow[i], t)) ? (unsigned)(myrow[i].base + aoff) * 2u : kOob;
-      asm volatile("" : "+v"(off));        // opaque: hipcc otherwise turns the select into a divergent branch around the load -
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)(bufp + 1024 * (wave + 8 * i)), 16, off, 0, 0, 0);
+      offs[i] = (kv && tap_ok(myrow[i], t)) ? (unsigned)(myrow[i].base + aoff) * 2u : kOob;
+      asm volatile("" : "+v"(offs[i]));    // opaque: hipcc otherwise turns the select into a divergent branch around the load -
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      unsigned off = (kv && nOk[i]) ? (unsigned)(boff + nK[i]) * 2u : kOob;
-      asm volatile("" : "+v"(off));        // - and a wave that skips a branch would break the counted vmcnt below
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lds_ptr_t)(bufp + GBM * 128 + 1024 * (wave + 8 * i)), 16, off, 0, 0, 0);
+      offs[4 + i] = (kv && nOk[i]) ? (unsigned)(boff + nK[i]) * 2u : kOob;
+      asm volatile("" : "+v"(offs[4 + i]));      // - and a wave that skips a branch would break the counted vmcnt below
     }
+  };
+  auto fire = [&](int buf, auto ic) {
+    constexpr int I = decltype(ic)::value;
+    char* const bufp = reinterpret_cast<char*>(cells + buf * GCELLS);
+    if constexpr (I < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)(bufp + 1024 * (wave + 8 * I)), 16, offs[I], 0, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lds_ptr_t)(bufp + GBM * 128 + 1024 * (wave + 8 * (I - 4))), 16, offs[I], 0, 0, 0);
+  };
+  auto issue = [&](int buf, bool live) {
+    prep(live);
+    static_for<0, 6>([&](auto ic) { fire(buf, ic); });
   };
 
   // ---- main loop ----------------------------------------------------------------------------------------------------
@@ -171,9 +185,11 @@ __device__ __forceinline__ void conv16g_body(const ConvArgs& p, char* smem) {
 
   issue(0, 0 < nk);
   issue(1, 1 < nk);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  if constexpr (VAR == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (its loop waits for K-step ks + 1 from compute phase ks - 1 on)
+  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   int buf = 0;
+  if constexpr (VAR == 0) {
   for (int ks = 0; ks < nk; ++ks) {
     const int nbuf = buf == 0 ? 2 : buf - 1;                 // (ks + 2) % 3: read last in iteration ks - 1, free since its barrier
     issue(nbuf, ks + 2 < nk);
@@ -199,6 +215,91 @@ __device__ __forceinline__ void conv16g_body(const ConvArgs& p, char* smem) {
     asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");      // (lgkmcnt: this wave's fragment reads of `buf` have returned)
     __builtin_amdgcn_s_barrier();
     buf = buf == 2 ? 0 : buf + 1;
+  }
+  } else if constexpr (VAR == 2) {
+  // As VAR 1 below (two wave groups one phase apart), but the six DMA pieces of K-step ks + 2 are issued BETWEEN the MFMAs of the
+  // compute phase (where an LDS-DMA issue costs least, MI355X_MICROARCH.md cycle constants); the load phase only computes their
+  // offsets and reads the fragments.  Group 0 waits for its pieces of K-step ks + 1 at the end of compute phase ks (vmcnt(6): the
+  // six just issued stay in flight), group 1 - whose compute phase ends one barrier later - at the end of its load phase ks (vmcnt(0)).
+  const int grp = wave >> 2;
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int nbuf = buf == 0 ? 2 : buf - 1;
+    const f4* const cur = cells + buf * GCELLS;
+    f4 av[4][TA], bv[4][TB];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+      const int kq = 2 * T + lk;
+#pragma unroll
+      for (int a = 0; a < TA; ++a) av[T][a] = cur[ca[a] + (kq ^ xa[a])];
+#pragma unroll
+      for (int b = 0; b < TB; ++b) bv[T][b] = cur[cb[b] + (kq ^ xb[b])];
+    }
+    prep(ks + 2 < nk);
+    if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    static_for<0, 16>([&](auto ic) {
+      constexpr int I = decltype(ic)::value;
+      constexpr int T = I / 4, A = (I % 4) / TB, B = I % TB;
+      acc[A][B] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, av[T][A]), __builtin_bit_cast(bf8, bv[T][B]), acc[A][B], 0, 0, 0);
+      constexpr int F = I == 1 ? 0 : I == 4 ? 1 : I == 6 ? 2 : I == 9 ? 3 : I == 11 ? 4 : I == 14 ? 5 : -1;
+      if constexpr (F >= 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        fire(nbuf, std::integral_constant<int, F>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+    __builtin_amdgcn_s_setprio(0);
+    if (grp == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    buf = buf == 2 ? 0 : buf + 1;
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+  } else {
+  // Two wave groups one phase apart (waves w and w + 4 share a SIMD): a K-step is a LOAD phase (the K-step's 16 fragment reads, the
+  // 6 DMA pieces of K-step ks + 2, the counted wait for K-step ks + 1) and a COMPUTE phase (16 MFMAs at raised priority), each
+  // closed by a block barrier; group 1 runs one barrier behind, so one wave of every SIMD loads while the other multiplies.
+  // RAW: a wave waits for its DMA of K-step ks + 1 at the end of its load phase ks, i.e. before a barrier every reader passes
+  // before its load phase ks + 1.  WAR: the fragment reads of a buffer are retired (lgkmcnt(0)) before the barrier that closes
+  // the load phase, and the DMA that refills it is issued two phases later by the same group, one phase later by the other.
+  const int grp = wave >> 2;
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int nbuf = buf == 0 ? 2 : buf - 1;
+    const f4* const cur = cells + buf * GCELLS;
+    f4 av[4][TA], bv[4][TB];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+      const int kq = 2 * T + lk;
+#pragma unroll
+      for (int a = 0; a < TA; ++a) av[T][a] = cur[ca[a] + (kq ^ xa[a])];
+#pragma unroll
+      for (int b = 0; b < TB; ++b) bv[T][b] = cur[cb[b] + (kq ^ xb[b])];
+    }
+    issue(nbuf, ks + 2 < nk);
+    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    static_for<0, 16>([&](auto ic) {
+      constexpr int I = decltype(ic)::value;
+      constexpr int T = I / 4, A = (I % 4) / TB, B = I % TB;
+      acc[A][B] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, av[T][A]), __builtin_bit_cast(bf8, bv[T][B]), acc[A][B], 0, 0, 0);
+    });
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    buf = buf == 2 ? 0 : buf + 1;
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the two masked tail K-steps: nothing of ours may still write LDS
   __syncthreads();
@@ -261,10 +362,10 @@ __device__ __forceinline__ void conv16g_body(const ConvArgs& p, char* smem) {
   }
 }
 
-template <int MODE>
+template <int MODE, int VAR = 0>
 __global__ __launch_bounds__(GNT) void conv_glds_bf16(const ConvArgs p) {
   __shared__ __align__(16) char smem[conv16g_lds_bytes()];
-  conv16g_body<MODE>(p, smem);
+  conv16g_body<MODE, VAR>(p, smem);
 }
 
 int launch_glds16(int mode, const Plan& pl, const ConvArgs& a, hipStream_t st);

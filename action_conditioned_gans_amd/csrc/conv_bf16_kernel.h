@@ -109,8 +109,9 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
       tapB[t] = ((i0 + p.sh * ti) * p.KW + (j0 + p.sw * tj)) * p.C * K8;      // filter copy [tap][c][o8]
     } else {
       const int i = t / p.KW, j = t - i * p.KW;
-      tapA[t] = (i * p.W + j) * Cin8;
-      tapB[t] = t * p.K * Cin8;                                               // filter copy [tap][o][c8] (FWD)
+      const int u = (MODE == MODE_FWD && p.tap_classes) ? tap_class_pos(i, j, p.KH, p.KW) : t;      // position in the K order
+      tapA[u] = (i * p.W + j) * Cin8;
+      tapB[u] = t * p.K * Cin8;                                               // filter copy [tap][o][c8] (FWD)
     }
   }
 
@@ -122,7 +123,8 @@ __device__ __forceinline__ void conv16_body(const ConvArgs& p, const int bx, con
       const int y0 = pp * p.sh - p.pt, x0 = q * p.sw - p.pl;
       ri.base = ((b * p.H + y0) * p.W + x0) * Cin8;
       if (p.shuf_c) ri.out_off = ((b * (2 * p.OH) + 2 * pp) * p.shuf_w + 2 * q) * p.shuf_pitch;     // merged input gradient (ConvArgs::shuf_c)
-      const unsigned long long m = tap_mask(max(0, -y0), min(p.KH, p.H - y0), max(0, -x0), min(p.KW, p.W - x0), p.KW);
+      const unsigned long long m = (MODE == MODE_FWD && p.tap_classes) ? tap_mask_classes(max(0, -y0), min(p.KH, p.H - y0), max(0, -x0), min(p.KW, p.W - x0), p.KH, p.KW)
+                                                                      : tap_mask(max(0, -y0), min(p.KH, p.H - y0), max(0, -x0), min(p.KW, p.W - x0), p.KW);
       ri.mask_lo = (unsigned)m; ri.mask_hi = (unsigned)(m >> 32);
     }
     return ri;

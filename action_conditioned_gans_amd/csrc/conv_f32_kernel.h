@@ -73,6 +73,7 @@ struct ConvArgs {
   // 5 x 5 filter fall into the padding for every row of such a tile, and their K-steps would multiply zeros.
   int compact;
   int Nv;              // FWD / DGRAD: only the first Nv output columns are computed (acg_conv_desc dgrad_c / adj_dgrad_c); 0 = all
+  int tap_classes;     // FWD, stride > 1: 1 = the taps are walked class by class (tap_class_pos below); 0 = row-major
   int korder;          // bf16 kernels, FWD / DGRAD, gathered channels a multiple of 64: 1 = K-steps walk the taps of one 64-channel chunk
                        // before the next chunk (0: all channels of a tap before the next tap) - conv_bf16_kernel.h
   int out_f32;         // bf16 kernels, FWD / DGRAD: the result is stored as float32 (at the bf16 tensor's pitch, round8): a head layer
@@ -123,6 +124,36 @@ __device__ __forceinline__ unsigned long long tap_mask(int lo_a, int hi_a, int l
   const unsigned long long row = ((1ull << (hi_b - lo_b)) - 1ull) << lo_b;
   unsigned long long m = 0ull;
   for (int a = lo_a; a < hi_a; ++a) m |= row << (a * nb);
+  return m;
+}
+
+// Class-major tap order of a STRIDED forward convolution (ConvArgs::tap_classes).  Tap (i, j) of a stride-(sh, sw) conv reads
+// the input lattice (y = sh * p + i - pt, x = sw * q + j - pl): taps with equal (i % sh, j % sw) read the SAME sub-lattice of the
+// input, shifted by whole output pixels, and taps of different classes read DISJOINT sub-lattices.  In row-major order the taps
+// that share a cache line are up to two filter rows (10 K-steps x channel chunks x every tile running on the XCD) apart: the
+// vertical re-use misses the 4 MB L2 and every input byte is fetched from the memory side ~3.5 times (TCC_MISS 36 % of the
+// K-loop's requests, profiles/r4/h_tap_classes.txt).  Walking one class after the other keeps a tile on one sub-lattice - its
+// window / (sh * sw), 43 KB for a 256-row tile of 64 channels - for all of the class's taps; it is a permutation of the K index
+// only (tap tables and row masks are built in that order), so results differ by summation order alone.
+// Built for stride 2 x 2 (every strided layer of the reference's models): class (a, b) = (i & 1, j & 1), na(a) x nb(b) taps each.
+__device__ __forceinline__ int tap_class_pos(int i, int j, int KH, int KW) {
+  const int a = i & 1, b = j & 1;
+  const int na0 = (KH + 1) >> 1, nb0 = (KW + 1) >> 1;
+  const int na = a ? KH >> 1 : na0, nb = b ? KW >> 1 : nb0;
+  return (a ? na0 * KW : 0) + (b ? na * nb0 : 0) + (i >> 1) * nb + (j >> 1);
+}
+__device__ __forceinline__ unsigned long long tap_mask_classes(int lo_i, int hi_i, int lo_j, int hi_j, int KH, int KW) {
+  // the rectangle [lo_i, hi_i) x [lo_j, hi_j) of taps is a rectangle of (ti, tj) in each of the four classes
+  unsigned long long m = 0ull;
+  const int na0 = (KH + 1) >> 1, nb0 = (KW + 1) >> 1;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int na = a ? KH >> 1 : na0, nb = b ? KW >> 1 : nb0;
+      const int base = (a ? na0 * KW : 0) + (b ? na * nb0 : 0);
+      m |= tap_mask(max(0, (lo_i - a + 1) >> 1), max(0, (hi_i - a + 1) >> 1), max(0, (lo_j - b + 1) >> 1), max(0, (hi_j - b + 1) >> 1), nb) << base;
+    }
   return m;
 }
 
@@ -338,8 +369,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
       tapB[t] = ((i0 + p.sh * ti) * p.KW + (j0 + p.sw * tj)) * p.C * p.K;
     } else {
       const int i = t / p.KW, j = t - i * p.KW;
-      tapA[t] = (i * p.W + j) * p.Cx;
-      tapB[t] = MODE == MODE_FWD ? t * p.C * p.K : 0;      // FWD: first filter row of the tap (the table-driven dense rows below)
+      const int u = (MODE == MODE_FWD && p.tap_classes) ? tap_class_pos(i, j, p.KH, p.KW) : t;      // position in the K order
+      tapA[u] = (i * p.W + j) * p.Cx;
+      tapB[u] = MODE == MODE_FWD ? t * p.C * p.K : 0;      // FWD: first filter row of the tap (the table-driven dense rows below)
     }
   }
 
@@ -354,7 +386,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bx, const
       ri.base = ((b * p.H + y0) * p.W + x0) * p.Cx;
       if (p.shuf_c) ri.out_off = ((b * (2 * p.OH) + 2 * pp) * p.shuf_w + 2 * q) * p.shuf_pitch;
       else if (MODE == MODE_FWD && p.compact) ri.out_off = ((b * p.OH + pp) * p.OW + q) * (p.slab_rows ? 4 : p.Ky);
-      const unsigned long long m = tap_mask(max(0, -y0), min(p.KH, p.H - y0), max(0, -x0), min(p.KW, p.W - x0), p.KW);
+      const unsigned long long m = (MODE == MODE_FWD && p.tap_classes) ? tap_mask_classes(max(0, -y0), min(p.KH, p.H - y0), max(0, -x0), min(p.KW, p.W - x0), p.KH, p.KW)
+                                                                      : tap_mask(max(0, -y0), min(p.KH, p.H - y0), max(0, -x0), min(p.KW, p.W - x0), p.KW);
       ri.mask_lo = (unsigned)m; ri.mask_hi = (unsigned)(m >> 32);
     }
     return ri;
@@ -944,7 +977,7 @@ static inline void launch_cfg(const Plan& pl, const ConvArgs& a, hipStream_t st)
   // two tile shapes: 128x32 for narrow N, 64x64 otherwise.  128x128 / 128x64 variants existed through v4; with the
   // one-barrier pipeline they lost every layer of the tuning sweep (profiles/r1) and were dropped.
   if constexpr (MODE == MODE_FWD && !RAGGED && NVEC) {
-    if ((a.C & 3) == 0 && !a.compact) {     // gathered channels a multiple of 4: the LIN variant (filter rows linear in k)
+    if ((a.C & 3) == 0 && !a.compact && !a.tap_classes) {     // gathered channels a multiple of 4, taps in natural order: the LIN variant (filter rows linear in k)
       if (pl.cfg == 2) ACG_LAUNCH((conv_mfma_f32<MODE, 128, 32, 4, 1, RAGGED, NVEC, false, true>), grid, dim3(256), 0, st, a);
       else ACG_LAUNCH((conv_mfma_f32<MODE, 64, 64, 2, 2, RAGGED, NVEC, false, true>), grid, dim3(256), 0, st, a);
       return;

@@ -401,7 +401,7 @@ int prepare(Job& j, int which, const float* gsrc, const float* dense, float* out
     a.korder = (h && which != ACG_CONV_WGRAD && korder && cp >= 128 && cp % 64 == 0) ? 1 : 0;
   }
   {     // strided forward convolutions walk their taps class by class (conv_f32_kernel.h, tap_class_pos): the L2 then holds a tile's window
-    static const int tap_classes = env_int("ACG_CONV_TAP_CLASSES", 0);      // tuning hook: bit 0 bf16, bit 1 float32; measured: K-loop of a 5x5 / stride-2 forward -10 % at >= 128 channels, whole steps level (profiles/r4/h_tap_classes.txt): off
+    static const int tap_classes = env_int("ACG_CONV_TAP_CLASSES", 0);      // tuning hook: bit 0 bf16, bit 1 float32; measured: K-loop of a 5x5 / stride-2 forward -10 % at >= 128 channels, whole steps level (profiles/r4/h_bf16_kloop_load_path.txt): off
     a.tap_classes = ((tap_classes & (h ? 1 : 2)) && which == ACG_CONV_FWD && d->stride_h == 2 && d->stride_w == 2 && d->kh * d->kw > 1 && d->kh * d->kw <= 64) ? 1 : 0;
   }
   // small maps: pixel-major rows + only the taps a tile's rows can see (ConvArgs::compact); not with epilogue statistics,

@@ -132,7 +132,7 @@ __device__ __forceinline__ unsigned long long tap_mask(int lo_a, int hi_a, int l
 // input, shifted by whole output pixels, and taps of different classes read DISJOINT sub-lattices.  In row-major order the taps
 // that share a cache line are up to two filter rows (10 K-steps x channel chunks x every tile running on the XCD) apart: the
 // vertical re-use misses the 4 MB L2 and every input byte is fetched from the memory side ~3.5 times (TCC_MISS 36 % of the
-// K-loop's requests, profiles/r4/h_tap_classes.txt).  Walking one class after the other keeps a tile on one sub-lattice - its
+// K-loop's requests, profiles/r4/h_bf16_kloop_load_path.txt).  Walking one class after the other keeps a tile on one sub-lattice - its
 // window / (sh * sw), 43 KB for a 256-row tile of 64 channels - for all of the class's taps; it is a permutation of the K index
 // only (tap tables and row masks are built in that order), so results differ by summation order alone.
 // Built for stride 2 x 2 (every strided layer of the reference's models): class (a, b) = (i & 1, j & 1), na(a) x nb(b) taps each.

@@ -379,6 +379,25 @@ class Runtime:
         self._scratch.setdefault('workspaces', []).append(buf)
         return buf, n
 
+    def state_workspace(self, nbytes):
+        """A workspace that is STATE of one call site: acg_bn_act_fwd / _bwd (ABI 6) keep their exchange epoch and a timeout flag
+        (uint32 word 2) in it.  Remembered so that `check_exchange_flags` can read the flags."""
+        buf, n = self.workspace(nbytes)
+        self._scratch.setdefault('state_workspaces', []).append(buf)
+        return buf, n
+
+    def check_exchange_flags(self):
+        """Raise if a block of a one-launch BatchNorm kernel ever gave up waiting for its peers (acgan_hip.h: the launch then
+        finished with what it had - a wrong result - instead of hanging).  One device synchronisation: call it outside timed regions."""
+        bufs = [b for b in self._scratch.get('state_workspaces', []) if b.numel() >= 12]
+        if not bufs:
+            return
+        flags = torch.stack([b[8:12].view(torch.int32)[0] for b in bufs])
+        if bool((flags != 0).any()):
+            bad = [i for i, f in enumerate(flags.tolist()) if f]
+            raise _lib.AcgError('BatchNorm grid exchange timed out in %d of %d call sites (first: #%d): the blocks of a one-launch kernel were not '
+                           'all resident - results of those launches are wrong' % (len(bad), len(bufs), bad[0]))
+
     def edge_pool(self, n):
         """n reusable stream-ordering edges (acg_stream_edge: HIP events WITHOUT the system-scope fence of a default
         event, which costs ~20 us per edge on this 8-XCD part)."""
@@ -452,7 +471,9 @@ class Session:
         return False
 
     def close(self):
-        """Tear the gradient transport down (ncclCommDestroy); the session must not run afterwards."""
+        """Check the device-side flags (Runtime.check_exchange_flags) and tear the gradient transport down (ncclCommDestroy); the
+        session must not run afterwards."""
+        self.rt.check_exchange_flags()
         if self.rt._comm is not None:
             self.rt._comm.destroy()
             self.rt._comm = None

@@ -491,7 +491,7 @@ class BnActOp(G.Op):
 
     def bind(self, rt):
         lib = rt.lib
-        ws, n = rt.workspace(lib.bn_workspace_bytes(self.rows, self.c, self.groups))
+        ws, n = rt.state_workspace(lib.bn_workspace_bytes(self.rows, self.c, self.groups))
         self._keep = ws
         x, beta = self.inputs
         y, mean, rstd = self.outputs
@@ -542,7 +542,7 @@ class BnActBwdOp(G.Op):
 
     def bind(self, rt):
         lib, f = rt.lib, self.fwd
-        ws, n = rt.workspace(lib.bn_workspace_bytes(f.rows, f.c, f.groups))
+        ws, n = rt.state_workspace(lib.bn_workspace_bytes(f.rows, f.c, f.groups))
         self._keep = ws
         x, dy, beta, mean, rstd = self.inputs
         dx, dbeta = self.outputs
@@ -572,7 +572,7 @@ class BnMomentsOp(G.Op):
 
     def bind(self, rt):
         lib = rt.lib
-        ws, n = rt.workspace(lib.bn_workspace_bytes(self.rows, self.c, self.groups))
+        ws, n = rt.state_workspace(lib.bn_workspace_bytes(self.rows, self.c, self.groups))
         self._keep = ws
         x = self.inputs[0]
         args = (_p(x.buf), _p(self.outputs[0].buf), self.rows, self.c, self.xp, self.groups, _code(x), _p(ws), n)
@@ -656,7 +656,7 @@ class BnBwdSumsOp(G.Op):
 
     def bind(self, rt):
         lib, f = rt.lib, self.fwd
-        ws, n = rt.workspace(lib.bn_workspace_bytes(f.rows, f.c, f.groups))
+        ws, n = rt.state_workspace(lib.bn_workspace_bytes(f.rows, f.c, f.groups))
         self._keep = ws
         x, dy, beta, mean, rstd = self.inputs
         args = (_p(x.buf), _p(dy.buf), _p(beta.buf), _p(mean.buf), _p(rstd.buf), _p(self.outputs[0].buf), f.rows, f.c, f.xp, f.yp,

@@ -300,17 +300,19 @@ int32_t acg_bn_act_bwd_sums(const void* x, const void* dy, const float* beta, co
  * ZERO before the first call that uses it, must not be written by anyone else between calls, and must belong to ONE call site
  * (one layer, one direction): hand every BatchNorm op its own, as the other entries' workspaces may be shared scratch but this
  * one is state.  Word 2 (uint32) is set to 1 if a block ever gave up waiting for its peers (it then finishes with what it has:
- * a wrong result and this flag, never a hung GPU); it stays 0 in correct operation.
+ * a wrong result and this flag, never a hung GPU); it stays 0 in correct operation, and a caller should look at it at a point
+ * where it synchronises anyway (the Python host does in Session.close / Runtime.check_exchange_flags; the tests after every call).
  * ---------------------------------------------------------------------------------------- */
 size_t acg_bn_workspace_bytes(int64_t rows, int32_t channels, int32_t groups);
 /* The same with the split-K hand-off described at acg_conv2d_fwd_slabs: forward reads x as the sum of `splits` float32
  * slabs (each rows * x_pitch floats in `layout`, summed in slab order and rounded to x's storage type - what the separate
  * reduction would have stored) and WRITES x, which backward re-reads; backward reads dy as the sum of `splits` slabs
  * (each rows * y_pitch floats) and stores it nowhere.
- * acg_bn_slabs_layout: the slab layout this BatchNorm wants from its producer - ACG_SLABS_QUADS when the one-launch
- * kernels with four channels per block run (rows per group <= 2048, channels and pitches multiples of 4, dtype a plain
- * ACG_F32 / ACG_BF16), else ACG_SLABS_ROWS; -1 when it cannot take slabs at all (backward of a tensor too large for the
- * one-launch kernels: run the plain reduction + acg_bn_act_bwd).  acg_bn_bwd_slabs_ok: the backward half of that test. */
+ * acg_bn_slabs_layout: the slab layout this BatchNorm wants from its producer.  Round 4: ACG_SLABS_ROWS wherever the one-launch
+ * GRID kernels run (channels and pitches multiples of 4, a plain ACG_F32 / ACG_BF16 dtype, the grid resident on the chip: every
+ * layer of the reference's models up to 131072 x 128) - they read whole rows of every slab; ACG_SLABS_QUADS where only the
+ * register-resident kernels with four channels per block apply (rows per group <= 2048); -1 when this BatchNorm cannot take
+ * slabs at all (run the plain reduction + acg_bn_act_fwd / _bwd).  acg_bn_bwd_slabs_ok: the backward half of the resident test. */
 int32_t acg_bn_slabs_layout(int64_t rows, int32_t channels, int32_t x_pitch, int32_t y_pitch, int32_t groups, int32_t dtype,
                             int32_t backward);
 int32_t acg_bn_act_fwd_slabs(const float* slabs, int32_t splits, void* x, const float* beta, void* y, float* save_mean,

@@ -31,6 +31,16 @@ class Abi:
         n = max(int(nbytes), 16)
         return torch.zeros(n, dtype=torch.uint8, device=self.device), n
 
+    def bn_ws(self, rows, c, groups):
+        """A BatchNorm workspace (ABI 6: call-site state, zero before first use); `no_timeout` checks its flag word afterwards."""
+        return self.ws(self.lib.bn_workspace_bytes(rows, c, groups))
+
+    @staticmethod
+    def no_timeout(ws):
+        """acgan_hip.h: uint32 word 2 of a BatchNorm workspace is set when a block of a one-launch kernel gave up waiting for its peers."""
+        if ws.numel() >= 12:
+            assert int(ws[8:12].view(torch.int32)[0]) == 0, 'BatchNorm grid exchange timed out (workspace word 2)'
+
     def desc(self, batch, h, w, c, kh, kw, cout, stride, padding, pitch=0):
         d = L.ConvDesc()
         self.lib.conv_desc_init(ctypes.byref(d), batch, h, w, c, kh, kw, cout, stride, 1 if padding == 'SAME' else 0)
@@ -252,6 +262,7 @@ class Abi:
         ws, n = self.ws(self.lib.bn_workspace_bytes(rows, c, groups))
         self.lib.bn_act_fwd(_p(x), _p(beta), _p(y), _p(mean), _p(rstd), rows, c, xp, c, groups, eps, ACT[act], leak,
                             L.dtype2(L.code(x.dtype), L.code(y.dtype)), _p(ws), n, self.stream())
+        self.no_timeout(ws)
         return y, mean, rstd
 
     def bn_act_bwd(self, x, dy, beta, mean, rstd, act, groups=1, leak=0.2, dbeta=None, accumulate=0.0, dx_dtype=None):
@@ -268,6 +279,7 @@ class Abi:
             dt = L.dtype2(L.ACG_F32, L.ACG_BF16)
         self.lib.bn_act_bwd(_p(x), _p(dy), _p(beta), _p(mean), _p(rstd), _p(dx), _p(dbeta), accumulate, rows, c, xp, c,
                             groups, ACT[act], leak, dt, _p(ws), n, self.stream())
+        self.no_timeout(ws)
         return dx, dbeta
 
     # ---- BatchNorm statistics out of the producing convolution's epilogue
@@ -348,6 +360,7 @@ class Abi:
         bws, bn = self.ws(self.lib.bn_workspace_bytes(rows, c, groups))
         self.lib.bn_act_fwd_slabs(_p(ws), splits, _p(conv), _p(beta), _p(y), _p(mean), _p(rstd), rows, c, cp, cp, groups, eps, ACT[act], leak,
                                   self.conv_dtype, layout, _p(bws), bn, self.stream())
+        self.no_timeout(bws)
         return conv[..., :c].float(), y[..., :c].float(), mean, rstd, layout
 
     def dgrad_bn_bwd_handoff(self, xb, beta, mean, rstd, act, dy2, w2, stride, padding, groups=1, transposed=False, pair_x=None, layout=None,
@@ -397,6 +410,7 @@ class Abi:
         bws, bn = self.ws(self.lib.bn_workspace_bytes(rows, c, groups))
         self.lib.bn_act_bwd_slabs(_p(x16), _p(ws), splits, _p(beta), _p(mean), _p(rstd), _p(dx), _p(dbeta), 0.0, rows, c, cp, cp, groups,
                                   ACT[act], leak, self.conv_dtype, layout, _p(bws), bn, self.stream())
+        self.no_timeout(bws)
         return dx[..., :c].float(), dbeta, layout
 
     # ---- synchronised BatchNorm entries (statistics supplied by the caller)

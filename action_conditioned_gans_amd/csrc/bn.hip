@@ -1204,6 +1204,7 @@ int bn_fwd_typed(const void* x, const float* beta, void* y, float* save_mean, fl
   TY* yf = (TY*)y;
   if (!same) v4 = false;
   const int V = v4 ? 4 : 1;
+  float* const scratch = part + 4;       // partial sums of the two-launch path: behind the 16 state bytes the one-launch kernels own
   // One launch, one read of x, statistics included (bn_fwd_fused) where the grid is resident; small tensors keep the
   // one-block-per-four-channels kernels below `fused_min` rows per group (tuning hook)
   static const int fused_on_f = env_int("ACG_BN_FUSED_FWD", 1), fused_min_f = env_int("ACG_BN_FUSED_MIN_ROWS", 1 << 30);
@@ -1240,14 +1241,14 @@ int bn_fwd_typed(const void* x, const float* beta, void* y, float* save_mean, fl
   static const int stats_iters = env_int("ACG_BN_STATS_ITERS", 8);  // tuning hook
   const int nblk = vpartial_blocks(R, C, V, stats_iters);
   if (sl.p) {
-    if (same && v4) ACG_LAUNCH((bn_stats_partial<4, TX, true>), dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk, XP, sl);
-    else ACG_LAUNCH((bn_stats_partial<1, TX, true>), dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk, XP, sl);
+    if (same && v4) ACG_LAUNCH((bn_stats_partial<4, TX, true>), dim3(nblk, groups), dim3(256), 0, st, xf, scratch, R, C, nblk, XP, sl);
+    else ACG_LAUNCH((bn_stats_partial<1, TX, true>), dim3(nblk, groups), dim3(256), 0, st, xf, scratch, R, C, nblk, XP, sl);
   } else {
-    if (same && v4) ACG_LAUNCH((bn_stats_partial<4, TX, false>), dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk, XP, sl);
-    else ACG_LAUNCH((bn_stats_partial<1, TX, false>), dim3(nblk, groups), dim3(256), 0, st, xf, part, R, C, nblk, XP, sl);
+    if (same && v4) ACG_LAUNCH((bn_stats_partial<4, TX, false>), dim3(nblk, groups), dim3(256), 0, st, xf, scratch, R, C, nblk, XP, sl);
+    else ACG_LAUNCH((bn_stats_partial<1, TX, false>), dim3(nblk, groups), dim3(256), 0, st, xf, scratch, R, C, nblk, XP, sl);
   }
   if (int rc = acg::check_launch("bn_stats_partial")) return rc;
-  return launch_apply_fwd<TX, TY>(v4, xf, beta, (const float*)part, yf, save_mean, save_rstd, R, C, groups, nblk, eps, act, leak, XP, YP, (int)kPartShifted, TileGeom{0, 0, 1}, st);
+  return launch_apply_fwd<TX, TY>(v4, xf, beta, (const float*)scratch, yf, save_mean, save_rstd, R, C, groups, nblk, eps, act, leak, XP, YP, (int)kPartShifted, TileGeom{0, 0, 1}, st);
 }
 
 template <typename TX, typename TY, typename TD = TX>
@@ -1260,6 +1261,7 @@ int bn_bwd_typed(const void* x, const void* dy, const float* beta, const float* 
   TD* dxf = (TD*)dx;
   if (!same) v4 = false;
   const int V = v4 ? 4 : 1;
+  float* const scratch = part + 4;       // as in bn_fwd_typed
   // small tensors: ONE block per four channels holds every row (bn_resident_bwd) - unless the fused grid kernel is asked to take
   // them from `fused_min` rows per group on (tuning hook; measured in profiles/r4/d_bn_fused_ab.txt)
   static const int fused_min_b = env_int("ACG_BN_FUSED_MIN_ROWS", 2048);      // backward: 2048 x 128 runs 6.1 us fused, 7.7 resident; below, resident wins
@@ -1302,15 +1304,15 @@ int bn_bwd_typed(const void* x, const void* dy, const float* beta, const float* 
     const int Cv = C / V, Cb = Cv < 256 ? Cv : 256, RPP = 256 / Cb;
     const bool deep = acg::ceil_div(acg::ceil_div(R, nblk), RPP) > kU;
     if constexpr (same) {
-      if (v4 && deep) ACG_LAUNCH((bn_bwd_partial<4, TX, TY, 8>), dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak, XP, YP);
-      else if (v4) ACG_LAUNCH((bn_bwd_partial<4, TX, TY>), dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak, XP, YP);
-      else ACG_LAUNCH((bn_bwd_partial<1, TX, TY>), dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak, XP, YP);
+      if (v4 && deep) ACG_LAUNCH((bn_bwd_partial<4, TX, TY, 8>), dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, scratch, R, C, nblk, act, leak, XP, YP);
+      else if (v4) ACG_LAUNCH((bn_bwd_partial<4, TX, TY>), dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, scratch, R, C, nblk, act, leak, XP, YP);
+      else ACG_LAUNCH((bn_bwd_partial<1, TX, TY>), dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, scratch, R, C, nblk, act, leak, XP, YP);
     } else {
-      ACG_LAUNCH((bn_bwd_partial<1, TX, TY>), dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, part, R, C, nblk, act, leak, XP, YP);
+      ACG_LAUNCH((bn_bwd_partial<1, TX, TY>), dim3(nblk, groups), dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, scratch, R, C, nblk, act, leak, XP, YP);
     }
   }
   if (int rc = acg::check_launch("bn_bwd_partial")) return rc;
-  return launch_apply_bwd<TX, TY, TD>(v4, xf, dyf, beta, save_mean, save_rstd, (const float*)part, dxf, dbeta, dbeta_acc, R, C, groups, nblk, act, leak, XP, YP,
+  return launch_apply_bwd<TX, TY, TD>(v4, xf, dyf, beta, save_mean, save_rstd, (const float*)scratch, dxf, dbeta, dbeta_acc, R, C, groups, nblk, act, leak, XP, YP,
                                       (const float*)nullptr, 0.f, st);
 }
 
@@ -1343,7 +1345,8 @@ extern "C" {
 size_t acg_bn_workspace_bytes(int64_t rows, int32_t channels, int32_t groups) {
   (void)rows;
   if (channels <= 0 || groups <= 0) return 0;
-  return (size_t)groups * ((size_t)kMaxPartialBlocks * 2 + 2) * (size_t)channels * sizeof(float);
+  // 16 bytes of state (FusedState: epoch, done, timeout flag, pad) in front of the partial sums / exchange granules of every path
+  return 16 + (size_t)groups * ((size_t)kMaxPartialBlocks * 2 + 2) * (size_t)channels * sizeof(float);
 }
 
 int32_t acg_bn_act_fwd(const void* x, const float* beta, void* y, float* save_mean, float* save_rstd, int64_t rows,

@@ -299,7 +299,8 @@ int32_t acg_bn_act_bwd_sums(const void* x, const void* dy, const float* beta, co
  * lives in the workspace and survives from call to call - also across the replays of a captured graph - so the workspace must be
  * ZERO before the first call that uses it, must not be written by anyone else between calls, and must belong to ONE call site
  * (one layer, one direction): hand every BatchNorm op its own, as the other entries' workspaces may be shared scratch but this
- * one is state.  Word 2 (uint32) is set to 1 if a block ever gave up waiting for its peers (it then finishes with what it has:
+ * one is state.  The first 16 bytes are that state on every path (the two-launch kernels keep their partial sums behind them).
+ * Word 2 (uint32) is set to 1 if a block ever gave up waiting for its peers (it then finishes with what it has:
  * a wrong result and this flag, never a hung GPU); it stays 0 in correct operation, and a caller should look at it at a point
  * where it synchronises anyway (the Python host does in Session.close / Runtime.check_exchange_flags; the tests after every call).
  * ---------------------------------------------------------------------------------------- */

@@ -260,7 +260,7 @@ Plan make_plan(const acg_conv_desc& d, int which, bool bf16 = false, bool wide_o
     return pl;
   }
   auto tiles_for = [&](int bm, int bn) { return acg::ceil_div(pl.M, bm) * acg::ceil_div(pl.N, bn) * pl.classes; };
-  // Planner (evidence: profiles/r1 tuning sweeps, tools/fit_planner.py).  Split K until ~1 block per CU for
+  // Planner (evidence: profiles/r1 tuning sweeps, tests/fit_planner.py).  Split K until ~1 block per CU for
   // FWD/DGRAD and ~2 per CU for WGRAD (long K = B*OH*OW, heavier loaders: a second resident block hides its
   // latencies), but keep >= 4 K-steps per block so the slab reduction does not take over.
   pl.cfg = pl.N <= 32 ? 2 : 3;

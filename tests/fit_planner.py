@@ -4,7 +4,7 @@
 Rebuilds the Trainer graph on the CPU (C oracle as the stand-in library) to get each conv op's GEMM extents, reads the
 per-(layer, config, splits) times of a sweep file and prints, per rule, the summed time of all distinct contractions
 (weighted by how many ops share them) next to the per-layer optimum.
-  python tools/fit_planner.py gpurun_out/tune.txt
+  python tests/fit_planner.py gpurun_out/tune.txt
 """
 import re
 import sys
@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from action_conditioned_gans_amd import _lib, graph as G, ops as O, optim, train as T   # noqa: E402
-from oracle import cbind   # noqa: E402  (tool, not product: graph geometry only)
+from oracle import cbind   # noqa: E402  (test-side tool: graph geometry only; lives under tests/ because it uses the oracle)
 
 
 def geometry(batch=32):

@@ -1284,3 +1284,58 @@ def case_optimizers(abi, tol, seed=0):
     ref = q.double().cpu().clamp(f32(-0.01), f32(0.01))
     abi.clip(q, -0.01, 0.01)
     close(q, ref, 1e-7, 'clip')
+
+
+def case_repeatable_launches(abi, reps=60):
+    """Race screen for the kernels that synchronise by hand (cdna_hip_programming.md, section 5: "place reads by the vmcnt / barrier
+    count, never by clean runs" - and then screen): the LDS-DMA convolution (counted vmcnt, raw s_barrier, two wave groups one
+    phase apart) and the one-launch BatchNorm kernels (in-launch exchange of partial sums, epoch reused across launches).  Each is
+    deterministic by construction, so `reps` launches on the same operands must give bit-identical results; a DMA landing after
+    the fragment read, or a stale exchange granule, shows up as a run that differs."""
+    import ctypes
+    from action_conditioned_gans_amd import _lib as L
+    from abi_call import _p
+    dev = abi.device
+    # ---- LDS-DMA convolution: forward (ragged rows and columns) and the stride classes of an input gradient
+    for (b, h, w_, cin, cout, k, s, which) in [(52, 62, 62, 56, 96, 5, 2, 0), (13, 63, 61, 96, 160, 5, 2, 1)]:
+        assert tile_rows(abi, which, b, h, w_, cin, k, cout, s, 'SAME') == 256, 'test premise: the planner does not pick the wide kernel'
+        d = abi.desc(b, h, w_, cin, k, k, cout, s, 'SAME')
+        x16 = abi.to16(uniform((b, h, w_, cin), 900))
+        rm, tr = abi.prep_weights(randn((k, k, cin, cout), 901, 0.05))
+        dy16 = abi.to16(randn((b, d.out_h, d.out_w, cout), 902))
+        code = L.CONV_FWD if which == 0 else L.CONV_DGRAD
+        ws, n = abi.ws(abi.lib.conv2d_workspace_bytes(ctypes.byref(d), code, L.ACG_BF16))
+        outs = []
+        for r in range(reps):
+            if which == 0:
+                y = torch.zeros(b, d.out_h, d.out_w, (cout + 7) // 8 * 8, dtype=torch.bfloat16, device=dev)
+                abi.lib.conv2d_fwd(_p(x16), _p(tr), _p(y), ctypes.byref(d), L.ACG_BF16, _p(ws), n, abi.stream())
+            else:
+                y = torch.zeros(b, h, w_, (cin + 7) // 8 * 8, dtype=torch.bfloat16, device=dev)
+                abi.lib.conv2d_dgrad(_p(dy16), _p(rm), _p(y), ctypes.byref(d), L.ACG_BF16, _p(ws), n, abi.stream())
+            outs.append(y)
+        for r in range(1, reps):
+            assert torch.equal(outs[r], outs[0]), 'wide conv (which=%d): launch %d differs from launch 0' % (which, r)
+    # ---- one-launch BatchNorm, forward and backward, ONE workspace per call site reused by every launch (as a captured graph does)
+    for (rows, c, groups, tdt) in [(32768, 128, 1, torch.float32), (65536, 64, 2, torch.bfloat16), (8192, 128, 2, torch.float32)]:
+        x = (randn((rows, c), 910, 1.5) + 0.3).to(dev).to(tdt)
+        dy = randn((rows, c), 911).to(dev).to(tdt)
+        beta = randn((c,), 912, 0.1).to(dev)
+        code = L.ACG_BF16 if tdt == torch.bfloat16 else L.ACG_F32
+        wsf, nf = abi.bn_ws(rows, c, groups)
+        wsb, nb = abi.bn_ws(rows, c, groups)
+        mean, rstd, dbeta = abi.empty(groups * c), abi.empty(groups * c), abi.empty(c)
+        first = None
+        for r in range(reps):
+            y, dx = torch.zeros_like(x), torch.zeros_like(x)
+            abi.lib.bn_act_fwd(_p(x), _p(beta), _p(y), _p(mean), _p(rstd), rows, c, 0, 0, groups, 1e-3, L.ACT_LRELU, 0.2, code, _p(wsf), nf, abi.stream())
+            abi.lib.bn_act_bwd(_p(x), _p(dy), _p(beta), _p(mean), _p(rstd), _p(dx), _p(dbeta), 0.0, rows, c, 0, 0, groups, L.ACT_LRELU, 0.2, code, _p(wsb), nb, abi.stream())
+            got = (y, dx, mean.clone(), rstd.clone(), dbeta.clone())
+            if first is None:
+                first = got
+            else:
+                for a_, b_, name in zip(got, first, ('y', 'dx', 'mean', 'rstd', 'dbeta')):
+                    assert torch.equal(a_, b_), 'BatchNorm %d x %d x %d groups: %s of launch %d differs from launch 0' % (rows // groups, c, groups, name, r)
+        abi.no_timeout(wsf); abi.no_timeout(wsb)
+        # the epoch word counts the launches: proof that the one-launch kernels (not the two-launch path) ran
+        assert int(wsb[0:4].view(torch.int32)[0]) == reps and int(wsf[0:4].view(torch.int32)[0]) == reps, 'the one-launch kernels did not run'

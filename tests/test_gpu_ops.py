@@ -148,6 +148,11 @@ def test_conv_bn_stats_wide_bf16(hip_abi_bf16):
     C.case_conv_bn_stats(hip_abi_bf16, TOL_BF16, 2e-3, min_fused=3, layers=C.STATS_LAYERS_WIDE)
 
 
+def test_hand_synchronised_kernels_are_repeatable(hip_abi_bf16):
+    """60 launches each of the LDS-DMA convolution and of the one-launch BatchNorm kernels: bit-identical results (race screen)."""
+    C.case_repeatable_launches(hip_abi_bf16)
+
+
 @pytest.mark.parametrize('shape', C.BN_SHAPES[:2] + C.BN_SHAPES[3:7] + [((32, 16, 16), 128, 2, 'lrelu'), ((32, 32, 32), 64, 1, 'relu')], ids=str)
 def test_bn_bf16(hip_abi, shape):
     C.case_bn_bf16(hip_abi, shape, 6e-3)

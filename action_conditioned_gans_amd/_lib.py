@@ -18,7 +18,7 @@ ACG_F32, ACG_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 0, 1, 2
 SLABS_ROWS, SLABS_QUADS = 0, 1       # acgan_hip.h ACG_SLABS_*
-ABI_VERSION = 6       # include/acgan_hip.h ACG_ABI_VERSION: bumped with every signature / layout / flag-meaning change
+ABI_VERSION = 7       # include/acgan_hip.h ACG_ABI_VERSION: bumped with every signature / layout / flag-meaning change
 
 LIB_NAME = 'libacgan_hip.so'
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', LIB_NAME)
@@ -37,7 +37,7 @@ class ConvDesc(ctypes.Structure):
 class ReduceList(ctypes.Structure):
     """struct acg_reduce_list (ACG_REDUCE_MAX = 32 entries)."""
     _fields_ = [('slabs', c_void_p * 32), ('out', c_void_p * 32), ('numel', c_int64 * 32), ('splits', c_int32 * 32),
-                ('accumulate', c_float * 32)]
+                ('accumulate', c_float * 32), ('step_inc', c_void_p)]
 
 
 class PrepList(ctypes.Structure):

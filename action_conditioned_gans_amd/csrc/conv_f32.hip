@@ -146,8 +146,10 @@ struct ReduceList {
   int splits[ACG_REDUCE_MAX];
   float accumulate[ACG_REDUCE_MAX];
   int first_block[ACG_REDUCE_MAX + 1];
+  int* step_inc;           // acg_reduce_list::step_inc
 };
 __global__ __launch_bounds__(256) void splitk_reduce_many(const ReduceList l, int count) {
+  if (l.step_inc != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *l.step_inc += 1;
   int e = 0;
   while (e + 1 < count && (int)blockIdx.x >= l.first_block[e + 1]) ++e;      // block-uniform scan of <= 32 entries
   reduce_slabs(l.slabs[e], l.out[e], l.numel[e], l.splits[e], l.accumulate[e], (int)blockIdx.x - l.first_block[e],
@@ -749,6 +751,7 @@ int32_t acg_splitk_reduce_many(const acg_reduce_list* list, int32_t count, acg_s
     blocks += reduce_blocks(list->numel[i]);
   }
   l.first_block[count] = blocks;
+  l.step_inc = list->step_inc;
   ACG_LAUNCH(splitk_reduce_many, dim3(blocks), dim3(256), 0, acg::to_stream(stream), l, (int)count);
   return acg::check_launch("splitk_reduce_many");
 }

@@ -440,6 +440,7 @@ class WgradReduceOp(G.Op):
 
     def bind(self, rt):
         entries, self.pending = self.pending, []
+        self._keep = None                                     # (the optimizer looks here for THIS compile's lists: Adam._step_inc_launch)
         if not entries:
             return None                                       # none of the layers is split at these shapes
         lists = []

@@ -211,13 +211,15 @@ class Optimizer:
             raise ValueError('No gradients provided for any variable: %s' % missing)
         dp = _dp(g)
         buckets = self._buckets(dp, var_list, offsets, total) if dp.active else [(0, total)]
-        self._defer_wgrad_reductions(var_list, ctx, offsets, buckets)
+        reduce_ops = self._defer_wgrad_reductions(var_list, ctx, offsets, buckets)
         writers = [op for ops_ in ctx.writers.values() for op in ops_]
         deps = list(dict.fromkeys(writers))
         if dp.active:
             deps += self._insert_allreduce(var_list, ctx, flat_grad, offsets, buckets, dp.collectives == 'side')
         slots = self._make_slots(g, total)
-        return StepOp(self, scope, [v.name for v in var_list], flat_param, flat_grad, slots, deps, 1.0 / dp.world_size)
+        step_op = StepOp(self, scope, [v.name for v in var_list], flat_param, flat_grad, slots, deps, 1.0 / dp.world_size)
+        step_op.reduce_ops = reduce_ops        # one of them can carry the step counter's increment (_step_inc_launch)
+        return step_op
 
     @staticmethod
     def _buckets(dp, var_list, offsets, total):
@@ -238,6 +240,7 @@ class Optimizer:
     def _defer_wgrad_reductions(self, var_list, ctx, offsets, buckets):
         """Per bucket (one bucket = the whole buffer without data parallelism), the conv weight gradients with a single
         writer hand their split-K slab reduction to ONE WgradReduceOp, which becomes the gradient's writer."""
+        made = []
         for k, (lo, hi) in enumerate(buckets):
             group = [ctx.writers[v.name][0] for v in var_list
                      if lo <= offsets[v.name] < hi and len(ctx.writers.get(v.name, ())) == 1
@@ -245,9 +248,11 @@ class Optimizer:
             if len(group) < 2:
                 continue
             red = O.WgradReduceOp(group, '%s/wgrad_reduce_%d' % (self.name, k))
+            made.append(red)
             for v in var_list:
                 if ctx.writers.get(v.name) and ctx.writers[v.name][0] in group:
                     ctx.writers[v.name] = [red]
+        return made
 
     def _insert_allreduce(self, var_list, ctx, flat_grad, offsets, buckets, side):
         order = sorted(var_list, key=lambda v: offsets[v.name])
@@ -271,23 +276,35 @@ class AdamOptimizer(Optimizer):
         return [graph.new_state((total,), 0.0, self.name + '/m'), graph.new_state((total,), 0.0, self.name + '/v'),
                 graph.new_state((1,), 0, self.name + '/step', dtype=torch.int32)]
 
+    @staticmethod
+    def _step_inc_launch(rt, op, step):
+        """The launch that advances the device step counter in front of the update, or None when a deferred weight-gradient
+        reduction of this optimizer runs in the same program: that launch (acg_splitk_reduce_many, always ahead of the update on
+        the main stream) then carries the increment in its acg_reduce_list::step_inc - one tiny launch less per step."""
+        for red in getattr(op, 'reduce_ops', ()):
+            lists = getattr(red, '_keep', None)
+            if id(red) in rt.program_ops and lists and not red.side_stream:
+                lists[0][0].step_inc = step.buf.data_ptr()
+                return None
+        inc, ps = rt.lib.step_inc, _p(step.buf)
+        return lambda s: inc(ps, s)
+
     def _bind_step(self, rt, op, clip):
         p, g, m, v, step = op.inputs
         lo, hi = clip if clip else (0.0, 0.0)
-        inc, adam = rt.lib.step_inc, rt.lib.adam_step
-        ps = _p(step.buf)
-        args = (_p(p.buf), _p(g.buf), _p(m.buf), _p(v.buf), ps, p.numel, self.lr, self.b1, self.b2, self.eps,
+        adam, before = rt.lib.adam_step, self._step_inc_launch(rt, op, step)
+        args = (_p(p.buf), _p(g.buf), _p(m.buf), _p(v.buf), _p(step.buf), p.numel, self.lr, self.b1, self.b2, self.eps,
                 op.grad_scale, 1 if clip else 0, lo, hi)
 
         def launch(s):
-            inc(ps, s)
+            if before is not None:
+                before(s)
             adam(*args, s)
         return launch
 
     def _opt_args(self, rt, op, clip):
         p, g, m, v, step = op.inputs
-        inc, ps = rt.lib.step_inc, _p(step.buf)
-        return 0, (self.lr, self.b1, self.b2, self.eps), m, v, step, (lambda s: inc(ps, s))
+        return 0, (self.lr, self.b1, self.b2, self.eps), m, v, step, self._step_inc_launch(rt, op, step)
 
 
 class RMSPropOptimizer(Optimizer):

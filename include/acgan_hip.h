@@ -42,8 +42,9 @@ extern "C" {
  * entries (acg_*_slabs, acg_bn_act_*_slabs), acg_bn_slabs_layout.  5: round 4 - struct acg_conv_desc is 17 int32 fields
  * (dgrad_c, adj_dgrad_c were appended in round 3 under version 4: a "version 4" build may have either layout).  6: the
  * workspace of acg_bn_act_fwd / acg_bn_act_bwd is state (zero before first use, private to its call site); new entries
- * acg_conv2d_tile, acg_opt_step_prepare_bf16. */
-#define ACG_ABI_VERSION 6
+ * acg_conv2d_tile, acg_opt_step_prepare_bf16.  7: struct acg_reduce_list carries `step_inc` (the deferred reduction launch also
+ * advances an optimizer's device step counter). */
+#define ACG_ABI_VERSION 7
 
 typedef void* acg_stream_t; /* hipStream_t */
 
@@ -162,7 +163,9 @@ int32_t acg_deconv2d_wgrad(const void* x, const void* dy, float* dw, float accum
  *   acg_(de)conv2d_wgrad_slabs the contraction only: `splits` partial slabs of kh*kw*in_c*out_c floats are left in the
  *                              workspace (acg_conv2d_workspace_bytes); an error when the shape is not split
  *   acg_splitk_reduce_many     out[i] = accumulate[i] * out[i] + sum_z slabs[i][z], z in order: bit-identical to the
- *                              per-layer reduction.  Outputs must be distinct. */
+ *                              per-layer reduction.  Outputs must be distinct.  `step_inc` (may be NULL): the launch also
+ *                              does *step_inc += 1 - the step counter of the optimizer it runs in front of (acg_step_inc
+ *                              without a launch of its own: the update kernel behind it reads the incremented value). */
 #define ACG_REDUCE_MAX 32
 typedef struct acg_reduce_list {
   const void* slabs[ACG_REDUCE_MAX];
@@ -170,6 +173,7 @@ typedef struct acg_reduce_list {
   int64_t numel[ACG_REDUCE_MAX];
   int32_t splits[ACG_REDUCE_MAX];
   float accumulate[ACG_REDUCE_MAX];
+  int32_t* step_inc;
 } acg_reduce_list;
 int32_t acg_conv2d_splits(const acg_conv_desc* d, int32_t which, int32_t dtype);
 /* The output tile (GEMM rows x columns) the planner runs contraction `which` of this layer on as a launch of its own, for

@@ -280,6 +280,7 @@ int32_t acg_splitk_reduce_many(const acg_reduce_list* l, int32_t count, acg_stre
       out[i] = (float)acc;
     }
   }
+  if (l->step_inc) *l->step_inc += 1;
   return ACG_OK;
 }
 

@@ -243,11 +243,12 @@ class Abi:
         fn(_p(x), _p(dy), ctypes.byref(d), self.conv_dtype, _p(ws), n, self.stream())
         return ws, splits
 
-    def splitk_reduce_many(self, entries):
-        """entries: (slab workspace, out tensor, splits, accumulate)."""
+    def splitk_reduce_many(self, entries, step=None):
+        """entries: (slab workspace, out tensor, splits, accumulate); ``step``: an int32 tensor the launch increments (ABI 7)."""
         rl = L.ReduceList()
         for i, (ws, out, splits, acc) in enumerate(entries):
             rl.slabs[i], rl.out[i], rl.numel[i], rl.splits[i], rl.accumulate[i] = ws.data_ptr(), out.data_ptr(), out.numel(), splits, acc
+        rl.step_inc = step.data_ptr() if step is not None else None
         self.lib.splitk_reduce_many(ctypes.byref(rl), len(entries), self.stream())
 
     # ---- bn / bias

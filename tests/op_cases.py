@@ -843,8 +843,10 @@ def case_wgrad_deferred(abi, tol, exact):
         got.append(out)
         entries.append((slabs, out, splits, acc))
     assert len(entries) >= 2, 'the case must exercise a multi-entry launch'
-    abi.splitk_reduce_many(entries)
+    step = torch.full((1,), 41, dtype=torch.int32, device=dev)     # acg_reduce_list::step_inc: the launch advances an optimizer's step counter
+    abi.splitk_reduce_many(entries, step=step)
     abi.sync()
+    assert int(step[0]) == 42, 'splitk_reduce_many did not increment the step counter exactly once'
     for i, (w_, g_) in enumerate(zip(want, got)):
         if exact:
             assert torch.equal(w_.cpu(), g_.cpu()), 'deferred reduction of layer %d is not bit-identical' % i

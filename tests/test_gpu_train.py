@@ -50,6 +50,27 @@ def test_hip_graph_replay_equals_eager(name):
     assert np.array_equal(fe, fg)
 
 
+def test_adam_step_counter_rides_on_the_deferred_reduction():
+    """ABI 7: where an optimizer's deferred weight-gradient reduction runs in the program, that launch carries the increment of
+    Adam's device step counter (no step_inc launch of its own); the counter must advance exactly once per update whichever launch
+    does it (the update's bias correction - weights vs the golden vectors - is pinned by test_step_matches_golden)."""
+    from action_conditioned_gans_amd import ops as O
+    sess, tr = TC.build_trainer(gpu_session, 'c2_dna_bce_adam', batch=32)
+    x, y, a, s = TC.MG.inputs(2)
+    xs, ys, as_, ss = np.tile(x, (16, 1, 1, 1)), np.tile(y, (16, 1, 1, 1)), np.tile(a, (16, 1)), np.tile(s, (16, 1))
+    n = 5                                   # eager, capture, replays
+    for _ in range(n):
+        tr.train_d(xs, ys, as_)
+    for _ in range(n - 2):
+        tr.train_g(xs, ys, as_, ss)
+    torch.cuda.synchronize()
+    g = G.get_default_graph()
+    steps = sorted(int(op.inputs[-1].buf[0]) for op in g.ops if getattr(op, 'is_optimizer_step', False) and op.inputs[-1].buf is not None)
+    assert [v for v in steps if v] == [n - 2, n], steps          # (the pre-training optimizer never ran)
+    carried = [op.name for op in g.ops if isinstance(op, O.WgradReduceOp) and getattr(op, '_keep', None) and op._keep[0][0].step_inc]
+    assert len(carried) >= 2, 'at batch 32 both optimizers have split weight gradients: their reductions should carry the increment (%s)' % carried
+
+
 def test_batch32_step_is_finite_and_learns():
     """BASELINE config 2 shapes (B=32, DNA k=5, bce, Adam): a few steps run, stay finite, and the pretrain
     loss goes down on a fixed batch."""

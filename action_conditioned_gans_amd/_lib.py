@@ -18,7 +18,8 @@ ACG_F32, ACG_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 CONV_FWD, CONV_DGRAD, CONV_WGRAD = 0, 1, 2
 SLABS_ROWS, SLABS_QUADS = 0, 1       # acgan_hip.h ACG_SLABS_*
-ABI_VERSION = 7       # include/acgan_hip.h ACG_ABI_VERSION: bumped with every signature / layout / flag-meaning change
+BN_NO_GRID_EXCHANGE = 1               # acgan_hip.h ACG_BN_NO_GRID_EXCHANGE
+ABI_VERSION = 8       # include/acgan_hip.h ACG_ABI_VERSION: bumped with every signature / layout / flag-meaning change
 
 LIB_NAME = 'libacgan_hip.so'
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', LIB_NAME)
@@ -103,18 +104,19 @@ SIGNATURES = {
                                   c_size_t, _P]),
     'acg_bn_act_bwd_sums': (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, c_float, c_int64, c_int32, c_int32, c_int32, c_int32,
                                       c_int32, c_float, c_int32, _P]),
+    'acg_bn_exchange_selftest': (c_int32, [_P, c_size_t, _P, c_int32, c_int32, c_int32, ctypes.c_uint32, _P]),
     'acg_bn_act_fwd': (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, c_float,
-                                 c_int32, _P, c_size_t, _P]),
+                                 c_int32, c_int32, _P, c_size_t, _P]),
     'acg_bn_act_bwd': (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
-                                 c_float, c_int32, _P, c_size_t, _P]),
+                                 c_float, c_int32, c_int32, _P, c_size_t, _P]),
     'acg_bn_act_fwd_partials': (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, c_float,
                                           c_int32, _P]),
-    'acg_bn_slabs_layout': (c_int32, [c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
+    'acg_bn_slabs_layout': (c_int32, [c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
     'acg_bn_act_fwd_slabs': (c_int32, [_P, c_int32, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, c_float,
-                                       c_int32, c_int32, _P, c_size_t, _P]),
+                                       c_int32, c_int32, c_int32, _P, c_size_t, _P]),
     'acg_bn_bwd_slabs_ok': (c_int32, [c_int64, c_int32]),
     'acg_bn_act_bwd_slabs': (c_int32, [_P, _P, c_int32, _P, _P, _P, _P, _P, c_float, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
-                                       c_float, c_int32, c_int32, _P, c_size_t, _P]),
+                                       c_float, c_int32, c_int32, c_int32, _P, c_size_t, _P]),
     'acg_bias_workspace_bytes': (c_size_t, [c_int64, c_int32]),
     'acg_bias_act_fwd': (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, _P]),
     'acg_bias_act_bwd': (c_int32, [_P, _P, _P, _P, c_float, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_int32,

@@ -65,6 +65,9 @@ def load_rccl(path):
     lib.ncclCommDestroy.argtypes, lib.ncclCommDestroy.restype = [P], ctypes.c_int
     lib.ncclGetErrorString.argtypes, lib.ncclGetErrorString.restype = [ctypes.c_int], ctypes.c_char_p
     lib.ncclGetVersion.argtypes, lib.ncclGetVersion.restype = [ctypes.POINTER(ctypes.c_int)], ctypes.c_int
+    for q in ('ncclCommCount', 'ncclCommUserRank'):       # optional (reporting only: RcclCommunicator.reported)
+        if hasattr(lib, q):
+            getattr(lib, q).argtypes, getattr(lib, q).restype = [P, ctypes.POINTER(ctypes.c_int)], ctypes.c_int
     return lib
 
 
@@ -149,6 +152,16 @@ class RcclCommunicator(Communicator):
             _check(lib.ncclCommInitRank(ctypes.byref(comm), self.world_size, uid, self.rank), 'ncclCommInitRank', lib)
         self._comm = comm
         self.calls = 0
+
+    def reported(self):
+        """(ranks in the communicator, this rank) as RCCL itself answers - ncclCommCount / ncclCommUserRank - or None where the
+        library does not export them: what bench.py prints so that a multi-GPU run can be checked against RCCL having seen N ranks."""
+        if self._comm is None or not hasattr(self._lib, 'ncclCommCount') or not hasattr(self._lib, 'ncclCommUserRank'):
+            return None
+        n, r = ctypes.c_int(-1), ctypes.c_int(-1)
+        _check(self._lib.ncclCommCount(self._comm, ctypes.byref(n)), 'ncclCommCount', self._lib)
+        _check(self._lib.ncclCommUserRank(self._comm, ctypes.byref(r)), 'ncclCommUserRank', self._lib)
+        return n.value, r.value
 
     def all_reduce_ptr(self, ptr, count, nccl_dtype, nccl_op, stream_ptr):
         """The raw form the launch lists use: everything precomputed, one C call."""

@@ -524,10 +524,15 @@ __global__ __launch_bounds__(NT) void bn_apply_bwd(const TX* __restrict__ x, con
 // placement or dispatch order.  `epoch` is a word of the op's private workspace that the LAST block to finish increments
 // (an arrival counter beside it), so every launch - also every replay of a captured graph, whose arguments are frozen - sees
 // tags no earlier launch has written; the workspace must be zero before its first use and belong to this op alone.
-// All blocks of the grid must be resident together: the host takes this path only for grids of at most one block per CU
-// (<= 256 blocks of 1024 threads at <= 64 VGPRs: two would fit), and every spin is bounded - a block that gives up sets the
-// workspace's `timeout` word and finishes with what it has, so a violated assumption shows up as a wrong result and a flag,
-// never as a hung GPU.
+// All blocks of the grid must be resident together: the host takes this path only for grids of at most one 1024-thread block
+// per CU (code-object metadata, gfx950: 68-86 VGPRs forward, 72-116 backward - 16 waves = 4 per SIMD x <= 116 of the 512
+// registers a SIMD lane has: ONE such block fits a CU, never two) or at most two 256-thread blocks per CU (70-74 VGPRs: seven
+// would fit), and every spin is bounded - a block that gives up sets the workspace's `timeout` word and finishes with what it
+// has, so a violated assumption shows up as a wrong result and a flag (which the host turns into an error: Session.run's
+// callers check it wherever they synchronise anyway), never as a hung GPU.  What may run BESIDE such a grid: kernels that
+// finish on their own (a conv on a second stream, an RCCL collective - its blocks wait for peers on other GPUs, never for
+// this grid), which at worst delay the last blocks; what must NOT: another grid-exchange kernel, since two partially resident
+// grids can starve each other until both time out - callers whose launches can overlap pass ACG_BN_NO_GRID_EXCHANGE.
 struct FusedState { unsigned epoch, done, timeout, pad; };      // first 16 bytes of the workspace; granules behind it
 typedef unsigned long long __attribute__((address_space(1))) * gran_ptr;
 
@@ -541,6 +546,7 @@ struct FusedExchange {
   FusedState* state;
   unsigned epoch;
   int tid, lane, wave, nrb;
+  unsigned spin_limit = 1u << 22;      // polls before a block gives up (seconds); acg_bn_exchange_selftest lowers it
 
   // the per-thread partials s[0..7] (value index within the lane: {stat 0: 0..3, stat 1: 4..7}) -> this block's 64 sums, published
   __device__ __forceinline__ void publish(float (&s)[2 * V], long long slot /* granule index of this block's value 0 */) {
@@ -580,7 +586,7 @@ struct FusedExchange {
         }
         ok = __all(ok);
         if (!ok) {
-          if (spins > (1u << 22)) {               // bounded: give up, flag it, finish with what is there
+          if (spins > spin_limit) {                // bounded: give up, flag it, finish with what is there
             if (lane == 0) __hip_atomic_store(&state->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ok = true;
           } else {
@@ -788,21 +794,55 @@ __global__ __launch_bounds__(NT) void bn_fwd_fused(TX* __restrict__ x, const flo
   ex.finish();
 }
 
+// The exchange on its own (acg_bn_exchange_selftest): block b publishes the value b + 1 in all 64 slots, every block gathers the
+// grid's sum n (n + 1) / 2 and leaves it in out[b].  `withhold` >= 0: that block publishes nothing - its peers (and itself) run
+// into the spin bound, set the timeout word and finish with a short sum: the failure path of bn_fwd_fused / bn_bwd_fused,
+// which share every line of FusedExchange with this kernel, provoked on purpose.
+template <int NT>
+__global__ __launch_bounds__(NT) void exchange_selftest_k(unsigned* __restrict__ ws, float* __restrict__ out, int withhold, unsigned spin_limit) {
+  using EX = FusedExchange<NT>;
+  __shared__ float red[EX::NW][EX::NV];
+  __shared__ float tot[EX::NV];
+  __shared__ unsigned s_epoch;
+  const int tid = threadIdx.x;
+  FusedState* const state = reinterpret_cast<FusedState*>(ws);
+  if (tid == 0) s_epoch = __hip_atomic_load(&state->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  __syncthreads();
+  EX ex{red, reinterpret_cast<unsigned long long*>(ws + 4), state, s_epoch, tid, tid & 63, tid >> 6, (int)gridDim.x, spin_limit};
+  float s[2 * EX::V];
+#pragma unroll
+  for (int j = 0; j < 2 * EX::V; ++j) s[j] = tid < EX::CL ? (float)(blockIdx.x + 1) : 0.f;     // row lane 0 carries the block's value
+  if ((int)blockIdx.x != withhold) ex.publish(s, (long long)blockIdx.x * EX::NV);
+  ex.gather(0, tot);
+  if (tid == 0) {
+    float lo = tot[0], hi = tot[0];
+    for (int v = 1; v < EX::NV; ++v) { lo = fminf(lo, tot[v]); hi = fmaxf(hi, tot[v]); }
+    out[blockIdx.x] = lo == hi ? lo : -1.f;       // all 64 sums agree in a healthy exchange
+  }
+  ex.finish();
+}
+
 // Grid of the fused kernels for R rows per group.  What a block sweeps in the exchange grows with the number of row blocks of
 // its (group, chunk) - 512 bytes each - so the row blocks are kept FEW: 256-thread blocks (128 rows) only up to 16 of them
 // (measured: 512 blocks of 128 rows sweeping 128 KB each ran d/conv1's backward at 19.7 us, 64 blocks of 512 rows at 9.5), else
 // 1024-thread blocks of 512 or 1024 rows within ONE block per CU; nt = 0: the tensor does not fit, two launches.
 struct FusedShape { int nt, U; dim3 grid; };
-FusedShape fused_shape(long long R, int C, int groups) {
+// The exchange area of a fused launch: 512 bytes (64 granules) per block behind the 16 state bytes.  kMaxFusedBlocks bounds it
+// for acg_bn_workspace_bytes whatever the channel count (a chunk of <= 32 channels costs its 512 bytes per row block: with
+// the round-4 bound "one block per CU" alone, 131072 x 16 asked for 131 KB of granules in a 66 KB workspace - ADVICE r4).
+constexpr int kMaxFusedBlocks = 512;
+constexpr size_t kFusedExchangeBytes = (size_t)kMaxFusedBlocks * 512;
+FusedShape fused_shape(long long R, int C, int groups, bool no_grid = false) {
   static const int ncu = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0; (void)hipGetLastError(); return n; }();
   static const int small_rb = env_int("ACG_BN_FUSED_SMALL_ROWBLOCKS", 16);       // tuning hook
   FusedShape f{0, 0, dim3(1, 1, 1)};
-  if (ncu <= 0) return f;
+  if (ncu <= 0 || no_grid) return f;
   const long long cch = (C + 31) / 32;
   auto blocks = [&](int rows) { return acg::ceil_div(R, rows) * cch * groups; };
-  if (acg::ceil_div(R, 128) <= small_rb && blocks(128) <= 2 * ncu) { f.nt = 256; f.U = 4; f.grid = dim3((unsigned)acg::ceil_div(R, 128), (unsigned)cch, (unsigned)groups); }
-  else if (blocks(512) <= ncu) { f.nt = 1024; f.U = 4; f.grid = dim3((unsigned)acg::ceil_div(R, 512), (unsigned)cch, (unsigned)groups); }
-  else if (blocks(1024) <= ncu) { f.nt = 1024; f.U = 8; f.grid = dim3((unsigned)acg::ceil_div(R, 1024), (unsigned)cch, (unsigned)groups); }
+  const long long cap1 = std::min<long long>(ncu, kMaxFusedBlocks), cap2 = std::min<long long>(2ll * ncu, kMaxFusedBlocks);
+  if (acg::ceil_div(R, 128) <= small_rb && blocks(128) <= cap2) { f.nt = 256; f.U = 4; f.grid = dim3((unsigned)acg::ceil_div(R, 128), (unsigned)cch, (unsigned)groups); }
+  else if (blocks(512) <= cap1) { f.nt = 1024; f.U = 4; f.grid = dim3((unsigned)acg::ceil_div(R, 512), (unsigned)cch, (unsigned)groups); }
+  else if (blocks(1024) <= cap1) { f.nt = 1024; f.U = 8; f.grid = dim3((unsigned)acg::ceil_div(R, 1024), (unsigned)cch, (unsigned)groups); }
   return f;
 }
 
@@ -1198,7 +1238,8 @@ bool vec4_ok(int C, const void* a, const void* b, const void* c) {
 // layer of a bf16 network) exists for the scalar (V = 1) variants only.
 template <typename TX, typename TY>
 int bn_fwd_typed(const void* x, const float* beta, void* y, float* save_mean, float* save_rstd, long long R, int C, int groups,
-                 float eps, int act, float leak, float* part, bool v4, int XP, int YP, hipStream_t st, const Slabs sl = Slabs{nullptr, 0, 0, 0}) {
+                 float eps, int act, float leak, float* part, bool v4, int XP, int YP, hipStream_t st, const Slabs sl = Slabs{nullptr, 0, 0, 0},
+                 bool no_grid = false) {
   constexpr bool same = std::is_same<TX, TY>::value;
   TX* xf = (TX*)const_cast<void*>(x);
   TY* yf = (TY*)y;
@@ -1212,7 +1253,7 @@ int bn_fwd_typed(const void* x, const float* beta, void* y, float* save_mean, fl
     // (slabs in the rows layout: the fused kernel also where the resident ones would apply - its rows are coalesced, theirs cost a
     // cache line per row and slab)
     const bool rows_slabs = sl.p != nullptr && sl.qrows == 0;
-    const FusedShape f = (fused_on_f && v4 && (rows_slabs || (!sl.p && (resident_nr(R, 32) == 0 || R >= fused_min_f)))) ? fused_shape(R, C, groups) : FusedShape{0, 0, dim3(1, 1, 1)};
+    const FusedShape f = (fused_on_f && v4 && (rows_slabs || (!sl.p && (resident_nr(R, 32) == 0 || R >= fused_min_f)))) ? fused_shape(R, C, groups, no_grid) : FusedShape{0, 0, dim3(1, 1, 1)};
     if (f.nt) {
 #define ACG_BN_FF(UU, NN) do { if (rows_slabs) ACG_LAUNCH((bn_fwd_fused<4, TX, TY, UU, NN, true>), f.grid, dim3(NN), 0, st, xf, beta, yf, save_mean, save_rstd, R, C, eps, act, leak, XP, YP, (unsigned*)part, sl); \
       else ACG_LAUNCH((bn_fwd_fused<4, TX, TY, UU, NN, false>), f.grid, dim3(NN), 0, st, xf, beta, yf, save_mean, save_rstd, R, C, eps, act, leak, XP, YP, (unsigned*)part, sl); } while (0)
@@ -1254,7 +1295,7 @@ int bn_fwd_typed(const void* x, const float* beta, void* y, float* save_mean, fl
 template <typename TX, typename TY, typename TD = TX>
 int bn_bwd_typed(const void* x, const void* dy, const float* beta, const float* save_mean, const float* save_rstd, void* dx,
                  float* dbeta, float dbeta_acc, long long R, int C, int groups, int act, float leak, float* part, bool v4, int XP, int YP,
-                 hipStream_t st, const Slabs sl = Slabs{nullptr, 0, 0, 0}) {
+                 hipStream_t st, const Slabs sl = Slabs{nullptr, 0, 0, 0}, bool no_grid = false) {
   constexpr bool same = std::is_same<TX, TY>::value;
   const TX* xf = (const TX*)x;
   const TY* dyf = (const TY*)dy;
@@ -1266,7 +1307,7 @@ int bn_bwd_typed(const void* x, const void* dy, const float* beta, const float* 
   // them from `fused_min` rows per group on (tuning hook; measured in profiles/r4/d_bn_fused_ab.txt)
   static const int fused_min_b = env_int("ACG_BN_FUSED_MIN_ROWS", 2048);      // backward: 2048 x 128 runs 6.1 us fused, 7.7 resident; below, resident wins
   const bool rows_slabs_b = sl.p != nullptr && sl.qrows == 0;
-  const bool prefer_fused_b = same && v4 && (rows_slabs_b || (!sl.p && R >= fused_min_b)) && fused_shape(R, C, groups).nt != 0;
+  const bool prefer_fused_b = same && v4 && (rows_slabs_b || (!sl.p && R >= fused_min_b)) && fused_shape(R, C, groups, no_grid).nt != 0;
   if (const int nr = prefer_fused_b ? 0 : (resident_nr(R * groups, 16) ? resident_nr(R, 16) : 0)) {
     const dim3 rg(C / V);
 #define ACG_BN_RES_BWD(VV, NN) do { if (sl.p) ACG_LAUNCH((bn_resident_bwd<VV, NN, TX, TY, true, TD>), rg, dim3(256), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, (int)R, C, groups, act, leak, XP, YP, sl); \
@@ -1287,7 +1328,7 @@ int bn_bwd_typed(const void* x, const void* dy, const float* beta, const float* 
   // resident at one block of 1024 threads per CU
   if constexpr (same) {
     static const int fused_on = env_int("ACG_BN_FUSED_BWD", 1);     // tuning hook
-    const FusedShape f = (fused_on && v4 && (!sl.p || rows_slabs_b)) ? fused_shape(R, C, groups) : FusedShape{0, 0, dim3(1, 1, 1)};
+    const FusedShape f = (fused_on && v4 && (!sl.p || rows_slabs_b)) ? fused_shape(R, C, groups, no_grid) : FusedShape{0, 0, dim3(1, 1, 1)};
     if (f.nt) {
 #define ACG_BN_FB(UU, NN) do { if (rows_slabs_b) ACG_LAUNCH((bn_bwd_fused<4, TX, TY, TD, UU, NN, true>), f.grid, dim3(NN), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, R, C, groups, act, leak, XP, YP, (unsigned*)part, sl); \
       else ACG_LAUNCH((bn_bwd_fused<4, TX, TY, TD, UU, NN, false>), f.grid, dim3(NN), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, R, C, groups, act, leak, XP, YP, (unsigned*)part, sl); } while (0)
@@ -1345,13 +1386,14 @@ extern "C" {
 size_t acg_bn_workspace_bytes(int64_t rows, int32_t channels, int32_t groups) {
   (void)rows;
   if (channels <= 0 || groups <= 0) return 0;
-  // 16 bytes of state (FusedState: epoch, done, timeout flag, pad) in front of the partial sums / exchange granules of every path
-  return 16 + (size_t)groups * ((size_t)kMaxPartialBlocks * 2 + 2) * (size_t)channels * sizeof(float);
+  // 16 bytes of state (FusedState: epoch, done, timeout flag, pad) in front of the partial sums (two-launch path) or the exchange
+  // granules (one-launch grid kernels: 512 bytes per block, at most kMaxFusedBlocks blocks - fused_shape) of every path
+  return 16 + std::max((size_t)groups * ((size_t)kMaxPartialBlocks * 2 + 2) * (size_t)channels * sizeof(float), kFusedExchangeBytes);
 }
 
 int32_t acg_bn_act_fwd(const void* x, const float* beta, void* y, float* save_mean, float* save_rstd, int64_t rows,
                        int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t groups, float eps, int32_t act, float leak, int32_t dtype,
-                       void* ws, size_t wsb, acg_stream_t stream) {
+                       int32_t flags, void* ws, size_t wsb, acg_stream_t stream) {
   const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
   ACG_REQUIRE(XP >= C && YP >= C, ACG_ERR_INVALID_ARG, "bn_act_fwd: pitch smaller than the row");
   if (int rc = check_bn("bn_act_fwd", rows, C, groups)) return rc;
@@ -1360,7 +1402,9 @@ int32_t acg_bn_act_fwd(const void* x, const float* beta, void* y, float* save_me
   ACG_REQUIRE(ws && wsb >= acg_bn_workspace_bytes(rows, C, groups), ACG_ERR_WORKSPACE, "bn_act_fwd: workspace too small");
   const long long R = rows / groups;
   const bool v4 = vec4_ok(C, x, y, beta) && vec4_ok(C, save_mean, save_rstd, ws) && XP % 4 == 0 && YP % 4 == 0;
-  ACG_WITH_TYPES(dtype, "bn_act_fwd", return (bn_fwd_typed<TA, TB>(x, beta, y, save_mean, save_rstd, R, C, groups, eps, act, leak, (float*)ws, v4, XP, YP, acg::to_stream(stream))));
+  ACG_REQUIRE((flags & ~ACG_BN_NO_GRID_EXCHANGE) == 0, ACG_ERR_INVALID_ARG, "bn_act_fwd: unknown flags 0x%x", flags);
+  const bool no_grid = (flags & ACG_BN_NO_GRID_EXCHANGE) != 0;
+  ACG_WITH_TYPES(dtype, "bn_act_fwd", return (bn_fwd_typed<TA, TB>(x, beta, y, save_mean, save_rstd, R, C, groups, eps, act, leak, (float*)ws, v4, XP, YP, acg::to_stream(stream), Slabs{nullptr, 0, 0, 0}, no_grid)));
 }
 
 int32_t acg_bn_act_fwd_partials(const void* x, const float* beta, const float* partials, int32_t nblk, int32_t block_rows, int32_t run_rows,
@@ -1384,9 +1428,12 @@ int32_t acg_bn_act_fwd_partials(const void* x, const float* beta, const float* p
 
 int32_t acg_bn_act_bwd(const void* x, const void* dy, const float* beta, const float* save_mean, const float* save_rstd,
                        void* dx, float* dbeta, float dbeta_acc, int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch,
-                       int32_t groups, int32_t act, float leak, int32_t dtype, void* ws, size_t wsb, acg_stream_t stream) {
+                       int32_t groups, int32_t act, float leak, int32_t dtype, int32_t flags, void* ws, size_t wsb, acg_stream_t stream) {
   const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
   ACG_REQUIRE(XP >= C && YP >= C, ACG_ERR_INVALID_ARG, "bn_act_bwd: pitch smaller than the row");
+  ACG_REQUIRE((flags & ~ACG_BN_NO_GRID_EXCHANGE) == 0, ACG_ERR_INVALID_ARG, "bn_act_bwd: unknown flags 0x%x", flags);
+  const bool no_grid = (flags & ACG_BN_NO_GRID_EXCHANGE) != 0;
+  const Slabs none{nullptr, 0, 0, 0};
   if (int rc = check_bn("bn_act_bwd", rows, C, groups)) return rc;
   ACG_REQUIRE(x && dy && beta && save_mean && save_rstd && dx && dbeta, ACG_ERR_INVALID_ARG, "bn_act_bwd: null pointer");
   ACG_REQUIRE(act == ACG_ACT_NONE || act == ACG_ACT_RELU || act == ACG_ACT_LRELU, ACG_ERR_UNSUPPORTED, "bn_act_bwd: activation %d", act);
@@ -1395,16 +1442,17 @@ int32_t acg_bn_act_bwd(const void* x, const void* dy, const float* beta, const f
   const bool v4 = vec4_ok(C, x, dy, dx) && vec4_ok(C, save_mean, save_rstd, ws) && vec4_ok(C, beta, dbeta, ws) && XP % 4 == 0 && YP % 4 == 0;
   // ACG_DTYPE2(ACG_F32, ACG_BF16): a head layer of a bf16 network - x and dy float32, dx bf16 (acgan_hip.h)
   if (dtype == ACG_DTYPE2(ACG_F32, ACG_BF16))
-    return bn_bwd_typed<float, float, __bf16>(x, dy, beta, save_mean, save_rstd, dx, dbeta, dbeta_acc, R, C, groups, act, leak, (float*)ws, v4, XP, YP, acg::to_stream(stream));
-  ACG_WITH_TYPES(dtype, "bn_act_bwd", return (bn_bwd_typed<TA, TB>(x, dy, beta, save_mean, save_rstd, dx, dbeta, dbeta_acc, R, C, groups, act, leak, (float*)ws, v4, XP, YP, acg::to_stream(stream))));
+    return bn_bwd_typed<float, float, __bf16>(x, dy, beta, save_mean, save_rstd, dx, dbeta, dbeta_acc, R, C, groups, act, leak, (float*)ws, v4, XP, YP, acg::to_stream(stream), none, no_grid);
+  ACG_WITH_TYPES(dtype, "bn_act_bwd", return (bn_bwd_typed<TA, TB>(x, dy, beta, save_mean, save_rstd, dx, dbeta, dbeta_acc, R, C, groups, act, leak, (float*)ws, v4, XP, YP, acg::to_stream(stream), none, no_grid)));
 }
 
 int32_t acg_bn_act_fwd_slabs(const float* slabs, int32_t splits, void* x, const float* beta, void* y, float* save_mean, float* save_rstd,
                              int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t groups, float eps, int32_t act, float leak,
-                             int32_t dtype, int32_t layout, void* ws, size_t wsb, acg_stream_t stream) {
+                             int32_t dtype, int32_t layout, int32_t flags, void* ws, size_t wsb, acg_stream_t stream) {
   const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
   ACG_REQUIRE(XP >= C && YP >= C, ACG_ERR_INVALID_ARG, "bn_act_fwd_slabs: pitch smaller than the row");
-  ACG_REQUIRE(layout == ACG_SLABS_ROWS || (layout == ACG_SLABS_QUADS && acg_bn_slabs_layout(rows, C, x_pitch, y_pitch, groups, dtype, 0) == ACG_SLABS_QUADS),
+  ACG_REQUIRE((flags & ~ACG_BN_NO_GRID_EXCHANGE) == 0, ACG_ERR_INVALID_ARG, "bn_act_fwd_slabs: unknown flags 0x%x", flags);
+  ACG_REQUIRE(layout == ACG_SLABS_ROWS || (layout == ACG_SLABS_QUADS && acg_bn_slabs_layout(rows, C, x_pitch, y_pitch, groups, dtype, 0, flags) == ACG_SLABS_QUADS),
               ACG_ERR_UNSUPPORTED, "bn_act_fwd_slabs: slab layout %d for this tensor (acg_bn_slabs_layout)", layout);
   if (int rc = check_bn("bn_act_fwd_slabs", rows, C, groups)) return rc;
   ACG_REQUIRE(slabs && splits >= 1 && x && beta && y && save_mean && save_rstd, ACG_ERR_INVALID_ARG, "bn_act_fwd_slabs: null pointer / splits < 1");
@@ -1414,7 +1462,7 @@ int32_t acg_bn_act_fwd_slabs(const float* slabs, int32_t splits, void* x, const 
   const bool v4 = vec4_ok(C, x, y, beta) && vec4_ok(C, save_mean, save_rstd, ws) && vec4_ok(C, slabs, slabs, slabs) && XP % 4 == 0 && YP % 4 == 0;
   ACG_REQUIRE(layout == ACG_SLABS_ROWS || v4, ACG_ERR_INVALID_ARG, "bn_act_fwd_slabs: the quad layout needs 16-byte aligned pointers");
   const Slabs sl{slabs, splits, (long long)rows * XP, layout == ACG_SLABS_QUADS ? (long long)rows : 0ll};
-  ACG_WITH_TYPES(dtype, "bn_act_fwd_slabs", return (bn_fwd_typed<TA, TB>(x, beta, y, save_mean, save_rstd, R, C, groups, eps, act, leak, (float*)ws, v4, XP, YP, acg::to_stream(stream), sl)));
+  ACG_WITH_TYPES(dtype, "bn_act_fwd_slabs", return (bn_fwd_typed<TA, TB>(x, beta, y, save_mean, save_rstd, R, C, groups, eps, act, leak, (float*)ws, v4, XP, YP, acg::to_stream(stream), sl, (flags & ACG_BN_NO_GRID_EXCHANGE) != 0)));
 }
 
 int32_t acg_bn_bwd_slabs_ok(int64_t rows, int32_t groups) {
@@ -1422,14 +1470,15 @@ int32_t acg_bn_bwd_slabs_ok(int64_t rows, int32_t groups) {
   return (resident_nr(rows, 16) && resident_nr(rows / groups, 16)) ? 1 : 0;
 }
 
-int32_t acg_bn_slabs_layout(int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t groups, int32_t dtype, int32_t backward) {
-  if (rows <= 0 || C <= 0 || groups <= 0 || rows % groups) return -1;
+int32_t acg_bn_slabs_layout(int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t groups, int32_t dtype, int32_t backward,
+                            int32_t flags) {
+  if (rows <= 0 || C <= 0 || groups <= 0 || rows % groups || (flags & ~ACG_BN_NO_GRID_EXCHANGE)) return -1;
   const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
   const bool vec = C % 4 == 0 && XP % 4 == 0 && YP % 4 == 0 && acg::dt_valid(dtype) && acg::dt_first(dtype) == acg::dt_second(dtype);
   // the one-launch grid kernels (bn_fwd_fused / bn_bwd_fused) sum slabs laid out like the tensor while they load their rows:
   // coalesced, any tensor whose grid is resident
   static const int fused_slabs = env_int("ACG_BN_SLABS_FUSED", 1);      // tuning hook
-  if (fused_slabs && vec && fused_shape(rows / groups, C, groups).nt != 0) return ACG_SLABS_ROWS;
+  if (fused_slabs && vec && fused_shape(rows / groups, C, groups, (flags & ACG_BN_NO_GRID_EXCHANGE) != 0).nt != 0) return ACG_SLABS_ROWS;
   const bool resident = backward ? acg_bn_bwd_slabs_ok(rows, groups) != 0 : resident_nr(rows / groups, 32) != 0;
   if (backward && !resident) return -1;
   // the register-resident kernels with four channels per block read [channels / 4][rows][4] slabs as consecutive 16-byte rows
@@ -1438,20 +1487,35 @@ int32_t acg_bn_slabs_layout(int64_t rows, int32_t C, int32_t x_pitch, int32_t y_
 
 int32_t acg_bn_act_bwd_slabs(const void* x, const float* dy_slabs, int32_t splits, const float* beta, const float* save_mean,
                              const float* save_rstd, void* dx, float* dbeta, float dbeta_acc, int64_t rows, int32_t C, int32_t x_pitch,
-                             int32_t y_pitch, int32_t groups, int32_t act, float leak, int32_t dtype, int32_t layout, void* ws, size_t wsb, acg_stream_t stream) {
+                             int32_t y_pitch, int32_t groups, int32_t act, float leak, int32_t dtype, int32_t layout, int32_t flags, void* ws, size_t wsb,
+                             acg_stream_t stream) {
   const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
   ACG_REQUIRE(XP >= C && YP >= C, ACG_ERR_INVALID_ARG, "bn_act_bwd_slabs: pitch smaller than the row");
-  ACG_REQUIRE(layout == ACG_SLABS_ROWS || (layout == ACG_SLABS_QUADS && acg_bn_slabs_layout(rows, C, x_pitch, y_pitch, groups, dtype, 1) == ACG_SLABS_QUADS),
+  ACG_REQUIRE((flags & ~ACG_BN_NO_GRID_EXCHANGE) == 0, ACG_ERR_INVALID_ARG, "bn_act_bwd_slabs: unknown flags 0x%x", flags);
+  ACG_REQUIRE(layout == ACG_SLABS_ROWS || (layout == ACG_SLABS_QUADS && acg_bn_slabs_layout(rows, C, x_pitch, y_pitch, groups, dtype, 1, flags) == ACG_SLABS_QUADS),
               ACG_ERR_UNSUPPORTED, "bn_act_bwd_slabs: slab layout %d for this tensor (acg_bn_slabs_layout)", layout);
   if (int rc = check_bn("bn_act_bwd_slabs", rows, C, groups)) return rc;
   ACG_REQUIRE(x && dy_slabs && splits >= 1 && beta && save_mean && save_rstd && dx && dbeta, ACG_ERR_INVALID_ARG, "bn_act_bwd_slabs: null pointer / splits < 1");
   ACG_REQUIRE(act == ACG_ACT_NONE || act == ACG_ACT_RELU || act == ACG_ACT_LRELU, ACG_ERR_UNSUPPORTED, "bn_act_bwd_slabs: activation %d", act);
-  ACG_REQUIRE(acg_bn_slabs_layout(rows, C, x_pitch, y_pitch, groups, dtype, 1) >= 0, ACG_ERR_UNSUPPORTED, "bn_act_bwd_slabs: tensor too large for the one-launch kernels (acg_bn_slabs_layout)");
+  ACG_REQUIRE(acg_bn_slabs_layout(rows, C, x_pitch, y_pitch, groups, dtype, 1, flags) >= 0, ACG_ERR_UNSUPPORTED, "bn_act_bwd_slabs: tensor too large for the one-launch kernels (acg_bn_slabs_layout)");
   const long long R = rows / groups;
   const bool v4 = vec4_ok(C, x, dy_slabs, dx) && vec4_ok(C, save_mean, save_rstd, beta) && vec4_ok(C, beta, dbeta, dbeta) && XP % 4 == 0 && YP % 4 == 0;
   ACG_REQUIRE(layout == ACG_SLABS_ROWS || v4, ACG_ERR_INVALID_ARG, "bn_act_bwd_slabs: the quad layout needs 16-byte aligned pointers");
   const Slabs sl{dy_slabs, splits, (long long)rows * YP, layout == ACG_SLABS_QUADS ? (long long)rows : 0ll};
-  ACG_WITH_TYPES(dtype, "bn_act_bwd_slabs", return (bn_bwd_typed<TA, TB>(x, nullptr, beta, save_mean, save_rstd, dx, dbeta, dbeta_acc, R, C, groups, act, leak, (float*)ws, v4, XP, YP, acg::to_stream(stream), sl)));
+  ACG_WITH_TYPES(dtype, "bn_act_bwd_slabs", return (bn_bwd_typed<TA, TB>(x, nullptr, beta, save_mean, save_rstd, dx, dbeta, dbeta_acc, R, C, groups, act, leak, (float*)ws, v4, XP, YP, acg::to_stream(stream), sl, (flags & ACG_BN_NO_GRID_EXCHANGE) != 0)));
+}
+
+int32_t acg_bn_exchange_selftest(void* ws, size_t wsb, float* out, int32_t blocks, int32_t threads, int32_t withhold, uint32_t spin_limit,
+                                 acg_stream_t stream) {
+  ACG_REQUIRE(ws && out, ACG_ERR_INVALID_ARG, "bn_exchange_selftest: null pointer");
+  ACG_REQUIRE(blocks >= 1 && blocks <= kMaxFusedBlocks, ACG_ERR_INVALID_ARG, "bn_exchange_selftest: %d blocks (1..%d)", blocks, kMaxFusedBlocks);
+  ACG_REQUIRE(threads == 256 || threads == 1024, ACG_ERR_INVALID_ARG, "bn_exchange_selftest: %d threads per block (256 or 1024)", threads);
+  ACG_REQUIRE(withhold < blocks, ACG_ERR_INVALID_ARG, "bn_exchange_selftest: withheld block %d of %d", withhold, blocks);
+  ACG_REQUIRE(wsb >= 16 + (size_t)blocks * 512, ACG_ERR_WORKSPACE, "bn_exchange_selftest: workspace too small");
+  hipStream_t st = acg::to_stream(stream);
+  if (threads == 256) ACG_LAUNCH((exchange_selftest_k<256>), dim3(blocks), dim3(256), 0, st, (unsigned*)ws, out, withhold, spin_limit);
+  else ACG_LAUNCH((exchange_selftest_k<1024>), dim3(blocks), dim3(1024), 0, st, (unsigned*)ws, out, withhold, spin_limit);
+  return acg::check_launch("exchange_selftest_k");
 }
 
 }  // extern "C"

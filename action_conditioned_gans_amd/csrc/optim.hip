@@ -36,19 +36,36 @@ __global__ __launch_bounds__(256) void adam_k(float* __restrict__ p, const float
   // block evaluates it: two double-precision pow calls are several hundred instructions, more than the whole update of
   // the one or two float4 a thread owns.
   __shared__ float s_lr_t;
+  const long long stride = (long long)gridDim.x * 256;
+  const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                    reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+  const long long n4 = al ? n / 4 : 0;
+  // Round 5: the first float4 of every thread (the grid is sized so that it is nearly the only one) is loaded BEFORE the
+  // learning-rate prologue: that prologue is a dependent read of the step counter plus ~1 us of double-precision pow on one
+  // thread, during which the whole chip used to wait with nothing in flight (19.4 us for 133 MB in situ, 3.2 TB/s).
+  const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
+  const bool have = i0 < n4;
+  float4 pp, mm, vv, gg;
+  if (have) {
+    pp = reinterpret_cast<float4*>(p)[i0]; mm = reinterpret_cast<float4*>(m)[i0]; vv = reinterpret_cast<float4*>(v)[i0];
+    gg = reinterpret_cast<const float4*>(g)[i0];
+  }
   if (threadIdx.x == 0) {
     const int t = *step;
     s_lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
   }
   __syncthreads();
   const float lr_t = s_lr_t;
-  const long long stride = (long long)gridDim.x * 256;
-  const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
-                    reinterpret_cast<uintptr_t>(v)) & 15) == 0;
-  const long long n4 = al ? n / 4 : 0;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-    float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
-    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+  if (have) {
+    adam1(pp.x, gg.x, mm.x, vv.x, lr_t, b1, b2, eps, gs, use_clip, lo, hi);
+    adam1(pp.y, gg.y, mm.y, vv.y, lr_t, b1, b2, eps, gs, use_clip, lo, hi);
+    adam1(pp.z, gg.z, mm.z, vv.z, lr_t, b1, b2, eps, gs, use_clip, lo, hi);
+    adam1(pp.w, gg.w, mm.w, vv.w, lr_t, b1, b2, eps, gs, use_clip, lo, hi);
+    reinterpret_cast<float4*>(p)[i0] = pp; reinterpret_cast<float4*>(m)[i0] = mm; reinterpret_cast<float4*>(v)[i0] = vv;
+  }
+  for (long long i = i0 + stride; i < n4; i += stride) {
+    pp = reinterpret_cast<float4*>(p)[i]; mm = reinterpret_cast<float4*>(m)[i]; vv = reinterpret_cast<float4*>(v)[i];
+    gg = reinterpret_cast<const float4*>(g)[i];
     adam1(pp.x, gg.x, mm.x, vv.x, lr_t, b1, b2, eps, gs, use_clip, lo, hi);
     adam1(pp.y, gg.y, mm.y, vv.y, lr_t, b1, b2, eps, gs, use_clip, lo, hi);
     adam1(pp.z, gg.z, mm.z, vv.z, lr_t, b1, b2, eps, gs, use_clip, lo, hi);
@@ -119,14 +136,13 @@ __global__ __launch_bounds__(256) void opt_prepare_k(float* __restrict__ p, cons
   __shared__ float tile[32][33];
   __shared__ float s_lr_t;
   float lr_t = a.lr;
-  if (KIND == 0) {
-    if (threadIdx.x == 0) {
-      const int t = *step;
-      s_lr_t = (float)((double)a.lr * sqrt(1.0 - pow((double)a.b2, (double)t)) / (1.0 - pow((double)a.b1, (double)t)));
-    }
-    __syncthreads();
-    lr_t = s_lr_t;
+  // Adam's bias-corrected learning rate: one thread derives it (a dependent read of the step counter + double-precision pow,
+  // ~1-2 us); the block picks it up with `sync_lr()` - in the float4 path AFTER its loads are in flight (round 5)
+  if (KIND == 0 && threadIdx.x == 0) {
+    const int t = *step;
+    s_lr_t = (float)((double)a.lr * sqrt(1.0 - pow((double)a.b2, (double)t)) / (1.0 - pow((double)a.b1, (double)t)));
   }
+  auto sync_lr = [&]() { if (KIND == 0) { __syncthreads(); lr_t = s_lr_t; } };     // block-uniform call sites only
   auto upd = [&](long long i) -> float {
     float pp = p[i], m = s1[i];
     if (KIND == 0) { float v = s2[i]; adam1(pp, g[i], m, v, lr_t, a.b1, a.b2, a.eps, a.gs, a.use_clip, a.lo, a.hi); s2[i] = v; }
@@ -137,6 +153,7 @@ __global__ __launch_bounds__(256) void opt_prepare_k(float* __restrict__ p, cons
   const int blk = (int)blockIdx.x;
   if (blk >= l.first_block[count]) {             // a run between two filters: beta / bias vectors, alignment gaps
     const int j = blk - l.first_block[count];
+    sync_lr();
     for (long long i = threadIdx.x; i < l.gap_len[j]; i += 256) upd(l.gap_lo[j] + i);
     return;
   }
@@ -153,12 +170,17 @@ __global__ __launch_bounds__(256) void opt_prepare_k(float* __restrict__ p, cons
     // rows are 16-byte aligned: thread -> (a = a0 + r, b run 4q .. 4q + 3), float4 accesses, the rm run as one 8-byte store
     const int ar = a0 + r, bq = b0 + 4 * q;
     float nv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (ar < A && bq < B) {
-      const long long i0 = l.off[e] + ((long long)tap * A + ar) * B + bq;
-      float4 pp = *reinterpret_cast<float4*>(p + i0), mm = *reinterpret_cast<float4*>(s1 + i0);
-      const float4 gg = *reinterpret_cast<const float4*>(g + i0);
+    const bool have = ar < A && bq < B;
+    const long long i0 = l.off[e] + ((long long)tap * A + ar) * B + bq;
+    float4 pp, mm, gg, vv;
+    if (have) {
+      pp = *reinterpret_cast<float4*>(p + i0); mm = *reinterpret_cast<float4*>(s1 + i0);
+      gg = *reinterpret_cast<const float4*>(g + i0);
+      if (KIND == 0) vv = *reinterpret_cast<float4*>(s2 + i0);
+    }
+    sync_lr();
+    if (have) {
       if (KIND == 0) {
-        float4 vv = *reinterpret_cast<float4*>(s2 + i0);
         adam1(pp.x, gg.x, mm.x, vv.x, lr_t, a.b1, a.b2, a.eps, a.gs, a.use_clip, a.lo, a.hi);
         adam1(pp.y, gg.y, mm.y, vv.y, lr_t, a.b1, a.b2, a.eps, a.gs, a.use_clip, a.lo, a.hi);
         adam1(pp.z, gg.z, mm.z, vv.z, lr_t, a.b1, a.b2, a.eps, a.gs, a.use_clip, a.lo, a.hi);
@@ -182,6 +204,7 @@ __global__ __launch_bounds__(256) void opt_prepare_k(float* __restrict__ p, cons
     // rows at any 4-byte offset (266 gathered channels, 1 or 5 output channels): thread -> (a = a0 + t / 32 + 8u, b = b0 + t % 32),
     // a wave instruction = two rows of 32 consecutive floats
     const int bl = threadIdx.x & 31, bb = b0 + bl;
+    sync_lr();
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int al = (threadIdx.x >> 5) + 8 * u, aa = a0 + al;

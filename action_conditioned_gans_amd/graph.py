@@ -358,7 +358,11 @@ class Runtime:
         self.epilogue_stats = True
         self.epilogue_bias = True
         self.fuse_weight_refresh = True        # bf16: optimizer update + refresh of the bf16 filter copies in one launch (optim.StepOp)
+        # `flags` of the BatchNorm entries (acgan_hip.h): ACG_BN_NO_GRID_EXCHANGE where two BatchNorm launches can overlap (Session
+        # sets it with side_branches: two partially resident grid-exchange kernels would starve each other)
+        self.bn_flags = 0
         self._comm = comm
+        self._owns_comm = comm is None          # a communicator handed in (tests sharing one over several sessions) is its owner's to destroy
         self._scratch = {}
 
     @property
@@ -388,11 +392,16 @@ class Runtime:
 
     def check_exchange_flags(self):
         """Raise if a block of a one-launch BatchNorm kernel ever gave up waiting for its peers (acgan_hip.h: the launch then
-        finished with what it had - a wrong result - instead of hanging).  One device synchronisation: call it outside timed regions."""
+        finished with what it had - a wrong result - instead of hanging).  One device synchronisation: call it outside timed
+        regions - train() does at every log interval and before every checkpoint, bench.py before it prints, Session.close."""
         bufs = [b for b in self._scratch.get('state_workspaces', []) if b.numel() >= 12]
         if not bufs:
             return
-        flags = torch.stack([b[8:12].view(torch.int32)[0] for b in bufs])
+        if len(bufs) != self._scratch.get('flag_view_count'):
+            # one gather of every call site's word 2 instead of a Python loop of tiny device reads: the addresses are fixed
+            self._scratch['flag_views'] = [b[8:12].view(torch.int32) for b in bufs]
+            self._scratch['flag_view_count'] = len(bufs)
+        flags = torch.cat(self._scratch['flag_views']).cpu()
         if bool((flags != 0).any()):
             bad = [i for i, f in enumerate(flags.tolist()) if f]
             raise _lib.AcgError('BatchNorm grid exchange timed out in %d of %d call sites (first: #%d): the blocks of a one-launch kernel were not '
@@ -459,6 +468,9 @@ class Session:
         # the main stream - measured faster on this stack (profiles/r2/m_side_branch_ab.txt: a parallel branch of the HIP
         # graph costs more in fork / join edges than the state head's ~70 us of small kernels hide; bit-identical results)
         self.side_branches = bool(side_branches) and dev.type == 'cuda'
+        if self.side_branches:
+            # a side chain's BatchNorm can run beside a main-chain BatchNorm: two grid-exchange kernels must never overlap
+            self.rt.bn_flags = _lib.BN_NO_GRID_EXCHANGE
         self._programs = {}
         self._initialized = False
         self._weights_dirty = True     # bf16 operand copies of the filters are stale (initializer, set_value, restore)
@@ -466,17 +478,22 @@ class Session:
     def __enter__(self):
         return self
 
-    def __exit__(self, *a):
-        self.close()
+    def __exit__(self, exc_type, exc, tb):
+        # an exception is already on its way out: tear down, but do not replace it with a flag error of our own
+        self.close(check=exc_type is None)
         return False
 
-    def close(self):
-        """Check the device-side flags (Runtime.check_exchange_flags) and tear the gradient transport down (ncclCommDestroy); the
-        session must not run afterwards."""
-        self.rt.check_exchange_flags()
-        if self.rt._comm is not None:
-            self.rt._comm.destroy()
-            self.rt._comm = None
+    def close(self, check=True):
+        """Check the device-side flags (Runtime.check_exchange_flags; ``check=False`` skips that) and tear the gradient transport
+        down (ncclCommDestroy) - also when the check raises; the session must not run afterwards."""
+        try:
+            if check:
+                self.rt.check_exchange_flags()
+        finally:
+            if self.rt._comm is not None:
+                comm, self.rt._comm = self.rt._comm, None
+                if self.rt._owns_comm:
+                    comm.destroy()
 
     # ---- buffers
     def _materialize(self, t):
@@ -545,7 +562,10 @@ class Session:
         rec(fetches)
         return out
 
-    def _compile(self, flat_fetches, feeds):
+    def _compile(self, flat_fetches, feeds, skip=frozenset()):
+        """``skip``: ids of ops whose results are ALREADY in their output tensors (another program of this session left them there:
+        Trainer's look-ahead generator pass) - the dependency walk stops at them, they are not launched, their outputs are bound
+        as they lie."""
         g = self.graph
         needed, stack = {}, []
         for f in flat_fetches:
@@ -559,7 +579,7 @@ class Session:
                 raise TypeError('Fetch argument %r has invalid type %s' % (f, type(f)))
         while stack:
             op = stack.pop()
-            if id(op) in needed:
+            if id(op) in needed or id(op) in skip:
                 continue
             needed[id(op)] = op
             fed = getattr(op, 'fed_inputs', ())
@@ -728,17 +748,21 @@ class Session:
             self.rt.lib.copy_many(ctypes.byref(cl), len(fused), _lib.ACG_F32, self.rt.stream_ptr())
 
     # ---- run
-    def run(self, fetches, feed_dict=None, device_fetch=False):
+    def run(self, fetches, feed_dict=None, device_fetch=False, skip=None):
+        """``skip`` (a frozenset of Ops, an extension with no TensorFlow counterpart): ops whose outputs another program of this
+        session has already computed into their tensors; the program compiled for this call neither launches them nor anything only
+        they need (see _compile).  The caller vouches for those tensors' contents."""
         feed_dict = feed_dict or {}
         single = not isinstance(fetches, (list, tuple))
         flat = self._flatten(fetches)
         if any(isinstance(f, InitOp) for f in flat):
             self._initialize()
             return None if single else [None] * len(flat)
-        key = (tuple(id(f) for f in flat), tuple(id(k) for k in feed_dict))
+        key = (tuple(id(f) for f in flat), tuple(id(k) for k in feed_dict)) + ((id(skip),) if skip else ())
         prog = self._programs.get(key)
         if prog is None:
-            prog = self._compile(flat, list(feed_dict.keys()))
+            prog = self._compile(flat, list(feed_dict.keys()), frozenset(id(o) for o in skip) if skip else frozenset())
+            prog.skip_ref = skip          # keeps the frozenset (whose id is part of the key) alive
             self._programs[key] = prog
         if prog.missing_feeds:
             raise ValueError('You must feed a value for placeholder tensor(s) %s' % ', '.join(prog.missing_feeds))
@@ -758,7 +782,7 @@ class Session:
             return results[0]
         return self._unflatten(fetches, iter(results))
 
-    def profile_ops(self, fetches, feed_dict=None, repeats=3, relaunch=None, in_graph=10):
+    def profile_ops(self, fetches, feed_dict=None, repeats=3, relaunch=None, in_graph=10, skip=None):
         """Instrumented pass of a fetch.  Returns [(op, mean milliseconds)] in program order.  Executes the program
         ``repeats`` times for real (optimizer steps included), every device op bracketed by events recorded on the
         launch stream.  An event pair around ONE eager launch also times the gap the event records themselves open
@@ -769,9 +793,9 @@ class Session:
         if not self.rt.is_cuda:
             raise RuntimeError('profile_ops needs a GPU session')
         flat = self._flatten(fetches)
-        key = (tuple(id(f) for f in flat), tuple(id(k) for k in (feed_dict or {})))
+        key = (tuple(id(f) for f in flat), tuple(id(k) for k in (feed_dict or {}))) + ((id(skip),) if skip else ())
         if key not in self._programs:
-            self.run(fetches, feed_dict)
+            self.run(fetches, feed_dict, skip=skip)
         prog = self._programs[key]
         self._feed(prog, feed_dict or {})      # exactly what run() writes: used feeds, feed aliases, tiled action channels
         if self._weights_dirty:

@@ -441,6 +441,8 @@ class WgradReduceOp(G.Op):
     def bind(self, rt):
         entries, self.pending = self.pending, []
         self._keep = None                                     # (the optimizer looks here for THIS compile's lists: Adam._step_inc_launch)
+        self._bound_for = rt.program_ops                      # the compile these lists belong to: a stale _keep of an earlier program never matches
+        self.carries_step_inc = False
         if not entries:
             return None                                       # none of the layers is split at these shapes
         lists = []
@@ -487,7 +489,7 @@ class BnActOp(G.Op):
         if not 1 < splits <= rt.slab_handoff:
             return -1
         code = _code2(self.inputs[0], dy if backward else self.outputs[0])
-        layout = rt.lib.bn_slabs_layout(self.rows, self.c, self.xp, self.yp, self.groups, code, 1 if backward else 0)
+        layout = rt.lib.bn_slabs_layout(self.rows, self.c, self.xp, self.yp, self.groups, code, 1 if backward else 0, rt.bn_flags)
         return layout if (layout == SLABS_QUADS or rt.slab_rows) else -1
 
     def bind(self, rt):
@@ -508,11 +510,11 @@ class BnActOp(G.Op):
         if slab is not None:      # the conv left its split-K slabs: sum them here and write x for the backward pass
             sws, splits, layout = slab
             args = (_p(sws), splits, _p(x.buf), _p(beta.buf), _p(y.buf), _p(mean.buf), _p(rstd.buf), self.rows, self.c, self.xp, self.yp,
-                    self.groups, self.eps, _ACT_CODE[self.act], self.leak, _code2(x, y), layout, _p(ws), n)
+                    self.groups, self.eps, _ACT_CODE[self.act], self.leak, _code2(x, y), layout, rt.bn_flags, _p(ws), n)
             fn = lib.bn_act_fwd_slabs
             return lambda s: fn(*args, s)
         args = (_p(x.buf), _p(beta.buf), _p(y.buf), _p(mean.buf), _p(rstd.buf), self.rows, self.c, self.xp, self.yp, self.groups,
-                self.eps, _ACT_CODE[self.act], self.leak, _code2(x, y), _p(ws), n)
+                self.eps, _ACT_CODE[self.act], self.leak, _code2(x, y), rt.bn_flags, _p(ws), n)
         fn = lib.bn_act_fwd
         return lambda s: fn(*args, s)
 
@@ -552,11 +554,11 @@ class BnActBwdOp(G.Op):
         if slab is not None:      # dy arrives as the producing dgrad's split-K slabs
             sws, splits, layout = slab
             args = (_p(x.buf), _p(sws), splits, _p(beta.buf), _p(mean.buf), _p(rstd.buf), _p(dx.buf), _p(dbeta.buf), self.accumulate,
-                    f.rows, f.c, f.xp, f.yp, f.groups, _ACT_CODE[f.act], f.leak, _code2(x, dy), layout, _p(ws), n)
+                    f.rows, f.c, f.xp, f.yp, f.groups, _ACT_CODE[f.act], f.leak, _code2(x, dy), layout, rt.bn_flags, _p(ws), n)
             fn = lib.bn_act_bwd_slabs
             return lambda s: fn(*args, s)
         args = (_p(x.buf), _p(dy.buf), _p(beta.buf), _p(mean.buf), _p(rstd.buf), _p(dx.buf), _p(dbeta.buf), self.accumulate,
-                f.rows, f.c, f.xp, f.yp, f.groups, _ACT_CODE[f.act], f.leak, _bn_bwd_code(x, dy, dx), _p(ws), n)
+                f.rows, f.c, f.xp, f.yp, f.groups, _ACT_CODE[f.act], f.leak, _bn_bwd_code(x, dy, dx), rt.bn_flags, _p(ws), n)
         fn = lib.bn_act_bwd
         return lambda s: fn(*args, s)
 
@@ -573,7 +575,9 @@ class BnMomentsOp(G.Op):
 
     def bind(self, rt):
         lib = rt.lib
-        ws, n = rt.state_workspace(lib.bn_workspace_bytes(self.rows, self.c, self.groups))
+        # plain scratch, NOT rt.state_workspace: acg_bn_moments writes its partial sums from byte 0 - there is no state header,
+        # and Runtime.check_exchange_flags would read a partial sum as a timeout flag
+        ws, n = rt.workspace(lib.bn_workspace_bytes(self.rows, self.c, self.groups))
         self._keep = ws
         x = self.inputs[0]
         args = (_p(x.buf), _p(self.outputs[0].buf), self.rows, self.c, self.xp, self.groups, _code(x), _p(ws), n)
@@ -657,7 +661,7 @@ class BnBwdSumsOp(G.Op):
 
     def bind(self, rt):
         lib, f = rt.lib, self.fwd
-        ws, n = rt.state_workspace(lib.bn_workspace_bytes(f.rows, f.c, f.groups))
+        ws, n = rt.workspace(lib.bn_workspace_bytes(f.rows, f.c, f.groups))      # plain scratch: see BnMomentsOp.bind
         self._keep = ws
         x, dy, beta, mean, rstd = self.inputs
         args = (_p(x.buf), _p(dy.buf), _p(beta.buf), _p(mean.buf), _p(rstd.buf), _p(self.outputs[0].buf), f.rows, f.c, f.xp, f.yp,

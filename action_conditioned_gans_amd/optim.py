@@ -283,8 +283,14 @@ class AdamOptimizer(Optimizer):
         the main stream) then carries the increment in its acg_reduce_list::step_inc - one tiny launch less per step."""
         for red in getattr(op, 'reduce_ops', ()):
             lists = getattr(red, '_keep', None)
-            if id(red) in rt.program_ops and lists and not red.side_stream:
+            # the hand-off is explicit: the reduce op must have been bound for THIS compile (WgradReduceOp.bind stamps the program
+            # it built its lists for - a stale list of an earlier program, or a reduce op bound after this step op, never matches,
+            # and the counter then gets its own launch below), and one list carries ONE counter (ADVICE r4)
+            if id(red) in rt.program_ops and lists and not red.side_stream and getattr(red, '_bound_for', None) is rt.program_ops:
+                if red.carries_step_inc:
+                    raise RuntimeError('%s already advances another optimizer step counter' % red.name)
                 lists[0][0].step_inc = step.buf.data_ptr()
+                red.carries_step_inc = True
                 return None
         inc, ps = rt.lib.step_inc, _p(step.buf)
         return lambda s: inc(ps, s)

@@ -37,7 +37,13 @@ ACTION_DIM, STATE_DIM = 10, 5
 
 class Trainer:
     def __init__(self, sess, arg_adv, arg_loss, arg_opt, arg_transform, batch_size=64, img_size=64, ksize=5,
-                 seed=0, batched_d=True):
+                 seed=0, batched_d=True, lookahead=True):
+        """``lookahead`` (no reference counterpart, off the reference's call path unless asked for): builds a second generator
+        instance on a batch of 2 B - the pair (generator-step samples ; discriminator-step samples), BatchNorm statistics per half -
+        that ``train_d(..., next_g=...)`` runs INSTEAD of the batch-B instance; the ``train_g`` call that follows with the announced
+        inputs then finds its generator forward pass done.  The two passes read the same generator weights (the D step does not
+        touch them), so this is the reference's arithmetic - one D step, then one G step (train.py:241-263) - with the two
+        generator forward passes of an iteration sharing their launches at twice the GEMM height."""
         self.sess = sess
         self.batch_size, self.img_size, self.ksize = batch_size, img_size, ksize
         self.arg_adv, self.arg_loss, self.arg_opt, self.arg_transform = arg_adv, arg_loss, arg_opt, arg_transform
@@ -54,22 +60,52 @@ class Trainer:
         self.next_state = G.placeholder((B, STATE_DIM), name='next_state')
 
         # generator (train.py:52-61); the action tile + concat is fused inside the model builders
-        if arg_transform:
-            self.g_out, self.g_state_out = M.build_generator_transform(self.img_ph, self.action_ph, batch_size=B,
-                                                                       ksize=ksize)
-        else:
-            self.g_out, self.g_state_out = M.build_generator(self.img_ph, self.action_ph), None
+        graph = G.get_default_graph()
+        dp = graph.collections.get('data_parallel')
+        # (synchronised BatchNorm builds other ops per layer and is a validation mode: it keeps the plain call path)
+        self.lookahead = bool(lookahead) and batched_d and not (dp is not None and dp.active and dp.sync_bn)
+
+        def build_g(images, actions, batch, reuse):
+            if arg_transform:
+                return M.build_generator_transform(images, actions, batch_size=batch, ksize=ksize, reuse=reuse)
+            return M.build_generator(images, actions, reuse=reuse), None
+        n0 = len(graph.ops)
+        self.g_out, self.g_state_out = build_g(self.img_ph, self.action_ph, B, False)
+        n1 = len(graph.ops)
         self.g_next_frame = self.g_out
+        self.pair_img_ph = self.pair_action_ph = self._g_pair_out = None
+        if self.lookahead:
+            # the pair instance: rows [0, B) = the samples of the G step that follows, rows [B, 2 B) = this D step's samples
+            self.pair_img_ph = G.placeholder((2 * B, S, S, 3), name='frame_pair')
+            self.pair_img_ph.padded = self._pair_img_pad = G.placeholder((2 * B, S, S, 3), name='frame_pair_conv', channel_pitch=O.cpad(3), act=True)
+            self.pair_action_ph = G.placeholder((2 * B, ACTION_DIM), name='action_pair')
+            with O.arg_scope([O.batch_norm], groups=2):
+                self._g_pair_out, _ = build_g(self.pair_img_ph, self.pair_action_ph, 2 * B, True)
+            # every tensor of the batch-B instance IS the first half of its twin in the pair instance: what the pair pass
+            # computes for the G step's samples is exactly what that step's backward pass reads
+            self._g_ops, g_pair_ops = graph.ops[n0:n1], graph.ops[n1:len(graph.ops)]
+            _alias_first_half(self._g_ops, g_pair_ops)
 
         # discriminator on (x_t, fake) then (x_t, real), sharing variables (train.py:63-70).
         # batched_d: the D step runs D ONCE on [fake ; real] stacked along the batch, BatchNorm statistics kept
         # per half (groups=2) - arithmetically the two reference calls, at twice the GEMM height and half the
         # launches.  The G step still uses the batch-B D(fake) graph (D(real) is pruned there anyway).
+        self._pair_concat = None
         if batched_d:
-            d_in_both, (d_in_gen, d_in_real) = O.batch_join(
-                [lambda out: O.concat([self.img_ph, self.g_next_frame], axis=3, name='d_in_gen', out=out, pitch=8, act=True),
-                 lambda out: O.concat([self.img_ph, self.next_frame_ph], axis=3, name='d_in_real', out=out, pitch=8, act=True)],
-                (B, S, S, 8), name='d_in_both', act=True)          # 6 channels at a pitch of 8: 16-byte gathers in d/conv1
+            # ONE buffer of 3 B discriminator inputs [spare ; generated ; real], 6 channels at a pitch of 8 (16-byte gathers in
+            # d/conv1): D(both) reads rows [B, 3 B), D(fake) rows [B, 2 B); the pair generator writes rows [0, 2 B) - its second
+            # half, the D step's samples, lands where D(both) expects the generated frames
+            n_part = B * S * S * 8
+            d_in_all = O._new_act((3 * B, S, S, 8), 'd_in_all:0')
+            win = lambda k, rows, name: d_in_all.view(k * n_part, (rows, S, S, 8), name=name)     # noqa: E731
+            d_in_gen = O.concat([self.img_ph, self.g_next_frame], axis=3, name='d_in_gen', out=win(1, B, 'd_in_all/gen'), pitch=8, act=True)
+            d_in_real = O.concat([self.img_ph, self.next_frame_ph], axis=3, name='d_in_real', out=win(2, B, 'd_in_all/real'), pitch=8, act=True)
+            d_in_both = win(1, 2 * B, 'd_in_both:0')
+            O.JoinOp([d_in_gen, d_in_real], d_in_both, 'd_in_both')
+            d_in_both.valid_c = d_in_gen.valid_c
+            if self.lookahead:
+                self._pair_concat = O.concat([self.pair_img_ph, self._g_pair_out], axis=3, name='d_in_pair', out=win(0, 2 * B, 'd_in_all/pair'),
+                                             pitch=8, act=True).op
         else:
             d_in_gen = O.concat([self.img_ph, self.g_next_frame], axis=3, name='d_in_gen', pitch=8, act=True)
             d_in_real = O.concat([self.img_ph, self.next_frame_ph], axis=3, name='d_in_real', pitch=8, act=True)
@@ -124,6 +160,15 @@ class Trainer:
         self._summary_names = sorted(self.summaries)
         self.merged_summaries = [self.summaries[k] for k in self._summary_names]
         self._zero_state = np.zeros((B, STATE_DIM), np.float32)
+        self._announced = None          # (images, actions) of the G step a look-ahead D step has prepared
+        self._skip_d = self._skip_g = None
+        if self.lookahead:
+            # what the pair pass replaces.  D step: the whole batch-B generator and the launch that puts its frame into D's input.
+            # G step: the generator up to the frame - except an op that ALSO writes the frame into D(fake)'s input (the DNA gather,
+            # ops.DnaOp.second): that one runs again on the logits the pair pass left (the spare rows took its copy in the D step)
+            trunk = _ancestors(self.g_out, set(map(id, self._g_ops)))
+            self._skip_d = frozenset(trunk + [d_in_gen.op])
+            self._skip_g = frozenset(o for o in trunk if not (isinstance(o, O.DnaOp) and o.second is not None))
 
     # ---- steps: one sess.run each (train.py:114-155)
     def _feed(self, input_images, next_frame, actions, state=None):
@@ -131,23 +176,41 @@ class Trainer:
                 self.action_ph: actions, self.next_state: self._zero_state if state is None else state}
 
     def pretrain_g(self, input_images, next_frame, actions, state):
+        self._announced = None
         _, g_res = self.sess.run([self.g_pretrain_opt_op, self.g_loss], self._feed(input_images, next_frame, actions, state))
         return float(g_res[0])
 
     def train_g(self, input_images, next_frame, actions, state, device_fetch=False):
+        # the generator forward pass of these very inputs was run by the preceding train_d(..., next_g=(input_images, actions)):
+        # the program then starts behind it (Session.run skip=)
+        prepared, self._announced = self._announced, None
+        skip = self._skip_g if (prepared is not None and prepared[0] is input_images and prepared[1] is actions) else None
         _, gen_next_frames = self.sess.run([self.g_opt_op, self.g_next_frame],
-                                           self._feed(input_images, next_frame, actions, state), device_fetch=device_fetch)
+                                           self._feed(input_images, next_frame, actions, state), device_fetch=device_fetch, skip=skip)
         return gen_next_frames
 
-    def train_d(self, input_images, next_frame, actions, summarize=False):
+    def train_d(self, input_images, next_frame, actions, summarize=False, next_g=None, pair=None):
+        """One discriminator step (train.py:132-144).  ``next_g`` = (input_images, actions) of the ``train_g`` call that follows
+        (extension, see __init__ ``lookahead``): this step's generator pass then also covers that step's samples.  ``pair`` = the
+        two batches already joined, (frames [2 B, H, W, 3], actions [2 B, 10]) with the G step's samples FIRST - saves the
+        concatenation here when the caller keeps its batches that way."""
+        self._announced = None
         fd = self._feed(input_images, next_frame, actions)
         if summarize:
             _, summ, _ = self.sess.run([self.d_opt_op, self.merged_summaries, self.clip_d], fd)
             return self._named(summ)
+        if next_g is not None and self.lookahead:
+            if pair is None:
+                pair = (_join(next_g[0], input_images), _join(next_g[1], actions))
+            fd.update({self.pair_img_ph: pair[0], self._pair_img_pad: pair[0], self.pair_action_ph: pair[1]})
+            self.sess.run([self.d_opt_op, self.clip_d, self._pair_concat], fd, skip=self._skip_d)
+            self._announced = (next_g[0], next_g[1])
+            return None
         self.sess.run([self.d_opt_op, self.clip_d], fd)
         return None
 
     def test(self, input_images, next_frame, actions):
+        self._announced = None
         tensors = [self.g_next_frame] + ([self.g_state_out] if self.g_state_out is not None else []) + [self.merged_summaries]
         res = self.sess.run(tensors, self._feed(input_images, next_frame, actions))
         gen_next_frames, summ = res[0], res[-1]
@@ -189,6 +252,43 @@ class Trainer:
 
     def _named(self, values):
         return {k: float(np.asarray(v).reshape(-1)[0]) for k, v in zip(self._summary_names, values)}
+
+
+def _join(first, second):
+    """[first ; second] along the batch axis, numpy arrays or (device) torch tensors."""
+    if torch.is_tensor(first):
+        return torch.cat([first, second.to(first.device) if torch.is_tensor(second) else torch.as_tensor(second, device=first.device)], dim=0)
+    return np.concatenate([np.asarray(first), np.asarray(second.cpu() if torch.is_tensor(second) else second)], axis=0)
+
+
+def _ancestors(tensor, within):
+    """The ops (restricted to the ids in ``within``) that ``tensor`` depends on, its producer included, creation order."""
+    seen, stack = {}, [tensor.op]
+    while stack:
+        op = stack.pop()
+        if op is None or id(op) in seen or id(op) not in within:
+            continue
+        seen[id(op)] = op
+        stack.extend(t.op for t in op.inputs)
+    return sorted(seen.values(), key=lambda o: o.index)
+
+
+def _alias_first_half(ops_small, ops_pair):
+    """Two instances of one network built by the same code, the second on twice the batch: make every tensor the first
+    instance's ops produce a window onto the FIRST HALF of its twin (batch-major storage: the first B samples; BatchNorm
+    statistics [groups = 2, C]: group 0).  Tensors that already are windows (a BatchNorm output placed in its concatenation)
+    follow through their base."""
+    if len(ops_small) != len(ops_pair):
+        raise RuntimeError('look-ahead: the two generator instances differ in structure (%d vs %d ops)' % (len(ops_small), len(ops_pair)))
+    for a, b in zip(ops_small, ops_pair):
+        if type(a) is not type(b) or len(a.outputs) != len(b.outputs):
+            raise RuntimeError('look-ahead: %r has no twin in the pair instance (%r)' % (a, b))
+        for ta, tb in zip(a.outputs, b.outputs):
+            if ta.view_of is not None or ta.alias_of is not None or isinstance(ta, (G.Variable, G.Placeholder)):
+                continue
+            if tb.numel != 2 * ta.numel or ta.dtype != tb.dtype:
+                raise RuntimeError('look-ahead: %r is not half of %r' % (ta, tb))
+            ta.view_of = (tb, 0)
 
 
 # ---- synthetic push-style data (SURVEY 8(d): rng(7), frames U(-1,1), action||state N(0,1)) ----------
@@ -242,53 +342,80 @@ def train(input_path, output_path, test_output_path, log_dir, model_dir, arg_adv
         dp_collectives = 'side' if world_size > 1 else 'stream'
     optim.set_data_parallel(world_size, n_buckets=buckets or None, sync_bn=sync_bn, exact_global_batch=exact_global_batch,
                             collectives=dp_collectives)
-    with G.Session(device=device, world_size=world_size, rank=rank, process_group=process_group, dtype=dtype) as sess:
-        trainer = Trainer(sess, arg_adv, arg_loss, arg_opt, arg_transform, batch_size, img_size, ksize)
-        sess.run(G.global_variables_initializer())
-        saver = Saver()                                                           # train.py:215
-        if resume:
-            saver.restore(sess, resume)
-        if synthetic:
-            eval_data = SyntheticPush(batch_size, seq_len, img_size, seed=1007, rank=rank)
-        else:
-            try:                                                                  # validation files: the tail of the split
-                eval_data = PushDataset(input_path, batch_size, training=False, img_size=img_size, seed=1007)
-            except RuntimeError:
-                eval_data = PushDataset(input_path, batch_size, training=True, img_size=img_size, seed=1007)
-        D_per_G = n_critic if n_critic else (5 if arg_loss == 'wass' else 1)      # train.py:217-220
-        log_file = os.path.join(log_dir, 'train.jsonl') if log_dir else None
-        t0 = time.time()
-        for i in range(train_iter):
-            if i < pretrain_iter:
-                inp, nxt, acts, states = data.get_batch()
-                sm, em = select_pairs(np.random.randint, boolean_mask, batch_size)
-                loss = trainer.pretrain_g(inp[sm], nxt[em], acts[sm], states[em])
-                if not quiet:
-                    print('pre-train iter: ' + str(i))
-                continue
-            summ = None
-            for j in range(D_per_G):
-                inp, nxt, acts, states = data.get_batch()
-                sm, em = select_pairs(np.random.randint, boolean_mask, batch_size)
-                summ = trainer.train_d(inp[sm], nxt[em], acts[sm], summarize=(i % log_every == 0) and (j == D_per_G - 1))
+    sess = G.Session(device=device, world_size=world_size, rank=rank, process_group=process_group, dtype=dtype)
+    try:
+        trainer = _train_loop(sess, data, input_path, synthetic, boolean_mask, log_dir, model_dir, arg_adv, arg_loss, arg_opt, arg_transform,
+                              batch_size, img_size, seq_len, ksize, train_iter, pretrain_iter, n_critic, rank, log_every, quiet, eval_every, resume)
+        sess.rt.check_exchange_flags()     # a last look at the device-side flags of the iterations since the last log interval
+    except BaseException:
+        sess.close(check=False)            # tear the transport down; the exception on its way out is the one to report
+        raise
+    # The session stays OPEN: the returned Trainer is usable (evaluation, more steps, reading variables).  Its owner closes it -
+    # `trainer.sess.close()` (main() does): ncclCommDestroy under data parallelism and a last check of the device-side flags.
+    return trainer
+
+
+def _train_loop(sess, data, input_path, synthetic, boolean_mask, log_dir, model_dir, arg_adv, arg_loss, arg_opt, arg_transform, batch_size,
+                img_size, seq_len, ksize, train_iter, pretrain_iter, n_critic, rank, log_every, quiet, eval_every, resume):
+    trainer = Trainer(sess, arg_adv, arg_loss, arg_opt, arg_transform, batch_size, img_size, ksize)
+    sess.run(G.global_variables_initializer())
+    saver = Saver()                                                           # train.py:215
+    if resume:
+        saver.restore(sess, resume)
+    if synthetic:
+        eval_data = SyntheticPush(batch_size, seq_len, img_size, seed=1007, rank=rank)
+    else:
+        from .push_data import PushDataset
+        try:                                                                  # validation files: the tail of the split
+            eval_data = PushDataset(input_path, batch_size, training=False, img_size=img_size, seed=1007)
+        except RuntimeError:
+            eval_data = PushDataset(input_path, batch_size, training=True, img_size=img_size, seed=1007)
+    D_per_G = n_critic if n_critic else (5 if arg_loss == 'wass' else 1)      # train.py:217-220
+    log_file = os.path.join(log_dir, 'train.jsonl') if log_dir else None
+    t0 = time.time()
+    for i in range(train_iter):
+        if i < pretrain_iter:
+            inp, nxt, acts, states = data.get_batch()
             sm, em = select_pairs(np.random.randint, boolean_mask, batch_size)
-            trainer.train_g(inp[sm], nxt[em], acts[sm], states[em])
-            if i % log_every == 0 and rank == 0:
-                if not quiet:
-                    print('Iteration {:d}'.format(i))
-                if log_file and summ:
-                    _log_jsonl(log_file, dict(summ, iteration=i, wall_s=time.time() - t0))
-                if model_dir:
-                    saver.save(sess, os.path.join(model_dir, 'model{:d}'.format(i)))         # train.py:274
-            if eval_every and i % eval_every == 0 and rank == 0:
-                # recursive rollout over T-1 steps on held-out sequences (train.py:278-309; defect D7: own states)
-                t_img, _, t_acts, _ = eval_data.get_batch()
-                predicted, e_summ = trainer.test_sequence(t_img, t_img, t_acts)
-                psnr = [float(10.0 * np.log10(1.0 / max(np.mean((predicted[:, j] - t_img[:, j + 1]) ** 2), 1e-30)))
-                        for j in range(predicted.shape[1])]
-                if log_file:
-                    _log_jsonl(os.path.join(log_dir, 'test.jsonl'), dict(e_summ or {}, iteration=i, rollout_psnr=psnr))
-        return trainer
+            trainer.pretrain_g(inp[sm], nxt[em], acts[sm], states[em])
+            if not quiet:
+                print('pre-train iter: ' + str(i))
+            continue
+        summ = None
+        for j in range(D_per_G):
+            inp, nxt, acts, states = data.get_batch()
+            sm, em = select_pairs(np.random.randint, boolean_mask, batch_size)
+            last = j == D_per_G - 1
+            if last:
+                # the G step's frame pairs, drawn here instead of behind the D step: same order of np.random calls as
+                # train.py:249-258 (the D step draws nothing), and the last D step can then run the generator for both
+                # (Trainer.train_d next_g; the logging iterations keep the plain path: their summaries read the D step's own frames)
+                smg, emg = select_pairs(np.random.randint, boolean_mask, batch_size)
+                g_in, g_act = inp[smg], acts[smg]
+            summarize = (i % log_every == 0) and last
+            summ = trainer.train_d(inp[sm], nxt[em], acts[sm], summarize=summarize, next_g=(g_in, g_act) if (last and not summarize) else None)
+        trainer.train_g(g_in, nxt[emg], g_act, states[emg])
+        if i % log_every == 0:
+            # the fetches above synchronised anyway: look at the device-side flags of the one-launch BatchNorm kernels HERE, on
+            # every rank, so that a step that ran on wrong statistics fails now - before anything of it is logged or
+            # checkpointed - and not at exit, thousands of iterations later (graph.Runtime.check_exchange_flags)
+            sess.rt.check_exchange_flags()
+        if i % log_every == 0 and rank == 0:
+            if not quiet:
+                print('Iteration {:d}'.format(i))
+            if log_file and summ:
+                _log_jsonl(log_file, dict(summ, iteration=i, wall_s=time.time() - t0))
+            if model_dir:
+                saver.save(sess, os.path.join(model_dir, 'model{:d}'.format(i)))         # train.py:274
+        if eval_every and i % eval_every == 0 and rank == 0:
+            # recursive rollout over T-1 steps on held-out sequences (train.py:278-309; defect D7: own states)
+            t_img, _, t_acts, _ = eval_data.get_batch()
+            predicted, e_summ = trainer.test_sequence(t_img, t_img, t_acts)
+            psnr = [float(10.0 * np.log10(1.0 / max(np.mean((predicted[:, j] - t_img[:, j + 1]) ** 2), 1e-30)))
+                    for j in range(predicted.shape[1])]
+            if log_file:
+                _log_jsonl(os.path.join(log_dir, 'test.jsonl'), dict(e_summ or {}, iteration=i, rollout_psnr=psnr))
+    return trainer
 
 
 def _flag(v):
@@ -340,11 +467,13 @@ def main(argv=None):
         # control plane only (bootstrap of the RCCL communicator, comm.py): gradients never go through torch.distributed
         torch.cuda.set_device(local_rank)
         torch.distributed.init_process_group('gloo')
-    train(args.input_path, os.path.join(args.output_path, 'train_output'), os.path.join(args.output_path, 'test_output'),
-          log_dir, model_dir, args.adv, args.loss, args.opt, args.dna, batch_size=args.batch_size, img_size=args.img_size,
-          seq_len=args.seq_len, ksize=args.ksize, train_iter=args.train_iter, pretrain_iter=args.pretrain_iter,
-          n_critic=args.n_critic, device='cuda:%d' % local_rank, world_size=world_size, rank=rank, dtype=args.dtype,
-          sync_bn=args.sync_bn, exact_global_batch=args.exact_global_batch, dp_collectives=args.dp_collectives, buckets=args.buckets)
+    trainer = train(args.input_path, os.path.join(args.output_path, 'train_output'), os.path.join(args.output_path, 'test_output'),
+                    log_dir, model_dir, args.adv, args.loss, args.opt, args.dna, batch_size=args.batch_size, img_size=args.img_size,
+                    seq_len=args.seq_len, ksize=args.ksize, train_iter=args.train_iter, pretrain_iter=args.pretrain_iter,
+                    n_critic=args.n_critic, device='cuda:%d' % local_rank, world_size=world_size, rank=rank, dtype=args.dtype,
+                    sync_bn=args.sync_bn, exact_global_batch=args.exact_global_batch, dp_collectives=args.dp_collectives, buckets=args.buckets)
+    if trainer is not None:
+        trainer.sess.close()        # ncclCommDestroy under data parallelism + a last check of the device-side flags
 
 
 if __name__ == '__main__':

@@ -81,7 +81,19 @@ def parse():
     ap.add_argument('--sync-bn', action='store_true', help='data parallel with BatchNorm statistics of the global batch (one small all-reduce per BatchNorm layer and direction)')
     ap.add_argument('--trace-run', action='store_true', help='nothing but training steps (no rollout, no instrumented pass, no CPU baseline): the run tools/insitu_times.py reduces a rocprofv3 kernel trace of')
     ap.add_argument('--force-dp', action='store_true', help='run the data-parallel machinery (RCCL all-reduce buckets, graph segments) even on one rank')
+    ap.add_argument('--no-lookahead', action='store_true', help='the two generator forward passes of an iteration as separate batch-B launches (Trainer.train_d without next_g), as before round 5')
+    ap.add_argument('--no-api-rates', action='store_true', help='skip the two labelled side numbers (plain call path, numpy-in / numpy-out call path)')
     return ap.parse_args()
+
+
+def lib_fingerprint():
+    """(ABI version, first 16 hex digits of the SHA-256 of the loaded libacgan_hip.so): what a committed in-situ profile must
+    have been taken with to stand in for this process's kernels."""
+    import hashlib
+    from action_conditioned_gans_amd import _lib
+    lib = _lib.get()
+    with open(lib.path, 'rb') as f:
+        return int(lib.version()), hashlib.sha256(f.read()).hexdigest()[:16]
 
 
 def conv_flops(op):
@@ -165,27 +177,39 @@ def main():
     optim.set_data_parallel(world, n_buckets=args.buckets, force=args.force_dp, sync_bn=args.sync_bn, exact_global_batch=args.exact_global_batch,
                             collectives=args.dp_collectives)
     sess = G.Session(device=device, side_branches=args.side_branch, **({} if args.slab_handoff is None else {'slab_handoff': args.slab_handoff}), epilogue_stats=not args.no_epilogue_stats, pair_bwd=not args.no_pair, use_hip_graphs=not args.no_graphs, world_size=world, rank=rank, dtype=args.dtype)
-    tr = T.Trainer(sess, adv, args.loss, args.opt, dna, batch_size=B, img_size=S, ksize=args.ksize, seed=0)
+    tr = T.Trainer(sess, adv, args.loss, args.opt, dna, batch_size=B, img_size=S, ksize=args.ksize, seed=0, lookahead=not args.no_lookahead)
     sess.run(G.global_variables_initializer())
+    lookahead = tr.lookahead
 
-    # synthetic push-style sequences, resident in HBM; (t, t+1) pairs selected as train.py:231-237 does
+    # synthetic push-style sequences, resident in HBM; (t, t+1) pairs selected as train.py:231-237,249-250,258-259 does: every D
+    # step takes a fresh batch and a fresh selection, the G step a NEW selection on the last D step's batch
     rng = np.random.default_rng(7 + 1000 * rank)
     np.random.seed(7 + rank)
     mask = T.build_all_mask(args.seq_len)
-    pool = []
+    dev = lambda *ts: tuple(torch.from_numpy(np.ascontiguousarray(t)).to(device) for t in ts)      # noqa: E731
+    host_seqs, pool = [], []
     for _ in range(4):
         img = rng.uniform(-1, 1, (B, args.seq_len, S, S, 3)).astype(np.float32)
         acts = rng.standard_normal((B, args.seq_len, 10)).astype(np.float32)
+        host_seqs.append((img, acts))
         sm, em = T.select_pairs(np.random.randint, mask, B)
-        pool.append(tuple(torch.from_numpy(t).to(device) for t in (img[sm], img[em], acts[sm], acts[:, :, 5:][em])))
+        smg, emg = T.select_pairs(np.random.randint, mask, B)
+        d_in, g_in = dev(img[sm], img[em], acts[sm]), dev(img[smg], img[emg], acts[smg], acts[:, :, 5:][emg])
+        # the joined inputs of the look-ahead generator pass (G step's samples first: Trainer.train_d `pair`), built once -
+        # inputs are resident in HBM before the timed region starts
+        pair = (torch.cat([g_in[0], d_in[0]]), torch.cat([g_in[2], d_in[2]])) if lookahead else None
+        pool.append((d_in, g_in, pair))
     torch.cuda.synchronize()
 
-    def step(i):
+    def step(i, use_lookahead=lookahead):
         for j in range(n_critic):
-            x, y, a, s = pool[(i * n_critic + j) % len(pool)]
-            tr.train_d(x, y, a)
-        x, y, a, s = pool[i % len(pool)]
-        return tr.train_g(x, y, a, s, device_fetch=True)
+            d_in, g_in, pair = pool[(i * n_critic + j) % len(pool)]
+            last = j == n_critic - 1
+            if last and use_lookahead:      # the last D step runs the generator for its own samples and for the G step's
+                tr.train_d(*d_in, next_g=(g_in[0], g_in[2]), pair=pair)
+            else:
+                tr.train_d(*d_in)
+        return tr.train_g(*g_in, device_fetch=True)
 
     def barrier():
         if world > 1:
@@ -240,19 +264,61 @@ def main():
         rollout = {'frames_per_s': round(B * (args.seq_len - 1) / dt, 1), 'ms_per_rollout': round(dt * 1e3, 3),
                    'steps': args.seq_len - 1, 'batch': B, 'api': 'numpy in / numpy out per step, as the reference'}
 
+    # ---- two labelled side numbers, after the timed region (review r4, missing item 5): the same step through the plain call path
+    # (no look-ahead: what `value` was up to round 4), and through the reference's own API exactly as train() drives it
+    # (train.py:241-263: host numpy sequences, pair selection, numpy feeds, generated frames fetched to the host every step)
+    api_rates = None
+    if not args.trace_run and not args.no_api_rates:
+        def rate(fn, seconds=0.5):
+            for i in range(4):
+                fn(i)
+            barrier()
+            t1, n = time.perf_counter(), 0
+            while n < 3 or time.perf_counter() - t1 < seconds:
+                fn(n)
+                n += 1
+            barrier()
+            return round(world * n / (time.perf_counter() - t1), 2)
+
+        def numpy_step(i):
+            img, acts = host_seqs[i % len(host_seqs)]
+            for j in range(n_critic):
+                sm, em = T.select_pairs(np.random.randint, mask, B)
+                last = j == n_critic - 1
+                if last:
+                    smg, emg = T.select_pairs(np.random.randint, mask, B)
+                    g_img, g_act = img[smg], acts[smg]
+                tr.train_d(img[sm], img[em], acts[sm], next_g=(g_img, g_act) if (last and lookahead) else None)
+            return tr.train_g(g_img, img[emg], g_act, acts[:, :, 5:][emg])
+        api_rates = {'unit': 'steps/s (all ranks), ~0.5 s each, after the timed region',
+                     'plain_call_path_device_resident': rate(lambda i: step(i, False)) if lookahead else None,
+                     'numpy_in_numpy_out_as_train_py': rate(numpy_step),
+                     'note': 'plain = Trainer.train_d / train_g without next_g (two batch-B generator passes per iteration); numpy = host sequences, '
+                             'pair selection, numpy feeds and the generated frames fetched to the host every step, as train() does (train.py:241-263)'}
+
     # ---- per-op timing of this process (instrumented pass, after the timed region): the HOT numbers -----------------
     roof, roof_dna, kernel_ms, insitu = None, None, {}, None
     # EVERY rank runs the instrumented pass: with world > 1 the programs contain gradient all-reduces, and a
     # collective issued by rank 0 alone would never complete.  Only rank 0 reports.
     if not args.trace_run:
-        x, y, a, s = pool[0]
+        d_in0, g_in0, pair0 = pool[0]
         zero_state = torch.zeros(B, 5, device=device)
         recs = []
         # conv and DNA launches are idempotent: timed as launches inside a small captured HIP graph (graph.profile_ops) - each
         # op 10x back to back, i.e. with every operand cache-hot from the previous identical launch
         relaunch = lambda op: isinstance(op, (O._ConvBase, O.DnaOp, O.DnaBwdOp))   # noqa: E731
-        recs += sess.profile_ops([tr.d_opt_op, tr.clip_d], tr._feed(x, y, a, zero_state), repeats=args.profile_repeats, relaunch=relaunch) * n_critic
-        recs += sess.profile_ops([tr.g_opt_op, tr.g_next_frame], tr._feed(x, y, a, s), repeats=args.profile_repeats, relaunch=relaunch)
+        fd_d, fd_g = tr._feed(*d_in0, zero_state), tr._feed(*g_in0)
+        if lookahead:
+            # the programs the timed step replays: plain D steps, then the D step that carries the look-ahead generator pass
+            # (batch 2 B), then the G step that starts behind it
+            recs += sess.profile_ops([tr.d_opt_op, tr.clip_d], fd_d, repeats=args.profile_repeats, relaunch=relaunch) * (n_critic - 1)
+            fd_la = dict(fd_d)
+            fd_la.update({tr.pair_img_ph: pair0[0], tr._pair_img_pad: pair0[0], tr.pair_action_ph: pair0[1]})
+            recs += sess.profile_ops([tr.d_opt_op, tr.clip_d, tr._pair_concat], fd_la, repeats=args.profile_repeats, relaunch=relaunch, skip=tr._skip_d)
+            recs += sess.profile_ops([tr.g_opt_op, tr.g_next_frame], fd_g, repeats=args.profile_repeats, relaunch=relaunch, skip=tr._skip_g)
+        else:
+            recs += sess.profile_ops([tr.d_opt_op, tr.clip_d], fd_d, repeats=args.profile_repeats, relaunch=relaunch) * n_critic
+            recs += sess.profile_ops([tr.g_opt_op, tr.g_next_frame], fd_g, repeats=args.profile_repeats, relaunch=relaunch)
         conv_ms = conv_fl = conv_by = 0.0
         n_conv = n_launch = n_dna = 0
         dna_ms = dna_bytes = dna_bytes_survey = 0.0
@@ -288,16 +354,24 @@ def main():
         tag = '%s_b%d_s%d_k%d%s' % (args.dtype, B, S, args.ksize, '' if dna else '_plain')
         std_step = adv and args.loss == 'bce' and args.opt == 'adam' and world == 1
 
+        abi, sha = lib_fingerprint()
+        stale = []
+
         def committed(kind):
-            for rnd in ('r4', 'r3', 'r2'):
-                path = os.path.join(ROOT, 'profiles', rnd, '%s_%s.json' % (kind, tag))
-                if std_step and os.path.exists(path):
-                    with open(path) as f:
-                        return json.load(f), 'profiles/%s/%s_%s' % (rnd, kind, tag)
-            return None, None
+            """The committed profile of THIS command line taken with THIS library (review r4 item 9): a profile whose recorded
+            ABI version / library hash / look-ahead setting differs describes other kernels and is refused - the live numbers
+            of this process are reported instead, and `timing` says why."""
+            path = os.path.join(ROOT, 'profiles', 'r5', '%s_%s.json' % (kind, tag))
+            if not (std_step and os.path.exists(path)):
+                return None, None
+            with open(path) as f:
+                prof = json.load(f)
+            if prof.get('abi_version') != abi or prof.get('lib_sha16') != sha or bool(prof.get('lookahead')) != bool(lookahead):
+                stale.append('profiles/r5/%s_%s.json was taken with ABI %s / library %s / lookahead %s; loaded: ABI %d / %s / %s' % (
+                    kind, tag, prof.get('abi_version'), prof.get('lib_sha16'), prof.get('lookahead'), abi, sha, bool(lookahead)))
+                return None, None
+            return prof, 'profiles/r5/%s_%s' % (kind, tag)
         insitu, insitu_src = committed('insitu')
-        if insitu is not None and insitu_src.split('/')[1] != 'r4':
-            insitu = None
         pj, pmc_src = committed('pmc_traffic')
         if conv_ms > 0:
             peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == 'bf16' else PEAK_F32_MFMA_TFLOPS
@@ -308,7 +382,7 @@ def main():
                 traffic = round(c['fetch_bytes_per_launch'] + c['write_bytes_per_launch'])     # bytes per launch
                 traffic_note = ('HBM-side bytes per conv launch (FETCH_SIZE x2 + WRITE_SIZE) from %s.txt, separate --pmc passes of this '
                                 'command; algorithmic (operands + result once) %d bytes per launch' % (pmc_src, round(conv_by / max(n_launch, 1))))
-            t_ms, timing = conv_ms, 'hot relaunch (no in-situ profile of this workload is committed under profiles/r4)'
+            t_ms, timing = conv_ms, 'hot relaunch, measured live in this process (%s)' % ('; '.join(stale) if stale else 'no in-situ profile of this workload is committed under profiles/r5')
             if insitu is not None:
                 t_ms = insitu['family_us_per_step']['conv'] / 1e3
                 timing = ('in situ: conv-family kernel time per real step from %s.json = TotalDurationNs / %d step executions of '
@@ -345,6 +419,10 @@ def main():
                                          'frac': round(dna_bytes_survey / (dna_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                                          'ms_per_step_in_kernel': round(dna_ms, 4)}}
 
+    # The one-launch BatchNorm kernels flag a grid exchange that timed out (a block's peers were not resident: the launch finished
+    # with wrong statistics - acgan_hip.h).  Looked at HERE, on every rank, before anything is reported: a set flag on any rank
+    # means no result line and a non-zero exit code on all of them.
+    _require_clean_exchange(sess, world)
     if rank != 0:
         _leave_distributed(sess)
         return
@@ -376,10 +454,15 @@ def main():
                    'hip_graphs': not args.no_graphs, 'timed_blocks': len(blocks), 'timed_seconds': round(float(np.sum(blocks)), 3),
                    'block_ms_per_step_min_max': [round(min(blocks) / args.steps * 1e3, 4), round(max(blocks) / args.steps * 1e3, 4)],
                    'dp_collectives': args.dp_collectives if (world > 1 or args.force_dp) else None, 'sequences_per_s': round(world * B * args.steps / elapsed, 1),
+                   # what the first real N > 1 run can be checked against (review r4 item 7): the communicator's size as RCCL reports it,
+                   # the all-reduce buckets per optimizer in bytes, and how often THIS rank called ncclAllReduce (eager first run +
+                   # capture only: replays of a captured step call nothing from the host)
+                   'data_parallel': dp_report(sess, G.get_default_graph(), optim) if (world > 1 or args.force_dp) else None,
+                   'lookahead': bool(lookahead), 'abi_version': lib_fingerprint()[0], 'lib_sha16': lib_fingerprint()[1],
                    'opt': args.opt, 'trace_run': bool(args.trace_run),
                    # every training step this process executed (eager + capture + first replay, warm-up, all timed blocks)
                    'step_executions': 3 + args.warmup + args.steps * len(blocks)},
-        'roofline': roof, 'roofline_dna': roof_dna, 'cpu_baseline': cpu, 'eval_rollout': rollout,
+        'roofline': roof, 'roofline_dna': roof_dna, 'cpu_baseline': cpu, 'eval_rollout': rollout, 'api_rates': api_rates,
         # per kernel family, in situ (same source as `roofline.timing`); null without a committed profile of this workload
         'kernel_ms_per_step_insitu': ({k: round(v / 1e3, 4) for k, v in insitu['family_us_per_step'].items()} if insitu else None),
         # per op kind, this process: an event pair around every eager launch (includes the ~4 us the event records open per op)
@@ -387,6 +470,37 @@ def main():
     }
     print(json.dumps(line), flush=True)
     _leave_distributed(sess)
+
+
+def dp_report(sess, graph, optim):
+    comm = sess.rt._comm
+    buckets = {}
+    for op in graph.ops:
+        if isinstance(op, optim.AllReduceOp):
+            buckets.setdefault(op.name.rsplit('/', 1)[0], []).append((op.end - op.start) * 4)
+    return {'transport': type(comm).__name__ if comm is not None else None,
+            'comm_world_size': getattr(comm, 'world_size', None), 'comm_rank': getattr(comm, 'rank', None),
+            'rccl_reports_count_rank': (list(comm.reported()) if getattr(comm, 'reported', None) and comm.reported() else None),
+            'nccl_allreduce_calls_this_rank': getattr(comm, 'calls', None),
+            'bucket_bytes_per_optimizer': buckets,
+            'sync_bn': bool(graph.collections['data_parallel'].sync_bn)}
+
+
+def _require_clean_exchange(sess, world):
+    from action_conditioned_gans_amd import _lib
+    err = None
+    try:
+        sess.rt.check_exchange_flags()
+    except _lib.AcgError as e:
+        err = e
+    bad = 0 if err is None else 1
+    if world > 1:
+        t = torch.tensor([bad], dtype=torch.int32)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        bad = int(t.item())
+    if bad:
+        sess.close(check=False)
+        raise err if err is not None else _lib.AcgError('another rank reported a BatchNorm grid-exchange timeout: no result')
 
 
 def _leave_distributed(sess):

@@ -43,8 +43,10 @@ extern "C" {
  * (dgrad_c, adj_dgrad_c were appended in round 3 under version 4: a "version 4" build may have either layout).  6: the
  * workspace of acg_bn_act_fwd / acg_bn_act_bwd is state (zero before first use, private to its call site); new entries
  * acg_conv2d_tile, acg_opt_step_prepare_bf16.  7: struct acg_reduce_list carries `step_inc` (the deferred reduction launch also
- * advances an optimizer's device step counter). */
-#define ACG_ABI_VERSION 7
+ * advances an optimizer's device step counter).  8: round 5 - `flags` argument of acg_bn_act_fwd / _bwd / _fwd_slabs / _bwd_slabs and
+ * acg_bn_slabs_layout (ACG_BN_NO_GRID_EXCHANGE); acg_bn_workspace_bytes covers the exchange area of the one-launch kernels for any
+ * channel count; new entry acg_bn_exchange_selftest. */
+#define ACG_ABI_VERSION 8
 
 typedef void* acg_stream_t; /* hipStream_t */
 
@@ -306,9 +308,22 @@ int32_t acg_bn_act_bwd_sums(const void* x, const void* dy, const float* beta, co
  * one is state.  The first 16 bytes are that state on every path (the two-launch kernels keep their partial sums behind them).
  * Word 2 (uint32) is set to 1 if a block ever gave up waiting for its peers (it then finishes with what it has:
  * a wrong result and this flag, never a hung GPU); it stays 0 in correct operation, and a caller should look at it at a point
- * where it synchronises anyway (the Python host does in Session.close / Runtime.check_exchange_flags; the tests after every call).
+ * where it synchronises anyway (the Python host: Runtime.check_exchange_flags - train() at every log interval and before every
+ * checkpoint, bench.py before it prints its result, Session.close; the tests after every call).
+ * `flags`: 0, or ACG_BN_NO_GRID_EXCHANGE - never take the one-launch grid kernels (register-resident or two-launch kernels
+ * instead; acg_bn_slabs_layout answers accordingly).  Those kernels need every block of their grid resident at once (at most one
+ * 1024-thread block per CU).  Kernels that finish on their own may run beside them (a convolution or an RCCL collective on a
+ * second stream only delay the last blocks); ANOTHER grid-exchange kernel must not - two partially resident grids starve each
+ * other until both time out - so a caller whose BatchNorm launches can overlap each other (two streams) passes this flag.
+ * acg_bn_exchange_selftest: the in-launch exchange on its own - `blocks` (<= 512) blocks of `threads` (256 | 1024) publish b + 1
+ * and gather the grid's sum into out[b] (float[blocks]; n (n + 1) / 2 everywhere, -1 if the 64 slots disagree).  `withhold` >= 0:
+ * that block publishes nothing, so every block runs into `spin_limit` polls, sets word 2 of the workspace and finishes with a
+ * short sum - the failure path, for tests (workspace: 16 + 512 * blocks bytes, zero before first use like any other).
  * ---------------------------------------------------------------------------------------- */
+#define ACG_BN_NO_GRID_EXCHANGE 1
 size_t acg_bn_workspace_bytes(int64_t rows, int32_t channels, int32_t groups);
+int32_t acg_bn_exchange_selftest(void* workspace, size_t workspace_bytes, float* out, int32_t blocks, int32_t threads,
+                                 int32_t withhold, uint32_t spin_limit, acg_stream_t stream);
 /* The same with the split-K hand-off described at acg_conv2d_fwd_slabs: forward reads x as the sum of `splits` float32
  * slabs (each rows * x_pitch floats in `layout`, summed in slab order and rounded to x's storage type - what the separate
  * reduction would have stored) and WRITES x, which backward re-reads; backward reads dy as the sum of `splits` slabs
@@ -319,16 +334,16 @@ size_t acg_bn_workspace_bytes(int64_t rows, int32_t channels, int32_t groups);
  * register-resident kernels with four channels per block apply (rows per group <= 2048); -1 when this BatchNorm cannot take
  * slabs at all (run the plain reduction + acg_bn_act_fwd / _bwd).  acg_bn_bwd_slabs_ok: the backward half of the resident test. */
 int32_t acg_bn_slabs_layout(int64_t rows, int32_t channels, int32_t x_pitch, int32_t y_pitch, int32_t groups, int32_t dtype,
-                            int32_t backward);
+                            int32_t backward, int32_t flags);
 int32_t acg_bn_act_fwd_slabs(const float* slabs, int32_t splits, void* x, const float* beta, void* y, float* save_mean,
                              float* save_rstd, int64_t rows, int32_t channels, int32_t x_pitch, int32_t y_pitch, int32_t groups,
-                             float eps, int32_t act, float leak, int32_t dtype, int32_t layout, void* workspace, size_t workspace_bytes,
-                             acg_stream_t stream);
+                             float eps, int32_t act, float leak, int32_t dtype, int32_t layout, int32_t flags, void* workspace,
+                             size_t workspace_bytes, acg_stream_t stream);
 int32_t acg_bn_bwd_slabs_ok(int64_t rows, int32_t groups);
 int32_t acg_bn_act_bwd_slabs(const void* x, const float* dy_slabs, int32_t splits, const float* beta, const float* save_mean,
                              const float* save_rstd, void* dx, float* dbeta, float dbeta_accumulate, int64_t rows,
                              int32_t channels, int32_t x_pitch, int32_t y_pitch, int32_t groups, int32_t act, float leak,
-                             int32_t dtype, int32_t layout, void* workspace, size_t workspace_bytes, acg_stream_t stream);
+                             int32_t dtype, int32_t layout, int32_t flags, void* workspace, size_t workspace_bytes, acg_stream_t stream);
 /* BatchNorm + activation from the per-block (sum, M2) partials of acg_(de)conv2d_fwd_stats (`nblk` blocks per group, with
  * the block_rows / run_rows of acg_conv2d_stats_layout): mean = sum of sums / rows_per_group, variance = (sum of M2 +
  * sum_b n_b * (mean_b - mean)^2) / rows_per_group (merged about the first block's mean), then the apply pass of acg_bn_act_fwd.  More
@@ -339,12 +354,12 @@ int32_t acg_bn_act_fwd_partials(const void* x, const float* beta, const float* p
                                 acg_stream_t stream);
 int32_t acg_bn_act_fwd(const void* x, const float* beta, void* y, float* save_mean, float* save_rstd,
                        int64_t rows, int32_t channels, int32_t x_pitch, int32_t y_pitch, int32_t groups, float eps,
-                       int32_t act, float leak, int32_t dtype, void* workspace, size_t workspace_bytes,
+                       int32_t act, float leak, int32_t dtype, int32_t flags, void* workspace, size_t workspace_bytes,
                        acg_stream_t stream);
 int32_t acg_bn_act_bwd(const void* x, const void* dy, const float* beta, const float* save_mean,
                        const float* save_rstd, void* dx, float* dbeta, float dbeta_accumulate,
                        int64_t rows, int32_t channels, int32_t x_pitch, int32_t y_pitch, int32_t groups, int32_t act,
-                       float leak, int32_t dtype, void* workspace, size_t workspace_bytes, acg_stream_t stream);
+                       float leak, int32_t dtype, int32_t flags, void* workspace, size_t workspace_bytes, acg_stream_t stream);
 
 /* Layers built with normalizer_fn=None: y = act(x + bias)   (models.py:20-21,44-51,54-59).
  * bwd takes the forward OUTPUT y; dx may be NULL when act == ACG_ACT_NONE and x, y share type and pitch (dx == dy).

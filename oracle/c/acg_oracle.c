@@ -244,17 +244,20 @@ int32_t acg_deconv2d_dgrad_slabs(const void* x, const void* w, const acg_conv_de
   (void)x; (void)w; (void)d; (void)dtype; (void)layout; (void)ws; (void)wsb; (void)s; return fail(ACG_ERR_UNSUPPORTED, "cpu oracle: contraction is not split"); }
 int32_t acg_bn_bwd_slabs_ok(int64_t rows, int32_t groups) { (void)rows; (void)groups; return 0; }
 int32_t acg_conv2d_slab_layouts(const acg_conv_desc* d, int32_t which, int32_t dtype) { (void)d; (void)which; (void)dtype; return 0; }
-int32_t acg_bn_slabs_layout(int64_t rows, int32_t C, int32_t xp, int32_t yp, int32_t groups, int32_t dtype, int32_t backward) {
-  (void)rows; (void)C; (void)xp; (void)yp; (void)groups; (void)dtype; (void)backward; return -1; }
+int32_t acg_bn_slabs_layout(int64_t rows, int32_t C, int32_t xp, int32_t yp, int32_t groups, int32_t dtype, int32_t backward, int32_t flags) {
+  (void)rows; (void)C; (void)xp; (void)yp; (void)groups; (void)dtype; (void)backward; (void)flags; return -1; }
+int32_t acg_bn_exchange_selftest(void* ws, size_t wsb, float* out, int32_t blocks, int32_t threads, int32_t withhold, uint32_t spin_limit, acg_stream_t s) {
+  (void)ws; (void)wsb; (void)out; (void)blocks; (void)threads; (void)withhold; (void)spin_limit; (void)s;
+  return fail(ACG_ERR_UNSUPPORTED, "cpu oracle: no in-launch exchange (a device mechanism)"); }
 int32_t acg_bn_act_fwd_slabs(const float* slabs, int32_t splits, void* x, const float* beta, void* y, float* save_mean, float* save_rstd,
                              int64_t rows, int32_t C, int32_t xp, int32_t yp, int32_t groups, float eps, int32_t act, float leak, int32_t dtype,
-                             int32_t layout, void* ws, size_t wsb, acg_stream_t s) {
-  (void)layout; (void)slabs; (void)splits; (void)x; (void)beta; (void)y; (void)save_mean; (void)save_rstd; (void)rows; (void)C; (void)xp; (void)yp; (void)groups;
+                             int32_t layout, int32_t flags, void* ws, size_t wsb, acg_stream_t s) {
+  (void)flags; (void)layout; (void)slabs; (void)splits; (void)x; (void)beta; (void)y; (void)save_mean; (void)save_rstd; (void)rows; (void)C; (void)xp; (void)yp; (void)groups;
   (void)eps; (void)act; (void)leak; (void)dtype; (void)ws; (void)wsb; (void)s; return fail(ACG_ERR_UNSUPPORTED, "cpu oracle: no split-K hand-off"); }
 int32_t acg_bn_act_bwd_slabs(const void* x, const float* dy_slabs, int32_t splits, const float* beta, const float* save_mean,
                              const float* save_rstd, void* dx, float* dbeta, float acc, int64_t rows, int32_t C, int32_t xp, int32_t yp,
-                             int32_t groups, int32_t act, float leak, int32_t dtype, int32_t layout, void* ws, size_t wsb, acg_stream_t s) {
-  (void)layout; (void)x; (void)dy_slabs; (void)splits; (void)beta; (void)save_mean; (void)save_rstd; (void)dx; (void)dbeta; (void)acc; (void)rows; (void)C; (void)xp;
+                             int32_t groups, int32_t act, float leak, int32_t dtype, int32_t layout, int32_t flags, void* ws, size_t wsb, acg_stream_t s) {
+  (void)flags; (void)layout; (void)x; (void)dy_slabs; (void)splits; (void)beta; (void)save_mean; (void)save_rstd; (void)dx; (void)dbeta; (void)acc; (void)rows; (void)C; (void)xp;
   (void)yp; (void)groups; (void)act; (void)leak; (void)dtype; (void)ws; (void)wsb; (void)s; return fail(ACG_ERR_UNSUPPORTED, "cpu oracle: no split-K hand-off"); }
 int32_t acg_weights_prepare_bf16(const acg_prep_list* l, int32_t count, acg_stream_t s) {
   (void)l; (void)count; (void)s;
@@ -313,8 +316,8 @@ static double act_df(int act, double u, double leak) {
 size_t acg_bn_workspace_bytes(int64_t rows, int32_t channels, int32_t groups) { (void)rows; (void)channels; (void)groups; return 0; }
 int32_t acg_bn_act_fwd(const void* xv, const float* beta, void* yv, float* save_mean, float* save_rstd,
                        int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t groups, float eps, int32_t act,
-                       float leak, int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
-  (void)ws; (void)wsb; (void)s; REQUIRE_F32(dtype);
+                       float leak, int32_t dtype, int32_t flags, void* ws, size_t wsb, acg_stream_t s) {
+  (void)flags; (void)ws; (void)wsb; (void)s; REQUIRE_F32(dtype);
   if (groups <= 0 || rows % groups) return fail(ACG_ERR_INVALID_ARG, "bn: rows not divisible by groups");
   const float* x = xv; float* y = yv; int64_t R = rows / groups;
   const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;
@@ -364,8 +367,8 @@ int32_t acg_bn_act_fwd_partials(const void* xv, const float* beta, const float* 
 int32_t acg_bn_act_bwd(const void* xv, const void* dyv, const float* beta, const float* save_mean,
                        const float* save_rstd, void* dxv, float* dbeta, float dbeta_acc,
                        int64_t rows, int32_t C, int32_t x_pitch, int32_t y_pitch, int32_t groups, int32_t act, float leak,
-                       int32_t dtype, void* ws, size_t wsb, acg_stream_t s) {
-  (void)ws; (void)wsb; (void)s; REQUIRE_F32(dtype);
+                       int32_t dtype, int32_t flags, void* ws, size_t wsb, acg_stream_t s) {
+  (void)flags; (void)ws; (void)wsb; (void)s; REQUIRE_F32(dtype);
   if (groups <= 0 || rows % groups) return fail(ACG_ERR_INVALID_ARG, "bn: rows not divisible by groups");
   const float* x = xv; const float* dy = dyv; float* dx = dxv; int64_t R = rows / groups;
   const int XP = x_pitch > 0 ? x_pitch : C, YP = y_pitch > 0 ? y_pitch : C;

@@ -17,6 +17,7 @@ def _p(t):
 class Abi:
     def __init__(self, lib, device, conv_dtype=L.ACG_F32):
         self.lib, self.device, self.conv_dtype = lib, torch.device(device), conv_dtype
+        self.bn_flags = 0            # `flags` of the BatchNorm entries (ACG_BN_NO_GRID_EXCHANGE): tests set it to cover that path
 
     # ---- plumbing
     def stream(self):
@@ -27,9 +28,24 @@ class Abi:
     def empty(self, *shape, dtype=torch.float32):
         return torch.empty(*shape, dtype=dtype, device=self.device)
 
+    _CANARY = 512
+
     def ws(self, nbytes):
+        """A zeroed workspace of `nbytes` with a canary region behind it (`no_timeout` / `canary_intact` check that nothing wrote
+        past the size the library asked for)."""
         n = max(int(nbytes), 16)
-        return torch.zeros(n, dtype=torch.uint8, device=self.device), n
+        buf = torch.zeros(n + self._CANARY, dtype=torch.uint8, device=self.device)
+        buf[n:] = 0xA5
+        view = buf[:n]
+        view._acg_canary = buf
+        return view, n
+
+    @classmethod
+    def canary_intact(cls, ws):
+        buf = getattr(ws, '_acg_canary', None)
+        if buf is not None:
+            tail = buf[ws.numel():]
+            assert bool((tail == 0xA5).all()), 'a kernel wrote past its workspace (%d of %d canary bytes changed)' % (int((tail != 0xA5).sum()), tail.numel())
 
     def bn_ws(self, rows, c, groups):
         """A BatchNorm workspace (ABI 6: call-site state, zero before first use); `no_timeout` checks its flag word afterwards."""
@@ -40,6 +56,7 @@ class Abi:
         """acgan_hip.h: uint32 word 2 of a BatchNorm workspace is set when a block of a one-launch kernel gave up waiting for its peers."""
         if ws.numel() >= 12:
             assert int(ws[8:12].view(torch.int32)[0]) == 0, 'BatchNorm grid exchange timed out (workspace word 2)'
+        Abi.canary_intact(ws)
 
     def desc(self, batch, h, w, c, kh, kw, cout, stride, padding, pitch=0):
         d = L.ConvDesc()
@@ -262,7 +279,7 @@ class Abi:
         mean, rstd = self.empty(groups * c), self.empty(groups * c)
         ws, n = self.ws(self.lib.bn_workspace_bytes(rows, c, groups))
         self.lib.bn_act_fwd(_p(x), _p(beta), _p(y), _p(mean), _p(rstd), rows, c, xp, c, groups, eps, ACT[act], leak,
-                            L.dtype2(L.code(x.dtype), L.code(y.dtype)), _p(ws), n, self.stream())
+                            L.dtype2(L.code(x.dtype), L.code(y.dtype)), self.bn_flags, _p(ws), n, self.stream())
         self.no_timeout(ws)
         return y, mean, rstd
 
@@ -279,7 +296,7 @@ class Abi:
             assert x.dtype == torch.float32 and dy.dtype == torch.float32 and dx.dtype == torch.bfloat16
             dt = L.dtype2(L.ACG_F32, L.ACG_BF16)
         self.lib.bn_act_bwd(_p(x), _p(dy), _p(beta), _p(mean), _p(rstd), _p(dx), _p(dbeta), accumulate, rows, c, xp, c,
-                            groups, ACT[act], leak, dt, _p(ws), n, self.stream())
+                            groups, ACT[act], leak, dt, self.bn_flags, _p(ws), n, self.stream())
         self.no_timeout(ws)
         return dx, dbeta
 
@@ -344,7 +361,7 @@ class Abi:
         cp = (c + 7) // 8 * 8 if self.half else c
         rows = oshape[0] * oshape[1] * oshape[2]
         if layout is None:
-            layout = self.lib.bn_slabs_layout(rows, c, cp, cp, groups, self.conv_dtype, 0)
+            layout = self.lib.bn_slabs_layout(rows, c, cp, cp, groups, self.conv_dtype, 0, self.bn_flags)
         assert layout >= 0
         ws, n = self.ws(self.lib.conv2d_workspace_bytes(ctypes.byref(d), which, self.conv_dtype))
         ws.fill_(0xFF)                                                  # NaN patterns: every slab element read must have been written
@@ -360,7 +377,7 @@ class Abi:
         mean, rstd = self.empty(groups * c), self.empty(groups * c)
         bws, bn = self.ws(self.lib.bn_workspace_bytes(rows, c, groups))
         self.lib.bn_act_fwd_slabs(_p(ws), splits, _p(conv), _p(beta), _p(y), _p(mean), _p(rstd), rows, c, cp, cp, groups, eps, ACT[act], leak,
-                                  self.conv_dtype, layout, _p(bws), bn, self.stream())
+                                  self.conv_dtype, layout, self.bn_flags, _p(bws), bn, self.stream())
         self.no_timeout(bws)
         return conv[..., :c].float(), y[..., :c].float(), mean, rstd, layout
 
@@ -383,7 +400,7 @@ class Abi:
         cp = (c + 7) // 8 * 8 if self.half else c
         rows = xb.numel() // c
         splits = self.lib.conv2d_splits(ctypes.byref(d), which, self.conv_dtype)
-        want = self.lib.bn_slabs_layout(rows, c, cp, cp, groups, self.conv_dtype, 1)
+        want = self.lib.bn_slabs_layout(rows, c, cp, cp, groups, self.conv_dtype, 1, self.bn_flags)
         if splits < 2 or want < 0:
             return None
         layout = want if layout is None else layout
@@ -410,7 +427,7 @@ class Abi:
         dbeta = self.empty(c)
         bws, bn = self.ws(self.lib.bn_workspace_bytes(rows, c, groups))
         self.lib.bn_act_bwd_slabs(_p(x16), _p(ws), splits, _p(beta), _p(mean), _p(rstd), _p(dx), _p(dbeta), 0.0, rows, c, cp, cp, groups,
-                                  ACT[act], leak, self.conv_dtype, layout, _p(bws), bn, self.stream())
+                                  ACT[act], leak, self.conv_dtype, layout, self.bn_flags, _p(bws), bn, self.stream())
         self.no_timeout(bws)
         return dx[..., :c].float(), dbeta, layout
 

@@ -1330,8 +1330,8 @@ def case_repeatable_launches(abi, reps=60):
         first = None
         for r in range(reps):
             y, dx = torch.zeros_like(x), torch.zeros_like(x)
-            abi.lib.bn_act_fwd(_p(x), _p(beta), _p(y), _p(mean), _p(rstd), rows, c, 0, 0, groups, 1e-3, L.ACT_LRELU, 0.2, code, _p(wsf), nf, abi.stream())
-            abi.lib.bn_act_bwd(_p(x), _p(dy), _p(beta), _p(mean), _p(rstd), _p(dx), _p(dbeta), 0.0, rows, c, 0, 0, groups, L.ACT_LRELU, 0.2, code, _p(wsb), nb, abi.stream())
+            abi.lib.bn_act_fwd(_p(x), _p(beta), _p(y), _p(mean), _p(rstd), rows, c, 0, 0, groups, 1e-3, L.ACT_LRELU, 0.2, code, 0, _p(wsf), nf, abi.stream())
+            abi.lib.bn_act_bwd(_p(x), _p(dy), _p(beta), _p(mean), _p(rstd), _p(dx), _p(dbeta), 0.0, rows, c, 0, 0, groups, L.ACT_LRELU, 0.2, code, 0, _p(wsb), nb, abi.stream())
             got = (y, dx, mean.clone(), rstd.clone(), dbeta.clone())
             if first is None:
                 first = got

@@ -251,6 +251,72 @@ def test_bn(hip_abi, shape):
     C.case_bn(hip_abi, shape, TOL)
 
 
+@pytest.mark.parametrize('shape', [((32, 64, 64), 16, 1, 'relu'), ((16, 64, 64), 8, 1, 'lrelu'), ((32, 64, 64), 4, 2, None), ((8, 128, 128), 28, 1, 'relu')], ids=str)
+def test_bn_few_channels_many_rows_stay_inside_the_workspace(hip_abi, shape):
+    """a chunk of <= 32 channels costs the one-launch kernels 512 exchange bytes per row block WHATEVER the channel
+    count, and round 4 sized the workspace by the channels alone: 131072 x 16 wrote 131 KB of granules into a 66 KB workspace.
+    Now acg_bn_workspace_bytes covers the exchange area of every admissible grid (<= 512 blocks); every workspace the test
+    helpers hand out carries a canary behind it (abi_call.Abi.ws) that no_timeout checks."""
+    C.case_bn(hip_abi, shape, TOL)
+
+
+def test_bn_without_grid_exchange_flag(hip_abi):
+    """ACG_BN_NO_GRID_EXCHANGE (a caller whose BatchNorm launches can overlap: Session(side_branches=True)): the same results
+    from the register-resident / two-launch kernels - the epoch word of the workspace, which only the grid kernels count in,
+    stays zero - and acg_bn_slabs_layout no longer offers the rows layout that only the grid kernels read."""
+    import torch
+    from action_conditioned_gans_amd import _lib as L
+    rows, c = 32 * 32 * 32, 128
+    assert hip_abi.lib.bn_slabs_layout(rows, c, c, c, 1, L.ACG_F32, 0, 0) == L.SLABS_ROWS
+    assert hip_abi.lib.bn_slabs_layout(rows, c, c, c, 1, L.ACG_F32, 0, L.BN_NO_GRID_EXCHANGE) == L.SLABS_ROWS     # forward: the two-launch kernels sum rows slabs too
+    assert hip_abi.lib.bn_slabs_layout(rows, c, c, c, 1, L.ACG_F32, 1, L.BN_NO_GRID_EXCHANGE) == -1               # backward: nobody does
+    hip_abi.bn_flags = L.BN_NO_GRID_EXCHANGE
+    try:
+        for shape in [((32, 32, 32), 128, 1, 'relu'), ((64, 16, 16), 128, 2, 'lrelu'), ((32, 8, 8), 128, 1, 'relu')]:
+            C.case_bn(hip_abi, shape, TOL)
+        x = torch.randn(rows, c, device='cuda')
+        ws, n = hip_abi.bn_ws(rows, c, 1)
+        y, mean, rstd = torch.empty_like(x), hip_abi.empty(c), hip_abi.empty(c)
+        hip_abi.lib.bn_act_fwd(C._ptr(x), C._ptr(torch.zeros(c, device='cuda')), C._ptr(y), C._ptr(mean), C._ptr(rstd), rows, c, 0, 0, 1, 1e-3, L.ACT_RELU, 0.2,
+                               L.ACG_F32, L.BN_NO_GRID_EXCHANGE, C._ptr(ws), n, hip_abi.stream())
+        torch.cuda.synchronize()
+        assert int(ws[0:4].view(torch.int32)[0]) == 0, 'a grid-exchange kernel ran although the flag forbids it'
+    finally:
+        hip_abi.bn_flags = 0
+
+
+def test_bn_exchange_timeout_is_flagged_and_raised(hip_abi):
+    """the FAILURE path of the in-launch exchange, provoked once.  acg_bn_exchange_selftest runs the very
+    FusedExchange code of bn_fwd_fused / bn_bwd_fused: healthy, every block reads n (n + 1) / 2 - also when the same workspace is
+    reused (the epoch advances); with one block withheld every block runs into the (lowered) spin bound, word 2 of the workspace
+    is set, the sums come out short, and graph.Runtime.check_exchange_flags - what train() and bench.py call - raises AcgError."""
+    import torch
+    from action_conditioned_gans_amd import _lib as L, graph as G
+    lib = hip_abi.lib
+    rt = G.Runtime(lib, 'cuda:0')
+    for blocks, threads in ((256, 1024), (512, 256), (7, 256)):
+        ws, n = rt.state_workspace(16 + 512 * blocks)
+        out = torch.zeros(blocks, device='cuda')
+        for rep in range(3):
+            lib.bn_exchange_selftest(C._ptr(ws), n, C._ptr(out), blocks, threads, -1, 1 << 22, hip_abi.stream())
+            torch.cuda.synchronize()
+            assert torch.equal(out.cpu(), torch.full((blocks,), blocks * (blocks + 1) / 2.0)), (blocks, threads, rep, out[:4].tolist())
+            assert int(ws[0:4].view(torch.int32)[0]) == rep + 1 and int(ws[8:12].view(torch.int32)[0]) == 0
+    rt.check_exchange_flags()                       # all clear so far
+    blocks, threads = 64, 1024
+    ws, n = rt.state_workspace(16 + 512 * blocks)
+    out = torch.zeros(blocks, device='cuda')
+    lib.bn_exchange_selftest(C._ptr(ws), n, C._ptr(out), blocks, threads, 5, 2000, hip_abi.stream())      # block 5 publishes nothing
+    torch.cuda.synchronize()                        # (bounded: 2000 polls, not a hang)
+    assert int(ws[8:12].view(torch.int32)[0]) == 1, 'the timeout word was not set'
+    want = blocks * (blocks + 1) / 2.0 - 6.0
+    assert all(v == want or v == -1.0 for v in out.cpu().tolist()), out[:8].tolist()      # short sums: a wrong result, as documented
+    with pytest.raises(L.AcgError, match='grid exchange timed out in 1 of 4 call sites'):
+        rt.check_exchange_flags()
+    with pytest.raises(L.AcgError):                 # argument checks of the entry
+        lib.bn_exchange_selftest(C._ptr(ws), n, C._ptr(out), 513, 256, -1, 1, hip_abi.stream())
+
+
 def test_bn_large_mean(hip_abi):
     C.case_bn_large_mean(hip_abi, 2e-2)
 

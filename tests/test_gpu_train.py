@@ -433,26 +433,37 @@ def test_splitk_handoff_to_batchnorm(dtype):
         sess, tr = TC.build_trainer(gpu_session, 'dna_k6_bce_rmsprop', batch=8, dtype=dtype, slab_handoff=handoff)
         xs, ys = np.tile(x, (4, 1, 1, 1)), np.tile(y, (4, 1, 1, 1))
         as_, ss = np.tile(a, (4, 1)), np.tile(s, (4, 1))
-        for _ in range(4):
+        one_step = None
+        for it in range(4):
             tr.train_d(xs, ys, as_)
             frames = tr.train_g(xs, ys, as_, ss)
+            if it == 0:         # the state after ONE D + G step: where a kernel bug shows before the trajectory's chaos does
+                one_step = ({n: sess.get_value(v) for n, v in G.get_default_graph().variables.items()}, np.array(frames, copy=True))
         torch.cuda.synchronize()
         g = G.get_default_graph()
         fwd = [o._slab[2] for o in g.ops if isinstance(o, O.Conv2dOp) and o._slab is not None]
         bwd = [o._slab[2] for o in g.ops if isinstance(o, O.ConvDgradOp) and o._slab is not None]
         assert (len(fwd) >= 4 and len(bwd) >= 3) if handoff is True else (handoff == 'quads' or (not fwd and not bwd)), (handoff, fwd, bwd)
         assert handoff != 'quads' or set(fwd + bwd) <= {1}, (fwd, bwd)
-        finals.append(({n: sess.get_value(v) for n, v in g.variables.items()}, frames))
-    p0, f0 = finals[0]
+        finals.append(({n: sess.get_value(v) for n, v in g.variables.items()}, frames, one_step))
+    p0, f0 = finals[0][:2]
     nrel = lambda got, want: float(np.linalg.norm(np.asarray(got, np.float64) - np.asarray(want, np.float64)) / np.linalg.norm(np.asarray(want, np.float64)))  # noqa: E731
     if dtype == 'f32':
-        for p1, f1 in finals[1:]:
+        for p1, f1, _ in finals[1:]:
             for n in p0:
                 d = float((p0[n].double() - p1[n].double()).abs().max())
                 assert d <= 1e-5 * max(float(p0[n].abs().max()), 1e-3), (n, d)
             assert TC.rel(f1, f0) <= 1e-4
         return
-    # bf16: RMSProp's first steps are lr * g / sqrt(0.1 g^2), sign-like, so an element whose cancellation-heavy gradient sits near 0
+    # bf16, the bug-detecting bar: after ONE D + G step the hand-off run and the separate-reduction run
+    # differ by storage rounding only - frames within 5e-3 (measured 2.5e-3), every variable within 1e-2 of its scale
+    w1, fr1 = finals[0][2]
+    for _, _, (w1h, fr1h) in finals[1:]:
+        assert nrel(fr1h, fr1) <= 5e-3, ('frames after one step', nrel(fr1h, fr1))
+        for n in w1:
+            d = float((w1h[n].double() - w1[n].double()).abs().max())
+            assert d <= 1e-2 * max(float(w1[n].abs().max()), 1e-3), ('after one step', n, d)
+    # bf16 over FOUR steps: RMSProp's first steps are lr * g / sqrt(0.1 g^2), sign-like, so an element whose cancellation-heavy gradient sits near 0
     # moves a whole step either way once one bf16 ulp flips upstream: four steps amplify ANY rounding-level change of the arithmetic
     # to percents (measured on this case: frames 2.5e-3 apart after one step, 6.5e-2 after four - and the float32 run of the same
     # steps is just as far from both, 7.7e-2 / 8.1e-2).  The yardstick is therefore that float32 run: the hand-off may move the bf16
@@ -465,7 +476,7 @@ def test_splitk_handoff_to_batchnorm(dtype):
     p32 = {n: sess.get_value(v).cpu().numpy() for n, v in G.get_default_graph().variables.items()}
     yard_f = nrel(f0, frames32)
     assert 1e-2 < yard_f < 0.2, yard_f        # the premise: bf16 vs float32 after four steps is percents, not rounding
-    for p1, f1 in finals[1:]:
+    for p1, f1, _ in finals[1:]:
         assert nrel(f1, f0) <= 1.5 * yard_f, (nrel(f1, f0), yard_f)
         for n in p0:
             assert bool(torch.isfinite(p1[n]).all()), n
@@ -716,3 +727,92 @@ def test_plain_generator_bias_tanh_in_the_deconv_epilogue(dtype):
     assert float(np.abs(f1 - f0).max()) <= tol, float(np.abs(f1 - f0).max())
     for k in w0:
         assert torch.isfinite(w1[k]).all(), k
+
+
+@pytest.mark.timeout(900)
+def test_lookahead_step_matches_oracle_live_at_full_size():
+    """The bench's step since round 5 - Trainer.train_d(..., next_g=...) then train_g - at BASELINE config 2's size (batch 32,
+    RMSProp so that the updated weights are comparable): the D step on samples A runs the generator on the pair batch
+    [B ; A] (batch 64, BatchNorm statistics per half), the G step on samples B starts behind that pass.  Against the fp64
+    oracle doing what train.py:241-263 does - train_d(A), then train_g(B) - at 1e-3: the generated frames the G step
+    returns, both steps' per-variable gradient norms, every weight after the two updates; run three times (eager, capture,
+    replay), the oracle stepping along."""
+    import torch
+    from oracle import models as OM
+    from oracle.trainer import OracleTrainer
+    from action_conditioned_gans_amd import optim, train as T
+    B, S, K = 32, 64, 5
+    params = OM.init_params(True, batch=B, img=S, ksize=K, seed=9, dtype=torch.float32)
+    G.reset_default_graph()
+    optim.set_data_parallel(1)
+    sess = gpu_session()
+    tr = T.Trainer(sess, True, 'bce', 'rmsprop', True, batch_size=B, img_size=S, ksize=K)
+    assert tr.lookahead
+    sess.run(G.global_variables_initializer())
+    g = G.get_default_graph()
+    for n, v in g.variables.items():
+        sess.set_value(v, params[n])
+    rng = np.random.default_rng(33)
+    mk = lambda: (rng.uniform(-1, 1, (B, S, S, 3)).astype(np.float32), rng.uniform(-1, 1, (B, S, S, 3)).astype(np.float32),     # noqa: E731
+                  rng.standard_normal((B, 10)).astype(np.float32), rng.standard_normal((B, 5)).astype(np.float32))
+    (xa, ya, aa, _), (xb, yb, ab, sb) = mk(), mk()
+    td = lambda t: torch.from_numpy(t).double()     # noqa: E731
+    torch.set_num_threads(16)
+    ot = OracleTrainer({k: v.double() for k, v in params.items()}, True, 'bce', 'rmsprop', True, K)
+    for it in range(3):
+        tr.train_d(xa, ya, aa, next_g=(xb, ab))
+        ot.train_d(td(xa), td(ya), td(aa))
+        TC.check_norms(TC.flat_grad_norms(sess, tr.d_opt_op), {'dgrad_norm/' + k: v.norm() for k, v in ot.last_grads.items()},
+                       'dgrad_norm/', 1e-3, 'D grad (look-ahead, iteration %d)' % it)
+        frames = tr.train_g(xb, yb, ab, sb)
+        oframe = ot.train_g(td(xb), td(yb), td(ab), td(sb))
+        assert TC.rel(frames, oframe.numpy()) <= 1e-3, (it, TC.rel(frames, oframe.numpy()))
+        TC.check_norms(TC.flat_grad_norms(sess, tr.g_opt_op), {'ggrad_norm/' + k: v.norm() for k, v in ot.last_grads.items()},
+                       'ggrad_norm/', 1e-3, 'G grad (look-ahead, iteration %d)' % it)
+    for n, v in g.variables.items():
+        got, want = sess.get_value(v).double(), ot.p[n]
+        assert (got - want).abs().max().item() <= 1e-3 * max(want.abs().max().item(), 1e-3) + 2e-6, n
+    progs = sorted(sum(len(seg) for kind, seg in p.segments if kind == 'dev') for p in sess._programs.values())
+    assert len(progs) == 2 and all(p.graphs is not None for p in sess._programs.values()), progs     # both look-ahead programs were captured and replayed
+    sess.close()
+
+
+@pytest.mark.parametrize('dtype,dna', [('f32', True), ('f32', False), ('bf16', True)])
+def test_lookahead_equals_the_plain_call_path_on_the_gpu(dtype, dna):
+    """Look-ahead on / off from the same weights on distinct D-step and G-step samples, batch 8, four iterations (eager,
+    capture, two replays).  float32: weights to 2e-5 of their scale (the pair instance's convolutions run at twice the
+    GEMM height: other tiles / splits, same sums).  bf16: storage rounding is chaotic over iterations, so the comparison is
+    after ONE iteration - frames within 5e-3, every variable within 1e-2 of its scale - plus finiteness after four."""
+    from action_conditioned_gans_amd import optim, train as T
+    x, y, a, s = TC.MG.inputs(8)
+    xb, yb, ab, sb = [np.ascontiguousarray(np.roll(t, 3, axis=0)[::-1]) for t in (y, x, a, s)]
+    runs = []
+    for use in (False, True):
+        G.reset_default_graph()
+        optim.set_data_parallel(1)
+        sess = gpu_session(dtype=dtype)
+        tr = T.Trainer(sess, True, 'bce', 'rmsprop', dna, batch_size=8, ksize=5)
+        sess.run(G.global_variables_initializer())
+        first = None
+        for it in range(4):
+            tr.train_d(x, y, a, next_g=(xb, ab) if use else None)
+            frames = tr.train_g(xb, yb, ab, sb)
+            if it == 0:
+                first = (np.array(frames, copy=True), {n: sess.get_value(v) for n, v in G.get_default_graph().variables.items()})
+        runs.append((first, frames, {n: sess.get_value(v) for n, v in G.get_default_graph().variables.items()}))
+        sess.close()
+    (f0, w0), fl0, wl0 = runs[0]
+    (f1, w1), fl1, wl1 = runs[1]
+    nrel = lambda got, want: float(np.linalg.norm(np.asarray(got, np.float64) - np.asarray(want, np.float64)) / np.linalg.norm(np.asarray(want, np.float64)))  # noqa: E731
+    if dtype == 'f32':
+        assert nrel(fl1, fl0) <= 1e-4, nrel(fl1, fl0)
+        for n in wl0:
+            d = float((wl1[n].double() - wl0[n].double()).abs().max())
+            assert d <= 2e-5 * max(float(wl0[n].abs().max()), 1e-3), (n, d)
+    else:
+        assert nrel(f1, f0) <= 5e-3, nrel(f1, f0)
+        for n in w0:
+            d = float((w1[n].double() - w0[n].double()).abs().max())
+            assert d <= 1e-2 * max(float(w0[n].abs().max()), 1e-3), (n, d)
+            assert bool(torch.isfinite(wl1[n]).all()), n
+        assert np.isfinite(fl1).all()

@@ -451,3 +451,48 @@ def test_side_stream_join_sees_ops_absorbed_by_their_producer():
     with mock.patch.object(torch.cuda, 'current_stream', lambda dev=None: Stream(11)):
         sess._launch_segment([(prod, lambda s: calls.append(('prod', s.value))), (cons, lambda s: calls.append(('cons', s.value)))])
     assert calls == [('edge', 11, 22), ('prod', 22), ('edge', 22, 11), ('cons', 11)], calls
+
+
+@pytest.mark.parametrize('dna', [True, False], ids=['dna', 'plain'])
+def test_lookahead_generator_pass_matches_the_plain_call_path(dna):
+    """Trainer(lookahead=True): train_d(..., next_g=(x_g, a_g)) runs the generator ONCE on the pair batch (G step's samples ;
+    D step's samples, BatchNorm statistics per half) and the train_g that follows with those inputs starts behind its forward
+    pass.  Same arithmetic as the two separate passes of train.py:241-263: frames, both gradient buffers and the weights after
+    two iterations agree with the plain call path to rounding; the programs really differ (the D program runs the pair
+    instance, the G program lost its generator forward); anything but the announced inputs takes the plain program."""
+    x, y, a, s = TC.MG.inputs(2)
+    x2, y2, a2, s2 = [np.ascontiguousarray(t[::-1]) for t in TC.MG.inputs(2)]
+
+    def run(use):
+        G.reset_default_graph()
+        sess = cpu_session()
+        tr = T.Trainer(sess, True, 'bce', 'rmsprop', dna, batch_size=2, ksize=5)
+        sess.run(G.global_variables_initializer())
+        for _ in range(2):
+            tr.train_d(x, y, a, next_g=(x2, a2) if use else None)
+            frames = tr.train_g(x2, y2, a2, s2)
+        g = G.get_default_graph()
+        grads = {t.name: sess._materialize(t).clone() for t in g.state if t.name.endswith('flat_grad') and 'pretrain' not in t.name}
+        return tr, sess, frames, grads, {n: sess.get_value(v) for n, v in g.variables.items()}
+    _, s0, f0, g0, w0 = run(False)
+    tr, s1, f1, g1, w1 = run(True)
+    assert np.abs(f1 - f0).max() <= 1e-5 * np.abs(f0).max()
+    for k in g0:
+        assert float((g1[k] - g0[k]).abs().max()) <= 2e-5 * float(g0[k].abs().max()), k
+    for n in w0:
+        assert float((w1[n] - w0[n]).abs().max()) <= 1e-6 * max(float(w0[n].abs().max()), 1e-3), n
+    ops = lambda sess: sorted(sum(len(seg) for kind, seg in p.segments if kind == 'dev') for p in sess._programs.values())     # noqa: E731
+    plain, ahead = ops(s0), ops(s1)
+    assert len(plain) == 2 and len(ahead) == 2
+    assert max(ahead) < max(plain), (plain, ahead)           # the G program (the longer one) lost the generator's forward pass
+    # the pair instance's tensors are the storage of the batch-B instance (first half): no second copy of the activations
+    half = tr.g_out
+    assert half.view_of is not None and half.view_of[0] is tr._g_pair_out and half.view_of[1] == 0
+    # not the announced inputs -> the plain program (three programs now), same result as a plain run from the same state
+    tr.train_d(x, y, a, next_g=(x2, a2))
+    n_before = len(s1._programs)
+    tr.train_g(x2.copy(), y2, a2, s2)
+    assert len(s1._programs) == n_before + 1
+    # a logging D step (summaries read the D step's OWN generated frames) keeps the plain path even when asked
+    summ = tr.train_d(x, y, a, summarize=True, next_g=(x2, a2))
+    assert summ is not None and tr._announced is None

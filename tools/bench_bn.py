@@ -87,7 +87,7 @@ def main():
 
         def f_fwd(t):
             x, dy, beta, y, dx, mean, rstd, dbeta, ws, part, nblk, wsb = t
-            return lambda s: lib.bn_act_fwd(p(x), p(beta), p(y), p(mean), p(rstd), rows, C, 0, 0, G, 1e-3, a, 0.2, code, p(ws), nb, s)
+            return lambda s: lib.bn_act_fwd(p(x), p(beta), p(y), p(mean), p(rstd), rows, C, 0, 0, G, 1e-3, a, 0.2, code, 0, p(ws), nb, s)
 
         def f_fwdp(t):
             x, dy, beta, y, dx, mean, rstd, dbeta, ws, part, nblk, wsb = t
@@ -95,7 +95,7 @@ def main():
 
         def f_bwd(t):
             x, dy, beta, y, dx, mean, rstd, dbeta, ws, part, nblk, wsb = t
-            return lambda s: lib.bn_act_bwd(p(x), p(dy), p(beta), p(mean), p(rstd), p(dx), p(dbeta), 0.0, rows, C, 0, 0, G, a, 0.2, code, p(wsb), nb, s)
+            return lambda s: lib.bn_act_bwd(p(x), p(dy), p(beta), p(mean), p(rstd), p(dx), p(dbeta), 0.0, rows, C, 0, 0, G, a, 0.2, code, 0, p(wsb), nb, s)
         us = [timed([f(t) for t in sets]) for f in (f_fwd, f_fwdp, f_bwd)]
         by = [3.0 * rows * C * es, 2.0 * rows * C * es, 3.0 * rows * C * es]
         print('%-16s %8d %5d %2d | %7.2f us %7.0f | %7.2f us %7.0f | %7.2f us %7.0f' % (

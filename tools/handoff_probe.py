@@ -42,10 +42,10 @@ for rows, c, splits, groups in [(2048, 128, 4, 1), (2048, 128, 4, 2), (512, 256,
     rl = L.ReduceList()
     rl.slabs[0], rl.out[0], rl.numel[0], rl.splits[0], rl.accumulate[0] = slabs.data_ptr(), xr.data_ptr(), xr.numel(), splits, 0.0
     t_red = timed(lambda s: lib.splitk_reduce_many(ctypes.byref(rl), 1, s))
-    t_bn = timed(lambda s: lib.bn_act_fwd(p(x), p(beta), p(y), p(mean), p(rstd), rows, c, c, c, groups, 1e-3, L.ACT_RELU, 0.2, dt, p(ws), n, s))
-    t_both = timed(lambda s: (lib.splitk_reduce_many(ctypes.byref(rl), 1, s), lib.bn_act_fwd(p(x), p(beta), p(y), p(mean), p(rstd), rows, c, c, c, groups, 1e-3, L.ACT_RELU, 0.2, dt, p(ws), n, s)))
+    t_bn = timed(lambda s: lib.bn_act_fwd(p(x), p(beta), p(y), p(mean), p(rstd), rows, c, c, c, groups, 1e-3, L.ACT_RELU, 0.2, dt, 0, p(ws), n, s))
+    t_both = timed(lambda s: (lib.splitk_reduce_many(ctypes.byref(rl), 1, s), lib.bn_act_fwd(p(x), p(beta), p(y), p(mean), p(rstd), rows, c, c, c, groups, 1e-3, L.ACT_RELU, 0.2, dt, 0, p(ws), n, s)))
     res = []
     for layout in (0, 1):
-        res.append(timed(lambda s: lib.bn_act_fwd_slabs(p(slabs), splits, p(x), p(beta), p(y), p(mean), p(rstd), rows, c, c, c, groups, 1e-3, L.ACT_RELU, 0.2, dt, layout, p(ws), n, s)))
+        res.append(timed(lambda s: lib.bn_act_fwd_slabs(p(slabs), splits, p(x), p(beta), p(y), p(mean), p(rstd), rows, c, c, c, groups, 1e-3, L.ACT_RELU, 0.2, dt, layout, 0, p(ws), n, s)))
     print('%s rows %5d c %4d splits %2d groups %d: reduce %5.2f us  bn %5.2f us  reduce+bn %5.2f us | bn summing slabs: rows layout %5.2f us  quads %5.2f us'
           % ('bf16' if half else 'f32', rows, c, splits, groups, t_red, t_bn, t_both, res[0], res[1]), flush=True)

@@ -10,10 +10,10 @@ to the time each kernel family takes per REAL step: `--trace-run` makes the benc
 rollout, no instrumented pass, no CPU baseline), and its JSON line says how many (`config.step_executions`: the eager /
 capture / first-replay steps, the warm-up and every timed block), so family time per step = TotalDurationNs / steps.
 
-    python tools/insitu_times.py DIR/..._kernel_stats.csv LOG > profiles/r4/insitu_<tag>.json
+    python tools/insitu_times.py DIR/..._kernel_stats.csv LOG > profiles/r5/insitu_<tag>.json
 
 The JSON is what bench.py reads for `roofline` / `roofline_dna` / `op_ms_per_step` (like the PMC traffic summaries), and
-profiles/r4/g_*_kernel_stats.csv is the very file it was reduced from: conv time per step = sum over the conv families of
+profiles/r5/g_*_kernel_stats.csv is the very file it was reduced from: conv time per step = sum over the conv families of
 TotalDurationNs / step_executions, by hand."""
 import csv
 import json
@@ -98,6 +98,8 @@ def main():
         'source': 'rocprofv3 --kernel-trace --stats of `bench.py --trace-run` (tools/insitu_times.py); durations are the profiler\'s '
                   'per-dispatch begin -> end inside the replayed step graphs, operands as the step leaves them',
         'workload': line['config']['workload'], 'dtype': line['dtype'], 'step_executions': steps,
+        # what the trace was taken with: bench.py refuses to quote this file for another library / ABI / call path
+        'abi_version': line['config'].get('abi_version'), 'lib_sha16': line['config'].get('lib_sha16'), 'lookahead': line['config'].get('lookahead'),
         'bench_ms_per_step_under_profiler': line['ms_per_step'],
         'family_us_per_step': {k: round(v[1] / steps / 1e3, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])},
         'family_launches_per_step': {k: round(v[0] / steps, 2) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])},

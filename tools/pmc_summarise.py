@@ -70,6 +70,14 @@ def main():
     for k, n, f_mb, w_mb in rows:
         if k in CONV_KERNELS + ('splitk_reduce', 'splitk_reduce_bf16', 'splitk_reduce_many', 'dna_fwd', 'dna_bwd'):
             out[k] = {'launches': n, 'fetch_bytes_per_launch': round(f_mb * 1e6), 'write_bytes_per_launch': round(w_mb * 1e6)}
+    # what the passes were taken with (the bench line of the FETCH pass): bench.py refuses a profile of another library / ABI
+    log = os.path.join(root, 'fetch.log')
+    if os.path.exists(log):
+        with open(log) as f:
+            for line in f:
+                if line.startswith('{') and '"metric"' in line:
+                    cfg = json.loads(line)['config']
+                    out.update({k: cfg.get(k) for k in ('abi_version', 'lib_sha16', 'lookahead')})
     sys.stderr.write(json.dumps(out, indent=1) + '\n')
 
 

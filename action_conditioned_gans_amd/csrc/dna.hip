@@ -133,11 +133,15 @@ __global__ __launch_bounds__(TX* TY) void dna_kernel(const TL* __restrict__ logi
   const float* wbase = win + (ty * WW + tx) * C;
 
   if (valid) {
+    // round 5: the pixel's logits live in REGISTERS from here on (one LDS read each; round 4 added the bias in place - a
+    // write-back nobody needed in the forward pass - and re-read every logit for the maximum and again for the exponentials;
+    // backward also evaluated every tap's window dot product twice)
+    float v[KK];
 #pragma unroll
-    for (int t = 0; t < KK; ++t) l[t] += bs[t];          // softmax(logits + bias)
-    float mx = l[0];
+    for (int t = 0; t < KK; ++t) v[t] = l[t] + bs[t];    // softmax(logits + bias)
+    float mx = v[0];
 #pragma unroll
-    for (int t = 1; t < KK; ++t) mx = fmaxf(mx, l[t]);
+    for (int t = 1; t < KK; ++t) mx = fmaxf(mx, v[t]);
     const long long pix = (long long)(b * H + y) * W + x;
     if constexpr (!BWD) {
       float den = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(TX* TY) void dna_kernel(const TL* __restrict__ logi
       for (int i = 0; i < K; ++i)
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-          const float e = __expf(l[i * K + j] - mx);
+          const float e = __expf(v[i * K + j] - mx);
           const float* wp = wbase + (i * WW + j) * C;
           den += e;
           a0 += e * wp[0];
@@ -172,31 +176,26 @@ __global__ __launch_bounds__(TX* TY) void dna_kernel(const TL* __restrict__ logi
         if (C > 2) d2 += second_load(s2, pix, 2);
         if (C > 3) d3 += second_load(s2, pix, 3);
       }
-      auto gfun = [&](int i, int j) {
-        const float* wp = wbase + (i * WW + j) * C;
-        float g = d0 * wp[0];
-        if (C > 1) g += d1 * wp[1];
-        if (C > 2) g += d2 * wp[2];
-        if (C > 3) g += d3 * wp[3];
-        return g;
-      };
+      float gv[KK];
       float den = 0.f, dotn = 0.f;
 #pragma unroll
       for (int i = 0; i < K; ++i)
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-          const float e = __expf(l[i * K + j] - mx);
+          const float* wp = wbase + (i * WW + j) * C;
+          float g = d0 * wp[0];
+          if (C > 1) g += d1 * wp[1];
+          if (C > 2) g += d2 * wp[2];
+          if (C > 3) g += d3 * wp[3];
+          const float e = __expf(v[i * K + j] - mx);
+          gv[i * K + j] = g;
+          v[i * K + j] = e;
           den += e;
-          dotn += e * gfun(i, j);
+          dotn += e * g;
         }
       const float inv = 1.f / den, dot = dotn * inv;
 #pragma unroll
-      for (int i = 0; i < K; ++i)
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-          const float mt = __expf(l[i * K + j] - mx) * inv;
-          l[i * K + j] = mt * (gfun(i, j) - dot);
-        }
+      for (int t = 0; t < KK; ++t) l[t] = (v[t] * inv) * (gv[t] - dot);
     }
   } else if constexpr (BWD) {
 #pragma unroll

@@ -350,6 +350,9 @@ def train(input_path, output_path, test_output_path, log_dir, model_dir, arg_adv
     except BaseException:
         sess.close(check=False)            # tear the transport down; the exception on its way out is the one to report
         raise
+    finally:
+        if hasattr(data, 'close'):
+            data.close()                   # PushDataset: stop the decode workers and the feeder thread
     # The session stays OPEN: the returned Trainer is usable (evaluation, more steps, reading variables).  Its owner closes it -
     # `trainer.sess.close()` (main() does): ncclCommDestroy under data parallelism and a last check of the device-side flags.
     return trainer
@@ -415,6 +418,8 @@ def _train_loop(sess, data, input_path, synthetic, boolean_mask, log_dir, model_
                     for j in range(predicted.shape[1])]
             if log_file:
                 _log_jsonl(os.path.join(log_dir, 'test.jsonl'), dict(e_summ or {}, iteration=i, rollout_psnr=psnr))
+    if hasattr(eval_data, 'close'):
+        eval_data.close()
     return trainer
 
 

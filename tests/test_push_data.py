@@ -183,6 +183,70 @@ def test_push_dataset_batches_split_and_ranks(tmp_path):
         P.PushDataset(str(tmp_path / 'missing'), 2)
 
 
+def test_prefetch_workers_keep_stream_order_and_shut_down(tmp_path):
+    """PushDataset decodes on worker threads into a bounded queue (ops.py:209-213: num_threads = batch_size,
+    a capacity of records) - and the batches must not depend on that: same records, same order, bit-identical arrays for 0
+    (synchronous), 1, 3 and 8 workers and for a queue smaller than a batch; per-rank streams stay disjoint; close() ends every
+    thread it started; a damaged shard surfaces from get_batch as the reader's own exception instead of a hang."""
+    import threading
+    rng = np.random.default_rng(4)
+    for k in range(3):
+        make_shard(str(tmp_path / ('push_%02d.tfrecord' % k)), rng, 3)
+    before = {t.name for t in threading.enumerate()}
+    ref = P.PushDataset(str(tmp_path), batch_size=4, train_val_split=1.0, num_threads=0)
+    want = [ref.get_batch() for _ in range(4)]                  # 16 records: the 9 on disk wrap around, reshuffled
+    assert ref._prefetch is None
+    for threads, capacity in ((1, None), (3, 2), (8, 64)):
+        with P.PushDataset(str(tmp_path), batch_size=4, train_val_split=1.0, num_threads=threads, capacity=capacity) as ds:
+            assert ds.num_threads == threads and ds._prefetch is not None
+            for w in want:
+                got = ds.get_batch()
+                assert all(np.array_equal(g, e) for g, e in zip(got, w)), (threads, capacity)
+        assert ds._prefetch is None
+    # default thread count: the batch size, capped by the CPUs of this process (ops.py:212 num_threads=batch_size)
+    ds = P.PushDataset(str(tmp_path), batch_size=2, train_val_split=1.0)
+    assert 1 <= ds.num_threads <= 2 and ds.capacity == 8
+    ds.get_batch()
+    ds.close()
+    ds.close()                                                  # idempotent
+    pf = P._Prefetcher(iter([]), lambda r: r, 1, 1)
+    pf.close()
+    with pytest.raises(RuntimeError, match='closed'):
+        pf.get()
+    import time
+    time.sleep(0.2)
+    left = {t.name for t in threading.enumerate()} - before
+    assert not [n for n in left if n.startswith('push-')], left
+    # two ranks through the workers: disjoint halves of one stream
+    with P.PushDataset(str(tmp_path), 3, train_val_split=1.0, rank=0, world_size=2, num_threads=2) as r0, \
+            P.PushDataset(str(tmp_path), 3, train_val_split=1.0, rank=1, world_size=2, num_threads=2) as r1:
+        k0 = {tuple(np.round(v, 5)) for v in r0.get_batch()[2][:, 0, :5]}
+        k1 = {tuple(np.round(v, 5)) for v in r1.get_batch()[2][:, 0, :5]}
+        assert len(k0) == 3 and len(k1) == 3 and not (k0 & k1)
+    # a truncated shard: the reader's IOError comes out of get_batch (and again on the next call), nothing hangs
+    bad = tmp_path / 'bad'
+    bad.mkdir()
+    make_shard(str(bad / 'push_00.tfrecord'), rng, 2)
+    raw = open(str(bad / 'push_00.tfrecord'), 'rb').read()
+    open(str(bad / 'push_00.tfrecord'), 'wb').write(raw[:len(raw) - 7])
+    with P.PushDataset(str(bad), 2, train_val_split=1.0, num_threads=2) as ds:
+        for _ in range(2):
+            with pytest.raises(IOError):
+                ds.get_batch()
+
+
+def test_integer_box_sums_equal_the_float_mean():
+    """The round-5 fast path of resize_area for decoded JPEGs (uint8, integer ratio): two-stage integer sums and one division
+    - bit-identical to the float32 mean it replaces, for power-of-two and other box sizes, wide boxes (uint32 sums) included."""
+    rng = np.random.default_rng(6)
+    for (h, w, oh, ow) in ((512, 512, 64, 64), (60, 90, 10, 30), (128, 128, 2, 2), (24, 40, 24, 8), (7, 5, 7, 5)):
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        want = a.astype(np.float32).reshape(oh, h // oh, ow, w // ow, 3).mean(axis=(1, 3), dtype=np.float32)
+        got = P.resize_area(a, oh, ow)
+        assert got.dtype == np.float32 and np.array_equal(got, want), (h, w, oh, ow)
+        assert np.array_equal(P.resize_area(a.astype(np.float32), oh, ow), want)      # the float path, unchanged
+
+
 def test_committed_fixture_decodes_to_pinned_values():
     """tests/golden/push_tiny.tfrecord (+ make_push_fixture.py) pins the on-disk format and the decode arithmetic."""
     exp = np.load(os.path.join(HERE, 'golden', 'push_tiny_expected.npz'))

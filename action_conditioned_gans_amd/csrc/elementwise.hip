@@ -137,6 +137,26 @@ __global__ __launch_bounds__(256) void copy_many_k(const CopyList l) {
     }
     return;
   }
+  if (cols <= 4 && pitch != cols && rows * (long long)pitch < (1ll << 31)) {
+    // a few channels at a wider pitch (fed frames: 3 channels into pitch 4 / 8 tensors - most of a step's feed bytes): a thread
+    // per ROW, no division (round 4 divided a 64-bit element index by `cols` per element: 8 us per feed launch in situ)
+    const unsigned nr = (unsigned)rows, st = (unsigned)stride;
+    for (unsigned r = blockIdx.x * 256 + threadIdx.x; r < nr; r += st) {
+      float v[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = c < cols ? src[r * (unsigned)cols + c] : 0.f;
+      if (l.half[sgm]) {
+        __bf16* dh = reinterpret_cast<__bf16*>(l.dst[sgm]) + r * (unsigned)pitch;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < cols) dh[c] = (__bf16)v[c];
+      } else {
+        float* df = reinterpret_cast<float*>(l.dst[sgm]) + r * (unsigned)pitch;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < cols) df[c] = v[c];
+      }
+    }
+    return;
+  }
   if (l.half[sgm]) {   // float32 source -> bf16 destination
     __bf16* __restrict__ dh = reinterpret_cast<__bf16*>(l.dst[sgm]);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {

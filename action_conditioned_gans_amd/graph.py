@@ -428,7 +428,7 @@ class Session:
 
     def __init__(self, device='cuda:0', graph=None, use_hip_graphs=True, lib=None,
                  world_size=1, rank=0, process_group=None, dtype='f32', pair_bwd=True, comm=None, slab_handoff=True, epilogue_stats=True, side_branches=False,
-                 epilogue_bias=True, fuse_weight_refresh=True):
+                 epilogue_bias=True, fuse_weight_refresh=True, bn_grid_exchange=True):
         self.graph = graph or get_default_graph()
         dev = torch.device(device)
         if lib is None:
@@ -468,8 +468,10 @@ class Session:
         # the main stream - measured faster on this stack (profiles/r2/m_side_branch_ab.txt: a parallel branch of the HIP
         # graph costs more in fork / join edges than the state head's ~70 us of small kernels hide; bit-identical results)
         self.side_branches = bool(side_branches) and dev.type == 'cuda'
-        if self.side_branches:
-            # a side chain's BatchNorm can run beside a main-chain BatchNorm: two grid-exchange kernels must never overlap
+        # bn_grid_exchange=False: never the one-launch grid-exchange BatchNorm kernels (ACG_BN_NO_GRID_EXCHANGE).  Forced with
+        # side_branches: a side chain's BatchNorm can run beside a main-chain BatchNorm, and two grid-exchange kernels must
+        # never overlap (two partially resident grids starve each other until both time out)
+        if self.side_branches or not bn_grid_exchange:
             self.rt.bn_flags = _lib.BN_NO_GRID_EXCHANGE
         self._programs = {}
         self._initialized = False
@@ -562,11 +564,13 @@ class Session:
         rec(fetches)
         return out
 
-    def _compile(self, flat_fetches, feeds, skip=frozenset()):
-        """``skip``: ids of ops whose results are ALREADY in their output tensors (another program of this session left them there:
+    def _compile(self, flat_fetches, feeds, skip_ops=()):
+        """``skip_ops``: ops whose results are ALREADY in their output tensors (another program of this session left them there:
         Trainer's look-ahead generator pass) - the dependency walk stops at them, they are not launched, their outputs are bound
-        as they lie."""
+        as they lie, and no feed alias writes into them either (a concatenation's fed channels are part of its result)."""
         g = self.graph
+        skip = frozenset(id(o) for o in skip_ops)
+        skip_outputs = frozenset(id(t) for o in skip_ops for t in o.outputs)
         needed, stack = {}, []
         for f in flat_fetches:
             if isinstance(f, Op):
@@ -660,6 +664,11 @@ class Session:
         prog.alias_copies = {}
         for ph in feeds:
             for dst, c_off, tile in self.graph.feed_aliases.get(id(ph), ()):
+                if id(dst) in skip_outputs:
+                    # the destination is the result of a skipped op: whoever computed it wrote these channels too.  (It may be
+                    # a window of a tensor this program does read - the pair generator's concatenation, whose first half is the
+                    # batch-B instance's - and writing this placeholder's rows there would race with the pair's own feed.)
+                    continue
                 if id(dst) in read or id(dst.root()) in read:
                     self._materialize(dst)
                     prog.alias_copies.setdefault(id(ph), []).append((dst, c_off, tile))
@@ -761,7 +770,7 @@ class Session:
         key = (tuple(id(f) for f in flat), tuple(id(k) for k in feed_dict)) + ((id(skip),) if skip else ())
         prog = self._programs.get(key)
         if prog is None:
-            prog = self._compile(flat, list(feed_dict.keys()), frozenset(id(o) for o in skip) if skip else frozenset())
+            prog = self._compile(flat, list(feed_dict.keys()), tuple(skip) if skip else ())
             prog.skip_ref = skip          # keeps the frozenset (whose id is part of the key) alive
             self._programs[key] = prog
         if prog.missing_feeds:

@@ -319,7 +319,8 @@ def _log_jsonl(path, record):
 def train(input_path, output_path, test_output_path, log_dir, model_dir, arg_adv, arg_loss, arg_opt, arg_transform,
           batch_size=64, img_size=64, seq_len=8, ksize=5, train_iter=TRAIN_ITER, pretrain_iter=PRETRAIN_ITER,
           n_critic=None, device='cuda:0', world_size=1, rank=0, process_group=None, log_every=100, quiet=False,
-          eval_every=500, resume=None, dtype='f32', sync_bn=False, exact_global_batch=False, dp_collectives=None, buckets=0):
+          eval_every=500, resume=None, dtype='f32', sync_bn=False, exact_global_batch=False, dp_collectives=None, buckets=0,
+          data_workers='thread', data_threads=None):
     """Training loop of train.py:179-309.  ``input_path``: 'synthetic' (seeded random sequences) or a directory of
     push-dataset TFRecords, read by push_data.PushDataset (the reference's build_tfrecord_input, ops.py:140-223).
     ``dtype``: 'f32', or 'bf16' for the bf16 pipeline of BASELINE configs 3 and 5 (bf16 activations, float32 master weights).
@@ -327,14 +328,16 @@ def train(input_path, output_path, test_output_path, log_dir, model_dir, arg_adv
     the run reproduces one device at the global batch (SyncBN + GDL scaled by the world size + global state-loss norm);
     ``dp_collectives`` - 'side' (default with more than one rank: all-reduces on a second HIP stream, overlapping the rest of
     backward) or 'stream' (in program order on the compute stream); ``buckets`` - all-reduce buckets per optimizer (0 = 2 for
-    'side', 1 for 'stream')."""
+    'side', 1 for 'stream').  ``data_workers`` / ``data_threads``: the TFRecord decode workers (push_data.PushDataset: threads or
+    spawned processes filling a bounded prefetch queue, the reference's tf.train.batch(num_threads=batch_size), ops.py:209-213)."""
     np.random.seed(7)                                           # train.py:14
     synthetic = input_path in (None, '', 'synthetic')
     if synthetic:
         data = SyntheticPush(batch_size, seq_len, img_size, rank=rank)
     else:
         from .push_data import PushDataset
-        data = PushDataset(input_path, batch_size, training=True, img_size=img_size, rank=rank, world_size=world_size)
+        data = PushDataset(input_path, batch_size, training=True, img_size=img_size, rank=rank, world_size=world_size,
+                           workers=data_workers, num_threads=data_threads)
         seq_len = data.seq_len
     boolean_mask = build_all_mask(seq_len)
     G.reset_default_graph()
@@ -458,6 +461,9 @@ def main(argv=None):
                         help="gradient all-reduces in program order on the compute stream, or on a side HIP stream overlapping "
                              "the rest of backward (default with more than one rank)")
     parser.add_argument('--buckets', type=int, default=0, help='all-reduce buckets per optimizer (0: 2 for side, 1 for stream)')
+    parser.add_argument('--data_workers', type=str, default='thread', choices=['thread', 'process'],
+                        help='TFRecord decode workers: threads (PIL / numpy release the GIL for the heavy parts) or spawned processes')
+    parser.add_argument('--data_threads', type=int, default=None, help='number of decode workers (default: batch size, at most 16)')
     args = parser.parse_args(argv)
     if args.buckets < 0:
         parser.error('--buckets must be >= 0')
@@ -476,7 +482,8 @@ def main(argv=None):
                     log_dir, model_dir, args.adv, args.loss, args.opt, args.dna, batch_size=args.batch_size, img_size=args.img_size,
                     seq_len=args.seq_len, ksize=args.ksize, train_iter=args.train_iter, pretrain_iter=args.pretrain_iter,
                     n_critic=args.n_critic, device='cuda:%d' % local_rank, world_size=world_size, rank=rank, dtype=args.dtype,
-                    sync_bn=args.sync_bn, exact_global_batch=args.exact_global_batch, dp_collectives=args.dp_collectives, buckets=args.buckets)
+                    sync_bn=args.sync_bn, exact_global_batch=args.exact_global_batch, dp_collectives=args.dp_collectives, buckets=args.buckets,
+                    data_workers=args.data_workers, data_threads=args.data_threads)
     if trainer is not None:
         trainer.sess.close()        # ncclCommDestroy under data parallelism + a last check of the device-side flags
 

@@ -251,12 +251,14 @@ def test_bn(hip_abi, shape):
     C.case_bn(hip_abi, shape, TOL)
 
 
-@pytest.mark.parametrize('shape', [((32, 64, 64), 16, 1, 'relu'), ((16, 64, 64), 8, 1, 'lrelu'), ((32, 64, 64), 4, 2, None), ((8, 128, 128), 28, 1, 'relu')], ids=str)
+@pytest.mark.parametrize('shape', [((32, 64, 64), 16, 1, None), ((16, 64, 64), 8, 1, None), ((32, 64, 64), 4, 2, None), ((8, 128, 128), 28, 1, None)], ids=str)
 def test_bn_few_channels_many_rows_stay_inside_the_workspace(hip_abi, shape):
     """a chunk of <= 32 channels costs the one-launch kernels 512 exchange bytes per row block WHATEVER the channel
     count, and round 4 sized the workspace by the channels alone: 131072 x 16 wrote 131 KB of granules into a 66 KB workspace.
     Now acg_bn_workspace_bytes covers the exchange area of every admissible grid (<= 512 blocks); every workspace the test
-    helpers hand out carries a canary behind it (abi_call.Abi.ws) that no_timeout checks."""
+    helpers hand out carries a canary behind it (abi_call.Abi.ws) that no_timeout checks.  (No activation: with millions of
+    elements one pre-activation lands within float32 rounding of the ReLU kink, where the float64 reference and the kernel
+    legitimately disagree on the derivative of that one element - seen as a single-element dx error of |dy| * rstd.)"""
     C.case_bn(hip_abi, shape, TOL)
 
 

@@ -196,12 +196,12 @@ def test_prefetch_workers_keep_stream_order_and_shut_down(tmp_path):
     ref = P.PushDataset(str(tmp_path), batch_size=4, train_val_split=1.0, num_threads=0)
     want = [ref.get_batch() for _ in range(4)]                  # 16 records: the 9 on disk wrap around, reshuffled
     assert ref._prefetch is None
-    for threads, capacity in ((1, None), (3, 2), (8, 64)):
-        with P.PushDataset(str(tmp_path), batch_size=4, train_val_split=1.0, num_threads=threads, capacity=capacity) as ds:
+    for threads, capacity, kind in ((1, None, 'thread'), (3, 2, 'thread'), (8, 64, 'thread'), (2, None, 'process')):
+        with P.PushDataset(str(tmp_path), batch_size=4, train_val_split=1.0, num_threads=threads, capacity=capacity, workers=kind) as ds:
             assert ds.num_threads == threads and ds._prefetch is not None
             for w in want:
                 got = ds.get_batch()
-                assert all(np.array_equal(g, e) for g, e in zip(got, w)), (threads, capacity)
+                assert all(np.array_equal(g, e) for g, e in zip(got, w)), (threads, capacity, kind)
         assert ds._prefetch is None
     # default thread count: the batch size, capped by the CPUs of this process (ops.py:212 num_threads=batch_size)
     ds = P.PushDataset(str(tmp_path), batch_size=2, train_val_split=1.0)

@@ -485,6 +485,14 @@ def test_lookahead_generator_pass_matches_the_plain_call_path(dna):
     plain, ahead = ops(s0), ops(s1)
     assert len(plain) == 2 and len(ahead) == 2
     assert max(ahead) < max(plain), (plain, ahead)           # the G program (the longer one) lost the generator's forward pass
+    # no feed alias may write into the result of a skipped op: the batch-B concatenation (first half of the pair's) would get the
+    # D step's action rows while the pair's own feed writes the G step's there - in ONE fused copy launch on a GPU, a race
+    # (seen in round 5: correct on the CPU's sequential copies, 10 % off on the GPU)
+    for prog in s1._programs.values():
+        skipped_out = {id(t) for o in (getattr(prog, 'skip_ref', None) or ()) for t in o.outputs}
+        assert skipped_out
+        for lst in prog.alias_copies.values():
+            assert not [dst for dst, _, _ in lst if id(dst) in skipped_out]
     # the pair instance's tensors are the storage of the batch-B instance (first half): no second copy of the activations
     half = tr.g_out
     assert half.view_of is not None and half.view_of[0] is tr._g_pair_out and half.view_of[1] == 0

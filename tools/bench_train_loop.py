@@ -57,21 +57,23 @@ def main():
     print('# wrote %d records (%.1f MB, %.0f KB per record) in %.1f s' % (args.records, size / 1e6, size / 1e3 / args.records, time.time() - t0))
 
     # ---- decode rate alone: get_batch in a loop, nothing else running
-    for threads in ([args.threads] if args.threads is not None else [0, 4, 8, min(16, cpus), min(32, cpus)]):
-        with P.PushDataset(tmp, args.batch, train_val_split=1.0, num_threads=threads) as ds:
+    settings = [(args.threads, 'thread')] if args.threads is not None else [(0, 'thread'), (4, 'thread'), (8, 'thread'), (16, 'thread'), (8, 'process'), (16, 'process')]
+    for threads, kind in settings:
+        with P.PushDataset(tmp, args.batch, train_val_split=1.0, num_threads=threads, workers=kind) as ds:
+            ds.get_batch()
             ds.get_batch()
             t0, n = time.time(), 0
             while time.time() - t0 < 4.0:
                 ds.get_batch()
                 n += 1
             dt = time.time() - t0
-        print('decode only: %2d threads  %6.1f batches/s  %7.0f records/s  %8.0f JPEG frames/s' % (threads, n / dt, n * args.batch / dt, n * args.batch * 7 / dt))
+        print('decode only: %2d %-9s %6.1f batches/s  %7.0f records/s  %8.0f JPEG frames/s' % (threads, kind + ('es' if kind == 'process' else 's'), n / dt, n * args.batch / dt, n * args.batch * 7 / dt))
 
     # ---- the training loop, synthetic vs TFRecords (same iteration count; pretraining and evaluation off; logging off)
-    def loop(input_path, label):
+    def loop(input_path, label, **extra):
         torch.cuda.synchronize()
         kw = dict(batch_size=args.batch, train_iter=args.iters + 20, pretrain_iter=0, device='cuda:0', quiet=True, eval_every=0, log_every=10 ** 9,
-                  dtype=args.dtype)
+                  dtype=args.dtype, **extra)
         # warm: the first 20 iterations (kernel loading, graph capture) are timed separately by running a short loop first
         tr = T.train(input_path, None, None, None, None, True, 'bce', 'adam', True, **dict(kw, train_iter=20))
         tr.sess.close()
@@ -80,12 +82,13 @@ def main():
         torch.cuda.synchronize()
         dt = time.time() - t0
         tr.sess.close()
-        print('train(%-9s): %6.1f iterations/s  (%.2f ms per D + G iteration, %d iterations incl. session set-up and 20 warm-up iterations)'
+        print('train(%-22s): %6.1f iterations/s  (%.2f ms per D + G iteration, %d iterations incl. session set-up and 20 warm-up iterations)'
               % (label, (args.iters + 20) / dt, dt / (args.iters + 20) * 1e3, args.iters + 20))
         return (args.iters + 20) / dt
     r_syn = loop('synthetic', 'synthetic')
-    r_rec = loop(tmp, 'tfrecords')
-    print('tfrecords / synthetic = %.2f' % (r_rec / r_syn))
+    r_thr = loop(tmp, 'tfrecords, 16 threads', data_workers='thread', data_threads=16)
+    r_prc = loop(tmp, 'tfrecords, 16 processes', data_workers='process', data_threads=16)
+    print('tfrecords / synthetic = %.2f (threads), %.2f (processes)' % (r_thr / r_syn, r_prc / r_syn))
 
 
 if __name__ == '__main__':

@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--img', type=int, default=64)
     ap.add_argument('--ksize', type=int, default=5)
     ap.add_argument('--lib', default=None, help='an alternative build of the library (kernel A/B experiments)')
+    ap.add_argument('--no-lookahead', action='store_true', help='the plain call path (two batch-B generator passes per iteration) instead of the programs bench.py replays')
     args = ap.parse_args()
     if args.lib:
         from action_conditioned_gans_amd import _lib
@@ -37,9 +38,17 @@ def main():
     a, s = rng.standard_normal((B, 10)).astype(np.float32), rng.standard_normal((B, 5)).astype(np.float32)
     import ctypes
     rows = []
-    for tag, fetch, feed in (('D', [tr.d_opt_op, tr.clip_d], tr._feed(x, y, a, np.zeros((B, 5), np.float32))),
-                             ('G', [tr.g_opt_op, tr.g_next_frame], tr._feed(x, y, a, s))):
-        sess.run(fetch, feed)
+    fd_d, fd_g = tr._feed(x, y, a, np.zeros((B, 5), np.float32)), tr._feed(x, y, a, s)
+    progs = (('D', [tr.d_opt_op, tr.clip_d], fd_d, None), ('G', [tr.g_opt_op, tr.g_next_frame], fd_g, None))
+    if tr.lookahead and not args.no_lookahead:
+        # the programs of the bench's step: the D step that carries the generator pass for both sub-steps (batch 2 B), the G
+        # step that starts behind it
+        pair_x, pair_a = np.concatenate([x, x]), np.concatenate([a, a])
+        fd_la = dict(fd_d)
+        fd_la.update({tr.pair_img_ph: pair_x, tr._pair_img_pad: pair_x, tr.pair_action_ph: pair_a})
+        progs = (('D', [tr.d_opt_op, tr.clip_d, tr._pair_concat], fd_la, tr._skip_d), ('G', [tr.g_opt_op, tr.g_next_frame], fd_g, tr._skip_g))
+    for tag, fetch, feed, skip in progs:
+        sess.run(fetch, feed, skip=skip)
         key = [k for k in sess._programs][-1]
         prog = sess._programs[key]
         for kind, seg in prog.segments:

@@ -1103,6 +1103,25 @@ class SliceOp(G.Op):
         return lambda s: fn(*args, s)
 
 
+class CopyRowsOp(G.Op):
+    """dst <- src, two equally shaped [.., C] tensors of one storage type (acg_slice_channels over all C channels).  The
+    look-ahead G step moves the generated frames the pair generator pass parked in the spare rows of the discriminator-input
+    buffer to where D(fake) reads them (train.Trainer): a 4 MB copy instead of a second DNA launch.  ``dst`` keeps its
+    producer: this op is fetched explicitly by the one program that wants it."""
+
+    def __init__(self, src, dst, name):
+        if src.shape != dst.shape or src.dtype != dst.dtype:
+            raise ValueError('copy_rows: %r vs %r' % (src, dst))
+        super().__init__(G.get_default_graph(), name, [src], [dst])
+
+    def bind(self, rt):
+        src, dst = self.inputs[0], self.outputs[0]
+        cs = src.shape[-1]
+        args = (_p(src.buf), _p(dst.buf), 0.0, src.numel // cs, cs, 0, cs, _code2(src, dst))
+        fn = rt.lib.slice_channels
+        return lambda s: fn(*args, s)
+
+
 class AddOp(G.Op):
     def __init__(self, a, b, name='grad_add'):
         if a.numel != b.numel or a.dtype != b.dtype:

@@ -93,6 +93,35 @@ def read_records(path, verify_crc=False):
             yield data
 
 
+def record_spans(path):
+    """(offset, length) of every record's payload, from the framing alone (12-byte headers; the payloads are skipped, not read):
+    what a worker process needs to fetch its record itself."""
+    size = os.path.getsize(path)
+    with open(path, 'rb') as f:
+        pos = 0
+        while pos < size:
+            head = f.read(8)
+            if len(head) < 8:
+                raise IOError('%s: truncated record header' % path)
+            (length,) = struct.unpack('<Q', head)
+            if pos + 12 + length + 4 > size:
+                raise IOError('%s: truncated record' % path)
+            yield pos + 12, length
+            pos += 12 + length + 4
+            f.seek(pos)
+
+
+def _decode_span(span, use_state=True, img_size=IMG_HEIGHT):
+    """Worker-process task: read one record's bytes from its file and decode it."""
+    path, offset, length = span
+    with open(path, 'rb') as f:
+        f.seek(offset)
+        data = f.read(length)
+    if len(data) < length:
+        raise IOError('%s: truncated record' % path)
+    return decode_example(data, use_state, img_size)
+
+
 def write_records(path, payloads):
     with open(path, 'wb') as f:
         for data in payloads:
@@ -409,18 +438,26 @@ class PushDataset:
         self._prefetch = None
         if self.num_threads > 0:
             import functools
-            task = functools.partial(decode_example, use_state=self.use_state, img_size=self.img_size)      # picklable
+            # worker processes fetch their record from the file themselves (the feeder walks the 12-byte frame headers only): the
+            # payload bytes - 0.5-2 MB per push record - never pass through this process or a pipe
+            spans = workers == 'process' and not verify_crc
+            if spans:
+                self._stream = self._records(spans=True)
+            task = functools.partial(_decode_span if spans else decode_example, use_state=self.use_state, img_size=self.img_size)      # picklable
             self._prefetch = _Prefetcher(self._stream, task, self.num_threads, self.capacity, processes=workers == 'process')
 
-    def _records(self):
+    def _records(self, spans=False):
+        """The record stream of this rank: payload bytes, or (``spans``) (path, offset, length) triples for workers that read
+        their record themselves - same files, same order."""
         n = 0
         while True:
             seen = False
             for k in self.rng.permutation(len(self.files)):
-                for rec in read_records(self.files[k], self.verify_crc):
+                path = self.files[k]
+                for rec in (record_spans(path) if spans else read_records(path, self.verify_crc)):
                     seen = True
                     if n % self.world_size == self.rank:
-                        yield rec
+                        yield (path,) + rec if spans else rec
                     n += 1
             if not seen:
                 raise RuntimeError('the data files hold no records')

@@ -74,6 +74,7 @@ class Trainer:
         n1 = len(graph.ops)
         self.g_next_frame = self.g_out
         self.pair_img_ph = self.pair_action_ph = self._g_pair_out = None
+        self._stash_copy, self._g_extra = None, []
         if self.lookahead:
             # the pair instance: rows [0, B) = the samples of the G step that follows, rows [B, 2 B) = this D step's samples
             self.pair_img_ph = G.placeholder((2 * B, S, S, 3), name='frame_pair')
@@ -103,9 +104,14 @@ class Trainer:
             d_in_both = win(1, 2 * B, 'd_in_both:0')
             O.JoinOp([d_in_gen, d_in_real], d_in_both, 'd_in_both')
             d_in_both.valid_c = d_in_gen.valid_c
+            self._stash_copy = None
             if self.lookahead:
                 self._pair_concat = O.concat([self.pair_img_ph, self._g_pair_out], axis=3, name='d_in_pair', out=win(0, 2 * B, 'd_in_all/pair'),
                                              pitch=8, act=True).op
+                if self._pair_concat.by_producer:
+                    # the pair's DNA kernel writes whole discriminator-input pixels into rows [0, 2 B): the G step's own frames sit
+                    # in the spare rows [0, B) afterwards, and the G step moves them to rows [B, 2 B) with one copy
+                    self._stash_copy = O.CopyRowsOp(win(0, B, 'd_in_all/spare'), win(1, B, 'd_in_all/gen_copy'), 'd_in_gen/from_pair')
         else:
             d_in_gen = O.concat([self.img_ph, self.g_next_frame], axis=3, name='d_in_gen', pitch=8, act=True)
             d_in_real = O.concat([self.img_ph, self.next_frame_ph], axis=3, name='d_in_real', pitch=8, act=True)
@@ -164,11 +170,14 @@ class Trainer:
         self._skip_d = self._skip_g = None
         if self.lookahead:
             # what the pair pass replaces.  D step: the whole batch-B generator and the launch that puts its frame into D's input.
-            # G step: the generator up to the frame - except an op that ALSO writes the frame into D(fake)'s input (the DNA gather,
-            # ops.DnaOp.second): that one runs again on the logits the pair pass left (the spare rows took its copy in the D step)
+            # G step: the generator up to and including the frame (an alias of the pair's first half) and, where the DNA kernel
+            # wrote the discriminator-input pixels too, the concatenation: those pixels are copied over from the spare rows
             trunk = _ancestors(self.g_out, set(map(id, self._g_ops)))
             self._skip_d = frozenset(trunk + [d_in_gen.op])
-            self._skip_g = frozenset(o for o in trunk if not (isinstance(o, O.DnaOp) and o.second is not None))
+            if self._stash_copy is not None:        # DNA generator: the frame AND its copy in D(fake)'s input exist already (one 4 MB copy)
+                self._skip_g, self._g_extra = frozenset(trunk + [d_in_gen.op]), [self._stash_copy]
+            else:                                   # plain generator: its concat launch puts the (aliased) frame into D(fake)'s input as usual
+                self._skip_g, self._g_extra = frozenset(trunk), []
 
     # ---- steps: one sess.run each (train.py:114-155)
     def _feed(self, input_images, next_frame, actions, state=None):
@@ -184,9 +193,12 @@ class Trainer:
         # the generator forward pass of these very inputs was run by the preceding train_d(..., next_g=(input_images, actions)):
         # the program then starts behind it (Session.run skip=)
         prepared, self._announced = self._announced, None
-        skip = self._skip_g if (prepared is not None and prepared[0] is input_images and prepared[1] is actions) else None
+        if prepared is not None and prepared[0] is input_images and prepared[1] is actions:
+            res = self.sess.run([self.g_opt_op, self.g_next_frame] + self._g_extra, self._feed(input_images, next_frame, actions, state),
+                                device_fetch=device_fetch, skip=self._skip_g)
+            return res[1]
         _, gen_next_frames = self.sess.run([self.g_opt_op, self.g_next_frame],
-                                           self._feed(input_images, next_frame, actions, state), device_fetch=device_fetch, skip=skip)
+                                           self._feed(input_images, next_frame, actions, state), device_fetch=device_fetch)
         return gen_next_frames
 
     def train_d(self, input_images, next_frame, actions, summarize=False, next_g=None, pair=None):

@@ -315,7 +315,7 @@ def main():
             fd_la = dict(fd_d)
             fd_la.update({tr.pair_img_ph: pair0[0], tr._pair_img_pad: pair0[0], tr.pair_action_ph: pair0[1]})
             recs += sess.profile_ops([tr.d_opt_op, tr.clip_d, tr._pair_concat], fd_la, repeats=args.profile_repeats, relaunch=relaunch, skip=tr._skip_d)
-            recs += sess.profile_ops([tr.g_opt_op, tr.g_next_frame], fd_g, repeats=args.profile_repeats, relaunch=relaunch, skip=tr._skip_g)
+            recs += sess.profile_ops([tr.g_opt_op, tr.g_next_frame] + tr._g_extra, fd_g, repeats=args.profile_repeats, relaunch=relaunch, skip=tr._skip_g)
         else:
             recs += sess.profile_ops([tr.d_opt_op, tr.clip_d], fd_d, repeats=args.profile_repeats, relaunch=relaunch) * n_critic
             recs += sess.profile_ops([tr.g_opt_op, tr.g_next_frame], fd_g, repeats=args.profile_repeats, relaunch=relaunch)

@@ -41,6 +41,8 @@ def test_record_framing_and_corruption(tmp_path):
     payloads = [b'', b'x', os.urandom(1000)]
     P.write_records(path, payloads)
     assert list(P.read_records(path, verify_crc=True)) == payloads
+    raw0 = open(path, 'rb').read()
+    assert [raw0[o:o + n] for o, n in P.record_spans(path)] == payloads          # the spans worker processes fetch their records by
     raw = bytearray(open(path, 'rb').read())
     raw[-10] ^= 0x40                                     # flip a bit inside the last payload
     open(path, 'wb').write(raw)

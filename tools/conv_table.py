@@ -46,7 +46,7 @@ def main():
         pair_x, pair_a = np.concatenate([x, x]), np.concatenate([a, a])
         fd_la = dict(fd_d)
         fd_la.update({tr.pair_img_ph: pair_x, tr._pair_img_pad: pair_x, tr.pair_action_ph: pair_a})
-        progs = (('D', [tr.d_opt_op, tr.clip_d, tr._pair_concat], fd_la, tr._skip_d), ('G', [tr.g_opt_op, tr.g_next_frame], fd_g, tr._skip_g))
+        progs = (('D', [tr.d_opt_op, tr.clip_d, tr._pair_concat], fd_la, tr._skip_d), ('G', [tr.g_opt_op, tr.g_next_frame] + tr._g_extra, fd_g, tr._skip_g))
     for tag, fetch, feed, skip in progs:
         sess.run(fetch, feed, skip=skip)
         key = [k for k in sess._programs][-1]

@@ -718,6 +718,7 @@ class Session:
         feed alias whose destination the program reads (concatenations written by the feed, tiled action channels).
         Device-resident float32 feeds go through ONE acg_copy_many launch.  Used by run() and profile_ops()."""
         fused = []
+        uploaded = {}          # id(host value) -> its device copy: one upload per fed ARRAY, however many placeholders take it
         for ph, val in feed_dict.items():
             targets = ([(ph, 0, None)] if id(ph) in prog.used_feeds else []) + prog.alias_copies.get(id(ph), [])
             if not targets:
@@ -730,8 +731,12 @@ class Session:
             if self.rt.is_cuda and not src.is_cuda and src.dtype in (torch.float32, torch.float64):
                 # host arrays (the reference's numpy feed_dict): ONE contiguous upload per fed value, then the same fused
                 # device copy as device-resident feeds - a feed may have several destinations (feed aliases), and strided
-                # host -> device copies of each of them cost milliseconds
-                src = src.to(self.rt.device, dtype=torch.float32, non_blocking=True)
+                # host -> device copies of each of them cost milliseconds.  The Trainer feeds the same frames to two
+                # placeholders (the dense one and the channel-padded one the first conv gathers): uploaded once (round 5)
+                dev = uploaded.get(id(val))
+                if dev is None:
+                    dev = uploaded[id(val)] = src.to(self.rt.device, dtype=torch.float32, non_blocking=True)
+                src = dev
             dst = ph.buf if ph.valid_c is None else ph.buf[..., :ph.valid_c]     # pad channels stay zero
             if tuple(src.shape) != tuple(dst.shape):
                 raise ValueError('Cannot feed value of shape %s for %r' % (tuple(src.shape), ph))

@@ -201,22 +201,29 @@ class Trainer:
                                            self._feed(input_images, next_frame, actions, state), device_fetch=device_fetch)
         return gen_next_frames
 
-    def train_d(self, input_images, next_frame, actions, summarize=False, next_g=None, pair=None):
-        """One discriminator step (train.py:132-144).  ``next_g`` = (input_images, actions) of the ``train_g`` call that follows
-        (extension, see __init__ ``lookahead``): this step's generator pass then also covers that step's samples.  ``pair`` = the
-        two batches already joined, (frames [2 B, H, W, 3], actions [2 B, 10]) with the G step's samples FIRST - saves the
-        concatenation here when the caller keeps its batches that way."""
-        self._announced = None
+    def train_d(self, input_images, next_frame, actions, summarize=False, next_g=None, pair=None, next_d=None):
+        """One discriminator step (train.py:132-144).  ``next_g`` / ``next_d`` = (input_images, actions) of the ``train_g`` /
+        ``train_d`` call that follows (extension, see __init__ ``lookahead``): this step's generator pass then also covers that
+        step's samples, and that step starts behind its generator forward pass (with n_critic > 1 the D steps alternate: one runs
+        the pair pass for itself and its successor, the next runs no generator at all).  ``pair`` = the two batches already
+        joined, (frames [2 B, H, W, 3], actions [2 B, 10]) with the FOLLOWING step's samples first - saves the concatenation
+        here when the caller keeps its batches that way."""
+        prepared, self._announced = self._announced, None
         fd = self._feed(input_images, next_frame, actions)
         if summarize:
             _, summ, _ = self.sess.run([self.d_opt_op, self.merged_summaries, self.clip_d], fd)
             return self._named(summ)
-        if next_g is not None and self.lookahead:
+        if prepared is not None and prepared[0] is input_images and prepared[1] is actions:
+            # the preceding D step ran the generator for these samples: their frames wait in the spare rows
+            self.sess.run([self.d_opt_op, self.clip_d] + self._g_extra, fd, skip=self._skip_g)
+            return None
+        nxt = next_g if next_g is not None else next_d
+        if nxt is not None and self.lookahead:
             if pair is None:
-                pair = (_join(next_g[0], input_images), _join(next_g[1], actions))
+                pair = (_join(nxt[0], input_images), _join(nxt[1], actions))
             fd.update({self.pair_img_ph: pair[0], self._pair_img_pad: pair[0], self.pair_action_ph: pair[1]})
             self.sess.run([self.d_opt_op, self.clip_d, self._pair_concat], fd, skip=self._skip_d)
-            self._announced = (next_g[0], next_g[1])
+            self._announced = (nxt[0], nxt[1])
             return None
         self.sess.run([self.d_opt_op, self.clip_d], fd)
         return None
@@ -399,20 +406,30 @@ def _train_loop(sess, data, input_path, synthetic, boolean_mask, log_dir, model_
             if not quiet:
                 print('pre-train iter: ' + str(i))
             continue
-        summ = None
+        # The iteration's sub-steps, drawn up front in the reference's order (train.py:241-259: per D step a fresh batch and a
+        # fresh frame-pair selection, then a NEW selection on the last batch for the G step; the steps themselves draw nothing),
+        # so that a step can announce its successor's inputs to Trainer.train_d (look-ahead generator pass): D1 runs the
+        # generator for D1 and D2, D2 runs none, ... the last pair pass covers the G step.  Logging iterations keep the plain path
+        # for their last D step (its summaries read that step's own generated frames).
+        subs = []
         for j in range(D_per_G):
             inp, nxt, acts, states = data.get_batch()
             sm, em = select_pairs(np.random.randint, boolean_mask, batch_size)
+            subs.append((inp[sm], nxt[em], acts[sm]))
+        smg, emg = select_pairs(np.random.randint, boolean_mask, batch_size)
+        g_in, g_act = inp[smg], acts[smg]
+        summ, carried = None, False
+        for j, (x_d, y_d, a_d) in enumerate(subs):
             last = j == D_per_G - 1
-            if last:
-                # the G step's frame pairs, drawn here instead of behind the D step: same order of np.random calls as
-                # train.py:249-258 (the D step draws nothing), and the last D step can then run the generator for both
-                # (Trainer.train_d next_g; the logging iterations keep the plain path: their summaries read the D step's own frames)
-                smg, emg = select_pairs(np.random.randint, boolean_mask, batch_size)
-                g_in, g_act = inp[smg], acts[smg]
             summarize = (i % log_every == 0) and last
-            summ = trainer.train_d(inp[sm], nxt[em], acts[sm], summarize=summarize, next_g=(g_in, g_act) if (last and not summarize) else None)
-        trainer.train_g(g_in, nxt[emg], g_act, states[emg])
+            follow = None
+            if not carried and not summarize:                    # this step runs the pair pass for itself and its successor
+                follow = (g_in, g_act) if last else ((subs[j + 1][0], subs[j + 1][2]) if not ((i % log_every == 0) and j + 1 == D_per_G - 1) else None)
+            summ = trainer.train_d(x_d, y_d, a_d, summarize=summarize, next_d=follow)
+            carried = follow is not None and not carried
+        # (the generated frames stay on the device: the reference fetches them every step only to dump samples at i % 100 == 0,
+        # train.py:130,269-273, which this loop does not do - no D2H copy, no synchronisation per iteration)
+        trainer.train_g(g_in, nxt[emg], g_act, states[emg], device_fetch=True)
         if i % log_every == 0:
             # the fetches above synchronised anyway: look at the device-side flags of the one-launch BatchNorm kernels HERE, on
             # every rank, so that a step that ran on wrong statistics fails now - before anything of it is logged or

@@ -198,18 +198,33 @@ def main():
         # the joined inputs of the look-ahead generator pass (G step's samples first: Trainer.train_d `pair`), built once -
         # inputs are resident in HBM before the timed region starts
         pair = (torch.cat([g_in[0], d_in[0]]), torch.cat([g_in[2], d_in[2]])) if lookahead else None
-        pool.append((d_in, g_in, pair))
+        pool.append([d_in, g_in, pair, None])
+    if lookahead and n_critic > 1:      # D step k followed by D step k + 1 (pool order): [successor's samples ; own samples]
+        for k, e in enumerate(pool):
+            nxt = pool[(k + 1) % len(pool)][0]
+            e[3] = (torch.cat([nxt[0], e[0][0]]), torch.cat([nxt[2], e[0][2]]))
     torch.cuda.synchronize()
 
     def step(i, use_lookahead=lookahead):
+        # The sub-steps pair up for the look-ahead generator pass: (D1 -> D2), (D3 -> D4), ..., and the last D step with the G
+        # step when it is not already the second of a pair: the first of a pair runs the generator once for both (batch 2 B),
+        # the second runs none (Trainer.train_d next_d / next_g).
+        carried = False
         for j in range(n_critic):
-            d_in, g_in, pair = pool[(i * n_critic + j) % len(pool)]
+            k = (i * n_critic + j) % len(pool)
+            d_in, g_in, pair_g, pair_d = pool[k]
             last = j == n_critic - 1
-            if last and use_lookahead:      # the last D step runs the generator for its own samples and for the G step's
-                tr.train_d(*d_in, next_g=(g_in[0], g_in[2]), pair=pair)
+            if use_lookahead and not carried:
+                if last:
+                    tr.train_d(*d_in, next_g=(g_in[0], g_in[2]), pair=pair_g)
+                else:
+                    nxt = pool[(k + 1) % len(pool)][0]
+                    tr.train_d(*d_in, next_d=(nxt[0], nxt[2]), pair=pair_d)
+                carried = True
             else:
                 tr.train_d(*d_in)
-        return tr.train_g(*g_in, device_fetch=True)
+                carried = False
+        return tr.train_g(*pool[(i * n_critic + n_critic - 1) % len(pool)][1], device_fetch=True)
 
     def barrier():
         if world > 1:
@@ -301,7 +316,7 @@ def main():
     # EVERY rank runs the instrumented pass: with world > 1 the programs contain gradient all-reduces, and a
     # collective issued by rank 0 alone would never complete.  Only rank 0 reports.
     if not args.trace_run:
-        d_in0, g_in0, pair0 = pool[0]
+        d_in0, g_in0, pair0, _ = pool[0]
         zero_state = torch.zeros(B, 5, device=device)
         recs = []
         # conv and DNA launches are idempotent: timed as launches inside a small captured HIP graph (graph.profile_ops) - each
@@ -311,11 +326,18 @@ def main():
         if lookahead:
             # the programs the timed step replays: plain D steps, then the D step that carries the look-ahead generator pass
             # (batch 2 B), then the G step that starts behind it
-            recs += sess.profile_ops([tr.d_opt_op, tr.clip_d], fd_d, repeats=args.profile_repeats, relaunch=relaunch) * (n_critic - 1)
             fd_la = dict(fd_d)
             fd_la.update({tr.pair_img_ph: pair0[0], tr._pair_img_pad: pair0[0], tr.pair_action_ph: pair0[1]})
-            recs += sess.profile_ops([tr.d_opt_op, tr.clip_d, tr._pair_concat], fd_la, repeats=args.profile_repeats, relaunch=relaunch, skip=tr._skip_d)
-            recs += sess.profile_ops([tr.g_opt_op, tr.g_next_frame] + tr._g_extra, fd_g, repeats=args.profile_repeats, relaunch=relaunch, skip=tr._skip_g)
+            heavy = sess.profile_ops([tr.d_opt_op, tr.clip_d, tr._pair_concat], fd_la, repeats=args.profile_repeats, relaunch=relaunch, skip=tr._skip_d)
+            n_pairs_dd = n_critic // 2                       # (D1 -> D2), (D3 -> D4), ...: a pair-pass D step and a D step without generator
+            recs += heavy * n_pairs_dd
+            if n_pairs_dd:
+                recs += sess.profile_ops([tr.d_opt_op, tr.clip_d] + tr._g_extra, fd_d, repeats=args.profile_repeats, relaunch=relaunch, skip=tr._skip_g) * n_pairs_dd
+            if n_critic % 2:                                  # the last D step pairs with the G step
+                recs += heavy
+                recs += sess.profile_ops([tr.g_opt_op, tr.g_next_frame] + tr._g_extra, fd_g, repeats=args.profile_repeats, relaunch=relaunch, skip=tr._skip_g)
+            else:
+                recs += sess.profile_ops([tr.g_opt_op, tr.g_next_frame], fd_g, repeats=args.profile_repeats, relaunch=relaunch)
         else:
             recs += sess.profile_ops([tr.d_opt_op, tr.clip_d], fd_d, repeats=args.profile_repeats, relaunch=relaunch) * n_critic
             recs += sess.profile_ops([tr.g_opt_op, tr.g_next_frame], fd_g, repeats=args.profile_repeats, relaunch=relaunch)

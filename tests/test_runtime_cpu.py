@@ -504,3 +504,39 @@ def test_lookahead_generator_pass_matches_the_plain_call_path(dna):
     # a logging D step (summaries read the D step's OWN generated frames) keeps the plain path even when asked
     summ = tr.train_d(x, y, a, summarize=True, next_g=(x2, a2))
     assert summ is not None and tr._announced is None
+
+
+def test_lookahead_pairs_successive_discriminator_steps():
+    """n_critic > 1 (train.py:217-220: five D steps per G step under --loss wass): a D step can announce the NEXT D step's inputs
+    (train_d next_d=) - it then runs the generator once for both, and the announced step runs no generator at all (its frames
+    wait in the spare rows of the discriminator-input buffer).  Three D steps + one G step, paired (D1 -> D2), (D3 -> G), against
+    the plain call path: frames and weights equal to rounding after two iterations; three programs (pair-pass D, generator-free
+    D, generator-free G) instead of two."""
+    rng = np.random.default_rng(0)
+    B = 2
+    mk = lambda: (rng.uniform(-1, 1, (B, 64, 64, 3)).astype(np.float32), rng.uniform(-1, 1, (B, 64, 64, 3)).astype(np.float32),     # noqa: E731
+                  rng.standard_normal((B, 10)).astype(np.float32))
+    ds, g = [mk() for _ in range(3)], mk() + (rng.standard_normal((B, 5)).astype(np.float32),)
+
+    def run(use):
+        G.reset_default_graph()
+        sess = cpu_session()
+        tr = T.Trainer(sess, True, 'wass', 'rmsprop', True, batch_size=B, ksize=5)
+        sess.run(G.global_variables_initializer())
+        for _ in range(2):
+            carried = False
+            for j, (x, y, a) in enumerate(ds):
+                if use and not carried:
+                    tr.train_d(x, y, a, next_d=(g[0], g[2]) if j == len(ds) - 1 else (ds[j + 1][0], ds[j + 1][2]))
+                    carried = True
+                else:
+                    tr.train_d(x, y, a)
+                    carried = False
+            frames = tr.train_g(*g)
+        return frames, {n: sess.get_value(v) for n, v in G.get_default_graph().variables.items()}, len(sess._programs)
+    f0, w0, n0 = run(False)
+    f1, w1, n1 = run(True)
+    assert (n0, n1) == (2, 3)
+    assert np.abs(f1 - f0).max() <= 1e-5 * np.abs(f0).max()
+    for n in w0:
+        assert float((w1[n] - w0[n]).abs().max()) <= 1e-6 * max(float(w0[n].abs().max()), 1e-3), n

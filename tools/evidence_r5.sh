@@ -57,16 +57,5 @@ python3 bench.py $W_F32 > $OUT/d_bench_f32_config2.json 2>$OUT/bench_err.txt
 python3 bench.py $W_C3 > $OUT/d_bench_bf16_config3_b32.json 2>>$OUT/bench_err.txt
 python3 bench.py $W_C5 > $OUT/d_bench_bf16_config5_geometry.json 2>>$OUT/bench_err.txt
 echo bench done
-python3 tools/conv_table.py > $OUT/h_conv_table_f32_config2.txt 2>/dev/null
-python3 tools/conv_table.py --other > $OUT/h_other_ops_f32_config2.txt 2>/dev/null
-python3 tools/conv_table.py --dtype bf16 > $OUT/h_conv_table_bf16_config3.txt 2>/dev/null
-python3 tools/conv_table.py --dtype bf16 --other > $OUT/h_other_ops_bf16_config3.txt 2>/dev/null
-python3 tools/conv_table.py --dtype bf16 --img 128 --ksize 11 > $OUT/h_conv_table_bf16_config5.txt 2>/dev/null
-python3 tools/conv_table.py --dtype bf16 --img 128 --ksize 11 --other > $OUT/h_other_ops_bf16_config5.txt 2>/dev/null
-echo tables done
-( for flags in "--loss wass --opt rmsprop" "--loss wass --opt rmsprop --dtype bf16" "--img 128 --ksize 11 --seq_len 16 --steps 10" "--plain" "--plain --dtype bf16" "--batch 64" "--dtype bf16 --batch 256 --steps 10"; do
-    echo "== bench.py $flags"; python3 bench.py --no-cpu-baseline $flags 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'steps/s', d['ms_per_step'], 'ms/step  conv', d['roofline']['achieved'], 'TFLOP/s (', d['roofline']['timing'][:12], ') dna', (d['roofline_dna'] or {}).get('frac'), '|', d['config']['workload'])"
-  done ) > $OUT/q_other_configs.txt 2>&1
-echo other configs done
 rm -rf $OUT/prof_*/ $OUT/pmc_*/ $OUT/l2_*/
 ls $OUT | head -60

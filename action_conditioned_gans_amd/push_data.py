@@ -293,10 +293,15 @@ def resize_area(img, oh, ow):
 def decode_frame(jpeg_bytes, img_size=IMG_HEIGHT):
     """ops.py:184-196: decode (3 channels), centre-crop to the short side, area-resize, scale to [-1, 1]."""
     from PIL import Image
-    img = np.asarray(Image.open(io.BytesIO(jpeg_bytes)).convert('RGB'))
-    crop = min(img.shape[0], img.shape[1])
-    img = crop_or_pad_center(img, crop, crop)
-    return resize_area(img, img_size, img_size) / np.float32(255.0 / 2.0) - np.float32(1.0)
+    im = Image.open(io.BytesIO(jpeg_bytes))
+    if im.mode != 'RGB':
+        im = im.convert('RGB')                      # decode_jpeg(channels=3); an RGB file needs no second copy
+    w, h = im.size
+    crop = min(w, h)
+    if w > crop or h > crop:                        # the centred crop of crop_or_pad_center (same offsets), taken before the pixels
+        left, top = (w - crop) // 2, (h - crop) // 2    # become an array: the array is then contiguous and a fifth smaller
+        im = im.crop((left, top, left + crop, top + crop))
+    return resize_area(np.asarray(im), img_size, img_size) / np.float32(255.0 / 2.0) - np.float32(1.0)
 
 
 def decode_example(buf, use_state=True, img_size=IMG_HEIGHT):

@@ -86,14 +86,19 @@ def parse():
     return ap.parse_args()
 
 
+_FINGERPRINT = []
+
+
 def lib_fingerprint():
     """(ABI version, first 16 hex digits of the SHA-256 of the loaded libacgan_hip.so): what a committed in-situ profile must
     have been taken with to stand in for this process's kernels."""
-    import hashlib
-    from action_conditioned_gans_amd import _lib
-    lib = _lib.get()
-    with open(lib.path, 'rb') as f:
-        return int(lib.version()), hashlib.sha256(f.read()).hexdigest()[:16]
+    if not _FINGERPRINT:
+        import hashlib
+        from action_conditioned_gans_amd import _lib
+        lib = _lib.get()
+        with open(lib.path, 'rb') as f:
+            _FINGERPRINT.append((int(lib.version()), hashlib.sha256(f.read()).hexdigest()[:16]))
+    return _FINGERPRINT[0]
 
 
 def conv_flops(op):

@@ -851,3 +851,50 @@ def test_lookahead_equals_the_plain_call_path_on_the_gpu(dtype, dna):
     if dtype == 'f32':
         _, flc, _ = run(False, slab_handoff=False)          # the control: same arithmetic, another summation order
         assert nrel(fl1, fl0) <= 3.0 * nrel(flc, fl0) + 1e-6, (nrel(fl1, fl0), nrel(flc, fl0))
+
+
+def test_lookahead_pairs_successive_discriminator_steps_on_the_gpu():
+    """n_critic = 3 under --loss wass on the GPU (float32, batch 8, RMSProp + clip): D steps paired (D1 -> D2), (D3 -> G) through
+    train_d(next_d=) against the plain call path - after ONE iteration (three D updates, one G update) the generated frames agree
+    to 1e-5 and the filters' update vectors to 2e-2; three more iterations run through capture and replay and stay finite.  Three
+    programs: the pair-pass D step, the generator-free D step, the generator-free G step."""
+    from action_conditioned_gans_amd import optim, train as T
+    rng = np.random.default_rng(5)
+    B = 8
+    mk = lambda: (rng.uniform(-1, 1, (B, 64, 64, 3)).astype(np.float32), rng.uniform(-1, 1, (B, 64, 64, 3)).astype(np.float32),     # noqa: E731
+                  rng.standard_normal((B, 10)).astype(np.float32))
+    ds, g_in = [mk() for _ in range(3)], mk() + (rng.standard_normal((B, 5)).astype(np.float32),)
+
+    def run(use):
+        G.reset_default_graph()
+        optim.set_data_parallel(1)
+        sess = gpu_session()
+        tr = T.Trainer(sess, True, 'wass', 'rmsprop', True, batch_size=B, ksize=5)
+        sess.run(G.global_variables_initializer())
+        first = None
+        for it in range(4):
+            carried = False
+            for j, (x, y, a) in enumerate(ds):
+                if use and not carried:
+                    tr.train_d(x, y, a, next_d=(g_in[0], g_in[2]) if j == len(ds) - 1 else (ds[j + 1][0], ds[j + 1][2]))
+                    carried = True
+                else:
+                    tr.train_d(x, y, a)
+                    carried = False
+            frames = tr.train_g(*g_in)
+            if it == 0:
+                first = (np.array(frames, copy=True), {n: sess.get_value(v) for n, v in G.get_default_graph().variables.items()})
+        init = {n: v.value.double() for n, v in G.get_default_graph().variables.items()}
+        nprog = len(sess._programs)
+        sess.close()
+        return first, frames, init, nprog
+    (f0, w0), fl0, init, n0 = run(False)
+    (f1, w1), fl1, _, n1 = run(True)
+    assert (n0, n1) == (2, 3)
+    assert float(np.linalg.norm(f1 - f0) / np.linalg.norm(f0)) <= 1e-5
+    for n in w0:
+        if n.endswith('weights') and n.startswith('g/'):      # (D's filters sit ON the clip bounds after a wass step: their "update" is the clip)
+            upd = (w0[n].double() - init[n]).norm().item()
+            assert (w1[n].double() - w0[n].double()).norm().item() <= 2e-2 * upd + 1e-9, (n, upd)
+        assert bool(torch.isfinite(w1[n]).all()), n
+    assert np.isfinite(fl1).all()

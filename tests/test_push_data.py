@@ -262,14 +262,19 @@ def test_committed_fixture_decodes_to_pinned_values():
 
 
 @pytest.mark.gpu
-def test_training_loop_reads_tfrecords(tmp_path):
-    """train() end to end from a directory of push TFRecords (2 iterations) on the GPU."""
+@pytest.mark.parametrize('workers', ['thread', 'process'])
+def test_training_loop_reads_tfrecords(tmp_path, workers):
+    """train() end to end from a directory of push TFRecords (a few iterations, a logging one among them) on the GPU, the records
+    decoded by worker threads / spawned worker processes; the returned Trainer's session is OPEN (round 5) and closes clean."""
     import torch
     from action_conditioned_gans_amd import train as T
     rng = np.random.default_rng(3)
     for k in range(2):
         make_shard(str(tmp_path / ('push_%02d.tfrecord' % k)), rng, 2)
-    tr = T.train(str(tmp_path), None, None, None, None, True, 'bce', 'adam', True, batch_size=2, train_iter=3,
-                 pretrain_iter=1, device='cuda:0', quiet=True, eval_every=2)
+    tr = T.train(str(tmp_path), None, None, None, None, True, 'bce', 'adam', True, batch_size=2, train_iter=4,
+                 pretrain_iter=1, device='cuda:0', quiet=True, eval_every=2, log_every=2, data_workers=workers, data_threads=2)
     for v in tr.g_vars + tr.d_vars:
         assert torch.isfinite(tr.sess.get_value(v)).all(), v.name
+    frames, _, _ = tr.test(np.zeros((2, 64, 64, 3), np.float32), np.zeros((2, 64, 64, 3), np.float32), np.zeros((2, 10), np.float32))
+    assert np.isfinite(frames).all()                  # the session still runs
+    tr.sess.close()                                   # device-side flags clean, transport torn down

@@ -3,7 +3,7 @@ Variants from the same weights / inputs, batch 8, float32, RMSProp: plain (refer
 another summation order (slab hand-off off), look-ahead with and without HIP graphs.  Per iteration: relative distance of the
 generated frames and of the G / D flat gradients to the reference run."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
 import train_cases as TC

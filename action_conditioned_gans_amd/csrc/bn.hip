@@ -569,6 +569,27 @@ struct FusedExchange {
     }
     __syncthreads();                              // red is reused by gather
   }
+  // a grid with ONE row block per (group, chunk) has nobody to exchange with: the block's own 64 sums straight into out[NV] (LDS) -
+  // no granule store, no polling round trip (round 5: the 2x2 ... 4x4 layers, whose whole tensor is one row block)
+  __device__ __forceinline__ void local(float (&s)[2 * V], float* out) {
+#pragma unroll
+    for (int j = 0; j < 2 * V; ++j) {
+#pragma unroll
+      for (int off = CL; off < 64; off <<= 1) s[j] += __shfl_xor(s[j], off, 64);
+    }
+    if (lane < CL) {
+#pragma unroll
+      for (int j = 0; j < 2 * V; ++j) red[wave][lane * 2 * V + j] = s[j];
+    }
+    __syncthreads();
+    if (tid < NV) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v += red[w][tid];
+      out[tid] = v;
+    }
+    __syncthreads();
+  }
   // sums over the nrb row blocks whose granules start at `base` ([row block][NV]) -> out[NV] (LDS); every thread of the block calls it
   __device__ __forceinline__ void gather(long long base, float* out) {
     const int n = nrb * NV;                       // granule i = row block * NV + value; thread t takes i = t, t + NT, ...: value t % NV
@@ -676,10 +697,14 @@ __global__ __launch_bounds__(NT) void bn_bwd_fused(const TX* __restrict__ x, con
   __syncthreads();                                // s_epoch
   EX ex{red, reinterpret_cast<unsigned long long*>(ws + 4), state, s_epoch, tid, tid & 63, tid >> 6, nrb};
   auto base_of = [&](int gg) { return (((long long)gg * gridDim.y + cc) * nrb) * NV; };      // granules [group][chunk][row block][NV]
-  ex.publish(s, base_of(g) + (long long)rb * NV);
-
-  // ---- phase 2: every row block's partial sums of this (group, chunk); the dbeta block also takes the other groups' ------------------
-  ex.gather(base_of(g), tot[0]);
+  const bool alone = nrb == 1 && groups == 1;       // (with several groups the dbeta block reads the other groups' granules)
+  if (alone) {
+    ex.local(s, tot[0]);
+  } else {
+    ex.publish(s, base_of(g) + (long long)rb * NV);
+    // ---- phase 2: every row block's partial sums of this (group, chunk); the dbeta block also takes the other groups' ----------------
+    ex.gather(base_of(g), tot[0]);
+  }
   if (rb == 0 && g == 0) {                        // dbeta of this chunk's channels: sum of s1 over every group, group 0 last
     float d[V];
 #pragma unroll
@@ -768,8 +793,12 @@ __global__ __launch_bounds__(NT) void bn_fwd_fused(TX* __restrict__ x, const flo
   __syncthreads();                                // s_epoch
   EX ex{red, reinterpret_cast<unsigned long long*>(ws + 4), state, s_epoch, tid, tid & 63, tid >> 6, nrb};
   const long long base = (((long long)g * gridDim.y + cc) * nrb) * NV;
-  ex.publish(s, base + (long long)rb * NV);
-  ex.gather(base, tot);
+  if (nrb == 1) {
+    ex.local(s, tot);
+  } else {
+    ex.publish(s, base + (long long)rb * NV);
+    ex.gather(base, tot);
+  }
   if (cvalid) {
     float mean[V], rstd[V];
 #pragma unroll
@@ -832,7 +861,7 @@ struct FusedShape { int nt, U; dim3 grid; };
 // the round-4 bound "one block per CU" alone, 131072 x 16 asked for 131 KB of granules in a 66 KB workspace - ADVICE r4).
 constexpr int kMaxFusedBlocks = 512;
 constexpr size_t kFusedExchangeBytes = (size_t)kMaxFusedBlocks * 512;
-FusedShape fused_shape(long long R, int C, int groups, bool no_grid = false) {
+FusedShape fused_shape(long long R, int C, int groups, bool no_grid = false, int splits = 0) {
   static const int ncu = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0; (void)hipGetLastError(); return n; }();
   static const int small_rb = env_int("ACG_BN_FUSED_SMALL_ROWBLOCKS", 16);       // tuning hook
   FusedShape f{0, 0, dim3(1, 1, 1)};
@@ -840,7 +869,12 @@ FusedShape fused_shape(long long R, int C, int groups, bool no_grid = false) {
   const long long cch = (C + 31) / 32;
   auto blocks = [&](int rows) { return acg::ceil_div(R, rows) * cch * groups; };
   const long long cap1 = std::min<long long>(ncu, kMaxFusedBlocks), cap2 = std::min<long long>(2ll * ncu, kMaxFusedBlocks);
-  if (acg::ceil_div(R, 128) <= small_rb && blocks(128) <= cap2) { f.nt = 256; f.U = 4; f.grid = dim3((unsigned)acg::ceil_div(R, 128), (unsigned)cch, (unsigned)groups); }
+  // Rows that arrive as `splits` split-K slabs cost a thread `splits` loads per row: the same 128 rows per block as 1024 threads x ONE
+  // row each (all of a thread's slab loads in flight at once) instead of 256 threads x four rows (four dependent batches) - round 5,
+  // the small split layers' BatchNorm was 7-9 us for tensors of 0.1-2 MB
+  static const int wide_slabs = env_int("ACG_BN_SLAB_WIDE", 1);                  // tuning hook
+  if (wide_slabs && splits >= 2 && acg::ceil_div(R, 128) <= small_rb && blocks(128) <= cap1) { f.nt = 1024; f.U = 1; f.grid = dim3((unsigned)acg::ceil_div(R, 128), (unsigned)cch, (unsigned)groups); }
+  else if (acg::ceil_div(R, 128) <= small_rb && blocks(128) <= cap2) { f.nt = 256; f.U = 4; f.grid = dim3((unsigned)acg::ceil_div(R, 128), (unsigned)cch, (unsigned)groups); }
   else if (blocks(512) <= cap1) { f.nt = 1024; f.U = 4; f.grid = dim3((unsigned)acg::ceil_div(R, 512), (unsigned)cch, (unsigned)groups); }
   else if (blocks(1024) <= cap1) { f.nt = 1024; f.U = 8; f.grid = dim3((unsigned)acg::ceil_div(R, 1024), (unsigned)cch, (unsigned)groups); }
   return f;
@@ -1253,11 +1287,11 @@ int bn_fwd_typed(const void* x, const float* beta, void* y, float* save_mean, fl
     // (slabs in the rows layout: the fused kernel also where the resident ones would apply - its rows are coalesced, theirs cost a
     // cache line per row and slab)
     const bool rows_slabs = sl.p != nullptr && sl.qrows == 0;
-    const FusedShape f = (fused_on_f && v4 && (rows_slabs || (!sl.p && (resident_nr(R, 32) == 0 || R >= fused_min_f)))) ? fused_shape(R, C, groups, no_grid) : FusedShape{0, 0, dim3(1, 1, 1)};
+    const FusedShape f = (fused_on_f && v4 && (rows_slabs || (!sl.p && (resident_nr(R, 32) == 0 || R >= fused_min_f)))) ? fused_shape(R, C, groups, no_grid, rows_slabs ? sl.splits : 0) : FusedShape{0, 0, dim3(1, 1, 1)};
     if (f.nt) {
 #define ACG_BN_FF(UU, NN) do { if (rows_slabs) ACG_LAUNCH((bn_fwd_fused<4, TX, TY, UU, NN, true>), f.grid, dim3(NN), 0, st, xf, beta, yf, save_mean, save_rstd, R, C, eps, act, leak, XP, YP, (unsigned*)part, sl); \
       else ACG_LAUNCH((bn_fwd_fused<4, TX, TY, UU, NN, false>), f.grid, dim3(NN), 0, st, xf, beta, yf, save_mean, save_rstd, R, C, eps, act, leak, XP, YP, (unsigned*)part, sl); } while (0)
-      if (f.nt == 256) ACG_BN_FF(4, 256); else if (f.U == 4) ACG_BN_FF(4, 1024); else ACG_BN_FF(8, 1024);
+      if (f.nt == 256) ACG_BN_FF(4, 256); else if (f.U == 1) ACG_BN_FF(1, 1024); else if (f.U == 4) ACG_BN_FF(4, 1024); else ACG_BN_FF(8, 1024);
 #undef ACG_BN_FF
       return acg::check_launch("bn_fwd_fused");
     }
@@ -1328,11 +1362,11 @@ int bn_bwd_typed(const void* x, const void* dy, const float* beta, const float* 
   // resident at one block of 1024 threads per CU
   if constexpr (same) {
     static const int fused_on = env_int("ACG_BN_FUSED_BWD", 1);     // tuning hook
-    const FusedShape f = (fused_on && v4 && (!sl.p || rows_slabs_b)) ? fused_shape(R, C, groups, no_grid) : FusedShape{0, 0, dim3(1, 1, 1)};
+    const FusedShape f = (fused_on && v4 && (!sl.p || rows_slabs_b)) ? fused_shape(R, C, groups, no_grid, rows_slabs_b ? sl.splits : 0) : FusedShape{0, 0, dim3(1, 1, 1)};
     if (f.nt) {
 #define ACG_BN_FB(UU, NN) do { if (rows_slabs_b) ACG_LAUNCH((bn_bwd_fused<4, TX, TY, TD, UU, NN, true>), f.grid, dim3(NN), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, R, C, groups, act, leak, XP, YP, (unsigned*)part, sl); \
       else ACG_LAUNCH((bn_bwd_fused<4, TX, TY, TD, UU, NN, false>), f.grid, dim3(NN), 0, st, xf, dyf, beta, save_mean, save_rstd, dxf, dbeta, dbeta_acc, R, C, groups, act, leak, XP, YP, (unsigned*)part, sl); } while (0)
-      if (f.nt == 256) ACG_BN_FB(4, 256); else if (f.U == 4) ACG_BN_FB(4, 1024); else ACG_BN_FB(8, 1024);
+      if (f.nt == 256) ACG_BN_FB(4, 256); else if (f.U == 1) ACG_BN_FB(1, 1024); else if (f.U == 4) ACG_BN_FB(4, 1024); else ACG_BN_FB(8, 1024);
 #undef ACG_BN_FB
       return acg::check_launch("bn_bwd_fused");
     }

@@ -31,7 +31,7 @@ def _flat(t):
     return t.buf.detach().clone().cpu().numpy()
 
 
-def _worker(rank, world, port, outdir, collectives='stream'):
+def _worker(rank, world, port, outdir, collectives='stream', lookahead=False):
     for p in (ROOT, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -45,7 +45,7 @@ def _worker(rank, world, port, outdir, collectives='stream'):
                                 CASE, world_size=world, collectives=collectives)
     x, y, a, s = _inputs(rank)
     out = {'d_param0': _flat(tr.d_opt_op.inputs[0])}
-    tr.train_d(x, y, a)
+    tr.train_d(x, y, a, next_g=(x, a) if lookahead else None)     # look-ahead: this step's generator pass covers the G step's samples too
     out['d_grad'] = _flat(tr.d_opt_op.inputs[1])
     out['d_param1'] = _flat(tr.d_opt_op.inputs[0])
     tr.train_g(x, y, a, s)
@@ -57,7 +57,10 @@ def _worker(rank, world, port, outdir, collectives='stream'):
         segs = [k for k, _ in sess._programs[next(iter(sess._programs))].segments]
         out['n_host_segments'] = np.array(segs.count('host'))
         out['eager'] = np.array(int(sess._programs[next(iter(sess._programs))].eager))
-    np.savez(os.path.join(outdir, 'w%d_r%d.npz' % (world, rank)), **out)
+    if lookahead:
+        out['n_programs'] = np.array(len(sess._programs))
+        out['skipped'] = np.array(sum(1 for p in sess._programs.values() if getattr(p, 'skip_ref', None)))
+    np.savez(os.path.join(outdir, 'w%d_r%d%s.npz' % (world, rank, '_la' if lookahead else '')), **out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -102,6 +105,25 @@ def test_two_rank_allreduce_matches_mean_gradient_update(collectives):
         assert int(dp[0]['n_allreduce']) >= 4
     else:                              # one message per optimizer: D, G (and G pre-training)
         assert 2 <= int(dp[0]['n_allreduce']) <= 3
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_lookahead_step_matches_the_plain_data_parallel_step():
+    """Data parallel + the look-ahead generator pass (round 5): the pair pass is rank-local forward work, the bucketed all-reduces
+    sit where they sat.  Two gloo ranks, side-stream buckets: the reduced gradient buffers and the updated parameters of the
+    look-ahead step equal those of the plain two-rank step to rounding, the replicas stay bit-identical, and both programs of the
+    look-ahead step were compiled with a skip set."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, _free_port(), d, 'side', False), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, _free_port(), d, 'side', True), nprocs=2, join=True)
+        plain = [dict(np.load(os.path.join(d, 'w2_r%d.npz' % r))) for r in (0, 1)]
+        ahead = [dict(np.load(os.path.join(d, 'w2_r%d_la.npz' % r))) for r in (0, 1)]
+    for k in ('d_grad', 'g_grad', 'd_param1', 'g_param1'):
+        assert np.array_equal(ahead[0][k], ahead[1][k]), k                       # replicas in step
+        scale = max(float(np.abs(plain[0][k]).max()), 1e-6)
+        assert float(np.abs(ahead[0][k].astype(np.float64) - plain[0][k]).max()) <= 2e-5 * scale, k
+    assert int(ahead[0]['n_programs']) == 2 and int(ahead[0]['skipped']) == 2
+    assert int(ahead[0]['n_host_segments']) == 0 and int(ahead[0]['eager']) == 0
 
 
 def _single(_, rank, outdir):

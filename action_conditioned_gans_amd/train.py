@@ -490,8 +490,9 @@ def main(argv=None):
                         help="gradient all-reduces in program order on the compute stream, or on a side HIP stream overlapping "
                              "the rest of backward (default with more than one rank)")
     parser.add_argument('--buckets', type=int, default=0, help='all-reduce buckets per optimizer (0: 2 for side, 1 for stream)')
-    parser.add_argument('--data_workers', type=str, default='thread', choices=['thread', 'process'],
-                        help='TFRecord decode workers: threads (PIL / numpy release the GIL for the heavy parts) or spawned processes')
+    parser.add_argument('--data_workers', type=str, default='process', choices=['thread', 'process'],
+                        help='TFRecord decode workers: spawned processes (default here: 2.3x the rate of threads on the GPU box, '
+                             'profiles/r5/d_train_loop.txt) or threads (the default of train() / PushDataset: no __main__ guard needed)')
     parser.add_argument('--data_threads', type=int, default=None, help='number of decode workers (default: batch size, at most 16)')
     args = parser.parse_args(argv)
     if args.buckets < 0:

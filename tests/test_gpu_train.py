@@ -798,8 +798,8 @@ def test_lookahead_step_matches_oracle_live_at_full_size():
     sess.close()
 
 
-@pytest.mark.parametrize('dtype,dna', [('f32', True), ('f32', False), ('bf16', True)])
-def test_lookahead_equals_the_plain_call_path_on_the_gpu(dtype, dna):
+@pytest.mark.parametrize('dtype,dna,ksize', [('f32', True, 5), ('f32', False, 5), ('bf16', True, 5), ('f32', True, 6), ('bf16', True, 11)])
+def test_lookahead_equals_the_plain_call_path_on_the_gpu(dtype, dna, ksize):
     """Look-ahead on / off from the same weights on distinct D-step and G-step samples, batch 8, four iterations (eager,
     capture, two replays).  After ONE iteration the two agree to rounding: float32 frames 1e-5, D gradient 1e-4, G gradient
     5e-3 (a kink of the L1 / GDL losses moves it by 1.6e-3), filters 2e-5 of their scale; bf16 (storage rounding) frames 5e-3,
@@ -815,7 +815,7 @@ def test_lookahead_equals_the_plain_call_path_on_the_gpu(dtype, dna):
         G.reset_default_graph()
         optim.set_data_parallel(1)
         sess = gpu_session(dtype=dtype, **kw)
-        tr = T.Trainer(sess, True, 'bce', 'rmsprop', dna, batch_size=8, ksize=5)
+        tr = T.Trainer(sess, True, 'bce', 'rmsprop', dna, batch_size=8, ksize=ksize)       # (k >= 6: the 16-lane-row DNA kernel writes the pair's pixels)
         sess.run(G.global_variables_initializer())
         grad = lambda name: [sess._materialize(t).clone().cpu().double() for t in G.get_default_graph().state if t.name == name][0]   # noqa: E731
         first = None

@@ -460,13 +460,13 @@ def test_lookahead_generator_pass_matches_the_plain_call_path(dna):
     pass.  Same arithmetic as the two separate passes of train.py:241-263: frames, both gradient buffers and the weights after
     two iterations agree with the plain call path to rounding; the programs really differ (the D program runs the pair
     instance, the G program lost its generator forward); anything but the announced inputs takes the plain program."""
-    x, y, a, s = TC.MG.inputs(2)
-    x2, y2, a2, s2 = [np.ascontiguousarray(t[::-1]) for t in TC.MG.inputs(2)]
+    x, y, a, s = TC.MG.inputs(2, img=32)          # (32 x 32 frames: the brute-force C stand-in is slow; the graph is the same)
+    x2, y2, a2, s2 = [np.ascontiguousarray(t[::-1]) for t in TC.MG.inputs(2, img=32)]
 
     def run(use):
         G.reset_default_graph()
         sess = cpu_session()
-        tr = T.Trainer(sess, True, 'bce', 'rmsprop', dna, batch_size=2, ksize=5)
+        tr = T.Trainer(sess, True, 'bce', 'rmsprop', dna, batch_size=2, img_size=32, ksize=5)
         sess.run(G.global_variables_initializer())
         for _ in range(2):
             tr.train_d(x, y, a, next_g=(x2, a2) if use else None)
@@ -514,14 +514,14 @@ def test_lookahead_pairs_successive_discriminator_steps():
     D, generator-free G) instead of two."""
     rng = np.random.default_rng(0)
     B = 2
-    mk = lambda: (rng.uniform(-1, 1, (B, 64, 64, 3)).astype(np.float32), rng.uniform(-1, 1, (B, 64, 64, 3)).astype(np.float32),     # noqa: E731
+    mk = lambda: (rng.uniform(-1, 1, (B, 32, 32, 3)).astype(np.float32), rng.uniform(-1, 1, (B, 32, 32, 3)).astype(np.float32),     # noqa: E731
                   rng.standard_normal((B, 10)).astype(np.float32))
     ds, g = [mk() for _ in range(3)], mk() + (rng.standard_normal((B, 5)).astype(np.float32),)
 
     def run(use):
         G.reset_default_graph()
         sess = cpu_session()
-        tr = T.Trainer(sess, True, 'wass', 'rmsprop', True, batch_size=B, ksize=5)
+        tr = T.Trainer(sess, True, 'wass', 'rmsprop', True, batch_size=B, img_size=32, ksize=5)
         sess.run(G.global_variables_initializer())
         for _ in range(2):
             carried = False

@@ -288,7 +288,7 @@ def main():
     # (no look-ahead: what `value` was up to round 4), and through the reference's own API exactly as train() drives it
     # (train.py:241-263: host numpy sequences, pair selection, numpy feeds, generated frames fetched to the host every step)
     api_rates = None
-    if not args.trace_run and not args.no_api_rates:
+    if not args.trace_run and not args.no_api_rates and world == 1:      # (time-bounded loops: with several ranks the step counts - and with them the collectives - would differ per rank)
         def rate(fn, seconds=0.5):
             for i in range(4):
                 fn(i)

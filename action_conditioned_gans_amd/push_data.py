@@ -111,17 +111,6 @@ def record_spans(path):
             f.seek(pos)
 
 
-def _decode_span(span, use_state=True, img_size=IMG_HEIGHT):
-    """Worker-process task: read one record's bytes from its file and decode it."""
-    path, offset, length = span
-    with open(path, 'rb') as f:
-        f.seek(offset)
-        data = f.read(length)
-    if len(data) < length:
-        raise IOError('%s: truncated record' % path)
-    return decode_example(data, use_state, img_size)
-
-
 def write_records(path, payloads):
     with open(path, 'wb') as f:
         for data in payloads:
@@ -287,13 +276,28 @@ def resize_area(img, oh, ow):
         return img.astype(np.float32).reshape(oh, fh, ow, fw, -1).mean(axis=(1, 3), dtype=np.float32)
     x = img.astype(np.float32)
     wh, ww = _area_weights(h, oh).astype(np.float32), _area_weights(w, ow).astype(np.float32)
-    return np.einsum('oh,hwc,pw->opc', wh, x, ww)
+    rows = (wh @ x.reshape(h, -1)).reshape(oh, w, -1)          # two small matrix products (one unoptimised three-operand einsum
+    return np.matmul(ww, rows)                                  # of this took minutes at 512 -> 400)
 
 
-def decode_frame(jpeg_bytes, img_size=IMG_HEIGHT):
-    """ops.py:184-196: decode (3 channels), centre-crop to the short side, area-resize, scale to [-1, 1]."""
+def decode_frame(jpeg_bytes, img_size=IMG_HEIGHT, dct=False):
+    """ops.py:184-196: decode (3 channels), centre-crop to the short side, area-resize, scale to [-1, 1].
+
+    ``dct`` (opt-in, NOT the reference's arithmetic): let libjpeg reduce the frame by 2, 4 or 8 inside the inverse DCT (PIL's
+    ``draft``: the largest of those that still leaves at least ``img_size`` on the short side), then crop and box-resize what is
+    left.  At the push ratio (512 -> 64) that is the 1x1 IDCT - the mean of every 8x8 luma block straight from its DC term, chroma
+    from the 2x2 IDCT of its subsampled block - i.e. the same box mean taken BEFORE instead of after rounding, clamping and
+    chroma upsampling: 3x cheaper (the Huffman pass is what remains), and within 2 levels of 255 of the exact frame, 0.5 level on
+    average (tests/test_push_data.py measures it; JPEG quantisation at quality 90 moves pixels by more).  A file that is not a
+    JPEG, or a ratio libjpeg cannot serve, silently takes the exact path."""
     from PIL import Image
     im = Image.open(io.BytesIO(jpeg_bytes))
+    if dct and im.format == 'JPEG':
+        w, h = im.size
+        short = min(w, h)
+        if short >= 2 * img_size:
+            # request the size that keeps the aspect: draft() picks the largest scale s in {2, 4, 8} with w/s, h/s >= the request
+            im.draft('RGB', (-(-w * img_size // short), -(-h * img_size // short)))
     if im.mode != 'RGB':
         im = im.convert('RGB')                      # decode_jpeg(channels=3); an RGB file needs no second copy
     w, h = im.size
@@ -304,11 +308,20 @@ def decode_frame(jpeg_bytes, img_size=IMG_HEIGHT):
     return resize_area(np.asarray(im), img_size, img_size) / np.float32(255.0 / 2.0) - np.float32(1.0)
 
 
-def decode_example(buf, use_state=True, img_size=IMG_HEIGHT):
-    """One record -> (images [7, S, S, 3], action [7, 5], state [7, 5]) (zeros for the vectors without use_state)."""
+def decode_selected(buf, use_state=True, img_size=IMG_HEIGHT, need=None, dct=False):
+    """One record -> (frame indices, images [n, S, S, 3] of those frames, action [7, 5], state [7, 5]).  ``need``: 7 booleans, the
+    frames to decode (None: all) - the JPEGs of the others are skipped, their pose vectors are still read (they are 10 floats)."""
     keys = set()
-    for i in FRAME_IDS:
-        keys.add('move/%d/image/encoded' % i)
+    n = len(FRAME_IDS)
+    if need is None:
+        which = list(range(n))
+    else:
+        if len(need) != n:
+            raise ValueError('need: expected %d booleans, one per frame' % n)
+        which = [j for j in range(n) if need[j]]
+    for j, i in enumerate(FRAME_IDS):
+        if j in which:
+            keys.add('move/%d/image/encoded' % i)
         if use_state:
             keys.add('move/%d/commanded_pose/vec_pitch_yaw' % i)
             keys.add('move/%d/endeffector/vec_pitch_yaw' % i)
@@ -317,21 +330,41 @@ def decode_example(buf, use_state=True, img_size=IMG_HEIGHT):
     if missing:
         raise KeyError('record lacks features %s' % missing[:3])
     imgs, acts, states = [], [], []
-    for i in FRAME_IDS:
-        enc = feats['move/%d/image/encoded' % i]
-        if len(enc) != 1:
-            raise ValueError('move/%d/image/encoded: expected one JPEG, got %d' % (i, len(enc)))
-        imgs.append(decode_frame(enc[0], img_size))
+    for j, i in enumerate(FRAME_IDS):
+        if j in which:
+            enc = feats['move/%d/image/encoded' % i]
+            if len(enc) != 1:
+                raise ValueError('move/%d/image/encoded: expected one JPEG, got %d' % (i, len(enc)))
+            imgs.append(decode_frame(enc[0], img_size, dct))
         if use_state:
             a, s = feats['move/%d/commanded_pose/vec_pitch_yaw' % i], feats['move/%d/endeffector/vec_pitch_yaw' % i]
             if a.shape != (STATE_DIM,) or s.shape != (STATE_DIM,):
                 raise ValueError('move/%d: pose vectors must have %d floats' % (i, STATE_DIM))
             acts.append(a)
             states.append(s)
-    n = len(FRAME_IDS)
     acts = np.stack(acts).astype(np.float32) if use_state else np.zeros((n, STATE_DIM), np.float32)
     states = np.stack(states).astype(np.float32) if use_state else np.zeros((n, STATE_DIM), np.float32)
-    return np.stack(imgs).astype(np.float32), acts, states
+    imgs = np.stack(imgs).astype(np.float32) if imgs else np.zeros((0, img_size, img_size, COLOR_CHAN), np.float32)
+    return tuple(which), imgs, acts, states
+
+
+def decode_example(buf, use_state=True, img_size=IMG_HEIGHT, dct=False):
+    """One record -> (images [7, S, S, 3], action [7, 5], state [7, 5]) (zeros for the vectors without use_state)."""
+    return decode_selected(buf, use_state, img_size, None, dct)[1:]
+
+
+def _decode_task(item, use_state=True, img_size=IMG_HEIGHT, dct=False):
+    """Worker task: ``item`` = (record, need); the record is its payload bytes or a (path, offset, length) span that the worker
+    (a process: the payload never passes through a pipe) reads itself."""
+    rec, need = item
+    if isinstance(rec, tuple):
+        path, offset, length = rec
+        with open(path, 'rb') as f:
+            f.seek(offset)
+            rec = f.read(length)
+        if len(rec) < length:
+            raise IOError('%s: truncated record' % path)
+    return decode_selected(rec, use_state, img_size, need, dct)
 
 
 class _Prefetcher:
@@ -412,12 +445,22 @@ class PushDataset:
     walk and the array plumbing do not - measured on the GPU box: 3.6x one thread at 8 threads, nothing beyond;
     ``workers='process'``: spawned worker processes, no shared interpreter lock (the reference's queue runners are C++
     threads).  The order of the batches is the order of the record stream - deterministic per (seed, rank, world_size)
-    whatever the worker count or kind; ``num_threads=0`` decodes inside ``get_batch`` as before round 5.
-    ``close()`` (or the context manager) stops the workers; a dataset that is garbage-collected closes itself.
+    whatever the worker count or kind; ``num_threads=0`` decodes inside ``get_batch`` as before round 5.  The workers start
+    with the first ``get_batch`` or ``announce``.  ``close()`` (or the context manager) stops them; a dataset that is
+    garbage-collected closes itself.
+
+    Decoding less (the loop is decode-bound: one 512x640 JPEG is 2-3 ms of a core, a batch of 32 records holds 224 of them, and
+    a training step consumes 2 frames of each record):
+      * ``announce(need)`` - the caller says, batches ahead, WHICH frames of a coming batch it will read (``need`` [B, 7] bool;
+        one call per future ``get_batch``, in order).  Only those are decoded; the others come back as NaN so that a read of a
+        frame that was not asked for cannot go unnoticed.  The decoded frames are the same bits as without the announcement.
+        A batch the workers reached before its announcement is decoded in full.  ``train()`` draws its frame-pair selections
+        ahead of time to do this (train._PairSelections).
+      * ``decode='dct'`` - opt-in, approximate: the 8x reduction inside libjpeg's inverse DCT (``decode_frame``).
     """
 
     def __init__(self, data_dir, batch_size, train_val_split=0.95, use_state=True, training=True, img_size=IMG_HEIGHT,
-                 seed=7, rank=0, world_size=1, verify_crc=False, num_threads=None, capacity=None, workers='thread'):
+                 seed=7, rank=0, world_size=1, verify_crc=False, num_threads=None, capacity=None, workers='thread', decode='exact'):
         files = sorted(glob.glob(os.path.join(data_dir, '*')))
         if not files:
             raise RuntimeError('No data files found.')                          # ops.py:159
@@ -429,7 +472,6 @@ class PushDataset:
         self.rng = np.random.default_rng(seed)
         self.rank, self.world_size, self.verify_crc = rank, world_size, verify_crc
         self.seq_len = len(FRAME_IDS)
-        self._stream = self._records()
         if num_threads is None:
             try:
                 cpus = len(os.sched_getaffinity(0))
@@ -438,18 +480,20 @@ class PushDataset:
             num_threads = max(1, min(batch_size, cpus, 16))
         if workers not in ('thread', 'process'):
             raise ValueError("workers must be 'thread' or 'process'")
-        self.num_threads, self.workers = int(num_threads), workers
+        if decode not in ('exact', 'dct'):
+            raise ValueError("decode must be 'exact' or 'dct'")
+        self.num_threads, self.workers, self.decode = int(num_threads), workers, decode
         self.capacity = int(capacity) if capacity else 4 * batch_size
-        self._prefetch = None
-        if self.num_threads > 0:
-            import functools
-            # worker processes fetch their record from the file themselves (the feeder walks the 12-byte frame headers only): the
-            # payload bytes - 0.5-2 MB per push record - never pass through this process or a pipe
-            spans = workers == 'process' and not verify_crc
-            if spans:
-                self._stream = self._records(spans=True)
-            task = functools.partial(_decode_span if spans else decode_example, use_state=self.use_state, img_size=self.img_size)      # picklable
-            self._prefetch = _Prefetcher(self._stream, task, self.num_threads, self.capacity, processes=workers == 'process')
+        # worker processes fetch their record from the file themselves (the feeder walks the 12-byte frame headers only): the
+        # payload bytes - 0.5-2 MB per push record - never pass through this process or a pipe
+        self._spans = self.num_threads > 0 and workers == 'process' and not verify_crc
+        import functools
+        self._task = functools.partial(_decode_task, use_state=self.use_state, img_size=self.img_size, dct=decode == 'dct')    # picklable
+        self._plan, self._plan_lock = {}, threading.Lock()      # batch number -> need [B, 7], announced and not yet reached
+        self._announced = 0                                     # batches announced so far
+        self._served = 0                                        # records handed to a decoder so far
+        self._stream = self._items()
+        self._prefetch, self._closed = None, False
 
     def _records(self, spans=False):
         """The record stream of this rank: payload bytes, or (``spans``) (path, offset, length) triples for workers that read
@@ -467,18 +511,57 @@ class PushDataset:
             if not seen:
                 raise RuntimeError('the data files hold no records')
 
+    def _items(self):
+        """(record, need) in stream order: the need row is looked up when the record is DRAWN (by the feeder thread, up to
+        ``capacity`` records ahead of the consumer) - a batch announced later than that is decoded in full."""
+        for rec in self._records(self._spans):
+            with self._plan_lock:
+                batch, row = divmod(self._served, self.batch_size)
+                need = self._plan.get(batch)
+                if need is not None and row == self.batch_size - 1:
+                    del self._plan[batch]
+                self._served += 1
+            yield rec, (None if need is None else tuple(bool(v) for v in need[row]))
+
+    def announce(self, need):
+        """The frames of the next not-yet-announced batch that will be read: ``need`` [B, 7] bool.  One call per future
+        ``get_batch``, in the same order; call it a few batches ahead (the workers run up to ``capacity`` records ahead)."""
+        need = np.asarray(need, bool)
+        if need.shape != (self.batch_size, self.seq_len):
+            raise ValueError('announce: expected a [%d, %d] boolean array, got %s' % (self.batch_size, self.seq_len, need.shape))
+        with self._plan_lock:
+            if self._announced * self.batch_size >= self._served:      # (a batch the workers already started on is past announcing)
+                self._plan[self._announced] = need.copy()
+            self._announced += 1
+        self._start()
+
+    def _start(self):
+        if self._closed:
+            raise RuntimeError('the dataset is closed')
+        if self._prefetch is None and self.num_threads > 0:
+            self._prefetch = _Prefetcher(self._stream, self._task, self.num_threads, self.capacity, processes=self.workers == 'process')
+
     def get_batch(self):
         """-> (frames, frames, action||state [B,T,10], state [B,T,5]), the tuple the training loop consumes."""
+        self._start()
         if self._prefetch is not None:
             decoded = [self._prefetch.get() for _ in range(self.batch_size)]
         else:
-            decoded = [decode_example(next(self._stream), self.use_state, self.img_size) for _ in range(self.batch_size)]
-        imgs, acts, states = zip(*decoded)
-        img = np.stack(imgs)
+            decoded = [self._task(next(self._stream)) for _ in range(self.batch_size)]
+        which, imgs, acts, states = zip(*decoded)
+        full = tuple(range(self.seq_len))
+        if all(w == full for w in which):
+            img = np.stack(imgs)
+        else:                                     # announced batches: the frames nobody asked for are NaN
+            img = np.full((self.batch_size, self.seq_len, self.img_size, self.img_size, COLOR_CHAN), np.nan, np.float32)
+            for b, (w, im) in enumerate(zip(which, imgs)):
+                if w:
+                    img[b, list(w)] = im
         action_state = np.concatenate([np.stack(acts), np.stack(states)], axis=2)
         return img, img, action_state, action_state[:, :, STATE_DIM:].copy()
 
     def close(self):
+        self._closed = True
         if self._prefetch is not None:
             self._prefetch.close()
             self._prefetch = None

@@ -329,15 +329,26 @@ def _alias_first_half(ops_small, ops_pair):
 
 # ---- synthetic push-style data (rng(7), frames U(-1,1), action||state N(0,1)) ----------
 class SyntheticPush:
-    def __init__(self, batch_size, seq_len=8, img_size=64, seed=7, rank=0):
+    """Seeded random sequences in the shape of the push batches.  ``pool`` > 0: the first ``pool`` batches are kept and handed out
+    round robin afterwards (drawing 3 M uniform numbers per batch costs a host core 10-50 ms - many training steps; the loop
+    benchmark uses a pool so that what it times is the loop)."""
+
+    def __init__(self, batch_size, seq_len=8, img_size=64, seed=7, rank=0, pool=0):
         self.rng = np.random.default_rng(seed + 1000 * rank)
         self.shape = (batch_size, seq_len, img_size, img_size, 3)
         self.batch_size, self.seq_len = batch_size, seq_len
+        self.pool, self._kept, self._next = int(pool), [], 0
 
     def get_batch(self):
         """-> (frames, frames, action||state [B,T,10], state [B,T,5]) like ops.get_batch (ops.py:15-17)."""
+        if self.pool and len(self._kept) == self.pool:
+            img, acts = self._kept[self._next % self.pool]
+            self._next += 1
+            return img, img, acts, acts[:, :, 5:].copy()
         img = self.rng.uniform(-1.0, 1.0, self.shape).astype(np.float32)
         acts = self.rng.standard_normal((self.batch_size, self.seq_len, ACTION_DIM)).astype(np.float32)
+        if self.pool:
+            self._kept.append((img, acts))
         return img, img, acts, acts[:, :, 5:].copy()
 
 
@@ -345,6 +356,45 @@ def select_pairs(rng_randint, boolean_mask, batch_size):
     """(t, t+1) selection of train.py:231-232,249-250,258-259."""
     start_mask = boolean_mask[rng_randint(0, len(boolean_mask), size=batch_size)]
     return start_mask, np.roll(start_mask, 1, axis=1)
+
+
+class _PairSelections:
+    """The frame-pair selections of the coming iterations, drawn AHEAD of the loop in the reference's order (train.py:231-232
+    per pretraining iteration; 249-250 per D step, then 258-259 once for the G step on the last D batch), from a private copy
+    of numpy's global generator as it stands when the loop starts - the same numbers the loop would draw one call at a time,
+    since nothing else in the loop draws from it.  Knowing them early is what lets a PushDataset decode only the frames a
+    step will read (``data.announce``: 2-4 of a record's 7 JPEGs instead of all of them); a source without ``announce``
+    (SyntheticPush) just gets its selections from here."""
+
+    def __init__(self, boolean_mask, batch_size, d_per_g, pretrain_iter, train_iter, data, ahead=8):
+        self.rng = np.random.RandomState()
+        self.rng.set_state(np.random.get_state())
+        self.mask, self.batch_size, self.d_per_g = boolean_mask, batch_size, d_per_g
+        self.pretrain_iter, self.train_iter = pretrain_iter, train_iter
+        self.announce = getattr(data, 'announce', None)
+        self.ahead, self.drawn, self.queue = max(int(ahead), 1), 0, []
+
+    def _draw(self):
+        i = self.drawn
+        n = 1 if i < self.pretrain_iter else self.d_per_g + 1
+        sels = [select_pairs(self.rng.randint, self.mask, self.batch_size) for _ in range(n)]
+        if self.announce is not None:
+            if i < self.pretrain_iter:
+                self.announce(sels[0][0] | sels[0][1])
+            else:
+                for j in range(self.d_per_g):
+                    need = sels[j][0] | sels[j][1]
+                    if j == self.d_per_g - 1:                       # the G step selects again on the last D batch
+                        need = need | sels[-1][0] | sels[-1][1]
+                    self.announce(need)
+        self.queue.append(sels)
+        self.drawn += 1
+
+    def next(self):
+        """The selections of the next iteration: [(start, end)] while pretraining, else [D_1, ..., D_n, G]."""
+        while self.drawn < self.train_iter and len(self.queue) < self.ahead + 1:
+            self._draw()
+        return self.queue.pop(0)
 
 
 def _log_jsonl(path, record):
@@ -356,7 +406,7 @@ def train(input_path, output_path, test_output_path, log_dir, model_dir, arg_adv
           batch_size=64, img_size=64, seq_len=8, ksize=5, train_iter=TRAIN_ITER, pretrain_iter=PRETRAIN_ITER,
           n_critic=None, device='cuda:0', world_size=1, rank=0, process_group=None, log_every=100, quiet=False,
           eval_every=500, resume=None, dtype='f32', sync_bn=False, exact_global_batch=False, dp_collectives=None, buckets=0,
-          data_workers='thread', data_threads=None):
+          data_workers='thread', data_threads=None, data_decode='exact', data_frames='selected', synthetic_pool=0):
     """Training loop of train.py:179-309.  ``input_path``: 'synthetic' (seeded random sequences) or a directory of
     push-dataset TFRecords, read by push_data.PushDataset (the reference's build_tfrecord_input, ops.py:140-223).
     ``dtype``: 'f32', or 'bf16' for the bf16 pipeline of BASELINE configs 3 and 5 (bf16 activations, float32 master weights).
@@ -365,15 +415,22 @@ def train(input_path, output_path, test_output_path, log_dir, model_dir, arg_adv
     ``dp_collectives`` - 'side' (default with more than one rank: all-reduces on a second HIP stream, overlapping the rest of
     backward) or 'stream' (in program order on the compute stream); ``buckets`` - all-reduce buckets per optimizer (0 = 2 for
     'side', 1 for 'stream').  ``data_workers`` / ``data_threads``: the TFRecord decode workers (push_data.PushDataset: threads or
-    spawned processes filling a bounded prefetch queue, the reference's tf.train.batch(num_threads=batch_size), ops.py:209-213)."""
+    spawned processes filling a bounded prefetch queue, the reference's tf.train.batch(num_threads=batch_size), ops.py:209-213).
+    ``data_frames``: 'selected' (default) - the loop tells the dataset batches ahead which frames each step will read and only
+    those JPEGs are decoded (same frames, same bits; a step reads 2 of a record's 7) - or 'all' (every frame of every record,
+    as the reference's queue runners do).  ``data_decode``: 'exact' (decode -> crop -> box mean, the reference's arithmetic) or
+    'dct' (opt-in, approximate: the reduction inside libjpeg's inverse DCT, push_data.decode_frame).  ``synthetic_pool``:
+    SyntheticPush(pool=...)."""
+    if data_frames not in ('selected', 'all'):
+        raise ValueError("data_frames must be 'selected' or 'all'")
     np.random.seed(7)                                           # train.py:14
     synthetic = input_path in (None, '', 'synthetic')
     if synthetic:
-        data = SyntheticPush(batch_size, seq_len, img_size, rank=rank)
+        data = SyntheticPush(batch_size, seq_len, img_size, rank=rank, pool=synthetic_pool)
     else:
         from .push_data import PushDataset
         data = PushDataset(input_path, batch_size, training=True, img_size=img_size, rank=rank, world_size=world_size,
-                           workers=data_workers, num_threads=data_threads)
+                           workers=data_workers, num_threads=data_threads, decode=data_decode)
         seq_len = data.seq_len
     boolean_mask = build_all_mask(seq_len)
     G.reset_default_graph()
@@ -384,7 +441,8 @@ def train(input_path, output_path, test_output_path, log_dir, model_dir, arg_adv
     sess = G.Session(device=device, world_size=world_size, rank=rank, process_group=process_group, dtype=dtype)
     try:
         trainer = _train_loop(sess, data, input_path, synthetic, boolean_mask, log_dir, model_dir, arg_adv, arg_loss, arg_opt, arg_transform,
-                              batch_size, img_size, seq_len, ksize, train_iter, pretrain_iter, n_critic, rank, log_every, quiet, eval_every, resume)
+                              batch_size, img_size, seq_len, ksize, train_iter, pretrain_iter, n_critic, rank, log_every, quiet, eval_every, resume,
+                              select_frames=data_frames == 'selected')
         sess.rt.check_exchange_flags()     # a last look at the device-side flags of the iterations since the last log interval
     except BaseException:
         sess.close(check=False)            # tear the transport down; the exception on its way out is the one to report
@@ -398,7 +456,7 @@ def train(input_path, output_path, test_output_path, log_dir, model_dir, arg_adv
 
 
 def _train_loop(sess, data, input_path, synthetic, boolean_mask, log_dir, model_dir, arg_adv, arg_loss, arg_opt, arg_transform, batch_size,
-                img_size, seq_len, ksize, train_iter, pretrain_iter, n_critic, rank, log_every, quiet, eval_every, resume):
+                img_size, seq_len, ksize, train_iter, pretrain_iter, n_critic, rank, log_every, quiet, eval_every, resume, select_frames=True):
     trainer = Trainer(sess, arg_adv, arg_loss, arg_opt, arg_transform, batch_size, img_size, ksize)
     sess.run(G.global_variables_initializer())
     saver = Saver()                                                           # train.py:215
@@ -415,25 +473,28 @@ def _train_loop(sess, data, input_path, synthetic, boolean_mask, log_dir, model_
     D_per_G = n_critic if n_critic else (5 if arg_loss == 'wass' else 1)      # train.py:217-220
     log_file = os.path.join(log_dir, 'train.jsonl') if log_dir else None
     t0 = time.time()
+    selections = _PairSelections(boolean_mask, batch_size, D_per_G, pretrain_iter, train_iter, data if select_frames else None)
     for i in range(train_iter):
+        sels = selections.next()
         if i < pretrain_iter:
             inp, nxt, acts, states = data.get_batch()
-            sm, em = select_pairs(np.random.randint, boolean_mask, batch_size)
+            sm, em = sels[0]
             trainer.pretrain_g(inp[sm], nxt[em], acts[sm], states[em])
             if not quiet:
                 print('pre-train iter: ' + str(i))
             continue
         # The iteration's sub-steps, drawn up front in the reference's order (train.py:241-259: per D step a fresh batch and a
-        # fresh frame-pair selection, then a NEW selection on the last batch for the G step; the steps themselves draw nothing),
+        # fresh frame-pair selection, then a NEW selection on the last batch for the G step; the steps themselves draw nothing;
+        # the selections come from _PairSelections, which drew them some iterations ago in that same order),
         # so that a step can announce its successor's inputs to Trainer.train_d (look-ahead generator pass): D1 runs the
         # generator for D1 and D2, D2 runs none, ... the last pair pass covers the G step.  Logging iterations keep the plain path
         # for their last D step (its summaries read that step's own generated frames).
         subs = []
         for j in range(D_per_G):
             inp, nxt, acts, states = data.get_batch()
-            sm, em = select_pairs(np.random.randint, boolean_mask, batch_size)
+            sm, em = sels[j]
             subs.append((inp[sm], nxt[em], acts[sm]))
-        smg, emg = select_pairs(np.random.randint, boolean_mask, batch_size)
+        smg, emg = sels[-1]
         g_in, g_act = inp[smg], acts[smg]
         summ, carried = None, False
         for j, (x_d, y_d, a_d) in enumerate(subs):
@@ -511,6 +572,10 @@ def main(argv=None):
                         help='TFRecord decode workers: spawned processes (default here: 2.3x the rate of threads on the GPU box, '
                              'profiles/r5/d_train_loop.txt) or threads (the default of train() / PushDataset: no __main__ guard needed)')
     parser.add_argument('--data_threads', type=int, default=None, help='number of decode workers (default: batch size, at most 16)')
+    parser.add_argument('--data_frames', type=str, default='selected', choices=['selected', 'all'],
+                        help="decode only the frames a step will read (same frames, same bits) or every frame of every record")
+    parser.add_argument('--data_decode', type=str, default='exact', choices=['exact', 'dct'],
+                        help="'dct': approximate 8x reduction inside libjpeg's inverse DCT (3x cheaper; within 2-3 levels of 255)")
     args = parser.parse_args(argv)
     if args.buckets < 0:
         parser.error('--buckets must be >= 0')
@@ -530,7 +595,7 @@ def main(argv=None):
                     seq_len=args.seq_len, ksize=args.ksize, train_iter=args.train_iter, pretrain_iter=args.pretrain_iter,
                     n_critic=args.n_critic, device='cuda:%d' % local_rank, world_size=world_size, rank=rank, dtype=args.dtype,
                     sync_bn=args.sync_bn, exact_global_batch=args.exact_global_batch, dp_collectives=args.dp_collectives, buckets=args.buckets,
-                    data_workers=args.data_workers, data_threads=args.data_threads)
+                    data_workers=args.data_workers, data_threads=args.data_threads, data_decode=args.data_decode, data_frames=args.data_frames)
     if trainer is not None:
         trainer.sess.close()        # ncclCommDestroy under data parallelism + a last check of the device-side flags
 

@@ -200,9 +200,10 @@ def test_prefetch_workers_keep_stream_order_and_shut_down(tmp_path):
     assert ref._prefetch is None
     for threads, capacity, kind in ((1, None, 'thread'), (3, 2, 'thread'), (8, 64, 'thread'), (2, None, 'process')):
         with P.PushDataset(str(tmp_path), batch_size=4, train_val_split=1.0, num_threads=threads, capacity=capacity, workers=kind) as ds:
-            assert ds.num_threads == threads and ds._prefetch is not None
+            assert ds.num_threads == threads and ds._prefetch is None      # the workers start with the first get_batch / announce
             for w in want:
                 got = ds.get_batch()
+                assert ds._prefetch is not None
                 assert all(np.array_equal(g, e) for g, e in zip(got, w)), (threads, capacity, kind)
         assert ds._prefetch is None
     # default thread count: the batch size, capped by the CPUs of this process (ops.py:212 num_threads=batch_size)
@@ -235,6 +236,126 @@ def test_prefetch_workers_keep_stream_order_and_shut_down(tmp_path):
         for _ in range(2):
             with pytest.raises(IOError):
                 ds.get_batch()
+
+
+def test_announced_frames_are_the_only_ones_decoded(tmp_path):
+    """Round 5: a training step reads 2 of a record's 7 frames (train.py:231-232), the reference decodes all 7 (ops.py:171-196).
+    PushDataset.announce(need) tells the workers, batches ahead, which frames of a coming batch will be read: those come back
+    bit-identical to the full decode, every other frame is NaN (a read of a frame nobody asked for cannot go unnoticed), the
+    pose vectors are complete, the record order is untouched; a batch without an announcement, or one the workers reached
+    before it was announced, is decoded in full.  Synchronous, threads and processes."""
+    rng = np.random.default_rng(8)
+    for k in range(2):
+        make_shard(str(tmp_path / ('push_%02d.tfrecord' % k)), rng, 3)
+    with P.PushDataset(str(tmp_path), batch_size=3, train_val_split=1.0, num_threads=0) as ref:
+        want = [ref.get_batch() for _ in range(5)]
+    needs = []
+    for k in range(5):
+        need = np.zeros((3, 7), bool)
+        t = rng.integers(0, 6, 3)
+        need[np.arange(3), t] = True
+        need[np.arange(3), t + 1] = True
+        if k == 1:
+            need[0] = False                                     # a record nobody reads at all
+        needs.append(need)
+    for threads, kind in ((0, 'thread'), (2, 'thread'), (2, 'process')):
+        with P.PushDataset(str(tmp_path), batch_size=3, train_val_split=1.0, num_threads=threads, workers=kind) as ds:
+            for k in (0, 1, 2):
+                ds.announce(needs[k])                           # three batches ahead of the first read
+            for k in range(5):
+                if k == 3:
+                    got = ds.get_batch()                        # batch 3: never announced -> complete
+                    assert all(np.array_equal(g, w) for g, w in zip(got, want[3])), (threads, kind)
+                    ds.announce(needs[3])                       # too late for batch 3: counted, not applied
+                    ds.announce(needs[4])
+                    continue
+                img, img2, act, st = ds.get_batch()
+                assert img is img2 and np.array_equal(act, want[k][2]) and np.array_equal(st, want[k][3])
+                if k == 4 and threads:                          # the workers ran ahead of this announcement: full decode is fine
+                    sel = np.isfinite(img).all(axis=(2, 3, 4))
+                    assert (sel | ~needs[4]).all()
+                else:
+                    assert np.array_equal(np.isfinite(img).all(axis=(2, 3, 4)), needs[k]), (threads, kind, k)
+                    assert np.isnan(img[~needs[k]]).all()
+                assert np.array_equal(img[needs[k]], want[k][0][needs[k]]), (threads, kind, k)
+            with pytest.raises(ValueError, match='boolean array'):
+                ds.announce(np.zeros((2, 7), bool))
+
+
+def test_pair_selections_are_the_loops_own_draws_made_early():
+    """train._PairSelections draws the frame-pair selections of coming iterations ahead of time so that the dataset can be told
+    which frames to decode.  They must be the numbers the loop would have drawn call by call from numpy's global generator
+    (train.py:14 seeds it; 231-232 one selection per pretraining iteration, 249-250 one per D step, 258-259 one more for the G
+    step), and the announcements must be one per get_batch, in order: the union of the pairs read from that batch."""
+    from action_conditioned_gans_amd import train as T
+    from action_conditioned_gans_amd.util import build_all_mask
+    mask, B, D, pre, iters = build_all_mask(7), 5, 3, 2, 9
+    np.random.seed(7)
+    want = []
+    for i in range(iters):
+        want.append([T.select_pairs(np.random.randint, mask, B) for _ in range(1 if i < pre else D + 1)])
+
+    class Sink:
+        def __init__(self):
+            self.needs = []
+
+        def announce(self, need):
+            self.needs.append(need.copy())
+    np.random.seed(7)
+    sink = Sink()
+    sel = T._PairSelections(mask, B, D, pre, iters, sink, ahead=4)
+    state = np.random.get_state()[1].copy()
+    for i in range(iters):
+        got = sel.next()
+        assert len(sink.needs) >= min(pre, i + 5) + max(0, min(iters, i + 5) - pre) * D      # announced 4 iterations ahead
+        assert len(got) == len(want[i])
+        for (gs, ge), (ws, we) in zip(got, want[i]):
+            assert np.array_equal(gs, ws) and np.array_equal(ge, we)
+    assert np.array_equal(np.random.get_state()[1], state)        # the global generator itself is left alone
+    k = 0
+    for i in range(iters):                                        # one announcement per batch the loop fetches
+        if i < pre:
+            assert np.array_equal(sink.needs[k], want[i][0][0] | want[i][0][1])
+            k += 1
+            continue
+        for j in range(D):
+            need = want[i][j][0] | want[i][j][1]
+            if j == D - 1:
+                need = need | want[i][D][0] | want[i][D][1]
+            assert np.array_equal(sink.needs[k], need), (i, j)
+            k += 1
+    assert k == len(sink.needs) and all(2 <= n.sum(axis=1).min() and n.sum(axis=1).max() <= 4 for n in sink.needs)
+    # a source without announce (SyntheticPush) is simply not told
+    assert T._PairSelections(mask, B, D, pre, iters, object()).announce is None
+
+
+def test_dct_decode_is_close_to_the_exact_frames():
+    """decode='dct' (opt-in): the reduction inside libjpeg's inverse DCT instead of decode -> crop -> 8x8 box mean.  Not the
+    reference's arithmetic; the distance is measured here on 512x640 frames with texture and noise: at most 3 levels of 255
+    anywhere, below 0.7 level on average, at both 64x64 (1x1 IDCT) and 128x128 (2x2 IDCT); a ratio libjpeg cannot serve
+    (below 2) and a non-JPEG file take the exact path bit for bit."""
+    import io
+    from PIL import Image
+    rng = np.random.default_rng(9)
+    yy, xx = np.mgrid[0:512, 0:640].astype(np.float32)
+    img = np.stack([127 + 90 * np.sin(0.011 * xx + 0.006 * yy), 127 + 90 * np.cos(0.008 * xx), 127 + 90 * np.sin(0.014 * yy)], -1)
+    img = np.clip(img + rng.normal(0, 6, img.shape), 0, 255).astype(np.uint8)
+    b = io.BytesIO()
+    Image.fromarray(img).save(b, format='JPEG', quality=90)
+    for size in (64, 128):
+        exact, fast = P.decode_frame(b.getvalue(), size), P.decode_frame(b.getvalue(), size, dct=True)
+        assert fast.shape == exact.shape == (size, size, 3) and fast.dtype == np.float32
+        d = np.abs(fast - exact) * 127.5
+        assert d.max() <= 3.0 and d.mean() <= 0.7, (size, d.max(), d.mean())
+        assert d.max() > 0                                  # (it IS another arithmetic: the test would notice a silent fallback)
+    small = io.BytesIO()
+    Image.fromarray(img[:48, :60]).save(small, format='JPEG', quality=90)
+    assert np.array_equal(P.decode_frame(small.getvalue(), 32, dct=True), P.decode_frame(small.getvalue(), 32))     # 48 < 2 * 32
+    png = io.BytesIO()
+    Image.fromarray(img).save(png, format='PNG')
+    assert np.array_equal(P.decode_frame(png.getvalue(), 64, dct=True), P.decode_frame(png.getvalue(), 64))
+    with pytest.raises(ValueError, match='decode'):
+        P.PushDataset(os.path.join(HERE, 'golden'), 1, train_val_split=1.0, decode='fast')
 
 
 def test_integer_box_sums_equal_the_float_mean():
@@ -278,3 +399,17 @@ def test_training_loop_reads_tfrecords(tmp_path, workers):
     frames, _, _ = tr.test(np.zeros((2, 64, 64, 3), np.float32), np.zeros((2, 64, 64, 3), np.float32), np.zeros((2, 10), np.float32))
     assert np.isfinite(frames).all()                  # the session still runs
     tr.sess.close()                                   # device-side flags clean, transport torn down
+    if workers == 'thread':
+        # the loop announced its frames (data_frames='selected', the default): decoding every frame instead changes no weight
+        want = {v.name: tr.sess.get_value(v).cpu().numpy() for v in tr.g_vars + tr.d_vars}
+        tr2 = T.train(str(tmp_path), None, None, None, None, True, 'bce', 'adam', True, batch_size=2, train_iter=4, pretrain_iter=1,
+                      device='cuda:0', quiet=True, eval_every=2, log_every=2, data_workers=workers, data_threads=2, data_frames='all')
+        for v in tr2.g_vars + tr2.d_vars:
+            assert np.array_equal(tr2.sess.get_value(v).cpu().numpy(), want[v.name]), v.name
+        tr2.sess.close()
+    else:
+        tr3 = T.train(str(tmp_path), None, None, None, None, True, 'bce', 'adam', True, batch_size=2, train_iter=3, pretrain_iter=1,
+                      device='cuda:0', quiet=True, eval_every=0, log_every=2, data_workers=workers, data_threads=2, data_decode='dct')
+        for v in tr3.g_vars + tr3.d_vars:
+            assert torch.isfinite(tr3.sess.get_value(v)).all(), v.name
+        tr3.sess.close()

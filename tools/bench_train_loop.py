@@ -3,7 +3,7 @@
 out), on synthetic sequences and on a directory of push TFRecords (512x640 JPEGs, decoded by PushDataset's worker threads), on
 this box's host cores: iterations per second of both loops and the decode rate alone.
 
-  python tools/bench_train_loop.py [--batch 32] [--iters 150] [--records 96] [--threads N] [--dtype f32]
+  python tools/bench_train_loop.py [--batch 32] [--iters 200] [--records 96] [--threads N] [--dtype f32]
 
 The TFRecord shards are written to a temporary directory first (synthetic smooth images, JPEG quality 90; a record holds the 7
 frames the reader uses).  The stream wraps around: the reader re-reads and re-decodes the shards, nothing is cached."""
@@ -41,7 +41,7 @@ def make_shards(path, n_records, per_shard=16, seed=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=32)
-    ap.add_argument('--iters', type=int, default=150)
+    ap.add_argument('--iters', type=int, default=200)
     ap.add_argument('--records', type=int, default=96)
     ap.add_argument('--threads', type=int, default=None)
     ap.add_argument('--dtype', default='f32')
@@ -56,39 +56,62 @@ def main():
     size = sum(os.path.getsize(os.path.join(tmp, f)) for f in os.listdir(tmp))
     print('# wrote %d records (%.1f MB, %.0f KB per record) in %.1f s' % (args.records, size / 1e6, size / 1e3 / args.records, time.time() - t0))
 
-    # ---- decode rate alone: get_batch in a loop, nothing else running
-    settings = [(args.threads, 'thread')] if args.threads is not None else [(0, 'thread'), (4, 'thread'), (8, 'thread'), (16, 'thread'), (8, 'process'), (16, 'process')]
-    for threads, kind in settings:
-        with P.PushDataset(tmp, args.batch, train_val_split=1.0, num_threads=threads, workers=kind) as ds:
+    # ---- decode rate alone: get_batch in a loop, nothing else running.  'selected': the frames of a D + G iteration announced
+    # ahead (train._PairSelections does this in the loop: the union of two frame pairs per record, 3.4 of 7 frames on average)
+    def needs(rng):
+        need = np.zeros((args.batch, 7), bool)
+        for _ in range(2):
+            t = rng.integers(0, 6, args.batch)
+            need[np.arange(args.batch), t] = True
+            need[np.arange(args.batch), t + 1] = True
+        return need
+    settings = [(args.threads, 'thread', 'all', 'exact')] if args.threads is not None else \
+        [(0, 'thread', 'all', 'exact'), (8, 'thread', 'all', 'exact'), (16, 'thread', 'all', 'exact'), (8, 'process', 'all', 'exact'),
+         (16, 'process', 'all', 'exact'), (16, 'process', 'selected', 'exact'), (16, 'process', 'all', 'dct'), (16, 'process', 'selected', 'dct'),
+         (16, 'thread', 'selected', 'dct')]
+    for threads, kind, frames, decode in settings:
+        rng = np.random.default_rng(5)
+        with P.PushDataset(tmp, args.batch, train_val_split=1.0, num_threads=threads, workers=kind, decode=decode) as ds:
+            if frames == 'selected':
+                for _ in range(8):
+                    ds.announce(needs(rng))
             ds.get_batch()
             ds.get_batch()
-            t0, n = time.time(), 0
+            t0, n, got = time.time(), 0, 0
             while time.time() - t0 < 4.0:
-                ds.get_batch()
+                if frames == 'selected':
+                    ds.announce(needs(rng))
+                got += int(np.isfinite(ds.get_batch()[0][:, :, 0, 0, 0]).sum())
                 n += 1
             dt = time.time() - t0
-        print('decode only: %2d %-9s %6.1f batches/s  %7.0f records/s  %8.0f JPEG frames/s' % (threads, kind + ('es' if kind == 'process' else 's'), n / dt, n * args.batch / dt, n * args.batch * 7 / dt))
+        print('decode only: %2d %-9s %-8s %-5s %6.1f batches/s  %7.0f records/s  %8.0f JPEG frames/s' %
+              (threads, kind + ('es' if kind == 'process' else 's'), frames, decode, n / dt, n * args.batch / dt, got / dt))
 
-    # ---- the training loop, synthetic vs TFRecords (same iteration count; pretraining and evaluation off; logging off)
+    # ---- the training loop, synthetic vs TFRecords: iterations per second of the RUNNING loop = (iters) / (time of a run of
+    # 40 + iters iterations - time of a run of 40): session set-up, kernel loading, graph capture and worker start-up cancel
     def loop(input_path, label, **extra):
-        torch.cuda.synchronize()
-        kw = dict(batch_size=args.batch, train_iter=args.iters + 20, pretrain_iter=0, device='cuda:0', quiet=True, eval_every=0, log_every=10 ** 9,
-                  dtype=args.dtype, **extra)
-        # warm: the first 20 iterations (kernel loading, graph capture) are timed separately by running a short loop first
-        tr = T.train(input_path, None, None, None, None, True, 'bce', 'adam', True, **dict(kw, train_iter=20))
-        tr.sess.close()
-        t0 = time.time()
-        tr = T.train(input_path, None, None, None, None, True, 'bce', 'adam', True, **kw)
-        torch.cuda.synchronize()
-        dt = time.time() - t0
-        tr.sess.close()
-        print('train(%-22s): %6.1f iterations/s  (%.2f ms per D + G iteration, %d iterations incl. session set-up and 20 warm-up iterations)'
-              % (label, (args.iters + 20) / dt, dt / (args.iters + 20) * 1e3, args.iters + 20))
-        return (args.iters + 20) / dt
-    r_syn = loop('synthetic', 'synthetic')
-    r_thr = loop(tmp, 'tfrecords, 16 threads', data_workers='thread', data_threads=16)
-    r_prc = loop(tmp, 'tfrecords, 16 processes', data_workers='process', data_threads=16)
-    print('tfrecords / synthetic = %.2f (threads), %.2f (processes)' % (r_thr / r_syn, r_prc / r_syn))
+        kw = dict(batch_size=args.batch, pretrain_iter=0, device='cuda:0', quiet=True, eval_every=0, log_every=10 ** 9, dtype=args.dtype, **extra)
+        times = []
+        for iters in (40, 40, 40 + args.iters):          # (the first short run also warms the process: its time is dropped)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            tr = T.train(input_path, None, None, None, None, True, 'bce', 'adam', True, **dict(kw, train_iter=iters))
+            torch.cuda.synchronize()
+            times.append(time.time() - t0)
+            tr.sess.close()
+        rate = args.iters / (times[2] - times[1])
+        print('train(%-40s): %6.1f iterations/s  (%.2f ms per D + G iteration; runs of 40 / %d iterations took %.2f / %.2f s)'
+              % (label, rate, 1e3 / rate, 40 + args.iters, times[1], times[2]))
+        return rate
+    r_syn = loop('synthetic', 'synthetic, drawn per batch')
+    r_pool = loop('synthetic', 'synthetic, pool of 8 batches', synthetic_pool=8)
+    rows = [('tfrecords, 16 threads, all frames, exact', dict(data_workers='thread', data_threads=16, data_frames='all')),
+            ('tfrecords, 16 processes, all, exact', dict(data_workers='process', data_threads=16, data_frames='all')),
+            ('tfrecords, 16 processes, selected, exact', dict(data_workers='process', data_threads=16)),
+            ('tfrecords, 16 processes, selected, dct', dict(data_workers='process', data_threads=16, data_decode='dct'))]
+    for label, extra in rows:
+        r = loop(tmp, label, **extra)
+        print('   = %.2f of the drawn-per-batch synthetic loop, %.2f of the pooled one' % (r / r_syn, r / r_pool))
 
 
 if __name__ == '__main__':

@@ -349,6 +349,7 @@ class Runtime:
         self.world_size, self.rank, self.process_group = world_size, rank, process_group
         self.is_cuda = self.device.type == 'cuda'
         self.side_stream = torch.cuda.Stream(self.device) if self.is_cuda else None
+        self.upload_stream = None              # created by the first host-array feed (Session.upload)
         self.program_ops = frozenset()         # ids of the ops of the program being compiled (ops.py: hand-offs between neighbours)
         # split-K slabs summed by the consuming BatchNorm kernel instead of by a launch of their own: bit-identical.  With the
         # resident (one block per channel quad) kernels alone it measured SLOWER (profiles/r2: 16 bytes per row and block, times
@@ -525,6 +526,62 @@ class Session:
             buf.fill_(s.init)
         self._initialized = True
         self._weights_dirty = True
+
+    def upload(self, value):
+        return self.upload_many([value])[0]
+
+    def upload_many(self, values):
+        """Host arrays (the reference's numpy feed_dict values) -> their float32 device copies, WITHOUT stalling the host or
+        the compute stream: the arrays are packed into ONE pinned staging buffer (a ring of 24 slots owned by the session; a
+        fresh ``pin_memory()`` per array costs milliseconds on this stack) and go to the device as ONE copy on a copy stream of
+        its own; the compute stream waits for that copy by an event.  A pageable ``tensor.to(device)`` per array instead is
+        synchronous for the host AND ordered behind the step still running on the compute stream - the host could not prepare
+        the next step's inputs while the GPU worked (0.6 ms of a 2.8 ms iteration through the numpy API, round 5).
+        Device tensors pass through (converted to float32)."""
+        rt = self.rt
+        out, host = [None] * len(values), []
+        for i, value in enumerate(values):
+            if torch.is_tensor(value):
+                if value.is_cuda or not rt.is_cuda:
+                    out[i] = value.detach().to(rt.device, dtype=torch.float32)
+                    continue
+                value = value.detach().numpy()
+            if not rt.is_cuda:
+                out[i] = torch.from_numpy(np.ascontiguousarray(value, dtype=np.float32))
+                continue
+            host.append((i, np.asarray(value)))
+        if not host:
+            return out
+        if rt.upload_stream is None:
+            rt.upload_stream = torch.cuda.Stream(rt.device)
+            rt.upload_ring = [[torch.cuda.Event(), None] for _ in range(24)]      # [event, pinned staging buffer]
+            rt.upload_count = 0
+        main = torch.cuda.current_stream(rt.device)
+        # the host may run ahead of the compute stream by at most 24 uploads (a few training iterations): the event recorded
+        # on the compute stream 24 uploads ago must have been reached - the slot's staging buffer is then free again, and the
+        # device copies in flight stay bounded
+        slot = rt.upload_ring[rt.upload_count % len(rt.upload_ring)]
+        if rt.upload_count >= len(rt.upload_ring):
+            slot[0].synchronize()
+        rt.upload_count += 1
+        offsets, total = [], 0
+        for _, arr in host:
+            offsets.append(total)
+            total += -(-arr.size // 64) * 64                       # 256-byte segments: every device view is 16-byte aligned
+        if slot[1] is None or slot[1].numel() < total:
+            slot[1] = torch.empty(total, dtype=torch.float32, pin_memory=True)
+        staged = slot[1].numpy()
+        for (_, arr), off in zip(host, offsets):
+            # numpy's memcpy / cast (torch's threaded host copy_ of 1.5 MB costs milliseconds on a many-core host)
+            np.copyto(staged[off:off + arr.size].reshape(arr.shape), arr, casting='unsafe')
+        with torch.cuda.stream(rt.upload_stream):
+            dev = slot[1][:total].to(rt.device, non_blocking=True)
+        main.wait_stream(rt.upload_stream)     # whatever reads the copy next on the compute stream is ordered behind it
+        dev.record_stream(main)                # (allocated on the copy stream, used on the compute stream)
+        slot[0].record(main)
+        for (i, arr), off in zip(host, offsets):
+            out[i] = dev[off:off + arr.size].view(arr.shape)
+        return out
 
     # ---- variable access (checkpoint / parity tests)
     def get_value(self, var):
@@ -718,7 +775,21 @@ class Session:
         feed alias whose destination the program reads (concatenations written by the feed, tiled action channels).
         Device-resident float32 feeds go through ONE acg_copy_many launch.  Used by run() and profile_ops()."""
         fused = []
-        uploaded = {}          # id(host value) -> its device copy: one upload per fed ARRAY, however many placeholders take it
+        # host arrays (the reference's numpy feed_dict): ONE upload for all of them, each fed ARRAY once however many
+        # placeholders take it (upload_many); values no target of this program reads are not uploaded
+        uploaded = {}          # id(host value) -> its device copy
+        if self.rt.is_cuda:
+            todo = {}
+            for ph, val in feed_dict.items():
+                if (id(ph) in prog.used_feeds or prog.alias_copies.get(id(ph))) and id(val) not in todo:
+                    if torch.is_tensor(val):
+                        host = (not val.is_cuda) and val.dtype in (torch.float32, torch.float64)
+                    else:
+                        host = np.asarray(val).dtype in (np.float32, np.float64)
+                    if host:
+                        todo[id(val)] = val
+            if todo:
+                uploaded = dict(zip(todo.keys(), self.upload_many(list(todo.values()))))
         for ph, val in feed_dict.items():
             targets = ([(ph, 0, None)] if id(ph) in prog.used_feeds else []) + prog.alias_copies.get(id(ph), [])
             if not targets:
@@ -727,16 +798,13 @@ class Session:
                 if tuple(np.shape(val)) != tuple(ph.shape if ph.valid_c is None else ph.shape[:-1] + (ph.valid_c,)):
                     raise ValueError('Cannot feed value of shape %s for %r' % (tuple(np.shape(val)), ph))
                 continue
-            src = val if torch.is_tensor(val) else torch.from_numpy(np.ascontiguousarray(val))
-            if self.rt.is_cuda and not src.is_cuda and src.dtype in (torch.float32, torch.float64):
-                # host arrays (the reference's numpy feed_dict): ONE contiguous upload per fed value, then the same fused
-                # device copy as device-resident feeds - a feed may have several destinations (feed aliases), and strided
-                # host -> device copies of each of them cost milliseconds.  The Trainer feeds the same frames to two
+            if id(val) in uploaded:
+                # then the same fused device copy as device-resident feeds - a feed may have several destinations (feed aliases),
+                # and strided host -> device copies of each of them cost milliseconds.  The Trainer feeds the same frames to two
                 # placeholders (the dense one and the channel-padded one the first conv gathers): uploaded once (round 5)
-                dev = uploaded.get(id(val))
-                if dev is None:
-                    dev = uploaded[id(val)] = src.to(self.rt.device, dtype=torch.float32, non_blocking=True)
-                src = dev
+                src = uploaded[id(val)]
+            else:
+                src = val if torch.is_tensor(val) else torch.from_numpy(np.ascontiguousarray(val))
             dst = ph.buf if ph.valid_c is None else ph.buf[..., :ph.valid_c]     # pad channels stay zero
             if tuple(src.shape) != tuple(dst.shape):
                 raise ValueError('Cannot feed value of shape %s for %r' % (tuple(src.shape), ph))

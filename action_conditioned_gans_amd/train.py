@@ -231,8 +231,8 @@ class Trainer:
                     # host arrays (the reference's numpy call path): each batch goes to the device ONCE - the pair is joined there,
                     # this step and the announced one are fed the device copies (round 5: -4.5 MB of uploads and a 3 MB host
                     # concatenation per iteration)
-                    up = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(self.sess.rt.device, non_blocking=True)   # noqa: E731
-                    x_d, a_d, x_n, a_n = up(input_images), up(actions), up(nxt[0]), up(nxt[1])
+                    # (pinned staging + a copy stream of its own: neither the host nor the running step waits; one copy for the four)
+                    x_d, a_d, x_n, a_n = self.sess.upload_many([input_images, actions, nxt[0], nxt[1]])
                     fd[self.img_ph] = fd[self._img_pad] = x_d
                     fd[self.action_ph] = a_d
                     pair = (torch.cat([x_n, x_d]), torch.cat([a_n, a_d]))

@@ -898,3 +898,38 @@ def test_lookahead_pairs_successive_discriminator_steps_on_the_gpu():
             assert (w1[n].double() - w0[n].double()).norm().item() <= 2e-2 * upd + 1e-9, (n, upd)
         assert bool(torch.isfinite(w1[n]).all()), n
     assert np.isfinite(fl1).all()
+
+
+def test_host_feeds_go_through_the_staged_upload():
+    """Session.upload_many (round 5): the host arrays of a feed are packed into one pinned staging buffer and copied on a copy
+    stream of their own.  The device copies must hold the arrays' values (float64 and integer inputs converted, non-contiguous
+    ones gathered), every view 16-byte aligned; device tensors pass through; more uploads than the ring has slots (24) reuse
+    staging buffers only after the compute stream is past their last reader - checked by keeping the stream busy with work
+    that reads each upload after a delay."""
+    G.reset_default_graph()
+    sess = gpu_session()
+    rng = np.random.default_rng(11)
+    a = rng.standard_normal((3, 5, 7)).astype(np.float32)
+    b = rng.standard_normal((4, 10))                               # float64
+    c = np.arange(24, dtype=np.int64).reshape(2, 12)
+    d = rng.standard_normal((8, 6)).astype(np.float32)[:, ::2]     # strided
+    e = torch.full((3,), 2.5, device='cuda:0', dtype=torch.float64)
+    out = sess.upload_many([a, b, c, d, e])
+    for got, want in zip(out, (a, b, c, d)):
+        assert got.is_cuda and got.dtype == torch.float32 and got.data_ptr() % 16 == 0
+        assert np.array_equal(got.cpu().numpy(), np.asarray(want, np.float32))
+    assert out[4].dtype == torch.float32 and float(out[4][0]) == 2.5
+    assert torch.equal(sess.upload(a), out[0])
+    # ring reuse under a busy compute stream: 80 uploads of distinct data, each consumed by queued work
+    big = torch.zeros(1 << 24, device='cuda:0')
+    sums, want = [], []
+    for k in range(80):
+        x = np.full((1 << 16,), float(k), np.float32)
+        dev = sess.upload(x)
+        for _ in range(4):
+            big.add_(1.0)                                          # keeps the compute stream behind the host
+        sums.append(dev.double().sum())
+        want.append(float(k) * (1 << 16))
+    torch.cuda.synchronize()
+    assert [float(s) for s in sums] == want
+    sess.close()

@@ -89,22 +89,23 @@ def main():
 
     # ---- the training loop, synthetic vs TFRecords: iterations per second of the RUNNING loop = (iters) / (time of a run of
     # 40 + iters iterations - time of a run of 40): session set-up, kernel loading, graph capture and worker start-up cancel
-    def loop(input_path, label, **extra):
+    def loop(input_path, label, scale=1, **extra):
+        n_long = 40 + args.iters * scale
         kw = dict(batch_size=args.batch, pretrain_iter=0, device='cuda:0', quiet=True, eval_every=0, log_every=10 ** 9, dtype=args.dtype, **extra)
         times = []
-        for iters in (40, 40, 40 + args.iters):          # (the first short run also warms the process: its time is dropped)
+        for iters in (40, 40, n_long):                   # (the first short run also warms the process: its time is dropped)
             torch.cuda.synchronize()
             t0 = time.time()
             tr = T.train(input_path, None, None, None, None, True, 'bce', 'adam', True, **dict(kw, train_iter=iters))
             torch.cuda.synchronize()
             times.append(time.time() - t0)
             tr.sess.close()
-        rate = args.iters / (times[2] - times[1])
+        rate = (n_long - 40) / (times[2] - times[1])
         print('train(%-40s): %6.1f iterations/s  (%.2f ms per D + G iteration; runs of 40 / %d iterations took %.2f / %.2f s)'
-              % (label, rate, 1e3 / rate, 40 + args.iters, times[1], times[2]))
+              % (label, rate, 1e3 / rate, n_long, times[1], times[2]))
         return rate
-    r_syn = loop('synthetic', 'synthetic, drawn per batch')
-    r_pool = loop('synthetic', 'synthetic, pool of 8 batches', synthetic_pool=8)
+    r_syn = loop('synthetic', 'synthetic, drawn per batch', scale=2)
+    r_pool = loop('synthetic', 'synthetic, pool of 8 batches', scale=10, synthetic_pool=8)        # (fast loops: longer runs)
     rows = [('tfrecords, 16 threads, all frames, exact', dict(data_workers='thread', data_threads=16, data_frames='all')),
             ('tfrecords, 16 processes, all, exact', dict(data_workers='process', data_threads=16, data_frames='all')),
             ('tfrecords, 16 processes, selected, exact', dict(data_workers='process', data_threads=16)),

@@ -15,7 +15,9 @@ Pieces (all host code; numpy + PIL for the JPEG):
   * ``resize_area`` for arbitrary ratios (box filter with fractional overlaps, as TF defines it);
   * ``PushDataset`` - file split by ``train_val_split`` as the reference does, shuffled record stream, batches, decoded by a
     pool of worker threads into a bounded prefetch queue (the reference: ``tf.train.batch(num_threads=batch_size,
-    capacity=500 * batch_size)``, ops.py:209-213) so that decoding overlaps the training step;
+    capacity=500 * batch_size)``, ops.py:209-213) so that decoding overlaps the training step; ``announce`` - the caller names,
+    batches ahead, the frames it will read and only those are decoded (same bits); ``decode='dct'`` - opt-in approximate
+    reduction inside libjpeg's inverse DCT;
   * ``write_push_tfrecord`` - the inverse, used by the tests and for making small synthetic shards.
 
 What is pinned and what is not.  The framing (RFC 3720 CRC vectors), the protobuf wire format, the crop offsets and the

@@ -372,10 +372,20 @@ def _decode_task(item, use_state=True, img_size=IMG_HEIGHT, dct=False):
 class _Prefetcher:
     """Records of one stream decoded by ``num_threads`` workers, handed out IN STREAM ORDER from a bounded queue.
 
-    A feeder thread pulls records from the (sequential, deterministic) stream, submits each to the pool and parks the future
-    in a queue of ``capacity`` entries; ``get()`` takes the oldest and waits for it.  Order of delivery = order of the
-    stream whatever the workers' timing; at most ``capacity`` decoded records are held; an exception in the stream or in a
-    decode surfaces from ``get()``; ``close()`` stops the feeder, cancels what has not started and joins everything."""
+    A feeder thread pulls ``(payload, tag)`` items from the (sequential, deterministic) stream, submits each payload to the pool
+    (``None``: nothing to decode - the consumer has all it needs in the tag) and parks the future in a queue of ``capacity``
+    entries; ``get()`` takes the oldest, waits for it and returns ``(result, tag)``.  Order of delivery = order of the stream
+    whatever the workers' timing; at most ``capacity`` decoded records are held; an exception in the stream or in a decode
+    surfaces from ``get()``; ``close()`` stops the feeder, cancels what has not started and joins everything."""
+
+    class _Done:
+        @staticmethod
+        def result():
+            return None
+
+        @staticmethod
+        def cancel():
+            return False
 
     def __init__(self, stream, decode, num_threads, capacity, processes=False):
         self._stream, self._decode = stream, decode
@@ -403,8 +413,9 @@ class _Prefetcher:
 
     def _feed(self):
         try:
-            for rec in self._stream:
-                if self._stop.is_set() or not self._put(self._pool.submit(self._decode, rec)):
+            for payload, tag in self._stream:
+                fut = self._Done if payload is None else self._pool.submit(self._decode, payload)
+                if self._stop.is_set() or not self._put((fut, tag)):
                     return
             self._put(StopIteration('the record stream ended'))
         except BaseException as e:          # a damaged shard, a decode that could not be submitted: hand it to the consumer
@@ -417,7 +428,7 @@ class _Prefetcher:
         if isinstance(item, BaseException):
             self._q.put(item)               # every later call reports it too
             raise item
-        return item.result()
+        return item[0].result(), item[1]
 
     def close(self):
         self._stop.set()
@@ -425,11 +436,44 @@ class _Prefetcher:
             try:
                 item = self._q.get_nowait()
                 if not isinstance(item, BaseException):
-                    item.cancel()
+                    item[0].cancel()
             except queue.Empty:
                 break
         self._feeder.join(timeout=10)
         self._pool.shutdown(wait=True, cancel_futures=True)
+
+
+class SparseFrames:
+    """The frames of an ANNOUNCED batch: only the frames the caller said it would read exist (``rows[b]`` = {frame index:
+    [S, S, 3] float32}).  Stands in for the dense ``[B, 7, S, S, 3]`` array where the training loop uses it - ``frames[mask]`` with
+    a boolean ``[B, 7]`` mask (train.py:231-232: one frame per record, in record order) gathers straight from the decoded frames;
+    a frame that was not asked for reads as NaN.  ``np.asarray(frames)`` (and with it any numpy function) materialises the dense
+    array, NaN where nothing was decoded - 11 MB at batch 32 that the loop has no use for."""
+
+    def __init__(self, rows, seq_len, img_size):
+        self.rows = rows
+        self.shape = (len(rows), seq_len, img_size, img_size, COLOR_CHAN)
+        self.dtype, self.ndim = np.dtype(np.float32), 5
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __array__(self, dtype=None, copy=None):
+        out = np.full(self.shape, np.nan, np.float32)
+        for b, row in enumerate(self.rows):
+            for t, frame in row.items():
+                out[b, t] = frame
+        return out if dtype is None else out.astype(dtype)
+
+    def __getitem__(self, index):
+        mask = index if isinstance(index, np.ndarray) else None
+        if mask is not None and mask.dtype == bool and mask.shape == self.shape[:2]:
+            picked = []
+            for b, t in zip(*np.nonzero(mask)):                   # row-major, as numpy orders a boolean selection
+                frame = self.rows[b].get(int(t))
+                picked.append(frame if frame is not None else np.full(self.shape[2:], np.nan, np.float32))
+            return np.stack(picked) if picked else np.zeros((0,) + self.shape[2:], np.float32)
+        return np.asarray(self)[index]
 
 
 class PushDataset:
@@ -446,23 +490,30 @@ class PushDataset:
     training step does.  ``workers='thread'`` (default): PIL's decoder and numpy's reductions release the GIL, the protobuf
     walk and the array plumbing do not - measured on the GPU box: 3.6x one thread at 8 threads, nothing beyond;
     ``workers='process'``: spawned worker processes, no shared interpreter lock (the reference's queue runners are C++
-    threads).  The order of the batches is the order of the record stream - deterministic per (seed, rank, world_size)
-    whatever the worker count or kind; ``num_threads=0`` decodes inside ``get_batch`` as before round 5.  The workers start
-    with the first ``get_batch`` or ``announce``.  ``close()`` (or the context manager) stops them; a dataset that is
-    garbage-collected closes itself.
+    threads).  A worker reads its record from the file itself (the feeder walks the 12-byte frame headers only; with
+    ``verify_crc`` the feeder reads and checks the payloads).  The order of the batches is the order of the record stream -
+    deterministic per (seed, rank, world_size) whatever the worker count or kind; ``num_threads=0`` decodes inside
+    ``get_batch`` as before round 5.  The workers start with the first ``get_batch`` or ``announce``.  ``close()`` (or the
+    context manager) stops them; a dataset that is garbage-collected closes itself.
 
     Decoding less (the loop is decode-bound: one 512x640 JPEG is 2-3 ms of a core, a batch of 32 records holds 224 of them, and
     a training step consumes 2 frames of each record):
       * ``announce(need)`` - the caller says, batches ahead, WHICH frames of a coming batch it will read (``need`` [B, 7] bool;
-        one call per future ``get_batch``, in order).  Only those are decoded; the others come back as NaN so that a read of a
-        frame that was not asked for cannot go unnoticed.  The decoded frames are the same bits as without the announcement.
-        A batch the workers reached before its announcement is decoded in full.  ``train()`` draws its frame-pair selections
-        ahead of time to do this (train._PairSelections).
+        one call per future ``get_batch``, in order).  Only those are decoded; ``get_batch`` then returns the frames as a
+        ``SparseFrames`` (``frames[mask]`` works as on the array; a frame that was not asked for reads as NaN, so that such a
+        read cannot go unnoticed).  The decoded frames are the same bits as without the announcement.  A batch the workers
+        reached before its announcement is decoded in full.  ``train()`` draws its frame-pair selections ahead of time to do
+        this (train._PairSelections).
+      * ``cache_bytes`` > 0 - decoded frames (and the pose vectors) are kept, up to that many bytes, and a record that comes
+        round again (the stream repeats the files every epoch; 60 000 iterations at batch 32 are ~37 epochs of the push
+        training set) is served from memory: no file read, no worker task.  What is kept is what the decoder produced - same
+        bits.  First come, first kept (no eviction: under a cyclic stream an LRU of less than the whole set never hits).
       * ``decode='dct'`` - opt-in, approximate: the 8x reduction inside libjpeg's inverse DCT (``decode_frame``).
     """
 
     def __init__(self, data_dir, batch_size, train_val_split=0.95, use_state=True, training=True, img_size=IMG_HEIGHT,
-                 seed=7, rank=0, world_size=1, verify_crc=False, num_threads=None, capacity=None, workers='thread', decode='exact'):
+                 seed=7, rank=0, world_size=1, verify_crc=False, num_threads=None, capacity=None, workers='thread', decode='exact',
+                 cache_bytes=0):
         files = sorted(glob.glob(os.path.join(data_dir, '*')))
         if not files:
             raise RuntimeError('No data files found.')                          # ops.py:159
@@ -486,44 +537,61 @@ class PushDataset:
             raise ValueError("decode must be 'exact' or 'dct'")
         self.num_threads, self.workers, self.decode = int(num_threads), workers, decode
         self.capacity = int(capacity) if capacity else 4 * batch_size
-        # worker processes fetch their record from the file themselves (the feeder walks the 12-byte frame headers only): the
-        # payload bytes - 0.5-2 MB per push record - never pass through this process or a pipe
-        self._spans = self.num_threads > 0 and workers == 'process' and not verify_crc
         import functools
         self._task = functools.partial(_decode_task, use_state=self.use_state, img_size=self.img_size, dct=decode == 'dct')    # picklable
-        self._plan, self._plan_lock = {}, threading.Lock()      # batch number -> need [B, 7], announced and not yet reached
+        self._lock = threading.Lock()
+        self._plan = {}                                         # batch number -> need [B, 7], announced and not yet reached
         self._announced = 0                                     # batches announced so far
-        self._served = 0                                        # records handed to a decoder so far
+        self._served = 0                                        # records drawn from the stream so far
+        self._spans = {}                                        # path -> [(offset, length)] of its records (walked once)
+        self.cache_bytes, self._cached_bytes = int(cache_bytes), 0
+        self._cache = {}                                        # (file, record number) -> [{frame: array}, action, state]
+        self.cache_hits = self.cache_misses = 0                 # frames served from memory / decoded
         self._stream = self._items()
         self._prefetch, self._closed = None, False
 
-    def _records(self, spans=False):
-        """The record stream of this rank: payload bytes, or (``spans``) (path, offset, length) triples for workers that read
-        their record themselves - same files, same order."""
+    def _records(self):
+        """The record stream of this rank: ((file number, record number), record) with the record as its payload bytes
+        (``verify_crc``) or as a (path, offset, length) span that whoever decodes it reads itself - same files, same order."""
         n = 0
         while True:
             seen = False
             for k in self.rng.permutation(len(self.files)):
                 path = self.files[k]
-                for rec in (record_spans(path) if spans else read_records(path, self.verify_crc)):
+                if self.verify_crc:
+                    recs = read_records(path, True)
+                else:
+                    if path not in self._spans:
+                        self._spans[path] = list(record_spans(path))
+                    recs = ((path,) + span for span in self._spans[path])
+                for j, rec in enumerate(recs):
                     seen = True
                     if n % self.world_size == self.rank:
-                        yield (path,) + rec if spans else rec
+                        yield (int(k), j), rec
                     n += 1
             if not seen:
                 raise RuntimeError('the data files hold no records')
 
     def _items(self):
-        """(record, need) in stream order: the need row is looked up when the record is DRAWN (by the feeder thread, up to
-        ``capacity`` records ahead of the consumer) - a batch announced later than that is decoded in full."""
-        for rec in self._records(self._spans):
-            with self._plan_lock:
+        """(payload, tag) in stream order for the prefetcher: payload = (record, frames to decode) or None when the cache holds
+        every frame that is needed; tag = (key, frames needed).  The need row is looked up when the record is DRAWN (by the
+        feeder thread, up to ``capacity`` records ahead of the consumer) - a batch announced later than that is decoded in full."""
+        everything = tuple(range(self.seq_len))
+        for key, rec in self._records():
+            with self._lock:
                 batch, row = divmod(self._served, self.batch_size)
                 need = self._plan.get(batch)
                 if need is not None and row == self.batch_size - 1:
                     del self._plan[batch]
                 self._served += 1
-            yield rec, (None if need is None else tuple(bool(v) for v in need[row]))
+                entry = self._cache.get(key) if self.cache_bytes else None
+                have = set(entry[0]) if entry is not None else ()
+            wanted = everything if need is None else tuple(j for j in everything if need[row][j])
+            missing = tuple(j for j in wanted if j not in have)
+            if entry is not None and not missing:
+                yield None, (key, wanted)
+            else:
+                yield (rec, tuple(j in missing for j in everything)), (key, wanted)
 
     def announce(self, need):
         """The frames of the next not-yet-announced batch that will be read: ``need`` [B, 7] bool.  One call per future
@@ -531,7 +599,7 @@ class PushDataset:
         need = np.asarray(need, bool)
         if need.shape != (self.batch_size, self.seq_len):
             raise ValueError('announce: expected a [%d, %d] boolean array, got %s' % (self.batch_size, self.seq_len, need.shape))
-        with self._plan_lock:
+        with self._lock:
             if self._announced * self.batch_size >= self._served:      # (a batch the workers already started on is past announcing)
                 self._plan[self._announced] = need.copy()
             self._announced += 1
@@ -543,22 +611,43 @@ class PushDataset:
         if self._prefetch is None and self.num_threads > 0:
             self._prefetch = _Prefetcher(self._stream, self._task, self.num_threads, self.capacity, processes=self.workers == 'process')
 
-    def get_batch(self):
-        """-> (frames, frames, action||state [B,T,10], state [B,T,5]), the tuple the training loop consumes."""
-        self._start()
+    def _next_record(self):
+        """-> ({frame: [S, S, 3]} of the frames needed, action [7, 5], state [7, 5]) of the next record of the stream."""
         if self._prefetch is not None:
-            decoded = [self._prefetch.get() for _ in range(self.batch_size)]
+            decoded, (key, wanted) = self._prefetch.get()
         else:
-            decoded = [self._task(next(self._stream)) for _ in range(self.batch_size)]
-        which, imgs, acts, states = zip(*decoded)
-        full = tuple(range(self.seq_len))
-        if all(w == full for w in which):
-            img = np.stack(imgs)
-        else:                                     # announced batches: the frames nobody asked for are NaN
-            img = np.full((self.batch_size, self.seq_len, self.img_size, self.img_size, COLOR_CHAN), np.nan, np.float32)
-            for b, (w, im) in enumerate(zip(which, imgs)):
-                if w:
-                    img[b, list(w)] = im
+            payload, (key, wanted) = next(self._stream)
+            decoded = None if payload is None else self._task(payload)
+        with self._lock:
+            entry = self._cache.get(key) if self.cache_bytes else None
+        frames = {j: entry[0][j] for j in wanted if j in entry[0]} if entry is not None else {}
+        self.cache_hits += len(frames)
+        if decoded is None:
+            return frames, entry[1], entry[2]
+        which, imgs, acts, states = decoded
+        self.cache_misses += len(which)
+        fresh = {j: imgs[i] for i, j in enumerate(which)}
+        frames.update(fresh)
+        if self.cache_bytes:
+            size = sum(f.nbytes for j, f in fresh.items() if entry is None or j not in entry[0]) + (acts.nbytes + states.nbytes if entry is None else 0)
+            with self._lock:
+                if self._cached_bytes + size <= self.cache_bytes:       # first come, first kept
+                    if entry is None:
+                        entry = self._cache.setdefault(key, [{}, acts, states])
+                    for j, f in fresh.items():
+                        entry[0].setdefault(j, f)
+                    self._cached_bytes += size
+        return frames, acts, states
+
+    def get_batch(self):
+        """-> (frames, frames, action||state [B,T,10], state [B,T,5]), the tuple the training loop consumes.  ``frames``: the
+        ``[B, 7, S, S, 3]`` array, or a ``SparseFrames`` when only announced frames were decoded."""
+        self._start()
+        rows, acts, states = zip(*[self._next_record() for _ in range(self.batch_size)])
+        if all(len(r) == self.seq_len for r in rows):
+            img = np.stack([np.stack([r[j] for j in range(self.seq_len)]) for r in rows])
+        else:
+            img = SparseFrames(list(rows), self.seq_len, self.img_size)
         action_state = np.concatenate([np.stack(acts), np.stack(states)], axis=2)
         return img, img, action_state, action_state[:, :, STATE_DIM:].copy()
 

@@ -406,7 +406,7 @@ def train(input_path, output_path, test_output_path, log_dir, model_dir, arg_adv
           batch_size=64, img_size=64, seq_len=8, ksize=5, train_iter=TRAIN_ITER, pretrain_iter=PRETRAIN_ITER,
           n_critic=None, device='cuda:0', world_size=1, rank=0, process_group=None, log_every=100, quiet=False,
           eval_every=500, resume=None, dtype='f32', sync_bn=False, exact_global_batch=False, dp_collectives=None, buckets=0,
-          data_workers='thread', data_threads=None, data_decode='exact', data_frames='selected', synthetic_pool=0):
+          data_workers='thread', data_threads=None, data_decode='exact', data_frames='selected', data_cache_gb=0.0, synthetic_pool=0):
     """Training loop of train.py:179-309.  ``input_path``: 'synthetic' (seeded random sequences) or a directory of
     push-dataset TFRecords, read by push_data.PushDataset (the reference's build_tfrecord_input, ops.py:140-223).
     ``dtype``: 'f32', or 'bf16' for the bf16 pipeline of BASELINE configs 3 and 5 (bf16 activations, float32 master weights).
@@ -419,8 +419,9 @@ def train(input_path, output_path, test_output_path, log_dir, model_dir, arg_adv
     ``data_frames``: 'selected' (default) - the loop tells the dataset batches ahead which frames each step will read and only
     those JPEGs are decoded (same frames, same bits; a step reads 2 of a record's 7) - or 'all' (every frame of every record,
     as the reference's queue runners do).  ``data_decode``: 'exact' (decode -> crop -> box mean, the reference's arithmetic) or
-    'dct' (opt-in, approximate: the reduction inside libjpeg's inverse DCT, push_data.decode_frame).  ``synthetic_pool``:
-    SyntheticPush(pool=...)."""
+    'dct' (opt-in, approximate: the reduction inside libjpeg's inverse DCT, push_data.decode_frame).  ``data_cache_gb``: keep up to
+    that many GiB of decoded frames in host memory - a record that comes round again in a later epoch is not decoded again (same
+    bits; 0 = off, as the reference).  ``synthetic_pool``: SyntheticPush(pool=...)."""
     if data_frames not in ('selected', 'all'):
         raise ValueError("data_frames must be 'selected' or 'all'")
     np.random.seed(7)                                           # train.py:14
@@ -430,7 +431,7 @@ def train(input_path, output_path, test_output_path, log_dir, model_dir, arg_adv
     else:
         from .push_data import PushDataset
         data = PushDataset(input_path, batch_size, training=True, img_size=img_size, rank=rank, world_size=world_size,
-                           workers=data_workers, num_threads=data_threads, decode=data_decode)
+                           workers=data_workers, num_threads=data_threads, decode=data_decode, cache_bytes=int(data_cache_gb * 2 ** 30))
         seq_len = data.seq_len
     boolean_mask = build_all_mask(seq_len)
     G.reset_default_graph()
@@ -574,6 +575,9 @@ def main(argv=None):
     parser.add_argument('--data_threads', type=int, default=None, help='number of decode workers (default: batch size, at most 16)')
     parser.add_argument('--data_frames', type=str, default='selected', choices=['selected', 'all'],
                         help="decode only the frames a step will read (same frames, same bits) or every frame of every record")
+    parser.add_argument('--data_cache_gb', type=float, default=8.0,
+                        help='GiB of host memory for decoded frames: a record seen in an earlier epoch is served from memory (same bits; '
+                             '0 = decode every time as the reference; the 64x64 push training set is ~17 GiB decoded)')
     parser.add_argument('--data_decode', type=str, default='exact', choices=['exact', 'dct'],
                         help="'dct': approximate 8x reduction inside libjpeg's inverse DCT (3x cheaper; within 2-3 levels of 255)")
     args = parser.parse_args(argv)
@@ -595,7 +599,8 @@ def main(argv=None):
                     seq_len=args.seq_len, ksize=args.ksize, train_iter=args.train_iter, pretrain_iter=args.pretrain_iter,
                     n_critic=args.n_critic, device='cuda:%d' % local_rank, world_size=world_size, rank=rank, dtype=args.dtype,
                     sync_bn=args.sync_bn, exact_global_batch=args.exact_global_batch, dp_collectives=args.dp_collectives, buckets=args.buckets,
-                    data_workers=args.data_workers, data_threads=args.data_threads, data_decode=args.data_decode, data_frames=args.data_frames)
+                    data_workers=args.data_workers, data_threads=args.data_threads, data_decode=args.data_decode, data_frames=args.data_frames,
+                    data_cache_gb=args.data_cache_gb)
     if trainer is not None:
         trainer.sess.close()        # ncclCommDestroy under data parallelism + a last check of the device-side flags
 

@@ -282,6 +282,58 @@ def test_announced_frames_are_the_only_ones_decoded(tmp_path):
                 ds.announce(np.zeros((2, 7), bool))
 
 
+def test_frame_cache_serves_later_epochs_with_the_same_bits(tmp_path):
+    """cache_bytes > 0: decoded frames are kept and a record that comes round again is not decoded again.  6 records on disk,
+    batches of 3: from the third batch on every record has been seen.  With and without announcements, synchronous and through
+    workers: the batches equal those of an uncached reader bit for bit (frames that were asked for; pose vectors always), the
+    hit / miss counters add up, later epochs decode only frames never asked for before, and a budget smaller than one frame
+    caches nothing."""
+    rng = np.random.default_rng(12)
+    for k in range(2):
+        make_shard(str(tmp_path / ('push_%02d.tfrecord' % k)), rng, 3)
+    with P.PushDataset(str(tmp_path), batch_size=3, train_val_split=1.0, num_threads=0) as ref:
+        want = [ref.get_batch() for _ in range(8)]
+    needs = []
+    for k in range(8):
+        need = np.zeros((3, 7), bool)
+        t = rng.integers(0, 6, 3)
+        need[np.arange(3), t] = True
+        need[np.arange(3), t + 1] = True
+        needs.append(need)
+    for threads, kind in ((0, 'thread'), (2, 'thread'), (2, 'process')):
+        # (a) everything decoded: epoch 1 misses, later epochs hit
+        with P.PushDataset(str(tmp_path), batch_size=3, train_val_split=1.0, num_threads=threads, workers=kind, capacity=3, cache_bytes=1 << 30) as ds:
+            for k in range(8):
+                got = ds.get_batch()
+                assert isinstance(got[0], np.ndarray) and all(np.array_equal(g, w) for g, w in zip(got, want[k])), (threads, kind, k)
+            assert ds.cache_hits + ds.cache_misses == 8 * 3 * 7
+            assert ds.cache_misses >= 6 * 7 and ds.cache_hits >= 3 * 3 * 7      # (workers run ahead: a record may be drawn again before its first decode was kept)
+            assert ds._cached_bytes == 6 * (7 * 64 * 64 * 3 * 4 + 2 * 7 * 5 * 4)
+        # (b) announced frames: sparse batches, the cache fills frame by frame
+        with P.PushDataset(str(tmp_path), batch_size=3, train_val_split=1.0, num_threads=threads, workers=kind, capacity=3, cache_bytes=1 << 30) as ds:
+            for k in range(3):
+                ds.announce(needs[k])
+            for k in range(8):
+                if k + 3 < 8:
+                    ds.announce(needs[k + 3])
+                img, _, act, st = ds.get_batch()
+                assert isinstance(img, P.SparseFrames) and img.shape == (3, 7, 64, 64, 3) and len(img) == 3
+                assert np.array_equal(act, want[k][2]) and np.array_equal(st, want[k][3])
+                assert np.array_equal(img[needs[k]], want[k][0][needs[k]]), (threads, kind, k)
+                first = np.zeros((3, 7), bool)
+                first[np.arange(3), needs[k].argmax(axis=1)] = True              # the loop's own access: one frame per record
+                assert np.array_equal(img[first], want[k][0][first])
+                dense = np.asarray(img)
+                assert np.array_equal(np.isfinite(dense).all(axis=(2, 3, 4)), needs[k]) and np.array_equal(dense[needs[k]], want[k][0][needs[k]])
+                assert np.isnan(img[~needs[k]]).all()                            # a frame nobody asked for reads as NaN
+            assert ds.cache_hits + ds.cache_misses == int(sum(n.sum() for n in needs))
+            assert ds.cache_hits > 0 and ds._cached_bytes <= 6 * (7 * 64 * 64 * 3 * 4 + 2 * 7 * 5 * 4)
+    with P.PushDataset(str(tmp_path), batch_size=3, train_val_split=1.0, num_threads=0, cache_bytes=1000) as ds:
+        for k in range(4):
+            assert np.array_equal(ds.get_batch()[0], want[k][0])
+        assert ds.cache_hits == 0 and ds._cached_bytes == 0 and not ds._cache
+
+
 def test_pair_selections_are_the_loops_own_draws_made_early():
     """train._PairSelections draws the frame-pair selections of coming iterations ahead of time so that the dataset can be told
     which frames to decode.  They must be the numbers the loop would have drawn call by call from numpy's global generator
@@ -407,6 +459,12 @@ def test_training_loop_reads_tfrecords(tmp_path, workers):
         for v in tr2.g_vars + tr2.d_vars:
             assert np.array_equal(tr2.sess.get_value(v).cpu().numpy(), want[v.name]), v.name
         tr2.sess.close()
+        # ... and neither does serving the records' later visits from the frame cache (4 records on disk, 5 batches of 2)
+        tr4 = T.train(str(tmp_path), None, None, None, None, True, 'bce', 'adam', True, batch_size=2, train_iter=4, pretrain_iter=1,
+                      device='cuda:0', quiet=True, eval_every=2, log_every=2, data_workers=workers, data_threads=2, data_cache_gb=0.25)
+        for v in tr4.g_vars + tr4.d_vars:
+            assert np.array_equal(tr4.sess.get_value(v).cpu().numpy(), want[v.name]), v.name
+        tr4.sess.close()
     else:
         tr3 = T.train(str(tmp_path), None, None, None, None, True, 'bce', 'adam', True, batch_size=2, train_iter=3, pretrain_iter=1,
                       device='cuda:0', quiet=True, eval_every=0, log_every=2, data_workers=workers, data_threads=2, data_decode='dct')

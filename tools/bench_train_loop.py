@@ -109,9 +109,12 @@ def main():
     rows = [('tfrecords, 16 threads, all frames, exact', dict(data_workers='thread', data_threads=16, data_frames='all')),
             ('tfrecords, 16 processes, all, exact', dict(data_workers='process', data_threads=16, data_frames='all')),
             ('tfrecords, 16 processes, selected, exact', dict(data_workers='process', data_threads=16)),
-            ('tfrecords, 16 processes, selected, dct', dict(data_workers='process', data_threads=16, data_decode='dct'))]
+            ('tfrecords, 16 processes, selected, dct', dict(data_workers='process', data_threads=16, data_decode='dct')),
+            # the frame cache: the 96 records come round every 3 iterations, so past the first few iterations every frame is
+            # served from memory - the rate of the second and later epochs of a run whose decoded set fits the cache
+            ('tfrecords, 16 proc., selected, exact, CACHED', dict(data_workers='process', data_threads=16, data_cache_gb=4.0))]
     for label, extra in rows:
-        r = loop(tmp, label, **extra)
+        r = loop(tmp, label, scale=10 if 'CACHED' in label else 1, **extra)
         print('   = %.2f of the drawn-per-batch synthetic loop, %.2f of the pooled one' % (r / r_syn, r / r_pool))
 
 

@@ -552,11 +552,18 @@ class Session:
             host.append((i, np.asarray(value)))
         if not host:
             return out
+        main = torch.cuda.current_stream(rt.device)
+        if main.query():
+            # the compute stream is idle (a caller that fetches results to the host every step, as the reference's loop does):
+            # nothing to overlap with, and the runtime's own pageable copy - which pins large user buffers in place instead of
+            # copying them - is then as fast (1.5 MB arrays) or faster (6 MB: 220 vs 198 steps/s at 128 x 128) than staging
+            for i, arr in host:
+                out[i] = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(rt.device, non_blocking=True)
+            return out
         if rt.upload_stream is None:
             rt.upload_stream = torch.cuda.Stream(rt.device)
             rt.upload_ring = [[torch.cuda.Event(), None] for _ in range(24)]      # [event, pinned staging buffer]
             rt.upload_count = 0
-        main = torch.cuda.current_stream(rt.device)
         # the host may run ahead of the compute stream by at most 24 uploads (a few training iterations): the event recorded
         # on the compute stream 24 uploads ago must have been reached - the slot's staging buffer is then free again, and the
         # device copies in flight stay bounded
@@ -571,11 +578,17 @@ class Session:
         if slot[1] is None or slot[1].numel() < total:
             slot[1] = torch.empty(total, dtype=torch.float32, pin_memory=True)
         staged = slot[1].numpy()
-        for (_, arr), off in zip(host, offsets):
-            # numpy's memcpy / cast (torch's threaded host copy_ of 1.5 MB costs milliseconds on a many-core host)
-            np.copyto(staged[off:off + arr.size].reshape(arr.shape), arr, casting='unsafe')
         with torch.cuda.stream(rt.upload_stream):
-            dev = slot[1][:total].to(rt.device, non_blocking=True)
+            dev = torch.empty(total, dtype=torch.float32, device=rt.device)
+            sent = 0
+            for k, ((_, arr), off) in enumerate(zip(host, offsets)):
+                # numpy's memcpy / cast (torch's threaded host copy_ of 1.5 MB costs milliseconds on a many-core host; slicing a
+                # 6 MB array over four threads of our own measured no faster than one memcpy)
+                np.copyto(staged[off:off + arr.size].reshape(arr.shape), arr, casting='unsafe')
+                end = total if k == len(host) - 1 else offsets[k + 1]
+                if end - sent >= (1 << 18) or end == total:        # >= 1 MB staged (or the rest): its DMA runs while the next array is staged
+                    dev[sent:end].copy_(slot[1][sent:end], non_blocking=True)
+                    sent = end
         main.wait_stream(rt.upload_stream)     # whatever reads the copy next on the compute stream is ordered behind it
         dev.record_stream(main)                # (allocated on the copy stream, used on the compute stream)
         slot[0].record(main)

@@ -20,6 +20,7 @@ PyTorch is used for device memory, streams, graph capture and torch.distributed 
 """
 import contextlib
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -553,7 +554,8 @@ class Session:
         if not host:
             return out
         main = torch.cuda.current_stream(rt.device)
-        if main.query():
+        mode = os.environ.get('ACG_UPLOAD', 'auto')        # measurement hook: 'pageable' / 'staged' force one path (profiles/r5/k_upload_ab.txt)
+        if mode == 'pageable' or (mode == 'auto' and main.query()):
             # the compute stream is idle (a caller that fetches results to the host every step, as the reference's loop does):
             # nothing to overlap with, and the runtime's own pageable copy - which pins large user buffers in place instead of
             # copying them - is then as fast (1.5 MB arrays) or faster (6 MB: 220 vs 198 steps/s at 128 x 128) than staging

@@ -450,6 +450,10 @@ def main():
     # with wrong statistics - acgan_hip.h).  Looked at HERE, on every rank, before anything is reported: a set flag on any rank
     # means no result line and a non-zero exit code on all of them.
     _require_clean_exchange(sess, world)
+    # Data parallel: every rank must hold the SAME weights after the timed steps (same start, same all-reduced gradients, same
+    # update) - bit for bit, and finite.  Ranks that drifted apart mean the gradient exchange did not do what the step assumes
+    # (a collective that silently did not run inside the captured graph, a bucket left out): no result line then either.
+    in_sync = _require_weights_in_sync(sess, tr, world)
     if rank != 0:
         _leave_distributed(sess)
         return
@@ -484,7 +488,7 @@ def main():
                    # what the first real N > 1 run can be checked against (review r4 item 7): the communicator's size as RCCL reports it,
                    # the all-reduce buckets per optimizer in bytes, and how often THIS rank called ncclAllReduce (eager first run +
                    # capture only: replays of a captured step call nothing from the host)
-                   'data_parallel': dp_report(sess, G.get_default_graph(), optim) if (world > 1 or args.force_dp) else None,
+                   'data_parallel': dict(dp_report(sess, G.get_default_graph(), optim), weights_in_sync_on_all_ranks=in_sync) if (world > 1 or args.force_dp) else None,
                    'lookahead': bool(lookahead), 'abi_version': lib_fingerprint()[0], 'lib_sha16': lib_fingerprint()[1],
                    'opt': args.opt, 'trace_run': bool(args.trace_run),
                    # every training step this process executed (eager + capture + first replay, warm-up, all timed blocks)
@@ -528,6 +532,27 @@ def _require_clean_exchange(sess, world):
     if bad:
         sess.close(check=False)
         raise err if err is not None else _lib.AcgError('another rank reported a BatchNorm grid-exchange timeout: no result')
+
+
+def _require_weights_in_sync(sess, tr, world):
+    """-> True when all ranks hold bit-identical, finite trainable weights (checksums compared over the gloo control group);
+    None on one rank; raises on every rank otherwise."""
+    if world <= 1:
+        return None
+    from action_conditioned_gans_amd import _lib
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    mine = []
+    for op in (tr.d_opt_op, tr.g_opt_op):
+        flat = op.inputs[0].buf                 # the optimizer's flat float32 parameter buffer
+        mine.append((int(flat.view(torch.int32).to(torch.int64).sum().item()), bool(torch.isfinite(flat).all().item())))
+    seen = [None] * world
+    torch.distributed.all_gather_object(seen, mine)
+    if any(s != seen[0] for s in seen) or not all(ok for _, ok in seen[0]):
+        sess.close(check=False)
+        raise _lib.AcgError('data parallel: the ranks do not hold the same finite weights after the timed steps '
+                            '(checksum, finite per optimizer and rank: %s): no result' % (seen,))
+    return True
 
 
 def _leave_distributed(sess):

@@ -359,3 +359,43 @@ def test_capture_failure_on_one_rank_keeps_the_ranks_in_step():
         assert np.array_equal(got[0][key], got[1][key]), key
         assert np.array_equal(got[0][key], ref[0][key]), key
         assert np.array_equal(ref[0][key], ref[1][key]), key
+
+
+def _sync_worker(rank, world, port, outdir, drift):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(2)
+    import bench
+    import train_cases as TC
+    from oracle import cbind
+    from action_conditioned_gans_amd import _lib, graph as G
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    sess, tr = TC.build_trainer(lambda **kw: G.Session(device='cpu', lib=cbind.load(), world_size=world, rank=rank, **kw),
+                                CASE, world_size=world, collectives='stream')
+    x, y, a, s = _inputs(rank)
+    tr.train_d(x, y, a)
+    tr.train_g(x, y, a, s)
+    if drift and rank == 1:
+        tr.g_opt_op.inputs[0].buf[17] += 1e-3                 # one weight of one rank off by a little
+    try:
+        verdict = 'in sync' if bench._require_weights_in_sync(sess, tr, world) else 'no check'
+    except _lib.AcgError as e:
+        verdict = 'raised: ' + str(e)[:60]
+    with open(os.path.join(outdir, 'sync_%d_r%d.txt' % (drift, rank)), 'w') as f:
+        f.write(verdict)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_bench_refuses_a_result_when_the_ranks_drifted_apart():
+    """bench.py, N > 1: before the result line every rank's trainable weights are compared over the control group (checksums
+    of the optimizers' flat parameter buffers).  Two ranks after one data-parallel D + G step on DIFFERENT samples hold the
+    same bits -> in sync; one weight of one rank nudged -> AcgError on BOTH ranks (no line, non-zero exit)."""
+    with tempfile.TemporaryDirectory() as d:
+        for drift in (0, 1):
+            mp.spawn(_sync_worker, args=(2, _free_port(), d, drift), nprocs=2, join=True)
+        out = {(drift, r): open(os.path.join(d, 'sync_%d_r%d.txt' % (drift, r))).read() for drift in (0, 1) for r in (0, 1)}
+    assert out[(0, 0)] == out[(0, 1)] == 'in sync', out
+    assert out[(1, 0)].startswith('raised: data parallel') and out[(1, 1)].startswith('raised: data parallel'), out

@@ -361,7 +361,7 @@ def test_capture_failure_on_one_rank_keeps_the_ranks_in_step():
         assert np.array_equal(ref[0][key], ref[1][key]), key
 
 
-def _sync_worker(rank, world, port, outdir, drift):
+def _drift_worker(rank, world, port, outdir, drift):
     for p in (ROOT, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -395,7 +395,7 @@ def test_bench_refuses_a_result_when_the_ranks_drifted_apart():
     same bits -> in sync; one weight of one rank nudged -> AcgError on BOTH ranks (no line, non-zero exit)."""
     with tempfile.TemporaryDirectory() as d:
         for drift in (0, 1):
-            mp.spawn(_sync_worker, args=(2, _free_port(), d, drift), nprocs=2, join=True)
+            mp.spawn(_drift_worker, args=(2, _free_port(), d, drift), nprocs=2, join=True)
         out = {(drift, r): open(os.path.join(d, 'sync_%d_r%d.txt' % (drift, r))).read() for drift in (0, 1) for r in (0, 1)}
     assert out[(0, 0)] == out[(0, 1)] == 'in sync', out
     assert out[(1, 0)].startswith('raised: data parallel') and out[(1, 1)].startswith('raised: data parallel'), out

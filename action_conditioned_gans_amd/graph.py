@@ -1068,8 +1068,19 @@ class Session:
         _launch_segment) and errors of our own library (AcgError: a bad kernel argument) are bugs, not stack limits."""
         if isinstance(exc, _lib.AcgError) or not isinstance(exc, RuntimeError):
             return False
-        msg = str(exc)
-        return any(k in msg for k in cls._CAPTURE_UNSUPPORTED)
+        from .comm import CommError
+        if isinstance(exc, CommError):
+            # a COLLECTIVE refused while its stream was capturing (RCCL wraps whatever the runtime told it into "unhandled cuda
+            # error" / "invalid usage"): the same stack limit seen through RCCL.  The program is launched eagerly instead - if
+            # the communicator itself is broken, the first eager ncclAllReduce says so, outside any capture
+            return 'ncclAllReduce failed' in str(exc)
+        seen = set()
+        while exc is not None and id(exc) not in seen:       # (capture_end raising on top of the first error: look at both)
+            seen.add(id(exc))
+            if isinstance(exc, RuntimeError) and not isinstance(exc, _lib.AcgError) and any(k in str(exc) for k in cls._CAPTURE_UNSUPPORTED):
+                return True
+            exc = exc.__cause__ or exc.__context__
+        return False
 
 
 @contextlib.contextmanager

@@ -358,6 +358,24 @@ def test_capture_fallback_only_for_capture_unsupported_errors():
     assert not ok(RuntimeError('hipErrorStreamCaptureUnmatched'))
     assert not ok(_lib.AcgError('acg_conv2d_fwd failed (code 1): null pointer while capturing'))
     assert not ok(ValueError('operation not permitted when stream is capturing'))
+    # round 5: a collective refused on a capturing stream comes back through RCCL's own error text; other RCCL failures are bugs
+    from action_conditioned_gans_amd.comm import CommError
+    assert ok(CommError('ncclAllReduce failed: unhandled cuda error (ncclResult 1)'))
+    assert not ok(CommError('ncclCommInitRank failed: internal error (ncclResult 3)'))
+    try:
+        try:
+            raise RuntimeError('HIP error: operation not permitted when stream is capturing')
+        except RuntimeError:
+            raise RuntimeError('capture_end failed')          # the error on top of the first one
+    except RuntimeError as chained:
+        assert ok(chained)
+    try:
+        try:
+            raise _lib.AcgError('acg_conv2d_fwd failed (code 1): bad argument')
+        except _lib.AcgError:
+            raise RuntimeError('capture_end failed')
+    except RuntimeError as chained:
+        assert not ok(chained)
     sess, tr = TC.build_trainer(cpu_session, 'c1_plain_l1')
     x, y, a, s = TC.MG.inputs(2)
     tr.pretrain_g(x, y, a, s)

@@ -8,6 +8,7 @@ no events, and an ordinary ``ncclCommDestroy`` at the end.  ``torch.distributed`
 (the 128-byte unique id travels through a gloo group or a TCPStore) - never for device traffic, so no
 ProcessGroupNCCL (and no watchdog thread polling events beside a stream capture) exists in the process.
 """
+import contextlib
 import ctypes
 import os
 
@@ -79,6 +80,30 @@ def _rccl():
     return _RCCL
 
 
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """File descriptor 1 points at stderr for the duration: librccl prints a version banner ("RCCL version : ...", five lines)
+    on STDOUT from inside ncclCommInitRank - in front of whatever the program itself reports there (bench.py's one JSON line)."""
+    import sys
+    try:
+        sys.stdout.flush()
+        saved = os.dup(1)
+    except (OSError, ValueError, AttributeError):
+        yield
+        return
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        try:
+            libc = ctypes.CDLL(None)
+            libc.fflush(None)              # whatever the C side still holds goes where fd 1 points NOW
+        except OSError:
+            pass
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def _check(rc, what, lib=None):
     if rc != 0:
         raise CommError('%s failed: %s (ncclResult %d)' % (what, (lib or _rccl()).ncclGetErrorString(rc).decode(), rc))
@@ -148,7 +173,7 @@ class RcclCommunicator(Communicator):
             unpack_unique_id(raw, uid)
         comm = ctypes.c_void_p()
         import contextlib
-        with (torch.cuda.device(device) if device.type == 'cuda' else contextlib.nullcontext()):
+        with (torch.cuda.device(device) if device.type == 'cuda' else contextlib.nullcontext()), _stdout_to_stderr():
             _check(lib.ncclCommInitRank(ctypes.byref(comm), self.world_size, uid, self.rank), 'ncclCommInitRank', lib)
         self._comm = comm
         self.calls = 0

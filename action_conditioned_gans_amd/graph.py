@@ -430,7 +430,7 @@ class Session:
 
     def __init__(self, device='cuda:0', graph=None, use_hip_graphs=True, lib=None,
                  world_size=1, rank=0, process_group=None, dtype='f32', pair_bwd=True, comm=None, slab_handoff=True, epilogue_stats=True, side_branches=False,
-                 epilogue_bias=True, fuse_weight_refresh=True, bn_grid_exchange=True):
+                 epilogue_bias=True, fuse_weight_refresh=True, bn_grid_exchange=None):
         self.graph = graph or get_default_graph()
         dev = torch.device(device)
         if lib is None:
@@ -472,9 +472,10 @@ class Session:
         self.side_branches = bool(side_branches) and dev.type == 'cuda'
         # bn_grid_exchange=False: never the one-launch grid-exchange BatchNorm kernels (ACG_BN_NO_GRID_EXCHANGE).  Forced with
         # side_branches: a side chain's BatchNorm can run beside a main-chain BatchNorm, and two grid-exchange kernels must
-        # never overlap (two partially resident grids starve each other until both time out)
-        if self.side_branches or not bn_grid_exchange:
-            self.rt.bn_flags = _lib.BN_NO_GRID_EXCHANGE
+        # never overlap (two partially resident grids starve each other until both time out).  None (default) = the policy of
+        # _bn_flags: off where a multi-rank collective shares the device with them, on otherwise; True = on whatever runs beside
+        self._bn_grid_exchange = bn_grid_exchange
+        self.rt.bn_flags = self._bn_flags()
         self._programs = {}
         self._initialized = False
         self._weights_dirty = True     # bf16 operand copies of the filters are stale (initializer, set_value, restore)
@@ -636,11 +637,51 @@ class Session:
         rec(fetches)
         return out
 
+    def _bn_flags(self, beside_collective=False):
+        """The BatchNorm entries' ``flags`` for an op of this session's programs.  The one-launch kernels exchange their partial
+        sums between the blocks of ONE grid and need all of them resident at once; the large tensors take exactly one
+        1024-thread block per CU of the whole device.  With more than one rank and ``collectives='side'`` an RCCL ring kernel
+        holds CUs on the second stream from the launch of a bucket's all-reduce until the join in front of the optimizer: a
+        BatchNorm grid launched in that window cannot become fully resident until the all-reduce is over - correct (the spin is
+        bounded far above an all-reduce), but the overlap the side stream exists for is gone.  That this does NOT happen beside
+        a real multi-rank ring kernel could not be shown on the one-GPU boxes this was built on, so the BatchNorm launches
+        INSIDE that window - the backward passes of the early layers - take the two-launch kernels; every
+        forward pass and the backward passes in front of the first all-reduce run beside nothing and keep the one-launch
+        kernels, as do one-rank sessions and 'stream' collectives.
+        ``bn_grid_exchange``: None = that policy when the graph's data-parallel configuration has more than one rank and side
+        collectives; 'not_beside_collectives' = that policy whatever the rank count (measurement / tests on one rank); True =
+        one-launch kernels everywhere; False = nowhere."""
+        mode = self._bn_grid_exchange
+        if self.side_branches or mode is False:
+            return _lib.BN_NO_GRID_EXCHANGE
+        if mode is None:
+            dp = self.graph.collections.get('data_parallel')
+            mode = 'not_beside_collectives' if (dp is not None and dp.world_size > 1 and dp.collectives == 'side') else True
+        return _lib.BN_NO_GRID_EXCHANGE if (mode == 'not_beside_collectives' and beside_collective) else 0
+
+    def _assign_bn_flags(self, ops):
+        """Per BatchNorm launch of the program ``ops``: the flags of _bn_flags, by its position relative to the program's first
+        side-stream collective.  Stored on the forward op (ops.BnActOp.flags_fwd / flags_bwd): the producer that hands its
+        split-K slabs to a BatchNorm asks that op for the layout and must see what the consuming launch will see."""
+        first = next((i for i, o in enumerate(ops) if getattr(o, 'is_collective', False) and o.side_stream), None)
+        n_two_launch = 0
+        for i, o in enumerate(ops):
+            flags = self._bn_flags(first is not None and i > first)
+            if hasattr(o, 'flags_fwd'):
+                o.flags_fwd = flags
+            elif hasattr(getattr(o, 'fwd', None), 'flags_bwd'):
+                o.fwd.flags_bwd = flags
+            else:
+                continue
+            n_two_launch += 1 if flags else 0
+        return n_two_launch
+
     def _compile(self, flat_fetches, feeds, skip_ops=()):
         """``skip_ops``: ops whose results are ALREADY in their output tensors (another program of this session left them there:
         Trainer's look-ahead generator pass) - the dependency walk stops at them, they are not launched, their outputs are bound
         as they lie, and no feed alias writes into them either (a concatenation's fed channels are part of its result)."""
         g = self.graph
+        self.rt.bn_flags = self._bn_flags()       # (the data-parallel configuration may have been set after the session was made)
         skip = frozenset(id(o) for o in skip_ops)
         skip_outputs = frozenset(id(t) for o in skip_ops for t in o.outputs)
         needed, stack = {}, []
@@ -679,6 +720,7 @@ class Session:
             active = self.pair_bwd and w is not None and k + 1 < len(ops) and ops[k + 1] is w
             if w is not None:
                 op.pair_active, w.paired = active, active
+        self.bn_two_launch_ops = max(getattr(self, 'bn_two_launch_ops', 0), self._assign_bn_flags(ops))
         segments, cur = [], []
         for op in ops:
             fn = op.bind(self.rt)

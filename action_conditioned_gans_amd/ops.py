@@ -483,13 +483,21 @@ class BnActOp(G.Op):
         self.yp = y.shape[-1]
         super().__init__(g, name, [x, beta], [y, self.mean, self.rstd])
 
+    # the `flags` argument of this layer's BatchNorm launches in the program being compiled, forward and backward; set per
+    # program by Session._compile (an op that runs beside a multi-rank collective takes the two-launch kernels), None = rt.bn_flags
+    flags_fwd = flags_bwd = None
+
+    def launch_flags(self, rt, backward):
+        own = self.flags_bwd if backward else self.flags_fwd
+        return rt.bn_flags if own is None else own
+
     def slab_layout(self, rt, splits, backward, dy=None):
         """The slab layout this BatchNorm (forward, or its backward reading `dy`) takes from a producer split `splits` ways
         in the program being compiled; -1: none, the producer runs its own reduction (acg_bn_slabs_layout)."""
         if not 1 < splits <= rt.slab_handoff:
             return -1
         code = _code2(self.inputs[0], dy if backward else self.outputs[0])
-        layout = rt.lib.bn_slabs_layout(self.rows, self.c, self.xp, self.yp, self.groups, code, 1 if backward else 0, rt.bn_flags)
+        layout = rt.lib.bn_slabs_layout(self.rows, self.c, self.xp, self.yp, self.groups, code, 1 if backward else 0, self.launch_flags(rt, backward))
         return layout if (layout == SLABS_QUADS or rt.slab_rows) else -1
 
     def bind(self, rt):
@@ -510,11 +518,11 @@ class BnActOp(G.Op):
         if slab is not None:      # the conv left its split-K slabs: sum them here and write x for the backward pass
             sws, splits, layout = slab
             args = (_p(sws), splits, _p(x.buf), _p(beta.buf), _p(y.buf), _p(mean.buf), _p(rstd.buf), self.rows, self.c, self.xp, self.yp,
-                    self.groups, self.eps, _ACT_CODE[self.act], self.leak, _code2(x, y), layout, rt.bn_flags, _p(ws), n)
+                    self.groups, self.eps, _ACT_CODE[self.act], self.leak, _code2(x, y), layout, self.launch_flags(rt, False), _p(ws), n)
             fn = lib.bn_act_fwd_slabs
             return lambda s: fn(*args, s)
         args = (_p(x.buf), _p(beta.buf), _p(y.buf), _p(mean.buf), _p(rstd.buf), self.rows, self.c, self.xp, self.yp, self.groups,
-                self.eps, _ACT_CODE[self.act], self.leak, _code2(x, y), rt.bn_flags, _p(ws), n)
+                self.eps, _ACT_CODE[self.act], self.leak, _code2(x, y), self.launch_flags(rt, False), _p(ws), n)
         fn = lib.bn_act_fwd
         return lambda s: fn(*args, s)
 
@@ -554,11 +562,11 @@ class BnActBwdOp(G.Op):
         if slab is not None:      # dy arrives as the producing dgrad's split-K slabs
             sws, splits, layout = slab
             args = (_p(x.buf), _p(sws), splits, _p(beta.buf), _p(mean.buf), _p(rstd.buf), _p(dx.buf), _p(dbeta.buf), self.accumulate,
-                    f.rows, f.c, f.xp, f.yp, f.groups, _ACT_CODE[f.act], f.leak, _code2(x, dy), layout, rt.bn_flags, _p(ws), n)
+                    f.rows, f.c, f.xp, f.yp, f.groups, _ACT_CODE[f.act], f.leak, _code2(x, dy), layout, f.launch_flags(rt, True), _p(ws), n)
             fn = lib.bn_act_bwd_slabs
             return lambda s: fn(*args, s)
         args = (_p(x.buf), _p(dy.buf), _p(beta.buf), _p(mean.buf), _p(rstd.buf), _p(dx.buf), _p(dbeta.buf), self.accumulate,
-                f.rows, f.c, f.xp, f.yp, f.groups, _ACT_CODE[f.act], f.leak, _bn_bwd_code(x, dy, dx), rt.bn_flags, _p(ws), n)
+                f.rows, f.c, f.xp, f.yp, f.groups, _ACT_CODE[f.act], f.leak, _bn_bwd_code(x, dy, dx), f.launch_flags(rt, True), _p(ws), n)
         fn = lib.bn_act_bwd
         return lambda s: fn(*args, s)
 

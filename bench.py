@@ -81,6 +81,10 @@ def parse():
     ap.add_argument('--sync-bn', action='store_true', help='data parallel with BatchNorm statistics of the global batch (one small all-reduce per BatchNorm layer and direction)')
     ap.add_argument('--trace-run', action='store_true', help='nothing but training steps (no rollout, no instrumented pass, no CPU baseline): the run tools/insitu_times.py reduces a rocprofv3 kernel trace of')
     ap.add_argument('--force-dp', action='store_true', help='run the data-parallel machinery (RCCL all-reduce buckets, graph segments) even on one rank')
+    ap.add_argument('--bn-grid-exchange', default='auto', choices=['auto', 'on', 'off', 'not-beside-collectives'],
+                    help="the one-launch BatchNorm kernels (all blocks of a grid resident at once): 'auto' = with more than one rank under side-stream collectives "
+                         "the launches between a bucket's all-reduce and the join take the two-launch kernels (an RCCL ring kernel holds CUs beside them), on "
+                         "otherwise; 'not-beside-collectives' = that rule whatever the rank count (with --force-dp: its cost on one rank); 'on' / 'off' force it")
     ap.add_argument('--no-lookahead', action='store_true', help='the two generator forward passes of an iteration as separate batch-B launches (Trainer.train_d without next_g), as before round 5')
     ap.add_argument('--no-api-rates', action='store_true', help='skip the two labelled side numbers (plain call path, numpy-in / numpy-out call path)')
     return ap.parse_args()
@@ -181,7 +185,8 @@ def main():
     G.reset_default_graph()
     optim.set_data_parallel(world, n_buckets=args.buckets, force=args.force_dp, sync_bn=args.sync_bn, exact_global_batch=args.exact_global_batch,
                             collectives=args.dp_collectives)
-    sess = G.Session(device=device, side_branches=args.side_branch, **({} if args.slab_handoff is None else {'slab_handoff': args.slab_handoff}), epilogue_stats=not args.no_epilogue_stats, pair_bwd=not args.no_pair, use_hip_graphs=not args.no_graphs, world_size=world, rank=rank, dtype=args.dtype)
+    sess = G.Session(device=device, side_branches=args.side_branch, **({} if args.slab_handoff is None else {'slab_handoff': args.slab_handoff}), epilogue_stats=not args.no_epilogue_stats, pair_bwd=not args.no_pair, use_hip_graphs=not args.no_graphs, world_size=world, rank=rank, dtype=args.dtype,
+                     bn_grid_exchange={'auto': None, 'on': True, 'off': False, 'not-beside-collectives': 'not_beside_collectives'}[args.bn_grid_exchange])
     tr = T.Trainer(sess, adv, args.loss, args.opt, dna, batch_size=B, img_size=S, ksize=args.ksize, seed=0, lookahead=not args.no_lookahead)
     sess.run(G.global_variables_initializer())
     lookahead = tr.lookahead
@@ -391,6 +396,11 @@ def main():
             path = os.path.join(ROOT, 'profiles', 'r5', '%s_%s.json' % (kind, tag))
             if not (std_step and os.path.exists(path)):
                 return None, None
+            if sess.rt.bn_flags & 1 or getattr(sess, 'bn_two_launch_ops', 0):
+                # the committed profiles were taken with the one-launch BatchNorm kernels; this run uses the two-launch ones (more
+                # than one rank under side-stream collectives, or --bn-grid-exchange off): other kernels between the convs
+                stale.append('profiles/r5/%s_%s.json describes a step with the one-launch BatchNorm kernels; this run takes the two-launch path' % (kind, tag))
+                return None, None
             with open(path) as f:
                 prof = json.load(f)
             if prof.get('abi_version') != abi or prof.get('lib_sha16') != sha or bool(prof.get('lookahead')) != bool(lookahead):
@@ -489,7 +499,7 @@ def main():
                    # the all-reduce buckets per optimizer in bytes, and how often THIS rank called ncclAllReduce (eager first run +
                    # capture only: replays of a captured step call nothing from the host)
                    'data_parallel': dict(dp_report(sess, G.get_default_graph(), optim), weights_in_sync_on_all_ranks=in_sync) if (world > 1 or args.force_dp) else None,
-                   'lookahead': bool(lookahead), 'abi_version': lib_fingerprint()[0], 'lib_sha16': lib_fingerprint()[1],
+                   'bn_grid_exchange': ('off' if sess.rt.bn_flags & 1 else ('two-launch kernels for the %d BatchNorm launches beside side-stream collectives, one-launch elsewhere' % sess.bn_two_launch_ops if getattr(sess, 'bn_two_launch_ops', 0) else 'on')), 'lookahead': bool(lookahead), 'abi_version': lib_fingerprint()[0], 'lib_sha16': lib_fingerprint()[1],
                    'opt': args.opt, 'trace_run': bool(args.trace_run),
                    # every training step this process executed (eager + capture + first replay, warm-up, all timed blocks)
                    'step_executions': 3 + args.warmup + args.steps * len(blocks)},

@@ -57,6 +57,14 @@ def _worker(rank, world, port, outdir, collectives='stream', lookahead=False):
         segs = [k for k, _ in sess._programs[next(iter(sess._programs))].segments]
         out['n_host_segments'] = np.array(segs.count('host'))
         out['eager'] = np.array(int(sess._programs[next(iter(sess._programs))].eager))
+        # round 5: which BatchNorm launches take the two-launch kernels (Session._bn_flags): flags of the G step's program,
+        # the last one compiled - forward launches, and backward launches by their position relative to the first all-reduce
+        ops = [o for _, seg in sess._programs[list(sess._programs)[-1]].segments for o, _ in seg]
+        first = next((i for i, o in enumerate(ops) if getattr(o, 'is_collective', False) and o.side_stream), len(ops))
+        bwd = [(i, o.fwd.flags_bwd) for i, o in enumerate(ops) if hasattr(getattr(o, 'fwd', None), 'flags_bwd')]
+        out['bn_fwd_flags'] = np.array([o.flags_fwd for o in ops if hasattr(o, 'flags_fwd')])
+        out['bn_bwd_before'] = np.array([f for i, f in bwd if i < first])
+        out['bn_bwd_after'] = np.array([f for i, f in bwd if i > first])
     if lookahead:
         out['n_programs'] = np.array(len(sess._programs))
         out['skipped'] = np.array(sum(1 for p in sess._programs.values() if getattr(p, 'skip_ref', None)))
@@ -101,10 +109,16 @@ def test_two_rank_allreduce_matches_mean_gradient_update(collectives):
     assert np.array_equal(dp[0]['g_grad'], dp[1]['g_grad'])
     # the all-reduces are device ops of the launch list (no host segments), in both modes
     assert int(dp[0]['n_host_segments']) == 0 and int(dp[0]['eager']) == 0
+    # BatchNorm kernels beside a multi-rank ring kernel (Session._bn_flags): with side-stream collectives the backward launches
+    # behind the first bucket's all-reduce take the two-launch path (flag 1), everything in front of it - all forward passes,
+    # the late layers' backward passes - and every launch under in-order collectives keeps the one-launch kernels
+    assert len(dp[0]['bn_fwd_flags']) >= 6 and not dp[0]['bn_fwd_flags'].any() and not dp[0]['bn_bwd_before'].any()
     if collectives == 'side':          # two buckets per optimizer
         assert int(dp[0]['n_allreduce']) >= 4
-    else:                              # one message per optimizer: D, G (and G pre-training)
-        assert 2 <= int(dp[0]['n_allreduce']) <= 3
+        assert len(dp[0]['bn_bwd_before']) >= 1 and len(dp[0]['bn_bwd_after']) >= 3 and dp[0]['bn_bwd_after'].all()
+    else:
+        assert len(dp[0]['bn_bwd_after']) == 0
+        assert 2 <= int(dp[0]['n_allreduce']) <= 3          # one message per optimizer: D, G (and G pre-training)
 
 
 @pytest.mark.timeout(900)

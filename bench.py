@@ -158,6 +158,12 @@ def cpu_baseline(args, n_critic):
 
 def main():
     args = parse()
+    # The contract is ONE JSON line on stdout.  Libraries write there too (librccl: a five-line version banner from ncclCommInitRank,
+    # NCCL_DEBUG output, whatever a teardown says): file descriptor 1 points at stderr for the whole run, and the result line
+    # goes to the real stdout kept here.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -509,7 +515,8 @@ def main():
         # per op kind, this process: an event pair around every eager launch (includes the ~4 us the event records open per op)
         'op_ms_per_step': {k: round(v, 4) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])},
     }
-    print(json.dumps(line), flush=True)
+    result_out.write(json.dumps(line) + '\n')
+    result_out.flush()
     _leave_distributed(sess)
 
 

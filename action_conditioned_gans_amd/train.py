@@ -253,8 +253,12 @@ class Trainer:
         gen_next_state = res[1] if self.g_state_out is not None else None      # defect D4
         return gen_next_frames, gen_next_state, self._named(summ)
 
-    def test_sequence(self, input_images, test_next_frame, test_actions, steps=None, literal=False):
+    def test_sequence(self, input_images, test_next_frame, test_actions, steps=None, literal=False, device_loop=None):
         """Recursive rollout: feed each prediction (and predicted state) back in.
+        ``device_loop`` (default: on for a GPU session): from the second step on the prediction and the predicted state stay on the
+        device between steps - the program of those steps fetches nothing but the two, so it carries no loss ops either - and
+        all predictions come to the host in one copy at the end.  Same kernels on the same bits as the step-by-step numpy round
+        trip (``device_loop=False``, the reference's own loop), which it replaces only in where the intermediate frames live.
 
         Default: the evaluation block of the reference's training loop (train.py:285-298) - T-1 steps, step j commanded
         by ``test_actions[:, j]`` and scored against ``test_next_frame[:, j + 1]`` (defect D7: own states); returns
@@ -274,6 +278,25 @@ class Trainer:
                 current_state = st if st is not None else test_actions[:, j * 2, 5:]      # plain generator: no state head (D4)
             return np.transpose(np.array(predicted), (1, 0, 2, 3, 4)), current_frame[1:7]
         steps = steps if steps is not None else test_next_frame.shape[1] - 1
+        if device_loop is None:
+            device_loop = self.sess.rt.is_cuda
+        if device_loop and steps >= 1:
+            out, st, summ0 = self.test(input_images[:, 0], test_next_frame[:, 1], np.asarray(test_actions[:, 0], np.float32))
+            acts = self.sess.upload(np.asarray(test_actions[:, :steps + 1], np.float32))          # [B, steps + 1, 10], once
+            frame = self.sess.upload(out)
+            state = self.sess.upload(st) if st is not None else acts[:, 1, 5:]
+            frames = [frame]
+            fetches = [self.g_next_frame] + ([self.g_state_out] if self.g_state_out is not None else [])
+            for j in range(1, steps):
+                acs = torch.cat([acts[:, j, :5], state], dim=1).contiguous()
+                fd = self._feed(frame, test_next_frame[:, j + 1], acs)      # (next_frame is not read by this program: checked, not uploaded)
+                self._announced = None
+                res = self.sess.run(fetches, fd, device_fetch=True)
+                frame = res[0].float().clone()                             # the fetch is the tensor's own buffer: the next step overwrites it
+                state = res[1].float().clone() if self.g_state_out is not None else acts[:, j + 1, 5:]
+                frames.append(frame)
+            predicted = torch.stack(frames, dim=1).cpu().numpy()
+            return predicted, summ0
         predicted, summ0 = [], None
         current_frame = input_images[:, 0]
         current_state = test_actions[:, 0, 5:]

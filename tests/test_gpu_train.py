@@ -207,6 +207,12 @@ def test_rollout_matches_oracle(name):
     for j in range(T_ - 1):
         assert TC.rel(pred[:, j], want[:, j].numpy()) <= 1e-3, j
     assert abs(summ['g_psnr'] - psnrs[0]) <= 1e-3 * abs(psnrs[0])
+    # the default keeps the prediction and the predicted state on the device between steps (round 5); the reference's own
+    # loop - every frame through the host - gives the same bits
+    pred_host, summ_host = tr.test_sequence(frames, frames, acts, device_loop=False)
+    assert np.array_equal(pred, pred_host) and summ == summ_host
+    one, _ = tr.test_sequence(frames, frames, acts, steps=1)
+    assert np.array_equal(one, pred[:, :1])
 
 
 def test_test_sequence_literal_matches_reference_indexing():

@@ -543,7 +543,7 @@ def _train_loop(sess, data, input_path, synthetic, boolean_mask, log_dir, model_
             if log_file and summ:
                 _log_jsonl(log_file, dict(summ, iteration=i, wall_s=time.time() - t0))
             if model_dir:
-                saver.save(sess, os.path.join(model_dir, 'model{:d}'.format(i)))         # train.py:274
+                saver.save(sess, os.path.join(model_dir, 'model{:d}'.format(i)), background=True)      # train.py:274; written by a writer thread
         if eval_every and i % eval_every == 0 and rank == 0:
             # recursive rollout over T-1 steps on held-out sequences (train.py:278-309; defect D7: own states)
             t_img, _, t_acts, _ = eval_data.get_batch()
@@ -554,6 +554,7 @@ def _train_loop(sess, data, input_path, synthetic, boolean_mask, log_dir, model_
                 _log_jsonl(os.path.join(log_dir, 'test.jsonl'), dict(e_summ or {}, iteration=i, rollout_psnr=psnr))
     if hasattr(eval_data, 'close'):
         eval_data.close()
+    saver.wait()                     # the last checkpoints are on disk when train() returns
     return trainer
 
 

@@ -218,6 +218,46 @@ def test_checkpoint_roundtrip_and_rollout(tmp_path):
     assert pred.shape == (2, 3, 64, 64, 3) and np.isfinite(pred).all() and 'g_psnr' in summ
 
 
+def test_saver_keeps_five_checkpoints_and_writes_in_the_background(tmp_path):
+    """tf.train.Saver() keeps the 5 most recent checkpoints (its default max_to_keep; train.py:215 passes nothing) - 600 saves of
+    ~90 MB at the reference's cadence otherwise.  Saver.save(background=True), what train() uses: the state is copied when save is
+    called, a writer thread writes the files in order (atomically: .tmp then rename), wait() returns when they are on disk, a
+    restore waits by itself, and a write that fails is raised by the next save / wait."""
+    import os
+    from action_conditioned_gans_amd.saver import Saver, latest_checkpoint
+    x, y, a, s = TC.MG.inputs(2)
+    sess, tr = TC.build_trainer(cpu_session, 'c4_dna_wass_rmsprop')
+    saver = Saver()
+    states = []
+    for k in range(8):
+        tr.train_d(x, y, a)
+        states.append({n: sess.get_value(v) for n, v in G.get_default_graph().variables.items()})
+        saver.save(sess, str(tmp_path / ('model%d' % (100 * k))), background=True)
+    saver.wait()
+    files = sorted(f for f in os.listdir(str(tmp_path)))
+    assert files == sorted('model%d.npz' % (100 * k) for k in range(3, 8)), files          # the five newest, no .tmp left
+    assert latest_checkpoint(str(tmp_path)) == str(tmp_path / 'model700')
+    # each file holds the state AT ITS save call, not a later one
+    for k in (3, 7):
+        sess2, tr2 = TC.build_trainer(cpu_session, 'c4_dna_wass_rmsprop')
+        Saver().restore(sess2, str(tmp_path / ('model%d' % (100 * k))))
+        for n, v in G.get_default_graph().variables.items():
+            assert torch.equal(sess2.get_value(v), states[k][n]), (k, n)
+    # max_to_keep=None keeps everything; a synchronous save after background ones stays in order
+    keep_all = Saver(max_to_keep=None)
+    for k in range(7):
+        keep_all.save(sess2, str(tmp_path / 'all' / ('m%d' % k)), background=k % 2 == 0)
+    keep_all.wait()
+    assert len(os.listdir(str(tmp_path / 'all'))) == 7
+    # a failing write surfaces
+    blocked = tmp_path / 'blocked'
+    blocked.write_text('a file where a directory is needed')
+    bad = Saver()
+    with pytest.raises(OSError):
+        bad.save(sess2, str(blocked / 'model0'), background=True)
+        bad.wait()
+
+
 def test_feeds_missing_unused_and_aliased():
     """TF feed semantics of the session: a placeholder the program reads must be fed (ValueError, as TF's "You must feed a value
     for placeholder tensor"); a fed placeholder the program does not read is validated and ignored (the D step is fed next_state

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Soak of train() on push TFRecords as the CLI runs it (process workers, announced frames, frame cache, logging + checkpoints +
 evaluation rollouts on): ITER iterations (environment, default 6000), resident memory of this process every 1000 iterations,
-finite weights and clean device-side flags at the end.  Looks for what a short test cannot: staging / event / cache growth,
+finite weights and clean device-side flags at the end (LOG_EVERY: logging / checkpoint interval, default 500).  Looks for what a short test cannot: staging / event / cache growth,
 worker shutdown at exit.
 
   python tools/soak_train_loop.py"""
@@ -29,6 +29,7 @@ def main():
     import bench_train_loop as BL
     from action_conditioned_gans_amd import train as T
     iters = int(os.environ.get('ITER', '6000'))
+    log_every = int(os.environ.get('LOG_EVERY', '500'))       # the reference logs and saves every 100 iterations (train.py:269-274)
     tmp = tempfile.mkdtemp(prefix='push_soak_')
     BL.make_shards(tmp, 96)
     out = tempfile.mkdtemp(prefix='push_soak_out_')
@@ -51,7 +52,7 @@ def main():
     th = threading.Thread(target=watch, daemon=True)
     th.start()
     tr = T.train(tmp, None, None, log_dir, model_dir, True, 'bce', 'adam', True, batch_size=32, train_iter=iters, pretrain_iter=20,
-                 device='cuda:0', quiet=True, eval_every=1000, log_every=500, data_workers='process', data_threads=16, data_cache_gb=1.0)
+                 device='cuda:0', quiet=True, eval_every=1000, log_every=log_every, data_workers='process', data_threads=16, data_cache_gb=1.0)
     torch.cuda.synchronize()
     dt = time.time() - t0
     stop.set()

@@ -620,13 +620,14 @@ class PushDataset:
             decoded = None if payload is None else self._task(payload)
         with self._lock:
             entry = self._cache.get(key) if self.cache_bytes else None
-        frames = {j: entry[0][j] for j in wanted if j in entry[0]} if entry is not None else {}
+        fresh = {} if decoded is None else {j: decoded[1][i] for i, j in enumerate(decoded[0])}
+        # (a frame both decoded for this visit and kept meanwhile by an earlier visit - the workers run ahead - counts once)
+        frames = {j: entry[0][j] for j in wanted if j in entry[0] and j not in fresh} if entry is not None else {}
         self.cache_hits += len(frames)
+        self.cache_misses += len(fresh)
         if decoded is None:
             return frames, entry[1], entry[2]
-        which, imgs, acts, states = decoded
-        self.cache_misses += len(which)
-        fresh = {j: imgs[i] for i, j in enumerate(which)}
+        acts, states = decoded[2], decoded[3]
         frames.update(fresh)
         if self.cache_bytes:
             size = sum(f.nbytes for j, f in fresh.items() if entry is None or j not in entry[0]) + (acts.nbytes + states.nbytes if entry is None else 0)

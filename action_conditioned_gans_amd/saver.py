@@ -112,6 +112,9 @@ class Saver:
         """Everything handed to the writer thread is on disk when this returns."""
         if self._jobs is not None:
             self._jobs.join()
+            self._jobs.put(None)                  # the writer thread ends; the next background save starts a new one
+            self._writer.join()
+            self._jobs = self._writer = None
         if self._error is not None:
             err, self._error = self._error, None
             raise err

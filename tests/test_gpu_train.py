@@ -301,7 +301,7 @@ def test_training_loop_runs_wass_rmsprop_n_critic(dtype):
 # the chaos of storage rounding amplified by the BatchNorm'd head (test_epilogue_statistics_match_the_statistics_pass).
 BF16_TOL = {'frame': 1.0e-2,      # max abs error of the predicted frame / frame scale        (measured 0.71e-2 / 0.37e-2)
             'state': 1.5e-2,      # predicted state (a 5-vector behind three strided convs)    (0.83e-2 / 1.0e-2)
-            'loss': 5e-3,         # D and G loss values, relative                              (<= 4e-5)
+            'loss': 1e-3,         # D and G loss values, relative (5e-3 until round 5)         (<= 4e-5)
             'grad_norm': 3e-2,    # per-variable gradient L2 norm, relative                    (2.5e-2 / 1.8e-2, betas)
             'grad_cos': 0.98}     # per-variable gradient direction: cosine with the oracle's  (0.9923 / 0.9837)
 
